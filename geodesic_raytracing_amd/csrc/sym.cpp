@@ -1,0 +1,695 @@
+// sym.cpp — see sym.hpp.
+#include "sym.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <stdexcept>
+#include <unordered_set>
+
+namespace sym {
+
+namespace {
+
+struct Key {
+    Op op;
+    Fn fn;
+    uint64_t cbits;
+    std::string name;
+    uint32_t a, b, s;
+    bool operator==(const Key& o) const {
+        return op == o.op && fn == o.fn && cbits == o.cbits && a == o.a && b == o.b && s == o.s &&
+               name == o.name;
+    }
+};
+struct KeyHash {
+    size_t operator()(const Key& k) const {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) {
+            h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+        };
+        mix(k.op);
+        mix(k.fn);
+        mix(k.cbits);
+        mix(std::hash<std::string>()(k.name));
+        mix(k.a);
+        mix(k.b);
+        mix(k.s);
+        return (size_t)h;
+    }
+};
+
+struct Pool {
+    std::deque<Node> nodes;
+    std::unordered_map<Key, E, KeyHash> table;
+    std::recursive_mutex mu;
+};
+Pool& pool() {
+    static Pool p;
+    return p;
+}
+
+uint32_t var_deps(const std::string& n) {
+    if (n == "v1") return DEP_V1;
+    if (n == "v2") return DEP_V2;
+    if (n == "v3") return DEP_V3;
+    if (n == "v4") return DEP_V4;
+    if (n.size() == 3 && n[0] == 'i' && n[1] == 'v') return DEP_IV;
+    if (n.size() == 3 && n[0] == 'd' && n[1] == 'v') return DEP_DV;
+    if (n.rfind("cfg->", 0) == 0) return DEP_CFG;
+    return DEP_OTHER;
+}
+
+E intern(Op op, Fn fn, double c, const std::string& name, E a, E b, E s) {
+    Pool& p = pool();
+    std::lock_guard<std::recursive_mutex> lock(p.mu);
+    Key k;
+    k.op = op;
+    k.fn = fn;
+    uint64_t bits = 0;
+    if (op == CONST) {
+        if (c == 0.0) c = 0.0;  // collapse -0.0
+        std::memcpy(&bits, &c, sizeof(bits));
+    }
+    k.cbits = bits;
+    k.name = name;
+    k.a = a ? a->id + 1 : 0;
+    k.b = b ? b->id + 1 : 0;
+    k.s = s ? s->id + 1 : 0;
+    auto it = p.table.find(k);
+    if (it != p.table.end()) return it->second;
+    Node n;
+    n.op = op;
+    n.fn = fn;
+    n.c = c;
+    n.name = name;
+    n.a = a;
+    n.b = b;
+    n.s = s;
+    n.id = (uint32_t)p.nodes.size();
+    n.deps = 0;
+    uint64_t size = 1;
+    if (op == VAR) n.deps = var_deps(name);
+    if (a) { n.deps |= a->deps; size += a->size; }
+    if (b) { n.deps |= b->deps; size += b->size; }
+    if (s) { n.deps |= s->deps; size += s->size; }
+    n.size = size > 0x7fffffffu ? 0x7fffffffu : (uint32_t)size;
+    p.nodes.push_back(n);
+    E e = &p.nodes.back();
+    p.table.emplace(k, e);
+    return e;
+}
+
+double apply1(Fn f, double x) {
+    switch (f) {
+        case F_SIN: return std::sin(x);
+        case F_COS: return std::cos(x);
+        case F_TAN: return std::tan(x);
+        case F_ASIN: return std::asin(x);
+        case F_ACOS: return std::acos(x);
+        case F_ATAN: return std::atan(x);
+        case F_EXP: return std::exp(x);
+        case F_LOG: return std::log(x);
+        case F_SQRT: return std::sqrt(x);
+        case F_FABS: return std::fabs(x);
+        case F_SINH: return std::sinh(x);
+        case F_COSH: return std::cosh(x);
+        case F_TANH: return std::tanh(x);
+        case F_SIGN: return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0);
+        default: throw std::runtime_error("apply1: bad function");
+    }
+}
+
+double apply2(Fn f, double x, double y) {
+    switch (f) {
+        case F_ATAN2: return std::atan2(x, y);
+        case F_POW: return std::pow(x, y);
+        case F_FMOD: return std::fmod(x, y);
+        case F_MIN: return std::min(x, y);
+        case F_MAX: return std::max(x, y);
+        case F_LT: return x < y ? 1.0 : 0.0;
+        case F_LE: return x <= y ? 1.0 : 0.0;
+        case F_EQ: return x == y ? 1.0 : 0.0;
+        case F_GT: return x > y ? 1.0 : 0.0;
+        case F_GE: return x >= y ? 1.0 : 0.0;
+        default: throw std::runtime_error("apply2: bad function");
+    }
+}
+
+const char* fn_name(Fn f) {
+    switch (f) {
+        case F_SIN: return "sin";
+        case F_COS: return "cos";
+        case F_TAN: return "tan";
+        case F_ASIN: return "asin";
+        case F_ACOS: return "acos";
+        case F_ATAN: return "atan";
+        case F_EXP: return "exp";
+        case F_LOG: return "log";
+        case F_SQRT: return "sqrt";
+        case F_FABS: return "fabs";
+        case F_SINH: return "sinh";
+        case F_COSH: return "cosh";
+        case F_TANH: return "tanh";
+        case F_SIGN: return "sign";
+        case F_ATAN2: return "atan2";
+        case F_POW: return "pow";
+        case F_FMOD: return "fmod";
+        case F_MIN: return "fmin";
+        case F_MAX: return "fmax";
+        default: return "?";
+    }
+}
+
+bool is_cmp(Fn f) { return f == F_LT || f == F_LE || f == F_EQ || f == F_GT || f == F_GE; }
+
+// float-valued constant folding: every literal is rounded to float when printed, and the kernels
+// compute in fp32, so fold through float to keep folded and unfolded evaluation consistent.
+double fl(double v) { return (double)(float)v; }
+
+}  // namespace
+
+namespace {
+// e == coef * term with a literal coefficient
+void split_coef(E e, double& coef, E& term) {
+    if (e->op == MUL && e->a->op == CONST) { coef = e->a->c; term = e->b; }
+    else if (e->op == NEG) { split_coef(e->a, coef, term); coef = -coef; }
+    else { coef = 1.0; term = e; }
+}
+}  // namespace
+
+E constant(double v) { return intern(CONST, F_NONE, v, "", nullptr, nullptr, nullptr); }
+E var(const std::string& name) { return intern(VAR, F_NONE, 0, name, nullptr, nullptr, nullptr); }
+
+E neg(E a) {
+    if (a->op == CONST) return constant(-a->c);
+    if (a->op == NEG) return a->a;
+    if (a->op == SUB) return sub(a->b, a->a);
+    return intern(NEG, F_NONE, 0, "", a, nullptr, nullptr);
+}
+
+E add(E a, E b) {
+    if (a->op == CONST && b->op == CONST) return constant(a->c + b->c);
+    if (is_zero(a)) return b;
+    if (is_zero(b)) return a;
+    if (b->op == NEG) return sub(a, b->a);
+    if (a->op == NEG) return sub(b, a->a);
+    if (b->op == CONST && b->c < 0) return sub(a, constant(-b->c));
+    {
+        double ca, cb; E ta, tb;
+        split_coef(a, ca, ta);
+        split_coef(b, cb, tb);
+        if (ta == tb && ta->op != CONST) return mul(constant(ca + cb), ta);
+    }
+    if (a->id > b->id) std::swap(a, b);
+    return intern(ADD, F_NONE, 0, "", a, b, nullptr);
+}
+
+E sub(E a, E b) {
+    if (a->op == CONST && b->op == CONST) return constant(a->c - b->c);
+    if (is_zero(b)) return a;
+    if (is_zero(a)) return neg(b);
+    if (a == b) return constant(0.0);
+    if (b->op == NEG) return add(a, b->a);
+    if (a->op == NEG) return neg(add(a->a, b));
+    if (b->op == CONST && b->c < 0) return add(a, constant(-b->c));
+    {
+        double ca, cb; E ta, tb;
+        split_coef(a, ca, ta);
+        split_coef(b, cb, tb);
+        if (ta == tb && ta->op != CONST) return mul(constant(ca - cb), ta);
+    }
+    return intern(SUB, F_NONE, 0, "", a, b, nullptr);
+}
+
+E mul(E a, E b) {
+    if (a->op == CONST && b->op == CONST) return constant(a->c * b->c);
+    if (is_zero(a) || is_zero(b)) return constant(0.0);
+    if (is_one(a)) return b;
+    if (is_one(b)) return a;
+    if (b->op == CONST) std::swap(a, b);  // constants on the left
+    if (a->op == CONST) {
+        if (a->c == -1.0) return neg(b);
+        if (a->c < 0) return neg(mul(constant(-a->c), b));
+        if (b->op == MUL && b->a->op == CONST) return mul(constant(a->c * b->a->c), b->b);
+        if (b->op == NEG) return neg(mul(a, b->a));
+        if (b->op == DIV && b->a->op == CONST) return div(constant(a->c * b->a->c), b->b);
+        return intern(MUL, F_NONE, 0, "", a, b, nullptr);
+    }
+    if (a->op == NEG && b->op == NEG) return mul(a->a, b->a);
+    if (a->op == NEG) return neg(mul(a->a, b));
+    if (b->op == NEG) return neg(mul(a, b->a));
+    // float constants migrate outwards: (c*x)*y -> c*(x*y)
+    if (a->op == MUL && a->a->op == CONST) return mul(a->a, mul(a->b, b));
+    if (b->op == MUL && b->a->op == CONST) return mul(b->a, mul(a, b->b));
+    if (a->id > b->id) std::swap(a, b);
+    return intern(MUL, F_NONE, 0, "", a, b, nullptr);
+}
+
+E div(E a, E b) {
+    if (b->op == CONST && b->c == 0.0) {
+        // keep the division visible (the scripts never do this on purpose)
+        return intern(DIV, F_NONE, 0, "", a, b, nullptr);
+    }
+    if (a->op == CONST && b->op == CONST) return constant(a->c / b->c);
+    if (is_zero(a)) return constant(0.0);
+    if (is_one(b)) return a;
+    if (b->op == CONST) return mul(constant(1.0 / b->c), a);
+    if (a == b) return constant(1.0);
+    if (a->op == NEG && b->op == NEG) return div(a->a, b->a);
+    if (a->op == NEG) return neg(div(a->a, b));
+    if (b->op == NEG) return neg(div(a, b->a));
+    if (a->op == CONST && a->c < 0) return neg(div(constant(-a->c), b));
+    if (b->op == MUL && b->a->op == CONST && a->op == CONST) return div(constant(a->c / b->a->c), b->b);
+    if (b->op == MUL && b->a->op == CONST) return mul(constant(1.0 / b->a->c), div(a, b->b));
+    if (a->op == MUL && a->a->op == CONST) return mul(a->a, div(a->b, b));
+    if (b->op == DIV) return div(mul(a, b->b), b->a);   // a/(p/q) -> (a*q)/p
+    return intern(DIV, F_NONE, 0, "", a, b, nullptr);
+}
+
+E powi(E a, int n) {
+    if (n == 0) return constant(1.0);
+    if (n < 0) return div(constant(1.0), powi(a, -n));
+    E result = nullptr;
+    E base = a;
+    while (n) {
+        if (n & 1) result = result ? mul(result, base) : base;
+        n >>= 1;
+        if (n) base = mul(base, base);
+    }
+    return result;
+}
+
+E fn1(Fn f, E a) {
+    if (a->op == CONST) {
+        double r = apply1(f, fl(a->c));
+        if (std::isfinite(r)) return constant(fl(r));
+    }
+    switch (f) {
+        case F_SIN:
+        case F_TAN:
+        case F_ASIN:
+        case F_ATAN:
+        case F_SINH:
+        case F_TANH:
+        case F_SIGN:
+            if (a->op == NEG) return neg(fn1(f, a->a));  // odd functions
+            break;
+        case F_COS:
+        case F_COSH:
+        case F_FABS:
+            if (a->op == NEG) return fn1(f, a->a);  // even functions
+            break;
+        default: break;
+    }
+    if (f == F_FABS && a->op == FN1 && (a->fn == F_FABS || a->fn == F_SQRT || a->fn == F_EXP || a->fn == F_COSH))
+        return a;
+    if (f == F_FABS && a->op == MUL && a->a == a->b) return a;  // |x*x|
+    return intern(FN1, f, 0, "", a, nullptr, nullptr);
+}
+
+E fn2(Fn f, E a, E b) {
+    if (a->op == CONST && b->op == CONST) {
+        double r = apply2(f, fl(a->c), fl(b->c));
+        if (std::isfinite(r)) return constant(fl(r));
+    }
+    if (f == F_POW && b->op == CONST) {
+        double n = b->c;
+        if (n == std::floor(n) && std::fabs(n) <= 8) return powi(a, (int)n);
+        if (n == 0.5) return fn1(F_SQRT, a);
+        if (n == -0.5) return div(constant(1.0), fn1(F_SQRT, a));
+    }
+    return intern(FN2, f, 0, "", a, b, nullptr);
+}
+
+E select(E cond, E t, E f) {
+    if (cond->op == CONST) return cond->c != 0.0 ? t : f;
+    if (t == f) return t;
+    return intern(SELECT, F_NONE, 0, "", cond, t, f);
+}
+
+// ----------------------------------------------------------------------------------------------
+
+namespace {
+struct DiffKey {
+    uint32_t id;
+    std::string v;
+    bool operator==(const DiffKey& o) const { return id == o.id && v == o.v; }
+};
+struct DiffKeyHash {
+    size_t operator()(const DiffKey& k) const { return std::hash<std::string>()(k.v) * 1000003u + k.id; }
+};
+std::unordered_map<DiffKey, E, DiffKeyHash>& diff_memo() {
+    static std::unordered_map<DiffKey, E, DiffKeyHash> m;
+    return m;
+}
+}  // namespace
+
+E diff(E e, const std::string& wrt) {
+    if (e->op == CONST) return constant(0.0);
+    if (e->op == VAR) return constant(e->name == wrt ? 1.0 : 0.0);
+    if ((e->deps & var_deps(wrt)) == 0) return constant(0.0);
+    std::lock_guard<std::recursive_mutex> lock(pool().mu);
+    DiffKey key{e->id, wrt};
+    auto& memo = diff_memo();
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    E r = nullptr;
+    E a = e->a, b = e->b;
+    switch (e->op) {
+        case ADD: r = add(diff(a, wrt), diff(b, wrt)); break;
+        case SUB: r = sub(diff(a, wrt), diff(b, wrt)); break;
+        case NEG: r = neg(diff(a, wrt)); break;
+        case MUL: r = add(mul(diff(a, wrt), b), mul(a, diff(b, wrt))); break;
+        case DIV: {
+            E da = diff(a, wrt), db = diff(b, wrt);
+            if (is_zero(db)) r = div(da, b);
+            else if (is_zero(da)) r = neg(div(mul(a, db), mul(b, b)));
+            else r = div(sub(mul(da, b), mul(a, db)), mul(b, b));
+            break;
+        }
+        case FN1: {
+            E da = diff(a, wrt);
+            if (is_zero(da)) { r = da; break; }
+            switch (e->fn) {
+                case F_SIN: r = mul(fn1(F_COS, a), da); break;
+                case F_COS: r = neg(mul(fn1(F_SIN, a), da)); break;
+                case F_TAN: r = mul(add(constant(1.0), mul(e, e)), da); break;
+                case F_ASIN: r = div(da, fn1(F_SQRT, sub(constant(1.0), mul(a, a)))); break;
+                case F_ACOS: r = neg(div(da, fn1(F_SQRT, sub(constant(1.0), mul(a, a))))); break;
+                case F_ATAN: r = div(da, add(constant(1.0), mul(a, a))); break;
+                case F_EXP: r = mul(e, da); break;
+                case F_LOG: r = div(da, a); break;
+                case F_SQRT: r = div(mul(constant(0.5), da), e); break;
+                case F_FABS: r = mul(fn1(F_SIGN, a), da); break;
+                case F_SINH: r = mul(fn1(F_COSH, a), da); break;
+                case F_COSH: r = mul(fn1(F_SINH, a), da); break;
+                case F_TANH: r = mul(sub(constant(1.0), mul(e, e)), da); break;
+                case F_SIGN: r = constant(0.0); break;
+                default: throw std::runtime_error("diff: bad unary function");
+            }
+            break;
+        }
+        case FN2: {
+            E da = diff(a, wrt), db = diff(b, wrt);
+            switch (e->fn) {
+                case F_ATAN2:  // atan2(a=y, b=x)
+                    r = div(sub(mul(b, da), mul(a, db)), add(mul(a, a), mul(b, b)));
+                    break;
+                case F_POW:
+                    if (is_zero(db)) {
+                        r = mul(mul(b, fn2(F_POW, a, sub(b, constant(1.0)))), da);
+                    } else {
+                        r = mul(e, add(mul(db, fn1(F_LOG, a)), div(mul(b, da), a)));
+                    }
+                    break;
+                case F_FMOD: r = da; break;
+                case F_MIN: r = select(fn2(F_LT, a, b), da, db); break;
+                case F_MAX: r = select(fn2(F_GT, a, b), da, db); break;
+                default: r = constant(0.0); break;  // comparisons
+            }
+            break;
+        }
+        case SELECT: r = select(e->a, diff(e->b, wrt), diff(e->s, wrt)); break;
+        default: throw std::runtime_error("diff: bad op");
+    }
+    memo.emplace(key, r);
+    return r;
+}
+
+namespace {
+E subst_rec(E e, const std::map<std::string, E>& m, std::unordered_map<E, E>& memo) {
+    if (e->op == CONST) return e;
+    if (e->op == VAR) {
+        auto it = m.find(e->name);
+        return it == m.end() ? e : it->second;
+    }
+    auto it = memo.find(e);
+    if (it != memo.end()) return it->second;
+    E r = nullptr;
+    switch (e->op) {
+        case ADD: r = add(subst_rec(e->a, m, memo), subst_rec(e->b, m, memo)); break;
+        case SUB: r = sub(subst_rec(e->a, m, memo), subst_rec(e->b, m, memo)); break;
+        case MUL: r = mul(subst_rec(e->a, m, memo), subst_rec(e->b, m, memo)); break;
+        case DIV: r = div(subst_rec(e->a, m, memo), subst_rec(e->b, m, memo)); break;
+        case NEG: r = neg(subst_rec(e->a, m, memo)); break;
+        case FN1: r = fn1(e->fn, subst_rec(e->a, m, memo)); break;
+        case FN2: r = fn2(e->fn, subst_rec(e->a, m, memo), subst_rec(e->b, m, memo)); break;
+        case SELECT:
+            r = select(subst_rec(e->a, m, memo), subst_rec(e->b, m, memo), subst_rec(e->s, m, memo));
+            break;
+        default: throw std::runtime_error("subst: bad op");
+    }
+    memo.emplace(e, r);
+    return r;
+}
+}  // namespace
+
+E subst(E e, const std::map<std::string, E>& m) {
+    std::unordered_map<E, E> memo;
+    return subst_rec(e, m, memo);
+}
+
+namespace {
+double eval_rec(E e, const std::map<std::string, double>& env, std::unordered_map<E, double>& memo) {
+    if (e->op == CONST) return e->c;
+    auto it = memo.find(e);
+    if (it != memo.end()) return it->second;
+    double r = 0;
+    switch (e->op) {
+        case VAR: {
+            auto v = env.find(e->name);
+            if (v == env.end()) throw std::runtime_error("eval: unbound variable " + e->name);
+            r = v->second;
+            break;
+        }
+        case ADD: r = eval_rec(e->a, env, memo) + eval_rec(e->b, env, memo); break;
+        case SUB: r = eval_rec(e->a, env, memo) - eval_rec(e->b, env, memo); break;
+        case MUL: r = eval_rec(e->a, env, memo) * eval_rec(e->b, env, memo); break;
+        case DIV: r = eval_rec(e->a, env, memo) / eval_rec(e->b, env, memo); break;
+        case NEG: r = -eval_rec(e->a, env, memo); break;
+        case FN1: r = apply1(e->fn, eval_rec(e->a, env, memo)); break;
+        case FN2: r = apply2(e->fn, eval_rec(e->a, env, memo), eval_rec(e->b, env, memo)); break;
+        case SELECT:
+            r = eval_rec(e->a, env, memo) != 0.0 ? eval_rec(e->b, env, memo) : eval_rec(e->s, env, memo);
+            break;
+        default: throw std::runtime_error("eval: bad op");
+    }
+    memo.emplace(e, r);
+    return r;
+}
+}  // namespace
+
+double eval(E e, const std::map<std::string, double>& env) {
+    std::unordered_map<E, double> memo;
+    return eval_rec(e, env, memo);
+}
+
+std::string const_to_c(double v) {
+    float f = (float)v;
+    if (std::isinf(f)) return f > 0 ? "INFINITY" : "(-INFINITY)";
+    if (std::isnan(f)) return "NAN";
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%.9g", (double)f);
+    std::string s = buf;
+    if (s.find('.') == std::string::npos && s.find('e') == std::string::npos && s.find("inf") == std::string::npos)
+        s += ".0";
+    s += "f";
+    if (f < 0) s = "(" + s + ")";
+    return s;
+}
+
+namespace {
+void to_c_rec(E e, const std::unordered_map<E, std::string>* names, std::string& out, bool top) {
+    if (names && !top) {
+        auto it = names->find(e);
+        if (it != names->end()) {
+            out += it->second;
+            return;
+        }
+    }
+    switch (e->op) {
+        case CONST: out += const_to_c(e->c); break;
+        case VAR: out += e->name; break;
+        case ADD:
+        case SUB:
+        case MUL:
+        case DIV: {
+            out += "(";
+            to_c_rec(e->a, names, out, false);
+            out += e->op == ADD ? "+" : e->op == SUB ? "-" : e->op == MUL ? "*" : "/";
+            to_c_rec(e->b, names, out, false);
+            out += ")";
+            break;
+        }
+        case NEG:
+            out += "(-";
+            to_c_rec(e->a, names, out, false);
+            out += ")";
+            break;
+        case FN1:
+            out += fn_name(e->fn);
+            out += "(";
+            to_c_rec(e->a, names, out, false);
+            out += ")";
+            break;
+        case FN2:
+            if (is_cmp(e->fn)) {
+                const char* o = e->fn == F_LT ? "<" : e->fn == F_LE ? "<=" : e->fn == F_EQ ? "==" : e->fn == F_GT ? ">" : ">=";
+                out += "((";
+                to_c_rec(e->a, names, out, false);
+                out += o;
+                to_c_rec(e->b, names, out, false);
+                out += ")?1.0f:0.0f)";
+            } else {
+                out += fn_name(e->fn);
+                out += "(";
+                to_c_rec(e->a, names, out, false);
+                out += ",";
+                to_c_rec(e->b, names, out, false);
+                out += ")";
+            }
+            break;
+        case SELECT:
+            out += "((";
+            to_c_rec(e->a, names, out, false);
+            out += "!=0.0f)?";
+            to_c_rec(e->b, names, out, false);
+            out += ":";
+            to_c_rec(e->s, names, out, false);
+            out += ")";
+            break;
+    }
+}
+}  // namespace
+
+std::string to_c(E e, const std::unordered_map<E, std::string>* names, bool is_definition) {
+    std::string out;
+    to_c_rec(e, names, out, is_definition);
+    return out;
+}
+
+OpCount count_ops(const std::vector<E>& roots) {
+    OpCount oc;
+    std::unordered_set<E> seen;
+    std::vector<E> stack(roots.begin(), roots.end());
+    while (!stack.empty()) {
+        E e = stack.back();
+        stack.pop_back();
+        if (!e || !seen.insert(e).second) continue;
+        switch (e->op) {
+            case CONST:
+            case VAR: break;
+            case FN1:
+                if (e->fn == F_FABS || e->fn == F_SIGN) oc.ops++;
+                else if (e->fn == F_SQRT) { oc.ops++; oc.transcendental++; }
+                else { oc.ops++; oc.transcendental++; }
+                break;
+            case FN2:
+                oc.ops++;
+                if (e->fn == F_ATAN2 || e->fn == F_POW || e->fn == F_FMOD) oc.transcendental++;
+                break;
+            default: oc.ops++; break;
+        }
+        if (e->a) stack.push_back(e->a);
+        if (e->b) stack.push_back(e->b);
+        if (e->s) stack.push_back(e->s);
+    }
+    return oc;
+}
+
+Temporaries hoist_position_temporaries(const std::vector<E>& roots, const std::string& prefix) {
+    // reference counts over the DAG (each parent edge + each root counts once)
+    std::unordered_map<E, int> refs;
+    std::vector<E> order;  // post-order
+    std::unordered_set<E> seen;
+    std::function<void(E)> visit = [&](E e) {
+        if (!e) return;
+        refs[e]++;
+        if (!seen.insert(e).second) return;
+        visit(e->a);
+        visit(e->b);
+        visit(e->s);
+        order.push_back(e);
+    };
+    for (E r : roots) visit(r);
+
+    Temporaries t;
+    const uint32_t pos_mask = DEP_V1 | DEP_V2 | DEP_V3 | DEP_V4 | DEP_CFG;
+    for (E e : order) {
+        if (e->op == CONST || e->op == VAR) continue;
+        if (e->deps & ~pos_mask) continue;   // depends on velocity or something else
+        if (e->deps == 0) continue;          // pure constant expression (should have folded)
+        if (refs[e] < 2) continue;
+        if (e->op == NEG && (e->a->op == VAR || e->a->op == CONST)) continue;
+        std::string name = prefix + std::to_string(t.defs.size());
+        t.defs.emplace_back(name, e);
+        t.names.emplace(e, name);
+    }
+    return t;
+}
+
+// ----------------------------------------------------------------------------------------------
+// complex
+
+Cx cx(E re) { return Cx{re, constant(0.0)}; }
+Cx cx(E re, E im) { return Cx{re, im}; }
+Cx cadd(Cx a, Cx b) { return Cx{add(a.re, b.re), add(a.im, b.im)}; }
+Cx csub(Cx a, Cx b) { return Cx{sub(a.re, b.re), sub(a.im, b.im)}; }
+Cx cneg(Cx a) { return Cx{neg(a.re), neg(a.im)}; }
+Cx cconj(Cx a) { return Cx{a.re, neg(a.im)}; }
+Cx cmul(Cx a, Cx b) {
+    return Cx{sub(mul(a.re, b.re), mul(a.im, b.im)), add(mul(a.re, b.im), mul(a.im, b.re))};
+}
+E cabs2(Cx a) { return add(mul(a.re, a.re), mul(a.im, a.im)); }
+E cabs(Cx a) {
+    if (is_zero(a.im)) return fn1(F_FABS, a.re);
+    if (is_zero(a.re)) return fn1(F_FABS, a.im);
+    return fn1(F_SQRT, cabs2(a));
+}
+Cx cdiv(Cx a, Cx b) {
+    if (is_zero(b.im)) return Cx{div(a.re, b.re), div(a.im, b.re)};
+    E d = cabs2(b);
+    Cx n = cmul(a, cconj(b));
+    return Cx{div(n.re, d), div(n.im, d)};
+}
+Cx cpowi(Cx a, int n) {
+    if (n == 0) return cx(constant(1.0));
+    if (n < 0) return cdiv(cx(constant(1.0)), cpowi(a, -n));
+    Cx r = a;
+    for (int i = 1; i < n; i++) r = cmul(r, a);
+    return r;
+}
+Cx csqrt_real(E a) {
+    // sqrt of a real that may be negative: sqrt(|a|) on the real axis for a>=0, imaginary otherwise
+    if (a->op == CONST) {
+        if (a->c >= 0) return cx(constant(std::sqrt(a->c)));
+        return Cx{constant(0.0), constant(std::sqrt(-a->c))};
+    }
+    E root = fn1(F_SQRT, fn1(F_FABS, a));
+    E nonneg = fn2(F_GE, a, constant(0.0));
+    return Cx{select(nonneg, root, constant(0.0)), select(nonneg, constant(0.0), root)};
+}
+Cx csqrt_principal(Cx a) {
+    if (is_zero(a.im)) return csqrt_real(a.re);
+    // principal branch: sqrt((|z|+re)/2) + i*sign(im)*sqrt((|z|-re)/2)
+    E m = cabs(a);
+    E re = fn1(F_SQRT, fn2(F_MAX, mul(constant(0.5), add(m, a.re)), constant(0.0)));
+    E imag = fn1(F_SQRT, fn2(F_MAX, mul(constant(0.5), sub(m, a.re)), constant(0.0)));
+    E sgn = select(fn2(F_LT, a.im, constant(0.0)), constant(-1.0), constant(1.0));
+    return Cx{re, mul(sgn, imag)};
+}
+Cx csin(Cx a) {
+    if (is_zero(a.im)) return cx(fn1(F_SIN, a.re));
+    return Cx{mul(fn1(F_SIN, a.re), fn1(F_COSH, a.im)), mul(fn1(F_COS, a.re), fn1(F_SINH, a.im))};
+}
+Cx ccos(Cx a) {
+    if (is_zero(a.im)) return cx(fn1(F_COS, a.re));
+    return Cx{mul(fn1(F_COS, a.re), fn1(F_COSH, a.im)), neg(mul(fn1(F_SIN, a.re), fn1(F_SINH, a.im)))};
+}
+
+}  // namespace sym
