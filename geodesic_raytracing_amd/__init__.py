@@ -1,0 +1,132 @@
+"""geodesic_raytracing_amd — ctypes binding of libgeodesic_hip.so (C ABI in include/geodesic_hip.h).
+
+The library is the product: metric code generator (host C++), hiprtc-specialised gfx950 kernels and
+the frame driver.  This module only binds it for tests, bench.py and scripting; it contains no
+compute path of its own and raises immediately if the shared library is missing.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgeodesic_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(there is no CPU fallback for the ray kernels)")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_char_p = ctypes.c_char_p
+c_size_t = ctypes.c_size_t
+
+
+class Features(ctypes.Structure):
+    """struct dynamic_feature_config (dynamic_feature_config.cpp:182-237), defaults main.cpp:1123-1158."""
+    _fields_ = [
+        ("adaptive_sampling_threshold", c_float), ("field_of_view", c_float), ("max_acceleration_change", c_float),
+        ("max_precision_radius", c_float), ("min_step", c_float), ("ray_skip", c_float), ("universe_size", c_float),
+        ("adaptive_sampling", c_int), ("redshift", c_int), ("reparameterisation", c_int), ("use_old_redshift", c_int),
+        ("use_triangle_rendering", c_int)]
+
+
+class MetricInfo(ctypes.Structure):
+    _fields_ = [("is_big", c_int), ("is_constant_theta", c_int), ("use_prepass", c_int), ("adaptive_precision", c_int),
+                ("max_acceleration_change", c_float), ("num_dynamic_vars", c_int), ("accel_ops", c_int),
+                ("accel_transcendentals", c_int), ("coord_ops", c_int)]
+
+
+class Camera(ctypes.Structure):
+    _fields_ = [("position", c_float * 4), ("quat", c_float * 4), ("basis_speed", c_float * 3), ("flip", c_float)]
+
+
+class FrameOptions(ctypes.Structure):
+    _fields_ = [("mode", c_int), ("tiled", c_int), ("use_prepass", c_int), ("max_probes", c_int), ("row_begin", c_int),
+                ("row_end", c_int), ("time_kernels", c_int), ("count_attempts", c_int)]
+
+
+MODE_REFERENCE, MODE_FUSED = 0, 1
+(STAGE_CAMERA, STAGE_PREPASS, STAGE_INIT, STAGE_TRACE, STAGE_RENDER_DATA, STAGE_ADAPTIVE, STAGE_RENDER) = range(7)
+STAGE_NAMES = ["camera", "prepass", "init", "trace", "render_data", "adaptive", "render"]
+(BUF_RAYS_IN, BUF_RAYS_COUNT, BUF_RENDER_DATA, BUF_TERMINATION, BUF_CAMERA_GENERIC, BUF_TETRAD0, BUF_TETRAD1, BUF_TETRAD2,
+ BUF_TETRAD3, BUF_RAYS_ADAPTIVE, BUF_RAYS_ADAPTIVE_COUNT, BUF_CFG, BUF_DFG, BUF_CAMERA_QUAT) = range(14)
+
+# every symbol include/geodesic_hip.h declares, with its signature
+_SIGNATURES = {
+    "gr_last_error": (c_char_p, []),
+    "gr_features_default": (None, [ctypes.POINTER(Features)]),
+    "gr_metric_builtin": (c_int, [c_char_p, ctypes.POINTER(c_void_p)]),
+    "gr_metric_load_script": (c_int, [c_char_p, c_char_p, ctypes.POINTER(c_void_p)]),
+    "gr_metric_destroy": (None, [c_void_p]),
+    "gr_metric_get_info": (c_int, [c_void_p, ctypes.POINTER(MetricInfo)]),
+    "gr_metric_dynamic_var_name": (c_char_p, [c_void_p, c_int]),
+    "gr_metric_dynamic_var_default": (c_float, [c_void_p, c_int]),
+    "gr_metric_argument_string": (c_int, [c_void_p, ctypes.POINTER(Features), c_int, ctypes.POINTER(c_float), c_int,
+                                          c_char_p, c_size_t, ctypes.POINTER(c_size_t)]),
+    "gr_program_create": (c_int, [c_char_p, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_program_precompile": (c_int, [c_char_p]),
+    "gr_program_destroy": (None, [c_void_p]),
+    "gr_program_kernel_info": (c_int, [c_void_p, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "gr_cart_to_generic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "gr_init_basis_vectors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float), c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
+    "gr_clear_termination_buffer": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "gr_init_rays_generic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                     c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "gr_tiled_slot_count": (c_int, [c_int, c_int]),
+    "gr_do_generic_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "gr_calculate_singularities": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int]),
+    "gr_calculate_render_data": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                         c_void_p, c_void_p]),
+    "gr_handle_adaptive_sampling": (c_int, [c_void_p] * 14 + [c_int, c_int, c_void_p, c_void_p]),
+    "gr_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                          c_int, c_int, c_int, c_void_p, c_void_p]),
+    "gr_render_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, c_void_p, c_void_p]),
+    "gr_prepass_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
+    "gr_trace_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gr_camera_default": (None, [ctypes.POINTER(Camera)]),
+    "gr_frame_options_default": (None, [ctypes.POINTER(FrameOptions)]),
+    "gr_render_state_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_render_state_destroy": (None, [c_void_p]),
+    "gr_render_frame": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Camera), ctypes.POINTER(Features),
+                                ctypes.POINTER(c_float), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                ctypes.POINTER(FrameOptions)]),
+    "gr_render_state_stage_ms": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float)]),
+    "gr_render_state_attempts": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "gr_render_state_buffer": (c_void_p, [c_void_p, c_int]),
+    "gr_device_download": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
+    "gr_device_upload": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
+    "gr_device_alloc": (c_int, [c_int, c_size_t, ctypes.POINTER(c_void_p)]),
+    "gr_device_free": (c_int, [c_int, c_void_p]),
+    "gr_device_synchronize": (c_int, [c_int]),
+    "gr_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "gr_pack_mipped_background": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+}
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(lib, _name)   # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED_SYMBOLS = sorted(_SIGNATURES)
+
+
+class GeodesicError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib.gr_last_error()
+        raise GeodesicError(f"libgeodesic_hip error {rc}: {msg.decode(errors='replace') if msg else ''}")
+
+
+from .pipeline import (Metric, Program, RenderState, default_camera, default_features, frame_options,  # noqa: E402,F401
+                       synthetic_background, pack_background)

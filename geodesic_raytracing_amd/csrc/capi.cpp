@@ -1,0 +1,494 @@
+// capi.cpp — the C ABI of libgeodesic_hip.so (include/geodesic_hip.h): metric -> macro string on the
+// host, macro string -> gfx950 code object through hiprtc, and one launcher per reference kernel.
+//
+// Reference counterparts: metric_manager.hpp:19-219 (program build + cache), main.cpp:139-205 and
+// 2244-2526 (the launches).  HIP is used directly (module API); there is no fallback of any kind:
+// without libamdhip64/hiprtc or without a device the calls fail with GR_ERROR_DEVICE/COMPILE.
+#include "../../include/geodesic_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "builtin_metrics.hpp"
+#include "jsfront.hpp"
+#include "metric_codegen.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(gr_status code, const std::string& msg) {
+    g_error = msg;
+    return (int)code;
+}
+
+#define GR_TRY_BEGIN try {
+#define GR_TRY_END                                                                 \
+    }                                                                              \
+    catch (const std::exception& e) { return fail(GR_ERROR_SCRIPT, e.what()); }    \
+    catch (...) { return fail(GR_ERROR_SCRIPT, "unknown exception"); }
+
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return fail(GR_ERROR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    } while (0)
+
+std::string library_dir() {
+    Dl_info info;
+    if (dladdr((void*)&gr_last_error, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.rfind('/');
+        if (s != std::string::npos) return p.substr(0, s);
+    }
+    return ".";
+}
+
+bool read_file(const std::string& path, std::string& out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return true;
+}
+
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+const char* const KERNEL_NAMES[] = {
+    "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
+    "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_prepass_fused"};
+enum KernelId {
+    K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_PREPASS_FUSED, K_COUNT
+};
+
+std::vector<std::string> split_arguments(const std::string& s) {
+    std::vector<std::string> out;
+    std::istringstream iss(s);
+    std::string tok;
+    while (iss >> tok) out.push_back(tok);
+    return out;
+}
+
+// Compiles (or fetches from the on-disk cache) the code object for one macro string.
+int compile_code_object(const std::string& argument_string, std::string& code) {
+    std::string source_path;
+    if (const char* env = getenv("GR_KERNEL_SOURCE")) source_path = env;
+    else source_path = library_dir() + "/csrc/kernels/geodesic_kernels.hip";
+    std::string source;
+    if (!read_file(source_path, source)) return fail(GR_ERROR_COMPILE, "cannot read kernel source " + source_path);
+
+    std::vector<std::string> opts = {
+        "--offload-arch=gfx950", "-O3", "-std=c++17",
+        // the reference builds with -cl-unsafe-math-optimizations (metric_manager.hpp:70): reassociation,
+        // reciprocal division, contraction - but NaN/Inf stay meaningful (IS_DEGENERATE, cl.cl:68)
+        "-ffp-contract=fast", "-fno-math-errno", "-freciprocal-math", "-fassociative-math",
+        "-fno-signed-zeros", "-fno-trapping-math"};
+    for (auto& tok : split_arguments(argument_string)) {
+        if (tok.rfind("-D", 0) == 0) opts.push_back(tok);
+        else if (tok.rfind("-cl-", 0) == 0 || tok == "-I" || tok == "./") continue;   // OpenCL-only prefix flags
+        else return fail(GR_ERROR_INVALID_ARGUMENT, "unsupported token in argument string: " + tok);
+    }
+    if (const char* extra = getenv("GR_EXTRA_FLAGS"))
+        for (auto& tok : split_arguments(extra)) opts.push_back(tok);
+
+    int rtc_major = 0, rtc_minor = 0;
+    hiprtcVersion(&rtc_major, &rtc_minor);
+    uint64_t h = fnv1a(source);
+    for (auto& o : opts) h = fnv1a(o + "\n", h);
+    h = fnv1a("hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor), h);
+    char name[64];
+    snprintf(name, sizeof(name), "%016llx.hsaco", (unsigned long long)h);
+
+    std::string cache_dir;
+    if (const char* env = getenv("GR_CACHE_DIR")) cache_dir = env;
+    else cache_dir = library_dir() + "/_cache";
+    std::string cache_path = cache_dir + "/" + name;
+    if (read_file(cache_path, code) && !code.empty()) return GR_OK;
+
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, source.c_str(), "geodesic_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(GR_ERROR_COMPILE, "hiprtcCreateProgram failed");
+    std::vector<const char*> copts;
+    for (auto& o : opts) copts.push_back(o.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(GR_ERROR_COMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    code.assign(n, '\0');
+    hiprtcGetCode(prog, &code[0]);
+    hiprtcDestroyProgram(&prog);
+
+    mkdir(cache_dir.c_str(), 0755);
+    std::string tmp = cache_path + ".tmp" + std::to_string((long)getpid());
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        f.write(code.data(), (std::streamsize)code.size());
+    }
+    rename(tmp.c_str(), cache_path.c_str());
+    return GR_OK;
+}
+
+}  // namespace
+
+struct gr_metric {
+    gr::MetricConfig cfg;
+    gr::MetricFunctions functions;
+    gr::DynamicVars vars;
+    gr::MetricDescriptor desc;
+    std::shared_ptr<void> keepalive;   // script interpreter state owning the closures
+};
+
+struct gr_program {
+    int device = 0;
+    hipModule_t module = nullptr;
+    hipFunction_t fn[K_COUNT] = {};
+    void* huge_count = nullptr;   // device int = INT_MAX: "no device-side count" for range launches
+    std::string arguments;
+};
+
+extern "C" {
+
+const char* gr_last_error(void) { return g_error.c_str(); }
+
+void gr_features_default(gr_features* f) {
+    if (!f) return;
+    // main.cpp:1123-1158
+    f->adaptive_sampling_threshold = 64.f;
+    f->field_of_view = 90.f;
+    f->max_acceleration_change = 0.01f;
+    f->max_precision_radius = 10.f;
+    f->min_step = 0.000001f;
+    f->ray_skip = 4.f;
+    f->universe_size = 20.f;
+    f->adaptive_sampling = 1;
+    f->redshift = 0;
+    f->reparameterisation = 0;
+    f->use_old_redshift = 0;
+    f->use_triangle_rendering = 0;
+}
+
+static gr::FeatureConfig to_feature_config(const gr_features* f) {
+    gr_features d;
+    gr_features_default(&d);
+    if (f) d = *f;
+    gr::FeatureConfig c;
+    c.set("adaptive_sampling_threshold", d.adaptive_sampling_threshold);
+    c.set("field_of_view", d.field_of_view);
+    c.set("max_acceleration_change", d.max_acceleration_change);
+    c.set("max_precision_radius", d.max_precision_radius);
+    c.set("min_step", d.min_step);
+    c.set("ray_skip", d.ray_skip);
+    c.set("universe_size", d.universe_size);
+    c.set("adaptive_sampling", d.adaptive_sampling != 0);
+    c.set("redshift", d.redshift != 0);
+    c.set("reparameterisation", d.reparameterisation != 0);
+    c.set("use_old_redshift", d.use_old_redshift != 0);
+    c.set("use_triangle_rendering", d.use_triangle_rendering != 0);
+    return c;
+}
+
+int gr_metric_builtin(const char* name, gr_metric** out) {
+    if (!name || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    GR_TRY_BEGIN
+    auto m = std::make_unique<gr_metric>();
+    if (!gr::builtin_metric(name, m->cfg, m->functions, m->vars))
+        return fail(GR_ERROR_INVALID_ARGUMENT, std::string("unknown built-in metric ") + name);
+    m->desc.load(m->functions, m->cfg);
+    *out = m.release();
+    return GR_OK;
+    GR_TRY_END
+}
+
+int gr_metric_load_script(const char* scripts_dir, const char* name, gr_metric** out) {
+    if (!scripts_dir || !name || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    GR_TRY_BEGIN
+    auto m = std::make_unique<gr_metric>();
+    m->keepalive = gr::load_metric_from_scripts(scripts_dir, name, m->cfg, m->functions, m->vars);
+    m->desc.load(m->functions, m->cfg);
+    *out = m.release();
+    return GR_OK;
+    GR_TRY_END
+}
+
+void gr_metric_destroy(gr_metric* m) { delete m; }
+
+int gr_metric_get_info(const gr_metric* m, gr_metric_info* out) {
+    if (!m || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    out->is_big = m->desc.is_big;
+    out->is_constant_theta = m->desc.is_spherical && m->cfg.system == gr::CoordinateSystem::X_Y_THETA_PHI;
+    out->use_prepass = m->cfg.use_prepass;
+    out->adaptive_precision = m->cfg.adaptive_precision;
+    out->max_acceleration_change = m->cfg.max_acceleration_change;
+    out->num_dynamic_vars = (int)m->vars.names.size();
+    out->accel_ops = m->desc.accel_ops.ops;
+    out->accel_transcendentals = m->desc.accel_ops.transcendental;
+    out->coord_ops = m->desc.coord_ops.ops;
+    return GR_OK;
+}
+
+const char* gr_metric_dynamic_var_name(const gr_metric* m, int i) {
+    if (!m || i < 0 || i >= (int)m->vars.names.size()) return nullptr;
+    return m->vars.names[i].c_str();
+}
+
+float gr_metric_dynamic_var_default(const gr_metric* m, int i) {
+    if (!m || i < 0 || i >= (int)m->vars.defaults.size()) return 0.f;
+    return m->vars.defaults[i];
+}
+
+int gr_metric_argument_string(const gr_metric* m, const gr_features* features, int is_static, const float* cfg_values,
+                              int num_cfg_values, char* buffer, size_t capacity, size_t* needed) {
+    if (!m) return fail(GR_ERROR_INVALID_ARGUMENT, "null metric");
+    GR_TRY_BEGIN
+    gr::FeatureConfig fc = to_feature_config(features);
+    std::string s;
+    if (is_static) {
+        std::vector<float> vals(cfg_values, cfg_values + (cfg_values ? num_cfg_values : 0));
+        gr::MetricImpl concrete = m->desc.concrete(m->vars.substitution(vals));
+        s = gr::build_argument_string(m->desc, concrete, m->cfg, m->vars, true, fc);
+    } else {
+        s = gr::build_argument_string(m->desc, m->desc.raw, m->cfg, m->vars, false, fc);
+    }
+    if (needed) *needed = s.size() + 1;
+    if (!buffer || capacity < s.size() + 1) return fail(GR_ERROR_BUFFER_TOO_SMALL, "buffer too small");
+    memcpy(buffer, s.c_str(), s.size() + 1);
+    return GR_OK;
+    GR_TRY_END
+}
+
+int gr_program_precompile(const char* argument_string) {
+    if (!argument_string) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument string");
+    std::string code;
+    return compile_code_object(argument_string, code);
+}
+
+int gr_program_create(const char* argument_string, int device, gr_program** out) {
+    if (!argument_string || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    std::string code;
+    int rc = compile_code_object(argument_string, code);
+    if (rc != GR_OK) return rc;
+    HIP_CHECK(hipSetDevice(device));
+    auto p = std::make_unique<gr_program>();
+    p->device = device;
+    p->arguments = argument_string;
+    HIP_CHECK(hipModuleLoadData(&p->module, code.data()));
+    for (int k = 0; k < K_COUNT; k++) HIP_CHECK(hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]));
+    const int huge = 0x7fffffff;
+    HIP_CHECK(hipMalloc(&p->huge_count, sizeof(int)));
+    HIP_CHECK(hipMemcpy(p->huge_count, &huge, sizeof(int), hipMemcpyHostToDevice));
+    *out = p.release();
+    return GR_OK;
+}
+
+void gr_program_destroy(gr_program* p) {
+    if (!p) return;
+    if (p->huge_count) (void)hipFree(p->huge_count);
+    if (p->module) (void)hipModuleUnload(p->module);
+    delete p;
+}
+
+int gr_program_kernel_info(const gr_program* p, const char* kernel_name, int* vgprs, int* sgprs, int* scratch_bytes) {
+    if (!p || !kernel_name) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    for (int k = 0; k < K_COUNT; k++) {
+        if (strcmp(kernel_name, KERNEL_NAMES[k]) != 0) continue;
+        int v = 0, l = 0;
+        HIP_CHECK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, p->fn[k]));
+        HIP_CHECK(hipFuncGetAttribute(&l, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, p->fn[k]));
+        if (vgprs) *vgprs = v;
+        if (sgprs) *sgprs = 0;
+        if (scratch_bytes) *scratch_bytes = l;
+        return GR_OK;
+    }
+    return fail(GR_ERROR_INVALID_ARGUMENT, "unknown kernel");
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------
+
+static int launch(gr_program* p, int k, void* stream, unsigned gx, unsigned gy, unsigned bx, unsigned by, void** args) {
+    if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
+    if (gx == 0 || gy == 0) return GR_OK;
+    HIP_CHECK(hipModuleLaunchKernel(p->fn[k], gx, gy, 1, bx, by, 1, 0, (hipStream_t)stream, args, nullptr));
+    return GR_OK;
+}
+
+static unsigned blocks(long long n, int b) { return n <= 0 ? 0u : (unsigned)((n + b - 1) / b); }
+
+int gr_cart_to_generic(gr_program* p, void* stream, const void* in, void* out, int count, float flip, const void* cfg) {
+    void* args[] = {&in, &out, &count, &flip, &cfg};
+    return launch(p, K_CART_TO_GENERIC, stream, blocks(count, 64), 1, 64, 1, args);
+}
+
+int gr_init_basis_vectors(gr_program* p, void* stream, const void* generic_in, int count, const float speed[3],
+                          void* e0, void* e1, void* e2, void* e3, const void* cfg) {
+    float sx = speed ? speed[0] : 0.f, sy = speed ? speed[1] : 0.f, sz = speed ? speed[2] : 0.f;
+    void* args[] = {&generic_in, &count, &sx, &sy, &sz, &e0, &e1, &e2, &e3, &cfg};
+    return launch(p, K_INIT_BASIS, stream, blocks(count, 64), 1, 64, 1, args);
+}
+
+int gr_clear_termination_buffer(gr_program* p, void* stream, void* buf, int width, int height) {
+    void* args[] = {&buf, &width, &height};
+    return launch(p, K_CLEAR_TERM, stream, blocks((long long)width * height, 256), 1, 256, 1, args);
+}
+
+int gr_tiled_slot_count(int width, int height) {
+    const int T = 8;
+    return ((width + T - 1) / T) * ((height + T - 1) / T) * T * T;
+}
+
+int gr_init_rays_generic(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rays,
+                         void* ray_count, int width, int height, const void* termination_buffer, int prepass_width,
+                         int prepass_height, int flip, const void* e0, const void* e1, const void* e2, const void* e3,
+                         const void* cfg, const void* dfg, int i_am_prepass, int tiled) {
+    long long slots = tiled ? gr_tiled_slot_count(width, height) : (long long)width * height;
+    void* args[] = {&camera_generic, &camera_quat, &rays, &ray_count, &width, &height, &termination_buffer,
+                    &prepass_width, &prepass_height, &flip, &e0, &e1, &e2, &e3, &cfg, &dfg, &i_am_prepass, &tiled};
+    return launch(p, K_INIT_RAYS, stream, blocks(slots, 256), 1, 256, 1, args);
+}
+
+int gr_do_generic_rays(gr_program* p, void* stream, void* rays, const void* ray_count, int num_rays, void* tmin, void* tmax,
+                       const void* cfg, const void* dfg, int width, int height, int mouse_x, int mouse_y, void* ray_write,
+                       void* ray_write_counts, int max_write, void* attempt_counter) {
+    void* args[] = {&rays, &ray_count, &tmin, &tmax, &cfg, &dfg, &width, &height, &mouse_x, &mouse_y,
+                    &ray_write, &ray_write_counts, &max_write, &attempt_counter};
+    return launch(p, K_DO_RAYS, stream, blocks(num_rays, 64), 1, 64, 1, args);
+}
+
+int gr_calculate_singularities(gr_program* p, void* stream, const void* rays, const void* count, int num_rays, void* term,
+                               int width, int height) {
+    void* args[] = {&rays, &count, &term, &width, &height};
+    return launch(p, K_CALC_SING, stream, blocks(num_rays, 256), 1, 256, 1, args);
+}
+
+int gr_calculate_render_data(gr_program* p, void* stream, const void* rays, const void* ray_count, int num_rays, void* rdata,
+                             void* rdata_count, int width, int height, const void* cfg, const void* dfg) {
+    void* args[] = {&rays, &ray_count, &rdata, &rdata_count, &width, &height, &cfg, &dfg};
+    return launch(p, K_CALC_RDATA, stream, blocks(num_rays, 256), 1, 256, 1, args);
+}
+
+int gr_handle_adaptive_sampling(gr_program* p, void* stream, const void* rays, const void* ray_count, void* rdata,
+                                void* rdata_count, void* new_rays, void* new_ray_count, const void* camera_generic,
+                                const void* camera_quat, const void* e0, const void* e1, const void* e2, const void* e3,
+                                int width, int height, const void* cfg, const void* dfg) {
+    void* args[] = {&rays, &ray_count, &rdata, &rdata_count, &new_rays, &new_ray_count, &camera_generic, &camera_quat,
+                    &e0, &e1, &e2, &e3, &width, &height, &cfg, &dfg};
+    return launch(p, K_ADAPTIVE, stream, blocks(width / 2, 8), blocks(height / 2, 8), 8, 8, args);
+}
+
+int gr_render(gr_program* p, void* stream, const void* rdata, const void* rdata_count, int num_pixels, void* out,
+              const void* bg1, const void* bg2, int bg_width, int bg_height, int bg_levels, int width, int height,
+              int max_probes, const void* cfg, const void* dfg) {
+    int first = 0;
+    void* args[] = {&rdata, &rdata_count, &out, &bg1, &bg2, &bg_width, &bg_height, &bg_levels, &width, &height,
+                    &max_probes, &cfg, &dfg, &first, &num_pixels};
+    return launch(p, K_RENDER, stream, blocks(num_pixels, 256), 1, 256, 1, args);
+}
+
+// fused / strip mode: render_data is indexed by pixel, rows [row_begin,row_end) are one contiguous range
+int gr_render_rows(gr_program* p, void* stream, const void* rdata, void* out, const void* bg1, const void* bg2, int bg_width,
+                   int bg_height, int bg_levels, int width, int height, int row_begin, int row_end, int max_probes,
+                   const void* cfg, const void* dfg) {
+    if (row_begin < 0 || row_end > height || row_begin > row_end) return fail(GR_ERROR_INVALID_ARGUMENT, "bad row range");
+    int first = row_begin * width;
+    int num = (row_end - row_begin) * width;
+    const void* rdata_count = p ? p->huge_count : nullptr;
+    void* args[] = {&rdata, &rdata_count, &out, &bg1, &bg2, &bg_width, &bg_height, &bg_levels, &width, &height,
+                    &max_probes, &cfg, &dfg, &first, &num};
+    return launch(p, K_RENDER, stream, blocks(num, 256), 1, 256, 1, args);
+}
+
+int gr_internal_fail(int code, const char* msg) { return fail((gr_status)code, msg ? msg : ""); }
+
+int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* term,
+                     int prepass_width, int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3,
+                     const void* cfg, const void* dfg) {
+    void* args[] = {&camera_generic, &camera_quat, &term, &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg};
+    return launch(p, K_PREPASS_FUSED, stream, blocks((long long)prepass_width * prepass_height, 64), 1, 64, 1, args);
+}
+
+int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
+                   int height, int row_begin, int row_end, const void* term, int prepass_width, int prepass_height,
+                   const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg,
+                   void* attempt_counter) {
+    if (row_begin < 0 || row_end > height || row_begin > row_end) return fail(GR_ERROR_INVALID_ARGUMENT, "bad row range");
+    const int T = 8;
+    long long tiles = (long long)((width + T - 1) / T) * ((row_end - row_begin + T - 1) / T);
+    void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &row_begin, &row_end, &term, &prepass_width,
+                    &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter};
+    return launch(p, K_TRACE_FUSED, stream, (unsigned)tiles, 1, 64, 1, args);
+}
+
+int gr_pack_mipped_background(const unsigned char* rgba, int width, int height, unsigned char* out) {
+    if (width <= 0 || height <= 0) return fail(GR_ERROR_INVALID_ARGUMENT, "bad size");
+    // graphics_settings.cpp:164-168
+    int levels = (int)std::floor(std::log2((double)std::min(width, height))) + 1;
+    if (levels > 10) levels = 10;
+    if (!out) return levels;
+    if (!rgba) return fail(GR_ERROR_INVALID_ARGUMENT, "null image");
+    std::vector<float> cur((size_t)width * height * 4);
+    for (size_t i = 0; i < cur.size(); i++) cur[i] = rgba[i] / 255.f;
+    int cw = width, ch = height;
+    for (int l = 0; l < levels; l++) {
+        if (l > 0) {
+            // 2x2 box filter (the reference takes the GL driver's mip chain)
+            int nw = std::max(cw / 2, 1), nh = std::max(ch / 2, 1);
+            std::vector<float> next((size_t)nw * nh * 4);
+            for (int y = 0; y < nh; y++)
+                for (int x = 0; x < nw; x++)
+                    for (int c = 0; c < 4; c++) {
+                        int x0 = std::min(2 * x, cw - 1), x1 = std::min(2 * x + 1, cw - 1);
+                        int y0 = std::min(2 * y, ch - 1), y1 = std::min(2 * y + 1, ch - 1);
+                        next[((size_t)y * nw + x) * 4 + c] =
+                            0.25f * (cur[((size_t)y0 * cw + x0) * 4 + c] + cur[((size_t)y0 * cw + x1) * 4 + c] +
+                                     cur[((size_t)y1 * cw + x0) * 4 + c] + cur[((size_t)y1 * cw + x1) * 4 + c]);
+                    }
+            cur.swap(next);
+            cw = nw;
+            ch = nh;
+        }
+        unsigned char* slice = out + (size_t)l * width * height * 4;
+        for (int y = 0; y < height; y++)
+            for (int x = 0; x < width; x++) {
+                int lx = std::min(x, cw - 1), ly = std::min(y, ch - 1);   // edge replicate
+                for (int c = 0; c < 4; c++) {
+                    float v = cur[((size_t)ly * cw + lx) * 4 + c];
+                    v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+                    slice[((size_t)y * width + x) * 4 + c] = (unsigned char)(v * 255);
+                }
+            }
+    }
+    return levels;
+}
+
+}  // extern "C"

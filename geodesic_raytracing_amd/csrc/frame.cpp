@@ -1,0 +1,373 @@
+// frame.cpp — per-frame device buffers and the frame enqueue sequence.
+//
+// Reference counterparts: render_state.hpp:97-197 (buffers), main.cpp:2244-2526 (the sequence of
+// launches on one in-order queue), execute_kernel main.cpp:139-205.  Everything is asynchronous on
+// the caller's stream; the only host->device traffic per frame is camera (48 B), cfg and features.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/geodesic_hip.h"
+
+extern "C" int gr_internal_fail(int code, const char* msg);   // capi.cpp
+
+#define HIP_CHECK(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return gr_internal_fail(GR_ERROR_DEVICE, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
+    } while (0)
+#define GR_CHECK(expr)            \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != GR_OK) return _rc; \
+    } while (0)
+
+struct gr_render_state {
+    int device = 0;
+    int width = 0, height = 0;
+    // small buffers (render_state.hpp:150-170)
+    void* camera_pos_cart = nullptr;
+    void* camera_quat = nullptr;
+    void* camera_pos_generic = nullptr;
+    void* tetrad[4] = {};
+    void* rays_count_in = nullptr;
+    void* rays_adaptive_count = nullptr;
+    void* render_data_count = nullptr;
+    void* cfg = nullptr;            // struct dynamic_config (floats in declaration order)
+    void* dfg = nullptr;            // struct dynamic_feature_config
+    void* attempts = nullptr;       // uint64
+    // per-pixel buffers (render_state.hpp:172-196); ray records are allocated on first use
+    void* rays_in = nullptr;
+    void* rays_adaptive = nullptr;
+    void* render_data = nullptr;
+    void* termination_buffer = nullptr;
+    size_t ray_capacity = 0;
+    hipEvent_t ev_start[GR_STAGE_COUNT] = {};
+    hipEvent_t ev_stop[GR_STAGE_COUNT] = {};
+    bool stage_timed[GR_STAGE_COUNT] = {};
+    std::vector<float> host_cfg;
+    gr_features host_features{};
+    bool features_valid = false;
+};
+
+static const int CFG_MAX = 64;
+
+extern "C" {
+
+void gr_camera_default(gr_camera* c) {
+    if (!c) return;
+    // camera::camera(), main.cpp:669-673: rot.load_from_axis_angle({1, 0, 0, -pi/2})
+    c->position[0] = 0; c->position[1] = 0; c->position[2] = -4; c->position[3] = 0;
+    float half = (float)(-M_PI / 2) / 2;
+    c->quat[0] = std::sin(half); c->quat[1] = 0; c->quat[2] = 0; c->quat[3] = std::cos(half);
+    c->basis_speed[0] = c->basis_speed[1] = c->basis_speed[2] = 0;
+    c->flip = 0;
+}
+
+void gr_frame_options_default(gr_frame_options* o) {
+    if (!o) return;
+    o->mode = GR_MODE_FUSED;
+    o->tiled = 1;
+    o->use_prepass = -1;
+    o->max_probes = 8;
+    o->row_begin = 0;
+    o->row_end = 0;
+    o->time_kernels = 0;
+    o->count_attempts = 0;
+}
+
+int gr_device_count(int* count) {
+    if (!count) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    HIP_CHECK(hipGetDeviceCount(count));
+    return GR_OK;
+}
+int gr_device_alloc(int device, size_t bytes, void** out) {
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipMalloc(out, bytes ? bytes : 1));
+    return GR_OK;
+}
+int gr_device_free(int device, void* ptr) {
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipFree(ptr));
+    return GR_OK;
+}
+int gr_device_download(int device, void* dst, const void* src, size_t bytes) {
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return GR_OK;
+}
+int gr_device_upload(int device, void* dst, const void* src, size_t bytes) {
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return GR_OK;
+}
+int gr_device_synchronize(int device) {
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipDeviceSynchronize());
+    return GR_OK;
+}
+
+int gr_render_state_create(int device, int width, int height, gr_render_state** out) {
+    if (!out || width <= 0 || height <= 0) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "bad render state size");
+    HIP_CHECK(hipSetDevice(device));
+    gr_render_state* s = new gr_render_state();
+    s->device = device;
+    s->width = width;
+    s->height = height;
+    auto alloc = [&](void** p, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
+        return e;
+    };
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = alloc(p, bytes); };
+    A(&s->camera_pos_cart, 16);
+    A(&s->camera_quat, 16);
+    A(&s->camera_pos_generic, 16);
+    for (auto& t : s->tetrad) A(&t, 16);
+    A(&s->rays_count_in, 4);
+    A(&s->rays_adaptive_count, 4);
+    A(&s->render_data_count, 4);
+    A(&s->cfg, CFG_MAX * sizeof(float));
+    A(&s->dfg, sizeof(gr_features));
+    A(&s->attempts, 8);
+    size_t px = (size_t)width * height;
+    A(&s->render_data, px * sizeof(gr_render_data));
+    A(&s->termination_buffer, px * sizeof(int));
+    for (int i = 0; i < GR_STAGE_COUNT && e == hipSuccess; i++) {
+        e = hipEventCreate(&s->ev_start[i]);
+        if (e == hipSuccess) e = hipEventCreate(&s->ev_stop[i]);
+    }
+    if (e != hipSuccess) {
+        gr_render_state_destroy(s);
+        return gr_internal_fail(GR_ERROR_DEVICE, (std::string("render state allocation: ") + hipGetErrorString(e)).c_str());
+    }
+    *out = s;
+    return GR_OK;
+}
+
+void gr_render_state_destroy(gr_render_state* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    void* ptrs[] = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
+                    s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
+                    s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < GR_STAGE_COUNT; i++) {
+        if (s->ev_start[i]) (void)hipEventDestroy(s->ev_start[i]);
+        if (s->ev_stop[i]) (void)hipEventDestroy(s->ev_stop[i]);
+    }
+    delete s;
+}
+
+void* gr_render_state_buffer(gr_render_state* s, int which) {
+    if (!s) return nullptr;
+    switch (which) {
+        case GR_BUF_RAYS_IN: return s->rays_in;
+        case GR_BUF_RAYS_COUNT: return s->rays_count_in;
+        case GR_BUF_RENDER_DATA: return s->render_data;
+        case GR_BUF_TERMINATION: return s->termination_buffer;
+        case GR_BUF_CAMERA_GENERIC: return s->camera_pos_generic;
+        case GR_BUF_TETRAD0: return s->tetrad[0];
+        case GR_BUF_TETRAD1: return s->tetrad[1];
+        case GR_BUF_TETRAD2: return s->tetrad[2];
+        case GR_BUF_TETRAD3: return s->tetrad[3];
+        case GR_BUF_RAYS_ADAPTIVE: return s->rays_adaptive;
+        case GR_BUF_RAYS_ADAPTIVE_COUNT: return s->rays_adaptive_count;
+        case GR_BUF_CFG: return s->cfg;
+        case GR_BUF_DFG: return s->dfg;
+        case GR_BUF_CAMERA_QUAT: return s->camera_quat;
+    }
+    return nullptr;
+}
+
+int gr_render_state_stage_ms(gr_render_state* s, int stage, float* ms) {
+    if (!s || !ms || stage < 0 || stage >= GR_STAGE_COUNT) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "bad stage");
+    *ms = 0;
+    if (!s->stage_timed[stage]) return GR_OK;
+    HIP_CHECK(hipEventSynchronize(s->ev_stop[stage]));
+    HIP_CHECK(hipEventElapsedTime(ms, s->ev_start[stage], s->ev_stop[stage]));
+    return GR_OK;
+}
+
+int gr_render_state_attempts(gr_render_state* s, unsigned long long* attempts) {
+    if (!s || !attempts) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    HIP_CHECK(hipSetDevice(s->device));
+    HIP_CHECK(hipMemcpy(attempts, s->attempts, 8, hipMemcpyDeviceToHost));
+    return GR_OK;
+}
+
+static int ensure_rays(gr_render_state* s, size_t slots, bool adaptive) {
+    if (s->ray_capacity < slots) {
+        if (s->rays_in) (void)hipFree(s->rays_in);
+        if (s->rays_adaptive) (void)hipFree(s->rays_adaptive);
+        s->rays_in = s->rays_adaptive = nullptr;
+        s->ray_capacity = 0;
+        HIP_CHECK(hipMalloc(&s->rays_in, slots * sizeof(gr_lightray)));
+        s->ray_capacity = slots;
+    }
+    if (adaptive && !s->rays_adaptive) HIP_CHECK(hipMalloc(&s->rays_adaptive, s->ray_capacity * sizeof(gr_lightray)));
+    return GR_OK;
+}
+
+int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void* stream_v, const gr_camera* camera,
+                    const gr_features* features_in, const float* cfg_values, int num_cfg_values, const void* bg1,
+                    const void* bg2, int bg_width, int bg_height, int bg_levels, void* out, const gr_frame_options* opt_in) {
+    if (!s || !p || !m || !camera) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_CHECK(hipSetDevice(s->device));
+    gr_frame_options opt;
+    gr_frame_options_default(&opt);
+    if (opt_in) opt = *opt_in;
+    gr_metric_info info;
+    GR_CHECK(gr_metric_get_info(m, &info));
+
+    gr_features features;
+    gr_features_default(&features);
+    if (features_in) features = *features_in;
+    else features.max_acceleration_change = info.max_acceleration_change;   // metric_manager.hpp:50
+
+    const int width = s->width, height = s->height;
+    bool use_prepass = opt.use_prepass < 0 ? info.use_prepass != 0 : opt.use_prepass != 0;
+    bool adaptive = features.adaptive_sampling != 0 && !features.use_triangle_rendering;
+
+    // dynamic_config: $cfg values in declaration order (metric_manager.hpp:60-66)
+    std::vector<float> cfg(info.num_dynamic_vars > 0 ? info.num_dynamic_vars : 1, 0.f);
+    for (int i = 0; i < info.num_dynamic_vars; i++)
+        cfg[i] = (cfg_values && i < num_cfg_values) ? cfg_values[i] : gr_metric_dynamic_var_default(m, i);
+    if ((int)cfg.size() > CFG_MAX) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "too many dynamic variables");
+    if (cfg != s->host_cfg) {
+        HIP_CHECK(hipMemcpyAsync(s->cfg, cfg.data(), cfg.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        s->host_cfg = cfg;
+    }
+    if (!s->features_valid || memcmp(&features, &s->host_features, sizeof(features)) != 0) {
+        HIP_CHECK(hipMemcpyAsync(s->dfg, &features, sizeof(features), hipMemcpyHostToDevice, stream));
+        s->host_features = features;
+        s->features_valid = true;
+    }
+    HIP_CHECK(hipMemcpyAsync(s->camera_pos_cart, camera->position, 16, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(s->camera_quat, camera->quat, 16, hipMemcpyHostToDevice, stream));
+
+    for (int i = 0; i < GR_STAGE_COUNT; i++) s->stage_timed[i] = false;
+    auto begin = [&](int st) -> int {
+        if (opt.time_kernels) { HIP_CHECK(hipEventRecord(s->ev_start[st], stream)); }
+        return GR_OK;
+    };
+    auto end = [&](int st) -> int {
+        if (opt.time_kernels) { HIP_CHECK(hipEventRecord(s->ev_stop[st], stream)); s->stage_timed[st] = true; }
+        return GR_OK;
+    };
+    void* attempts = nullptr;
+    if (opt.count_attempts) {
+        HIP_CHECK(hipMemsetAsync(s->attempts, 0, 8, stream));
+        attempts = s->attempts;
+    }
+
+    // camera position and tetrad (main.cpp:2311, 2329)
+    GR_CHECK(begin(GR_STAGE_CAMERA));
+    GR_CHECK(gr_cart_to_generic(p, stream, s->camera_pos_cart, s->camera_pos_generic, 1, camera->flip, s->cfg));
+    GR_CHECK(gr_init_basis_vectors(p, stream, s->camera_pos_generic, 1, camera->basis_speed, s->tetrad[0], s->tetrad[1],
+                                   s->tetrad[2], s->tetrad[3], s->cfg));
+    GR_CHECK(end(GR_STAGE_CAMERA));
+
+    int prepass_width = width / 16, prepass_height = height / 16;   // main.cpp:2380-2381
+    if (prepass_width < 1 || prepass_height < 1) use_prepass = false;
+
+    if (opt.mode == GR_MODE_FUSED) {
+        if (adaptive) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused mode traces every pixel: turn adaptive_sampling off");
+        int row_begin = opt.row_begin, row_end = opt.row_end;
+        if (row_begin == 0 && row_end == 0) row_end = height;
+        if (use_prepass) {
+            GR_CHECK(begin(GR_STAGE_PREPASS));
+            GR_CHECK(gr_prepass_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->termination_buffer, prepass_width,
+                                      prepass_height, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg));
+            GR_CHECK(end(GR_STAGE_PREPASS));
+        }
+        // the texture filter reads the right/below neighbour (cl.cl:5509-5520): trace one halo row
+        int trace_end = row_end < height ? row_end + 1 : row_end;
+        int trace_begin = row_begin;
+        if (row_end == height && row_begin == height - 1 && row_begin > 0) trace_begin = row_begin - 1;   // last row looks up
+        GR_CHECK(begin(GR_STAGE_TRACE));
+        GR_CHECK(gr_trace_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, trace_begin,
+                                trace_end, use_prepass ? s->termination_buffer : nullptr,
+                                use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
+                                s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
+        GR_CHECK(end(GR_STAGE_TRACE));
+        if (out) {
+            // shade rows [row_begin,row_end): render_data is indexed by pixel, so a row range is a contiguous slice
+            int count_host = width * height;
+            HIP_CHECK(hipMemcpyAsync(s->render_data_count, &count_host, 4, hipMemcpyHostToDevice, stream));
+            GR_CHECK(begin(GR_STAGE_RENDER));
+            GR_CHECK(gr_render_rows(p, stream, s->render_data, out, bg1, bg2, bg_width, bg_height, bg_levels, width, height,
+                                    row_begin, row_end, opt.max_probes, s->cfg, s->dfg));
+            GR_CHECK(end(GR_STAGE_RENDER));
+        }
+        return GR_OK;
+    }
+
+    // ---- reference-shaped sequence --------------------------------------------------------------------
+    int tiled = (opt.tiled && !adaptive) ? 1 : 0;
+    size_t slots = tiled ? (size_t)gr_tiled_slot_count(width, height) : (size_t)width * height;
+    GR_CHECK(ensure_rays(s, slots, adaptive));
+
+    if (use_prepass) {
+        GR_CHECK(begin(GR_STAGE_PREPASS));
+        GR_CHECK(gr_clear_termination_buffer(p, stream, s->termination_buffer, prepass_width, prepass_height));
+        HIP_CHECK(hipMemsetAsync(s->rays_count_in, 0, 4, stream));
+        GR_CHECK(gr_init_rays_generic(p, stream, s->camera_pos_generic, s->camera_quat, s->rays_in, s->rays_count_in,
+                                      prepass_width, prepass_height, s->termination_buffer, prepass_width, prepass_height, 0,
+                                      s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, 1, 0));
+        GR_CHECK(gr_do_generic_rays(p, stream, s->rays_in, s->rays_count_in, prepass_width * prepass_height, nullptr, nullptr,
+                                    s->cfg, s->dfg, width, height, 0, 0, nullptr, nullptr, 0, nullptr));
+        GR_CHECK(gr_calculate_singularities(p, stream, s->rays_in, s->rays_count_in, prepass_width * prepass_height,
+                                            s->termination_buffer, prepass_width, prepass_height));
+        GR_CHECK(end(GR_STAGE_PREPASS));
+    }
+    int pw = use_prepass ? prepass_width : width, ph = use_prepass ? prepass_height : height;
+
+    GR_CHECK(begin(GR_STAGE_INIT));
+    GR_CHECK(gr_init_rays_generic(p, stream, s->camera_pos_generic, s->camera_quat, s->rays_in, s->rays_count_in, width, height,
+                                  s->termination_buffer, pw, ph, 0, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3],
+                                  s->cfg, s->dfg, 0, tiled));
+    GR_CHECK(end(GR_STAGE_INIT));
+
+    GR_CHECK(begin(GR_STAGE_TRACE));
+    GR_CHECK(gr_do_generic_rays(p, stream, s->rays_in, s->rays_count_in, (int)slots, nullptr, nullptr, s->cfg, s->dfg, width,
+                                height, 0, 0, nullptr, nullptr, 0, attempts));
+    GR_CHECK(end(GR_STAGE_TRACE));
+
+    HIP_CHECK(hipMemsetAsync(s->render_data_count, 0, 4, stream));
+    GR_CHECK(begin(GR_STAGE_RENDER_DATA));
+    GR_CHECK(gr_calculate_render_data(p, stream, s->rays_in, s->rays_count_in, (int)slots, s->render_data, s->render_data_count,
+                                      width, height, s->cfg, s->dfg));
+    GR_CHECK(end(GR_STAGE_RENDER_DATA));
+
+    if (adaptive) {
+        GR_CHECK(begin(GR_STAGE_ADAPTIVE));
+        HIP_CHECK(hipMemsetAsync(s->rays_adaptive_count, 0, 4, stream));
+        GR_CHECK(gr_handle_adaptive_sampling(p, stream, s->rays_in, s->rays_count_in, s->render_data, s->render_data_count,
+                                             s->rays_adaptive, s->rays_adaptive_count, s->camera_pos_generic, s->camera_quat,
+                                             s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], width, height, s->cfg,
+                                             s->dfg));
+        GR_CHECK(gr_do_generic_rays(p, stream, s->rays_adaptive, s->rays_adaptive_count, width * height, nullptr, nullptr, s->cfg,
+                                    s->dfg, width, height, 0, 0, nullptr, nullptr, 0, attempts));
+        GR_CHECK(gr_calculate_render_data(p, stream, s->rays_adaptive, s->rays_adaptive_count, width * height, s->render_data,
+                                          s->render_data_count, width, height, s->cfg, s->dfg));
+        GR_CHECK(end(GR_STAGE_ADAPTIVE));
+    }
+
+    if (out) {
+        GR_CHECK(begin(GR_STAGE_RENDER));
+        GR_CHECK(gr_render(p, stream, s->render_data, s->render_data_count, width * height, out, bg1, bg2, bg_width, bg_height,
+                           bg_levels, width, height, opt.max_probes, s->cfg, s->dfg));
+        GR_CHECK(end(GR_STAGE_RENDER));
+    }
+    return GR_OK;
+}
+
+}  // extern "C"

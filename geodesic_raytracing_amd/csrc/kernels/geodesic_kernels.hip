@@ -1,0 +1,1325 @@
+// geodesic_kernels.hip — gfx950 (CDNA4, wave64) kernels of the per-pixel geodesic ray pipeline.
+//
+// This translation unit is compiled at run time (hiprtc, --offload-arch=gfx950) once per metric,
+// specialised by the same `-D` macro set the reference feeds to its OpenCL program
+// (producer metric.hpp:725-959, consumer cl.cl): F*_I, F*_P, TO_/FROM_(D)COORDn, GEO_ACCELn,
+// TEMPORARIES0, DISTANCE_FUNC, W_Vn, DYNVARS, feature macros, behaviour flags.
+//
+// Kernel <-> reference map (semantics, argument order):
+//   gr_cart_to_generic          cart_to_generic_kernel    cl.cl:6018-6034
+//   gr_init_basis_vectors       init_basis_vectors        cl.cl:2483-2507 (calculate_tetrads 2288-2439)
+//   gr_clear_termination_buffer clear_termination_buffer  cl.cl:4997-5006
+//   gr_init_rays_generic        init_rays_generic         cl.cl:3143-3251
+//   gr_do_generic_rays          do_generic_rays           cl.cl:3954-4247 (step_verlet 3273-3346,
+//                                                         calculate_ds_error 3431-3456)
+//   gr_calculate_singularities  calculate_singularities   cl.cl:5008-5020
+//   gr_calculate_render_data    calculate_render_data     cl.cl:5135-5213
+//   gr_handle_adaptive_sampling handle_adaptive_sampling  cl.cl:5223-5345
+//   gr_render                   render                    cl.cl:5453-5846 (read_mipmap 5421-5449)
+//   gr_trace_fused              (no counterpart) init -> integrate -> render-data in one launch,
+//                               ray state never leaves registers
+//
+// MI355X design notes
+//   * one ray per lane, one wave64 per 64 consecutive ray slots; ray slots are laid out in 8x8
+//     pixel tiles (GR_TILE) so a wave integrates an angularly compact bundle: step counts inside
+//     a wave stay close and the lock-step loop wastes few lanes;
+//   * the integrator state (position, velocity, acceleration, step, flags = 16 VGPRs) and every
+//     metric temporary live in registers; cfg / feature values are wave-uniform kernel-argument
+//     loads (SGPRs);
+//   * accept / reject of an adaptive step is a per-lane select - both outcomes ran the same
+//     step_verlet, so rejection costs no divergence; a wave leaves the loop on a ballot of
+//     finished lanes;
+//   * no MFMA: the work is a 4x4 per-ray ODE, bound by fp32 VALU issue, not by HBM or matrix rate.
+//
+// No double-precision arithmetic on the hot path; the few double expressions of the reference's
+// texture-space code (M_PI literals, cl.cl:3598-3610, 5272) are mirrored where they change results.
+
+#define GR_PI 3.14159265358979323846
+#define GR_PIf 3.14159274101257324f
+
+struct lightray {
+    float4 position;
+    float4 velocity;
+    float4 initial_quat;
+    float4 acceleration;
+    float ku_uobsu;
+    float running_dlambda_dnew;
+    int terminated;
+    int sx;
+    int sy;
+};   // 96 bytes (render_state.hpp:8-19)
+
+struct render_data {
+    float2 tex_coord;
+    float z_shift;
+    int sx;
+    int sy;
+    int terminated;
+    int side;
+};   // 32 bytes (render_state.hpp:21-29)
+
+struct dynamic_config {
+#ifdef DYNVARS
+    float DYNVARS;
+#else
+    float gr_unused;
+#endif
+};
+
+struct dynamic_feature_config {
+#ifdef DYNAMIC_FLOAT_FEATURES
+    float DYNAMIC_FLOAT_FEATURES;
+#endif
+#ifdef DYNAMIC_BOOL_FEATURES
+    int DYNAMIC_BOOL_FEATURES;
+#endif
+#if !defined(DYNAMIC_FLOAT_FEATURES) && !defined(DYNAMIC_BOOL_FEATURES)
+    int gr_unused;
+#endif
+};
+
+#ifdef KERNEL_IS_STATIC
+#define GET_FEATURE(name, dfg) FEATURE_##name
+#else
+#define GET_FEATURE(name, dfg) ((dfg)->name)
+#endif
+
+#if defined(GENERIC_CONSTANT_THETA)
+#define IS_CONSTANT_THETA
+#endif
+
+#ifndef GR_TILE
+#define GR_TILE 8
+#endif
+
+typedef const dynamic_config* __restrict__ cfg_t;
+typedef const dynamic_feature_config* __restrict__ dfg_t;
+
+// ------------------------------------------------------------------------------------------------
+// math used by the generated expressions.  Everything generated is evaluated inside namespace gm,
+// so unqualified sin/cos/... bind to these fp32 versions.
+namespace gm {
+
+#ifdef GR_FAST_TRIG
+__device__ __forceinline__ float sin(float x) { return __sinf(x); }
+__device__ __forceinline__ float cos(float x) { return __cosf(x); }
+#else
+__device__ __forceinline__ float sin(float x) { return ::sinf(x); }
+__device__ __forceinline__ float cos(float x) { return ::cosf(x); }
+#endif
+__device__ __forceinline__ float tan(float x) { return ::tanf(x); }
+__device__ __forceinline__ float asin(float x) { return ::asinf(x); }
+__device__ __forceinline__ float acos(float x) { return ::acosf(x); }
+__device__ __forceinline__ float atan(float x) { return ::atanf(x); }
+__device__ __forceinline__ float atan2(float y, float x) { return ::atan2f(y, x); }
+__device__ __forceinline__ float exp(float x) { return ::expf(x); }
+__device__ __forceinline__ float log(float x) { return ::logf(x); }
+__device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float fabs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ float sinh(float x) { return ::sinhf(x); }
+__device__ __forceinline__ float cosh(float x) { return ::coshf(x); }
+__device__ __forceinline__ float tanh(float x) { return ::tanhf(x); }
+__device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
+__device__ __forceinline__ float fmod(float x, float y) { return ::fmodf(x, y); }
+__device__ __forceinline__ float fmin(float x, float y) { return __builtin_fminf(x, y); }
+__device__ __forceinline__ float fmax(float x, float y) { return __builtin_fmaxf(x, y); }
+__device__ __forceinline__ float sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// --- generated-expression hosts (cl.cl:969-1355, 3377-3387) ---------------------------------------
+
+#define GR_POSITION_VARS(p) \
+    const float v1 = (p).x; const float v2 = (p).y; const float v3 = (p).z; const float v4 = (p).w; \
+    const float rs = RS_IMPL; const float c = C_IMPL; (void)v1; (void)v2; (void)v3; (void)v4; (void)rs; (void)c;
+
+// g_metric_out has 4 (diagonal) or 16 entries
+__device__ __forceinline__ void metric_at(float4 pos, float* g, cfg_t cfg) {
+    GR_POSITION_VARS(pos)
+    float TEMPORARIES0;
+#ifndef GENERIC_BIG_METRIC
+    g[0] = F1_I; g[1] = F2_I; g[2] = F3_I; g[3] = F4_I;
+#else
+    g[0] = F1_I; g[1] = F2_I; g[2] = F3_I; g[3] = F4_I;
+    g[4] = g[1]; g[5] = F6_I; g[6] = F7_I; g[7] = F8_I;
+    g[8] = g[2]; g[9] = g[6]; g[10] = F11_I; g[11] = F12_I;
+    g[12] = g[3]; g[13] = g[7]; g[14] = g[11]; g[15] = F16_I;
+#endif
+}
+
+// always the full symmetric 4x4
+__device__ __forceinline__ void metric_big_at(float4 pos, float* g, cfg_t cfg) {
+#ifndef GENERIC_BIG_METRIC
+    float d[4];
+    metric_at(pos, d, cfg);
+    for (int i = 0; i < 16; i++) g[i] = 0.f;
+    g[0] = d[0]; g[5] = d[1]; g[10] = d[2]; g[15] = d[3];
+#else
+    metric_at(pos, g, cfg);
+#endif
+}
+
+// closed-form geodesic acceleration (GEO_ACCELn; step_verlet cl.cl:3279-3309)
+__device__ __forceinline__ float4 geodesic_acceleration(float4 pos, float4 vel, cfg_t cfg) {
+#ifdef GENERIC_CONSTANT_THETA
+    pos.z = GR_PIf / 2;
+    vel.z = 0.f;
+#endif
+    GR_POSITION_VARS(pos)
+    const float iv1 = vel.x; const float iv2 = vel.y; const float iv3 = vel.z; const float iv4 = vel.w;
+    (void)iv1; (void)iv2; (void)iv3; (void)iv4;
+    float TEMPORARIES0;
+    float4 a;
+    a.x = GEO_ACCEL0;
+    a.y = GEO_ACCEL1;
+#ifndef GENERIC_CONSTANT_THETA
+    a.z = GEO_ACCEL2;
+#else
+    a.z = 0.f;
+#endif
+    a.w = GEO_ACCEL3;
+    return a;
+}
+
+__device__ __forceinline__ float4 generic_to_spherical(float4 in, cfg_t cfg) {
+    GR_POSITION_VARS(in)
+    return make_float4(TO_COORD1, TO_COORD2, TO_COORD3, TO_COORD4);
+}
+
+__device__ __forceinline__ float4 generic_velocity_to_spherical_velocity(float4 in, float4 inv, cfg_t cfg) {
+    GR_POSITION_VARS(in)
+    const float dv1 = inv.x; const float dv2 = inv.y; const float dv3 = inv.z; const float dv4 = inv.w;
+    (void)dv1; (void)dv2; (void)dv3; (void)dv4;
+    return make_float4(TO_DCOORD1, TO_DCOORD2, TO_DCOORD3, TO_DCOORD4);
+}
+
+__device__ __forceinline__ float4 spherical_to_generic(float4 in, cfg_t cfg) {
+    GR_POSITION_VARS(in)
+    return make_float4(FROM_COORD1, FROM_COORD2, FROM_COORD3, FROM_COORD4);
+}
+
+__device__ __forceinline__ float4 spherical_velocity_to_generic_velocity(float4 in, float4 inv, cfg_t cfg) {
+    GR_POSITION_VARS(in)
+    const float dv1 = inv.x; const float dv2 = inv.y; const float dv3 = inv.z; const float dv4 = inv.w;
+    (void)dv1; (void)dv2; (void)dv3; (void)dv4;
+    return make_float4(FROM_DCOORD1, FROM_DCOORD2, FROM_DCOORD3, FROM_DCOORD4);
+}
+
+__device__ __forceinline__ float distance_to_object(float4 polar, cfg_t cfg) {
+    GR_POSITION_VARS(polar)
+    return DISTANCE_FUNC;
+}
+
+}  // namespace gm
+
+// ------------------------------------------------------------------------------------------------
+// small vector helpers
+
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float4 f4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+__device__ __forceinline__ float3 yzw(float4 v) { return make_float3(v.y, v.z, v.w); }
+__device__ __forceinline__ float4 f4(float x, float3 v) { return make_float4(x, v.x, v.y, v.z); }
+__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 operator-(float3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float3 operator*(float s, float3 a) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float3 operator/(float3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return f4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return f4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator-(float4 a) { return f4(-a.x, -a.y, -a.z, -a.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float s) { return f4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return f4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 operator/(float4 a, float s) { return f4(a.x / s, a.y / s, a.z / s, a.w / s); }
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float length3(float3 a) { return __builtin_sqrtf(dot3(a, a)); }
+__device__ __forceinline__ float3 normalize3(float3 a) { return a / length3(a); }
+__device__ __forceinline__ float4 normalize4(float4 a) { return a / __builtin_sqrtf(dot4(a, a)); }
+__device__ __forceinline__ float fsign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(v, lo), hi); }
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ bool degenerate(float x) { return !(__builtin_fabsf(x) <= 3.402823466e+38f); }   // NaN or Inf
+__device__ __forceinline__ bool degenerate4(float4 v) { return degenerate(v.x) || degenerate(v.y) || degenerate(v.z) || degenerate(v.w); }
+__device__ __forceinline__ float get4(float4 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ void swap4(float4& a, float4& b) { float4 t = a; a = b; b = t; }
+
+// cl.cl:103-140, 185-204
+__device__ __forceinline__ float3 cartesian_to_polar(float3 in) {
+    float r = length3(in);
+    return f3(r, acosf(in.z / r), atan2f(in.y, in.x));
+}
+
+__device__ __forceinline__ float3 polar_to_cartesian(float3 in) {
+    float st = sinf(in.y), ct = cosf(in.y), sp = sinf(in.z), cp = cosf(in.z);
+    return f3(in.x * st * cp, in.x * st * sp, in.x * ct);
+}
+
+__device__ __forceinline__ float3 cartesian_velocity_to_polar_velocity(float3 p, float3 v) {
+    float r = length3(p);
+    float repeated_eq = r * __builtin_sqrtf(1 - (p.z * p.z / (r * r)));
+    float rdot = (p.x * v.x + p.y * v.y + p.z * v.z) / r;
+    float tdot = ((p.z * rdot) / (r * repeated_eq)) - v.z / repeated_eq;
+    float pdot = (p.x * v.y - p.y * v.x) / (p.x * p.x + p.y * p.y);
+    return f3(rdot, tdot, pdot);
+}
+
+__device__ __forceinline__ float3 spherical_velocity_to_cartesian_velocity(float3 p, float3 dp) {
+    float r = p.x, dr = dp.x, x = p.y, dx = dp.y, y = p.z, dy = dp.z;
+    float sx = sinf(x), cx = cosf(x), sy = sinf(y), cy = cosf(y);
+    float v1 = -r * sx * sy * dy + r * cx * cy * dx + sx * cy * dr;
+    float v2 = sx * sy * dr + r * sx * cy * dy + r * cx * sy * dx;
+    float v3 = cx * dr - r * sx * dx;
+    return f3(v1, v2, v3);
+}
+
+// cl.cl:176-191
+__device__ __forceinline__ float3 rot_quat_norm(float3 point, float4 q) {
+    float3 qv = f3(q.x, q.y, q.z);
+    float3 t = 2.f * cross3(qv, point);
+    return point + q.w * t + cross3(qv, t);
+}
+__device__ __forceinline__ float3 rot_quat(float3 point, float4 q) { return rot_quat_norm(point, normalize4(q)); }
+
+// ------------------------------------------------------------------------------------------------
+// metric algebra on the full 4x4 (cl.cl:830-907)
+
+__device__ __forceinline__ float4 lower_index_big(float4 v, const float* g) {
+    return f4(g[0] * v.x + g[1] * v.y + g[2] * v.z + g[3] * v.w,
+              g[4] * v.x + g[5] * v.y + g[6] * v.z + g[7] * v.w,
+              g[8] * v.x + g[9] * v.y + g[10] * v.z + g[11] * v.w,
+              g[12] * v.x + g[13] * v.y + g[14] * v.z + g[15] * v.w);
+}
+__device__ __forceinline__ float dot_big(float4 u, float4 v, const float* g) { return dot4(lower_index_big(u, g), v); }
+
+// general 4x4 inverse by cofactors (role of matrix_inverse, cl.cl:560-683)
+__device__ void matrix_inverse4(const float* m, float* out) {
+    float s0 = m[0] * m[5] - m[4] * m[1];
+    float s1 = m[0] * m[6] - m[4] * m[2];
+    float s2 = m[0] * m[7] - m[4] * m[3];
+    float s3 = m[1] * m[6] - m[5] * m[2];
+    float s4 = m[1] * m[7] - m[5] * m[3];
+    float s5 = m[2] * m[7] - m[6] * m[3];
+    float c5 = m[10] * m[15] - m[14] * m[11];
+    float c4 = m[9] * m[15] - m[13] * m[11];
+    float c3 = m[9] * m[14] - m[13] * m[10];
+    float c2 = m[8] * m[15] - m[12] * m[11];
+    float c1 = m[8] * m[14] - m[12] * m[10];
+    float c0 = m[8] * m[13] - m[12] * m[9];
+    float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    float id = 1.0f / det;
+    out[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
+    out[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+    out[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
+    out[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
+    out[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
+    out[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+    out[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
+    out[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
+    out[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
+    out[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+    out[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
+    out[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
+    out[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
+    out[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
+    out[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
+    out[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tetrads (cl.cl:1647-1861, 2072-2114, 2210-2224, 2288-2439)
+
+struct tetrad {
+    float4 e[4];
+};
+
+__device__ __forceinline__ float4 gram_project(float4 u, float4 v, const float* g) {
+    return (dot_big(u, v, g) / dot_big(u, u, g)) * u;
+}
+
+__device__ __forceinline__ float4 normalise_metric(float4 v, const float* g) {
+    return v / __builtin_sqrtf(__builtin_fabsf(dot_big(v, v, g)));
+}
+
+// returns the timelike slot found; fills `out` (cl.cl:1761-1850)
+__device__ int frame_basis_with_swap(const float* g, int index_swap, tetrad& out) {
+    float4 arr[4] = {f4(1, 0, 0, 0), f4(0, 1, 0, 0), f4(0, 0, 1, 0), f4(0, 0, 0, 1)};
+    float lengths[4] = {g[0], g[5], g[10], g[15]};
+    {
+        float4 t = arr[0]; arr[0] = arr[index_swap]; arr[index_swap] = t;
+        float l = lengths[0]; lengths[0] = lengths[index_swap]; lengths[index_swap] = l;
+    }
+    int indices[4] = {0, 1, 2, 3};
+    int first_nonzero = -1;
+    const float eps = 0.00001f;
+    for (int i = 0; i < 4; i++) {
+        if (!(__builtin_fabsf(lengths[i]) <= eps)) { first_nonzero = i; break; }
+    }
+    if (first_nonzero == -1) first_nonzero = 0;
+    if (first_nonzero != 0) {
+        float4 t = arr[0]; arr[0] = arr[first_nonzero]; arr[first_nonzero] = t;
+        int q = indices[0]; indices[0] = indices[first_nonzero]; indices[first_nonzero] = q;
+    }
+    // Gram-Schmidt in the metric (cl.cl:1647-1675)
+    float4 u1 = arr[0];
+    float4 u2 = arr[1];
+    u2 = u2 - gram_project(u1, u2, g);
+    float4 u3 = arr[2];
+    u3 = u3 - gram_project(u1, u3, g);
+    u3 = u3 - gram_project(u2, u3, g);
+    float4 u4 = arr[3];
+    u4 = u4 - gram_project(u1, u4, g);
+    u4 = u4 - gram_project(u2, u4, g);
+    u4 = u4 - gram_project(u3, u4, g);
+    float4 res[4] = {normalise_metric(u1, g), normalise_metric(u2, g), normalise_metric(u3, g), normalise_metric(u4, g)};
+    float4 sorted[4];
+    for (int i = 0; i < 4; i++) {
+        int old_index = indices[i];
+        for (int k = 0; k < 4; k++)
+            if (k == old_index) sorted[k] = res[i];
+    }
+    // which leg is timelike: most negative e_a.e_a (cl.cl:1713-1758)
+    int lowest = -1;
+    float lowest_value = 0;
+    for (int i = 0; i < 4; i++) {
+        float d = 0;
+        for (int k = 0; k < 4; k++)
+            if (k == i) d = dot_big(sorted[k], sorted[k], g);
+        if (d < lowest_value) { lowest = i; lowest_value = d; }
+    }
+    int which = lowest != -1 ? lowest : 0;
+    if (which > 0) {
+        for (int k = 1; k < 4; k++)
+            if (k == which) swap4(sorted[0], sorted[k]);
+    }
+    for (int i = 0; i < 4; i++) out.e[i] = sorted[i];
+    return which;
+}
+
+__device__ void frame_basis(const float* g, tetrad& out) {
+    int t = frame_basis_with_swap(g, 0, out);
+    if (t == 0) return;
+    frame_basis_with_swap(g, t, out);
+}
+
+// 3-d Gram-Schmidt (cl.cl:1549-1566)
+__device__ __forceinline__ float3 project3(float3 u, float3 v) { return (dot3(u, v) / dot3(u, u)) * u; }
+
+__device__ void calculate_tetrads(float4 at_metric, float3 basis_speed, tetrad& out, cfg_t cfg, int should_orient) {
+    float4 polar_camera = gm::generic_to_spherical(at_metric, cfg);
+    if (degenerate4(at_metric)) {
+        out.e[0] = f4(1, 0, 0, 0); out.e[1] = f4(0, 1, 0, 0); out.e[2] = f4(0, 0, 1, 0); out.e[3] = f4(0, 0, 0, 1);
+        return;
+    }
+    float g[16];
+    gm::metric_big_at(at_metric, g, cfg);
+    tetrad t;
+    frame_basis(g, t);
+    float4 e0 = t.e[0], e1 = t.e[1], e2 = t.e[2], e3 = t.e[3];
+
+    if (should_orient) {
+        // align the spatial legs with the global cartesian axes, y first (cl.cl:2329-2412)
+        float3 apolar = yzw(polar_camera);
+        apolar.x = __builtin_fabsf(apolar.x);
+        float3 cart_camera = polar_to_cartesian(apolar);
+
+        float m[16] = {e0.x, e1.x, e2.x, e3.x, e0.y, e1.y, e2.y, e3.y, e0.z, e1.z, e2.z, e3.z, e0.w, e1.w, e2.w, e3.w};
+        float inv[16];
+        matrix_inverse4(m, inv);
+        float4 lo0 = f4(inv[0], inv[1], inv[2], inv[3]);
+        float4 lo1 = f4(inv[4], inv[5], inv[6], inv[7]);
+        float4 lo2 = f4(inv[8], inv[9], inv[10], inv[11]);
+        float4 lo3 = f4(inv[12], inv[13], inv[14], inv[15]);
+
+        float3 sx = cartesian_velocity_to_polar_velocity(cart_camera, f3(1, 0, 0));
+        float3 sy = cartesian_velocity_to_polar_velocity(cart_camera, f3(0, 1, 0));
+        float3 sz = cartesian_velocity_to_polar_velocity(cart_camera, f3(0, 0, 1));
+        if (polar_camera.y < 0) { sx.x = -sx.x; sy.x = -sy.x; sz.x = -sz.x; }
+
+        float4 gx = gm::spherical_velocity_to_generic_velocity(polar_camera, f4(0, sx), cfg);
+        float4 gy = gm::spherical_velocity_to_generic_velocity(polar_camera, f4(0, sy), cfg);
+        float4 gz = gm::spherical_velocity_to_generic_velocity(polar_camera, f4(0, sz), cfg);
+
+        // coordinate -> tetrad components; order y, x, z
+        float4 tE1 = f4(dot4(lo0, gy), dot4(lo1, gy), dot4(lo2, gy), dot4(lo3, gy));
+        float4 tE2 = f4(dot4(lo0, gx), dot4(lo1, gx), dot4(lo2, gx), dot4(lo3, gx));
+        float4 tE3 = f4(dot4(lo0, gz), dot4(lo1, gz), dot4(lo2, gz), dot4(lo3, gz));
+
+        float3 u1 = yzw(tE1), u2 = yzw(tE2), u3 = yzw(tE3);
+        u2 = u2 - project3(u1, u2);
+        u3 = u3 - project3(u1, u3);
+        u3 = u3 - project3(u2, u3);
+        u1 = normalize3(u1); u2 = normalize3(u2); u3 = normalize3(u3);
+
+        // x_basis = second, y_basis = first, z_basis = third; back to coordinates with the original legs
+        float4 x_out = u2.x * e1 + u2.y * e2 + u2.z * e3;
+        float4 y_out = u1.x * e1 + u1.y * e2 + u1.z * e3;
+        float4 z_out = u3.x * e1 + u3.y * e2 + u3.z * e3;
+        e1 = x_out; e2 = y_out; e3 = z_out;
+    }
+
+    {
+        // boost into the observer's frame (cl.cl:2414-2433, 1919-1972, 2210-2224)
+        float v2 = dot3(basis_speed, basis_speed);
+        float Y = 1 / __builtin_sqrtf(1 - v2);
+        float4 observer_velocity = Y * e0 + (Y * basis_speed.x) * e1 + (Y * basis_speed.y) * e2 + (Y * basis_speed.z) * e3;
+
+        float4 lT4 = lower_index_big(e0, g);
+        float4 lu4 = lower_index_big(observer_velocity, g);
+        float T[4] = {e0.x, e0.y, e0.z, e0.w};
+        float lT[4] = {lT4.x, lT4.y, lT4.z, lT4.w};
+        float uo[4] = {observer_velocity.x, observer_velocity.y, observer_velocity.z, observer_velocity.w};
+        float luo[4] = {lu4.x, lu4.y, lu4.z, lu4.w};
+        float lorentz_factor = -dot4(lT4, observer_velocity);
+        float L[16];
+        for (int u = 0; u < 4; u++)
+            for (int v = 0; v < 4; v++)
+                L[u * 4 + v] = (u == v ? 1.f : 0.f) + (1 / (1 + lorentz_factor)) * (T[u] + uo[u]) * (lT[v] + luo[v]) - 2 * uo[u] * lT[v];
+        e0 = observer_velocity;
+        e1 = f4(dot4(f4(L[0], L[1], L[2], L[3]), e1), dot4(f4(L[4], L[5], L[6], L[7]), e1), dot4(f4(L[8], L[9], L[10], L[11]), e1), dot4(f4(L[12], L[13], L[14], L[15]), e1));
+        e2 = f4(dot4(f4(L[0], L[1], L[2], L[3]), e2), dot4(f4(L[4], L[5], L[6], L[7]), e2), dot4(f4(L[8], L[9], L[10], L[11]), e2), dot4(f4(L[12], L[13], L[14], L[15]), e2));
+        e3 = f4(dot4(f4(L[0], L[1], L[2], L[3]), e3), dot4(f4(L[4], L[5], L[6], L[7]), e3), dot4(f4(L[8], L[9], L[10], L[11]), e3), dot4(f4(L[12], L[13], L[14], L[15]), e3));
+    }
+    out.e[0] = e0; out.e[1] = e1; out.e[2] = e2; out.e[3] = e3;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ray set-up (cl.cl:2015-2059, 2949-3065)
+
+__device__ __forceinline__ float3 pixel_direction(int cx, int cy, float width, float height, float4 camera_quat, dfg_t dfg) {
+    float fov = GET_FEATURE(field_of_view, dfg);
+    float fov_rad = (fov / 360.f) * 2 * GR_PIf;
+    float f_stop = (width / 2) / tanf(fov_rad / 2);
+    float3 dir = normalize3(f3(cx - width / 2, cy - height / 2, f_stop));
+    return rot_quat(dir, camera_quat);
+}
+
+#ifdef GENERIC_CONSTANT_THETA
+__device__ float4 theta_adjustment_quat(float3 pixel_dir, float4 polar_camera, float angle_sign) {
+    if (length3(pixel_dir) < 0.00001f) pixel_dir = f3(0, 1, 0);
+    float3 apolar = yzw(polar_camera);
+    apolar.x = __builtin_fabsf(apolar.x);
+    float3 cam = polar_to_cartesian(apolar);
+    float3 bx = normalize3(pixel_dir);
+    float3 by = normalize3(-cam);
+    bx = normalize3(normalize3(bx - dot3(bx, by) * by));
+    float3 plane_n = -normalize3(cross3(bx, by));
+    float angle_to_flat = acosf(dot3(plane_n, f3(0, 0, 1)));
+    float3 axis = normalize3(cross3(plane_n, f3(0, 0, 1)));
+    float angle = angle_to_flat * angle_sign;
+    float s = sinf(angle / 2);
+    return normalize4(f4(axis.x * s, axis.y * s, axis.z * s, cosf(angle / 2)));
+}
+#endif
+
+// rotates the ray into the equatorial plane for spherically symmetric metrics; identity otherwise
+__device__ __forceinline__ void correct_lightray(float4& position, float4& velocity, float4& inverse_quat, cfg_t cfg) {
+    inverse_quat = f4(0, 0, 0, 1);
+#ifdef GENERIC_CONSTANT_THETA
+    float4 polar_pos = gm::generic_to_spherical(position, cfg);
+    float4 pos_sph = polar_pos;
+    float4 vel_sph = gm::generic_velocity_to_spherical_velocity(position, velocity, cfg);
+    float sgn = fsign(pos_sph.y);
+    pos_sph.y = __builtin_fabsf(pos_sph.y);
+    float3 pos_cart = polar_to_cartesian(yzw(pos_sph));
+    float3 vel_cart = spherical_velocity_to_cartesian_velocity(yzw(pos_sph), yzw(vel_sph));
+    float4 quat = theta_adjustment_quat(vel_cart, polar_pos, 1);
+    inverse_quat = theta_adjustment_quat(vel_cart, polar_pos, -1);
+    pos_cart = rot_quat(pos_cart, quat);
+    vel_cart = rot_quat(vel_cart, quat);
+    float3 next_pos = cartesian_to_polar(pos_cart);
+    float3 next_vel = cartesian_velocity_to_polar_velocity(pos_cart, vel_cart);
+    if (sgn < 0) next_pos.x = -next_pos.x;
+    position = gm::spherical_to_generic(f4(pos_sph.x, next_pos), cfg);
+    velocity = gm::spherical_velocity_to_generic_velocity(f4(pos_sph.x, next_pos), f4(vel_sph.x, next_vel), cfg);
+#endif
+}
+
+// full initial state of one primary ray (geodesic_to_render_ray, cl.cl:3000-3065).  The initial
+// acceleration is the same -Gamma v v the reference contracts numerically from F*_P
+// (cl.cl:738-797, 1443-1537); here it is evaluated through the closed form GEO_ACCELn.
+__device__ __forceinline__ lightray make_render_ray(int cx, int cy, float4 position, float4 velocity, float4 observer_velocity, cfg_t cfg) {
+    lightray ray;
+    correct_lightray(position, velocity, ray.initial_quat, cfg);
+#ifdef IS_CONSTANT_THETA
+    position.z = GR_PIf / 2;
+    velocity.z = 0;
+#endif
+    ray.position = position;
+    ray.velocity = velocity;
+    ray.acceleration = gm::geodesic_acceleration(position, velocity, cfg);
+    ray.running_dlambda_dnew = 1;
+    ray.terminated = 0;
+    {
+        float g[16];
+        gm::metric_big_at(position, g, cfg);
+        ray.ku_uobsu = dot4(velocity, lower_index_big(observer_velocity, g));
+    }
+    ray.sx = cx;
+    ray.sy = cy;
+    return ray;
+}
+
+__device__ __forceinline__ lightray make_pixel_ray(int cx, int cy, int width, int height, float4 camera, float4 camera_quat,
+                                                   float4 e0, float4 e1, float4 e2, float4 e3, int flip, cfg_t cfg, dfg_t dfg) {
+    float3 dir = normalize3(pixel_direction(cx, cy, (float)width, (float)height, camera_quat, dfg));
+#ifndef FORWARD_GEODESIC_PATH
+    float4 pixel_t = -e0;
+#else
+    float4 pixel_t = e0;
+#endif
+    if (flip) pixel_t = -pixel_t;
+    float4 velocity = dir.x * e1 + dir.y * e2 + dir.z * e3 + pixel_t;
+    return make_render_ray(cx, cy, camera, velocity, e0, cfg);
+}
+
+// ray slot -> pixel.  Linear (reference order, cl.cl:3159-3160) or GR_TILE x GR_TILE tiles so that the
+// 64 lanes of a wave own one compact pixel block.
+__device__ __forceinline__ bool slot_to_pixel(int id, int width, int height, int tiled, int& cx, int& cy) {
+    if (!tiled) {
+        cx = id % width;
+        cy = id / width;
+        return id < width * height;
+    }
+    const int T = GR_TILE;
+    int tiles_x = (width + T - 1) / T;
+    int tile = id / (T * T);
+    int in = id % (T * T);
+    cx = (tile % tiles_x) * T + in % T;
+    cy = (tile / tiles_x) * T + in / T;
+    return cx < width && cy < height;
+}
+
+__device__ __forceinline__ int early_terminate(int x, int y, int w, int h, const int* __restrict__ term) {
+    if (x < 0 || y < 0 || x > w - 1 || y > h - 1) return 0;
+    return term[y * w + x] == 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the integrator (cl.cl:3273-3346, 3400-3456, 3954-4247)
+
+#ifdef ADAPTIVE_PRECISION
+#define GR_W_MAX ((float)((W_V1 > W_V2 ? W_V1 : W_V2) > (W_V3 > W_V4 ? W_V3 : W_V4) ? (W_V1 > W_V2 ? W_V1 : W_V2) : (W_V3 > W_V4 ? W_V3 : W_V4)))
+
+// returns diff, writes the unclamped step suggestion (acceleration_to_precision)
+__device__ __forceinline__ float acceleration_to_precision(float4 acc, float max_acceleration, float& next_ds) {
+    float4 wa = f4(acc.x * (float)(W_V1), acc.y * (float)(W_V2), acc.z * (float)(W_V3), acc.w * (float)(W_V4));
+    float current = __builtin_sqrtf(dot4(wa, wa)) * 0.01f;
+    current /= GR_W_MAX;
+    const float scale = 65536.f;                 // I_HATE_COMPUTERS
+    float err = max_acceleration;
+    float diff = current * scale;
+    float floor_diff = err * scale / 1e10f;      // pow(max_timestep = 100000, 2)
+    if (diff < floor_diff) diff = floor_diff;
+    next_ds = __builtin_sqrtf((err * scale) / diff);
+    return diff;
+}
+#endif
+
+enum { DS_NONE = 0, DS_SKIP = 1, DS_RETURN = 2 };
+
+struct ray_state {
+    float4 position, velocity, acceleration;
+    float next_ds;
+    float running_dlambda_dnew;
+    float f_in_x;
+};
+
+// outcome of integrating one ray
+enum { RAY_LOST = 0, RAY_TERMINATED = 1 };
+
+// Integrates until termination.  Returns RAY_TERMINATED when the ray reached the outer boundary (or the
+// SINGULAR terminator) - position/velocity/running_dlambda_dnew are then final - and RAY_LOST on any
+// early return of the reference (singularity guards, NaN, step cap), where nothing is written back.
+__device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg, unsigned int* attempts) {
+    float4 position = s.position, velocity = s.velocity, acceleration = s.acceleration;
+    const float f_in_x = __builtin_fabsf(velocity.x);
+#ifdef IS_CONSTANT_THETA
+    position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
+#endif
+    float next_ds = 0.00001f;
+#ifdef ADAPTIVE_PRECISION
+    const float max_accel = GET_FEATURE(max_acceleration_change, dfg);
+    const float min_step = GET_FEATURE(min_step, dfg);
+    (void)acceleration_to_precision(acceleration, max_accel, next_ds);
+#endif
+    const float subambient_precision = 0.5f;
+    const float ambient_precision = 0.2f;
+    const float new_max = GET_FEATURE(max_precision_radius, dfg);
+    const float new_min = 3;
+    const float universe = GET_FEATURE(universe_size, dfg);
+    const bool reparam = GET_FEATURE(reparameterisation, dfg) != 0;
+    float running = 1;
+    const int loop_limit = 4096 * 4;
+    unsigned int tries = 0;
+    int result = RAY_LOST;
+
+    for (int i = 0; i < loop_limit;) {
+#ifdef IS_CONSTANT_THETA
+        position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
+#endif
+        float4 polar = gm::generic_to_spherical(position, cfg);
+#ifdef IS_CONSTANT_THETA
+        polar.z = GR_PIf / 2;
+#endif
+        float r_value = gm::distance_to_object(polar, cfg);
+        float ar = __builtin_fabsf(r_value);
+        float ds = mixf(ambient_precision, subambient_precision, (clampf(ar, new_min, new_max) - new_min) / (new_max - new_min));
+#ifdef ADAPTIVE_PRECISION
+        ds = next_ds;
+#endif
+        if (ar < new_max) ds = __builtin_fminf(ds, ambient_precision);
+        else ds = 0.1f * (ar - new_max) + ambient_precision;
+
+        bool should_terminate = __builtin_fabsf(polar.y) >= universe;
+#ifdef SINGULAR
+        should_terminate |= __builtin_fabsf(polar.y) < SINGULAR_TERMINATOR;
+#endif
+#ifdef HAS_CYLINDRICAL_SINGULARITY
+        if (position.y < CYLINDRICAL_TERMINATOR) break;
+#endif
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        if (__builtin_fabsf(velocity.x / running) > 1000 + f_in_x && __builtin_fabsf(acceleration.x / running) > 100) break;
+#endif
+        if (should_terminate) { result = RAY_TERMINATED; break; }
+
+        // velocity Verlet (step_verlet)
+        tries++;
+        float4 next_position = position + velocity * ds + (0.5f * acceleration) * (ds * ds);
+        float4 half_velocity = velocity + acceleration * ds;
+        float4 next_acceleration = gm::geodesic_acceleration(next_position, half_velocity, cfg);
+        float4 next_velocity = velocity + (0.5f * (acceleration + next_acceleration)) * ds;
+        float K = 1;
+        if (reparam) {
+            float md = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(next_velocity.x), __builtin_fabsf(next_velocity.y)),
+                                       __builtin_fmaxf(__builtin_fabsf(next_velocity.z), __builtin_fabsf(next_velocity.w)));
+            K = 1 / md;
+            next_velocity = next_velocity * K;
+            next_acceleration = next_acceleration * K * K;
+        }
+        running *= K;
+
+#ifdef ADAPTIVE_PRECISION
+        if (ar < new_max) {
+            // calculate_ds_error
+            float suggested;
+            float diff = acceleration_to_precision(next_acceleration, max_accel, suggested);
+            float nds = 0.99f * ds * clampf(suggested / ds, 0.3f, 2.f);
+            nds = __builtin_fmaxf(nds, min_step);
+            next_ds = nds;
+#ifdef SINGULARITY_DETECTION
+            if (nds == min_step && (diff / 65536.f) > max_accel * 10000) break;
+#endif
+            if (nds < ds / 1.95f) continue;   // back-step: retry from the same state with the smaller step
+        }
+#endif
+        position = next_position;
+        velocity = next_velocity;
+        acceleration = next_acceleration;
+        i++;
+        if (degenerate4(position) || degenerate4(velocity) || degenerate4(acceleration)) break;
+    }
+    s.position = position;
+    s.velocity = velocity;
+    s.acceleration = acceleration;
+    s.running_dlambda_dnew = running;
+    if (attempts) *attempts = tries;
+    return result;
+}
+
+// ------------------------------------------------------------------------------------------------
+// final position -> sky coordinates (cl.cl:211-263, 5024-5100)
+
+__device__ __forceinline__ float3 fix_ray_position_cart(float3 pos, float3 vel, float radius) {
+    vel = normalize3(vel);
+    float b = 2 * dot3(vel, pos);
+    float c = dot3(pos, pos) - radius * radius;
+    float discrim = b * b - 4 * c;
+    if (discrim < 0) return pos;
+    float sq = __builtin_sqrtf(discrim);
+    float t0 = (-b - sq) / 2;
+    float t1 = (-b + sq) / 2;
+    float t = __builtin_fabsf(t0) < __builtin_fabsf(t1) ? t0 : t1;
+    return pos + t * vel;
+}
+
+__device__ __forceinline__ float3 fix_ray_position(float3 polar_pos, float3 polar_vel, float radius) {
+    float sgn = fsign(polar_pos.x);
+    float3 cpos = polar_pos;
+    cpos.x = __builtin_fabsf(cpos.x);
+    polar_vel.x *= sgn;
+    float3 cart_vel = spherical_velocity_to_cartesian_velocity(cpos, polar_vel);
+    float3 cart_pos = polar_to_cartesian(cpos);
+    float3 fixed = cartesian_to_polar(fix_ray_position_cart(cart_pos, cart_vel, radius));
+#ifdef IS_CONSTANT_THETA
+    fixed.y = GR_PIf / 2;
+#endif
+    fixed.x *= sgn;
+    return fixed;
+}
+
+__device__ __forceinline__ float4 intersection_position(float4 ray_position, float4 ray_velocity, float4 initial_quat, cfg_t cfg, dfg_t dfg) {
+    float4 position = gm::generic_to_spherical(ray_position, cfg);
+    float4 velocity = gm::generic_velocity_to_spherical_velocity(ray_position, ray_velocity, cfg);
+#ifdef IS_CONSTANT_THETA
+    position.z = GR_PIf / 2;
+    velocity.z = 0;
+#endif
+    const float universe = GET_FEATURE(universe_size, dfg);
+    if (__builtin_fabsf(position.y) >= universe) {
+        float3 p = fix_ray_position(yzw(position), yzw(velocity), universe);
+        position = f4(position.x, p);
+    }
+#if defined(SINGULAR) && defined(TRAVERSABLE_EVENT_HORIZON)
+    if (__builtin_fabsf(position.y) < SINGULAR_TERMINATOR) {
+        float3 p = fix_ray_position(yzw(position), yzw(velocity), SINGULAR_TERMINATOR);
+        position = f4(position.x, p);
+    }
+#endif
+    float3 npolar = yzw(position);
+#ifdef GENERIC_CONSTANT_THETA
+    npolar = cartesian_to_polar(rot_quat(polar_to_cartesian(yzw(position)), initial_quat));
+#endif
+    (void)initial_quat;
+    return f4(position.x, npolar);
+}
+
+__device__ __forceinline__ float2 angle_to_tex(float theta, float phi) {
+    float thetaf = fmodf(theta, 2 * GR_PIf);
+    float phif = phi;
+    if (thetaf >= GR_PIf) { phif += GR_PIf; thetaf -= GR_PIf; }
+    phif = fmodf(phif, 2 * GR_PIf);
+    return make_float2(phif / (2 * GR_PIf) + 0.5f, thetaf / GR_PIf);
+}
+
+__device__ __forceinline__ float2 tex_to_angle(float2 tex) {
+    return make_float2((tex.x - 0.5f) * (2 * GR_PIf), tex.y * GR_PIf);
+}
+
+// render_data of one finished ray (body of calculate_render_data, cl.cl:5146-5212)
+__device__ __forceinline__ render_data make_render_data(float4 position, float4 velocity, float4 initial_quat, float ku_uobsu,
+                                                        float running, int terminated, int sx, int sy, cfg_t cfg, dfg_t dfg,
+                                                        bool need_redshift) {
+    render_data dat;
+    dat.terminated = terminated;
+    dat.sx = sx;
+    dat.sy = sy;
+    dat.z_shift = 0;
+    dat.tex_coord = make_float2(0, 0);
+    dat.side = 1;
+    if (terminated != 1) return dat;
+
+    float4 ipos = intersection_position(position, velocity, initial_quat, cfg, dfg);
+    float4 generic_velocity = velocity / running;
+    dat.side = gm::generic_to_spherical(position, cfg).y < 0 ? 0 : 1;
+#if !defined(TRAVERSABLE_EVENT_HORIZON)
+    if (__builtin_fabsf(ipos.y) <= 1) return dat;
+#endif
+    if (need_redshift) {
+        tetrad t;
+        calculate_tetrads(position, f3(0, 0, 0), t, cfg, 0);
+        float g[16];
+        gm::metric_big_at(position, g, cfg);
+        float4 obvs_low = lower_index_big(t.e[0], g);
+        float z_shift = (dot4(generic_velocity, obvs_low) / ku_uobsu) - 1;
+        dat.z_shift = __builtin_fmaxf(z_shift, -0.999f);
+    }
+    dat.tex_coord = angle_to_tex(ipos.z, ipos.w);
+    return dat;
+}
+
+// ================================================================================================
+// kernels
+
+extern "C" __global__ void gr_cart_to_generic(const float4* __restrict__ position_cart_in, float4* __restrict__ position_generic_out,
+                                              int count, float flip, cfg_t cfg) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    float4 in = position_cart_in[id];
+    float3 polar = cartesian_to_polar(yzw(in));
+    if (flip > 0) polar.x = -polar.x;
+    position_generic_out[id] = gm::spherical_to_generic(f4(in.x, polar), cfg);
+}
+
+extern "C" __global__ void gr_init_basis_vectors(const float4* __restrict__ generic_in, int count, float speed_x, float speed_y, float speed_z,
+                                                 float4* __restrict__ e0_out, float4* __restrict__ e1_out,
+                                                 float4* __restrict__ e2_out, float4* __restrict__ e3_out, cfg_t cfg) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    tetrad t;
+    calculate_tetrads(generic_in[id], f3(speed_x, speed_y, speed_z), t, cfg, 1);
+    e0_out[id] = t.e[0];
+    e1_out[id] = t.e[1];
+    e2_out[id] = t.e[2];
+    e3_out[id] = t.e[3];
+}
+
+extern "C" __global__ void gr_clear_termination_buffer(int* __restrict__ termination_buffer, int width, int height) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= width * height) return;
+    termination_buffer[id] = 1;
+}
+
+// `tiled` is an extension over the reference signature: 0 = reference slot order (slot = cy*width+cx),
+// 1 = 8x8 tile order (slot count is then rounded up to whole tiles; out-of-image slots get terminated = 2).
+extern "C" __global__ void gr_init_rays_generic(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+                                                lightray* __restrict__ metric_rays, int* __restrict__ metric_ray_count,
+                                                int width, int height, const int* __restrict__ termination_buffer,
+                                                int prepass_width, int prepass_height, int flip_geodesic_direction,
+                                                const float4* __restrict__ e0, const float4* __restrict__ e1,
+                                                const float4* __restrict__ e2, const float4* __restrict__ e3,
+                                                cfg_t cfg, dfg_t dfg, int i_am_prepass, int tiled) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    int cx, cy;
+    const int T = GR_TILE;
+    int slots = tiled ? ((width + T - 1) / T) * ((height + T - 1) / T) * T * T : width * height;
+    if (id >= slots) return;
+    bool inside = slot_to_pixel(id, width, height, tiled, cx, cy);
+
+    bool full = i_am_prepass || !GET_FEATURE(adaptive_sampling, dfg) || GET_FEATURE(use_triangle_rendering, dfg);
+    if (id == 0) *metric_ray_count = full ? slots : (height * width) / 4;
+
+    if (!inside) {
+        lightray dead;
+        dead.position = dead.velocity = dead.acceleration = f4(0, 0, 0, 0);
+        dead.initial_quat = f4(0, 0, 0, 1);
+        dead.ku_uobsu = 1; dead.running_dlambda_dnew = 1; dead.terminated = 2; dead.sx = -1; dead.sy = -1;
+        metric_rays[id] = dead;
+        return;
+    }
+
+    lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3,
+                                  flip_geodesic_direction, cfg, dfg);
+
+    // prepass stencil (cl.cl:3213-3232)
+    if (prepass_width != width && prepass_height != height) {
+        float fx = (float)cx / width;
+        float fy = (float)cy / height;
+        int lx = (int)roundf(fx * prepass_width);
+        int ly = (int)roundf(fy * prepass_height);
+        if (early_terminate(lx - 1, ly, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx, ly, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx + 1, ly, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx, ly - 1, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx, ly + 1, prepass_width, prepass_height, termination_buffer)) {
+            ray.terminated = 2;
+        }
+    }
+
+    if (full) {
+        metric_rays[id] = ray;
+    } else {
+        if ((cx % 2) != 0 || (cy % 2) != 0) return;
+        metric_rays[(cy / 2) * (width / 2) + cx / 2] = ray;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+gr_do_generic_rays(lightray* __restrict__ generic_rays_in, const int* __restrict__ generic_count_in,
+                   int* __restrict__ ray_time_min, int* __restrict__ ray_time_max,
+                   cfg_t cfg, dfg_t dfg, int width, int height, int mouse_x, int mouse_y,
+                   float4* __restrict__ ray_write, int* __restrict__ ray_write_counts, int max_write,
+                   unsigned long long* __restrict__ attempt_counter) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= *generic_count_in) return;
+    if (ray_write_counts) ray_write_counts[id] = 0;
+    lightray* ray = &generic_rays_in[id];
+    if (ray->terminated == 2) return;
+
+    ray_state s;
+    s.position = ray->position;
+    s.velocity = ray->velocity;
+    s.acceleration = ray->acceleration;
+    unsigned int tries = 0;
+    int res = integrate_ray(s, cfg, dfg, &tries);
+    if (res == RAY_TERMINATED) {
+        ray->position = s.position;
+        ray->velocity = s.velocity;
+        ray->running_dlambda_dnew = s.running_dlambda_dnew;
+        ray->terminated = 1;
+    }
+    if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);   // one add per wave after compiler coalescing
+}
+
+extern "C" __global__ void gr_calculate_singularities(const lightray* __restrict__ finished_rays, const int* __restrict__ finished_count,
+                                                      int* __restrict__ termination_buffer, int width, int height) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= *finished_count) return;
+    int sx = id % width;
+    int sy = id / width;
+    termination_buffer[sy * width + sx] = !finished_rays[id].terminated;
+}
+
+extern "C" __global__ void gr_calculate_render_data(const lightray* __restrict__ rays_in, const int* __restrict__ rays_in_count,
+                                                    render_data* __restrict__ rdata, int* __restrict__ rdata_count,
+                                                    int width, int height, cfg_t cfg, dfg_t dfg) {
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= *rays_in_count) return;
+    if (gid == 0) *rdata_count = width * height;
+    const lightray* ray = &rays_in[gid];
+    int sx = ray->sx, sy = ray->sy;
+    if (sx < 0 || sy < 0 || sx >= width || sy >= height) return;   // padding slots of the tiled layout
+    render_data dat = make_render_data(ray->position, ray->velocity, ray->initial_quat, ray->ku_uobsu, ray->running_dlambda_dnew,
+                                       ray->terminated, sx, sy, cfg, dfg, true);
+    rdata[sy * width + sx] = dat;
+}
+
+// init -> integrate -> render-data for one pixel per lane, 8x8 tiles, nothing but the 32-byte result is stored
+extern "C" __global__ void __launch_bounds__(64)
+gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+               render_data* __restrict__ rdata, int width, int height, int row_begin, int row_end,
+               const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+               const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+               cfg_t cfg, dfg_t dfg, unsigned long long* __restrict__ attempt_counter) {
+    const int T = GR_TILE;
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    int tiles_x = (width + T - 1) / T;
+    int tile = id / (T * T);
+    int in = id % (T * T);
+    int cx = (tile % tiles_x) * T + in % T;
+    int cy = row_begin + (tile / tiles_x) * T + in / T;
+    if (cx >= width || cy >= row_end) return;
+
+    lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+    int terminated = 0;
+    if (termination_buffer && prepass_width != width && prepass_height != height) {
+        float fx = (float)cx / width;
+        float fy = (float)cy / height;
+        int lx = (int)roundf(fx * prepass_width);
+        int ly = (int)roundf(fy * prepass_height);
+        if (early_terminate(lx - 1, ly, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx, ly, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx + 1, ly, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx, ly - 1, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx, ly + 1, prepass_width, prepass_height, termination_buffer)) {
+            terminated = 2;
+        }
+    }
+    ray_state s;
+    s.position = ray.position;
+    s.velocity = ray.velocity;
+    s.acceleration = ray.acceleration;
+    s.running_dlambda_dnew = 1;
+    unsigned int tries = 0;
+    if (terminated != 2) {
+        int res = integrate_ray(s, cfg, dfg, &tries);
+        if (res == RAY_TERMINATED) terminated = 1;
+        else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
+    }
+    render_data dat = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew,
+                                       terminated, cx, cy, cfg, dfg, GET_FEATURE(redshift, dfg) != 0);
+    rdata[cy * width + cx] = dat;
+    if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);
+}
+
+// termination flags of the low-resolution prepass, straight from a fused trace (role of
+// clear_termination_buffer + init_rays_generic(prepass) + do_generic_rays + calculate_singularities)
+extern "C" __global__ void __launch_bounds__(64)
+gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+                 int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+                 const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+                 cfg_t cfg, dfg_t dfg) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= prepass_width * prepass_height) return;
+    int cx = id % prepass_width, cy = id / prepass_width;
+    lightray ray = make_pixel_ray(cx, cy, prepass_width, prepass_height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+    ray_state s;
+    s.position = ray.position;
+    s.velocity = ray.velocity;
+    s.acceleration = ray.acceleration;
+    int res = integrate_ray(s, cfg, dfg, nullptr);
+    termination_buffer[id] = res == RAY_TERMINATED ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive sampling (cl.cl:5215-5345)
+
+__device__ __forceinline__ float angle_between_angles(float2 a1, float2 a2) {
+    float3 v1 = polar_to_cartesian(f3(1.f, a1.x, a1.y));
+    float3 v2 = polar_to_cartesian(f3(1.f, a2.x, a2.y));
+    return acosf(clampf(dot3(v1, v2), -1.f, 1.f));
+}
+
+__device__ __forceinline__ render_data interpolate_render_data(render_data r1, render_data r2) {
+    float2 a1 = tex_to_angle(r1.tex_coord);
+    float2 a2 = tex_to_angle(r2.tex_coord);
+    float3 v1 = polar_to_cartesian(f3(1.f, a1.y, a1.x));
+    float3 v2 = polar_to_cartesian(f3(1.f, a2.y, a2.x));
+    float3 vc = (v1 + v2) / 2.f;
+    float3 fangle = cartesian_to_polar(vc);
+    render_data out;
+    out.tex_coord = angle_to_tex(fangle.y, fangle.z);
+    out.z_shift = (r1.z_shift + r2.z_shift) / 2.f;
+    out.terminated = r1.terminated;
+    out.sx = (r1.sx + r2.sx) / 2;
+    out.sy = (r1.sy + r2.sy) / 2;
+    out.side = (r1.side + r2.side) / 2;
+    return out;
+}
+
+extern "C" __global__ void gr_handle_adaptive_sampling(const lightray* __restrict__ rays_in, const int* __restrict__ rays_in_count,
+                                                       render_data* __restrict__ rdat, int* __restrict__ rdata_count,
+                                                       lightray* __restrict__ unprocessed_rays_out, int* __restrict__ unprocessed_rays_out_count,
+                                                       const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+                                                       const float4* __restrict__ e0, const float4* __restrict__ e1,
+                                                       const float4* __restrict__ e2, const float4* __restrict__ e3,
+                                                       int width, int height, cfg_t cfg, dfg_t dfg) {
+    int sx = blockIdx.x * blockDim.x + threadIdx.x;
+    int sy = blockIdx.y * blockDim.y + threadIdx.y;
+    int hw = width / 2, hh = height / 2;
+    if (sx >= hw || sy >= hh) return;
+
+    bool should_sample = true;
+    if (sx != 0 && sx != hw - 1 && sy != 0 && sy != hh - 1) {
+        const lightray* centre = &rays_in[sy * hw + sx];
+        const lightray* left = &rays_in[sy * hw + sx - 1];
+        const lightray* right = &rays_in[sy * hw + sx + 1];
+        const lightray* up = &rays_in[(sy - 1) * hw + sx];
+        const lightray* down = &rays_in[(sy + 1) * hw + sx];
+        const lightray* down_right = &rays_in[(sy + 1) * hw + sx + 1];
+
+        float4 lpos = intersection_position(left->position, left->velocity, left->initial_quat, cfg, dfg);
+        float4 rpos = intersection_position(right->position, right->velocity, right->initial_quat, cfg, dfg);
+        float4 upos = intersection_position(up->position, up->velocity, up->initial_quat, cfg, dfg);
+        float4 dpos = intersection_position(down->position, down->velocity, down->initial_quat, cfg, dfg);
+
+        float x_error = __builtin_fabsf(angle_between_angles(make_float2(lpos.z, lpos.w), make_float2(rpos.z, rpos.w)));
+        float y_error = __builtin_fabsf(angle_between_angles(make_float2(dpos.z, dpos.w), make_float2(upos.z, upos.w)));
+        // the reference's expression is ((xe.x+xe.y+ye.x+ye.y)/4.f)/2*M_PI with both lanes of each float2 equal (cl.cl:5272)
+        float relative_angular_error = (float)((double)(((x_error + x_error + y_error + y_error) / 4.f) / 2) * GR_PI);
+        float fov = GET_FEATURE(field_of_view, dfg);
+        float fov_angle_pi = (float)((double)(fov * 2) * GR_PI / (double)360.f);
+        float per_pixel = fov_angle_pi / width;
+        should_sample = relative_angular_error >= per_pixel * GET_FEATURE(adaptive_sampling_threshold, dfg);
+        int ct = centre->terminated;
+        if (ct != left->terminated || ct != right->terminated || ct != up->terminated || ct != down->terminated || ct != down_right->terminated)
+            should_sample = true;
+    }
+
+    if (should_sample) {
+        int base_sx = sx * 2, base_sy = sy * 2;
+        int px[3] = {base_sx + 1, base_sx, base_sx + 1};
+        int py[3] = {base_sy, base_sy + 1, base_sy + 1};
+        int root_id = atomicAdd(unprocessed_rays_out_count, 3);
+        for (int i = 0; i < 3; i++) {
+            unprocessed_rays_out[root_id + i] = make_pixel_ray(px[i], py[i], width, height, *g_generic_camera_in, *g_camera_quat,
+                                                               *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        }
+    } else {
+        int lsx = rays_in[sy * hw + sx].sx;
+        int lsy = rays_in[sy * hw + sx].sy;
+        render_data cdata = rdat[lsy * width + lsx];
+        render_data rdata_ = rdat[lsy * width + lsx + 2];
+        render_data ddata = rdat[(lsy + 2) * width + lsx];
+        render_data drdata = rdat[(lsy + 2) * width + lsx + 2];
+        rdat[lsy * width + lsx + 1] = interpolate_render_data(cdata, rdata_);
+        rdat[(lsy + 1) * width + lsx] = interpolate_render_data(cdata, ddata);
+        rdat[(lsy + 1) * width + lsx + 1] = interpolate_render_data(cdata, drdata);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// texture sampling and shading (cl.cl:326-350, 3598-3610, 5366-5449, 5453-5846)
+
+struct background {
+    const uchar4* __restrict__ texels;   // [levels][height][width] RGBA8, level L holds mip L in its top-left corner
+    int width, height, levels;
+};
+
+__device__ __forceinline__ float4 texel(const background& bg, int x, int y, int layer) {
+    uchar4 t = bg.texels[((size_t)layer * bg.height + y) * bg.width + x];
+    const float s = 1.f / 255.f;
+    return f4(t.x * s, t.y * s, t.z * s, t.w * s);
+}
+
+// read_imagef(image2d_array, NORMALIZED | REPEAT | LINEAR) per the OpenCL 1.2 specification (8.2, 8.4)
+__device__ float4 sample_bilinear_repeat(const background& bg, float s, float t, float layer_f) {
+    int layer = (int)rintf(layer_f);
+    layer = layer < 0 ? 0 : (layer > bg.levels - 1 ? bg.levels - 1 : layer);
+    float u = (s - floorf(s)) * bg.width;
+    float v = (t - floorf(t)) * bg.height;
+    int i0 = (int)floorf(u - 0.5f), j0 = (int)floorf(v - 0.5f);
+    int i1 = i0 + 1, j1 = j0 + 1;
+    if (i0 < 0) i0 += bg.width;
+    if (i1 > bg.width - 1) i1 -= bg.width;
+    if (j0 < 0) j0 += bg.height;
+    if (j1 > bg.height - 1) j1 -= bg.height;
+    float a = (u - 0.5f) - floorf(u - 0.5f);
+    float b = (v - 0.5f) - floorf(v - 0.5f);
+    float4 t00 = texel(bg, i0, j0, layer), t10 = texel(bg, i1, j0, layer);
+    float4 t01 = texel(bg, i0, j1, layer), t11 = texel(bg, i1, j1, layer);
+    return ((1 - a) * (1 - b)) * t00 + (a * (1 - b)) * t10 + ((1 - a) * b) * t01 + (a * b) * t11;
+}
+
+__device__ float4 read_mipmap(const background& bg1, const background& bg2, int side, float2 pos, float lod) {
+    lod = __builtin_fmaxf(lod, 0.f);
+    pos.x = fmodf(pos.x, 1.f);
+    pos.y = fmodf(pos.y, 1.f);
+    float mip_lower = floorf(lod);
+    float mip_upper = ceilf(lod);
+    float lower_divisor = exp2f(mip_lower);
+    float upper_divisor = exp2f(mip_upper);
+    float w = lod - mip_lower;
+    const background& bg = side >= 1 ? bg1 : bg2;
+    float4 lo = sample_bilinear_repeat(bg, pos.x / lower_divisor, pos.y / lower_divisor, mip_lower);
+    float4 hi = sample_bilinear_repeat(bg, pos.x / upper_divisor, pos.y / upper_divisor, mip_upper);
+    return lo + (hi - lo) * w;
+}
+
+__device__ __forceinline__ float srgb_to_lin_single(float in) {
+    return in < 0.04045f ? in / 12.92f : powf((in + 0.055f) / 1.055f, 2.4f);
+}
+__device__ __forceinline__ float lin_to_srgb_single(float in) {
+    return in <= 0.0031308f ? in * 12.92f : 1.055f * powf(in, 1.0f / 2.4f) - 0.055f;
+}
+__device__ __forceinline__ float3 srgb_to_lin(float3 c) { return f3(srgb_to_lin_single(c.x), srgb_to_lin_single(c.y), srgb_to_lin_single(c.z)); }
+__device__ __forceinline__ float3 lin_to_srgb(float3 c) { return f3(lin_to_srgb_single(c.x), lin_to_srgb_single(c.y), lin_to_srgb_single(c.z)); }
+__device__ __forceinline__ float energy_of(float3 v) { return v.x * 0.2125f + v.y * 0.7154f + v.z * 0.0721f; }
+__device__ __forceinline__ float3 clamp3(float3 v, float lo, float hi) { return f3(clampf(v.x, lo, hi), clampf(v.y, lo, hi), clampf(v.z, lo, hi)); }
+__device__ __forceinline__ float3 mix3(float3 a, float3 b, float t) { return a + (b - a) * t; }
+
+__device__ float3 redshift_colour(float3 v, float z, dfg_t dfg) {
+    float radiant_energy = energy_of(v);
+    float3 red = f3(1 / 0.2125f, 0.f, 0.f);
+    float3 green = f3(0, (float)(1 / 0.7154), 0.f);
+    float3 blue = f3(0.f, 0.f, (float)(1 / 0.0721));
+    float3 result;
+    if (z > 0) {
+        result = mix3(v, radiant_energy * red, tanhf(z));
+    } else {
+        float iv1pz = (1 / (1 + z)) - 1;
+        float3 col = mix3(v, radiant_energy * blue, tanhf(iv1pz));
+        if (!GET_FEATURE(use_old_redshift, dfg)) {
+            float final_energy = energy_of(clamp3(col, 0.f, 1.f));
+            float real_energy = energy_of(col);
+            float remaining = real_energy - final_energy;
+            col.x += remaining * (red.x + green.x);
+            col.y += remaining * (red.y + green.y);
+        }
+        result = col;
+    }
+    return clamp3(result, 0.f, 1.f);
+}
+
+// period-1 wrap of a difference of normalised texture coordinates; mixed double/float as in cl.cl:3598-3604
+__device__ __forceinline__ float circular_diff1(float f1, float f2) {
+    float g1 = (float)((double)f1 * (2 * GR_PI / (double)1.f));
+    float g2 = (float)((double)f2 * (2 * GR_PI / (double)1.f));
+    float d = g2 - g1;
+    return (float)((double)(1.f * atan2f(sinf(d), cosf(d))) / (2 * GR_PI));
+}
+
+extern "C" __global__ void gr_render(const render_data* __restrict__ rdata, const int* __restrict__ rdata_count, float4* __restrict__ out,
+                                     const uchar4* __restrict__ bg1_texels, const uchar4* __restrict__ bg2_texels,
+                                     int bg_width, int bg_height, int bg_levels,
+                                     int width, int height, int maxProbes, cfg_t cfg, dfg_t dfg,
+                                     int first_pixel, int num_pixels) {
+    // first_pixel / num_pixels (extension): shade a contiguous pixel range; (0, width*height) = reference
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= num_pixels) return;
+    int id = first_pixel + gid;
+    if (id >= *rdata_count) return;
+    render_data rdat = rdata[id];
+    int sx = rdat.sx, sy = rdat.sy, side = rdat.side;
+    if (rdat.terminated != 1) {
+        out[sy * width + sx] = f4(0, 0, 0, 1);
+        return;
+    }
+    background bg1{bg1_texels, bg_width, bg_height, bg_levels};
+    background bg2{bg2_texels, bg_width, bg_height, bg_levels};
+    float sxf = rdat.tex_coord.x, syf = rdat.tex_coord.y;
+
+    int dx = sx == width - 1 ? -1 : 1;
+    int dy = sy == height - 1 ? -1 : 1;
+    float2 tl = rdata[sy * width + sx].tex_coord;
+    float2 tr = rdata[sy * width + sx + dx].tex_coord;
+    float2 bl = rdata[(sy + dy) * width + sx].tex_coord;
+    const float bias_frac = 1.3f;
+    float2 dx_vtc = make_float2(circular_diff1(tl.x, tr.x) / bias_frac, circular_diff1(tl.y, tr.y) / bias_frac);
+    float2 dy_vtc = make_float2(circular_diff1(tl.x, bl.x) / bias_frac, circular_diff1(tl.y, bl.y) / bias_frac);
+    if (dx == -1) { dx_vtc.x = -dx_vtc.x; dx_vtc.y = -dx_vtc.y; }
+    if (dy == -1) { dy_vtc.x = -dy_vtc.x; dy_vtc.y = -dy_vtc.y; }
+    dx_vtc.x *= bg_width; dy_vtc.x *= bg_width;
+    dx_vtc.y *= bg_height; dy_vtc.y *= bg_height;
+
+    // Heckbert ellipse -> probe count and level of detail (cl.cl:5563-5623)
+    float dv_dx = dx_vtc.y, dv_dy = dy_vtc.y, du_dx = dx_vtc.x, du_dy = dy_vtc.x;
+    float Ann = dv_dx * dv_dx + dv_dy * dv_dy + 1;
+    float Bnn = -2 * (du_dx * dv_dx + du_dy * dv_dy);
+    float Cnn = du_dx * du_dx + du_dy * du_dy + 1;
+    float F = Ann * Cnn - Bnn * Bnn / 4;
+    float A = Ann / F, B = Bnn / F, C = Cnn / F;
+    float root = __builtin_sqrtf((A - C) * (A - C) + B * B);
+    float a_prime = (A + C - root) / 2;
+    float c_prime = (A + C + root) / 2;
+    float majorRadius = 1.f / __builtin_sqrtf(a_prime);
+    float minorRadius = 1.f / __builtin_sqrtf(c_prime);
+    float theta = atan2f(B, (A - C) / 2);
+    majorRadius = __builtin_fmaxf(majorRadius, 1.f);
+    minorRadius = __builtin_fmaxf(minorRadius, 1.f);
+    majorRadius = __builtin_fmaxf(majorRadius, minorRadius);
+    float fProbes = 2 * (majorRadius / minorRadius) - 1;
+    int iProbes = (int)floorf(fProbes + 0.5f);
+    iProbes = iProbes < maxProbes ? iProbes : maxProbes;
+    if (iProbes < fProbes) minorRadius = 2 * majorRadius / (iProbes + 1);
+    float levelofdetail = log2f(minorRadius);
+    int maxLod = bg_levels - 1;
+    if (levelofdetail > maxLod) { levelofdetail = maxLod; iProbes = 1; }
+
+    float4 end_result = f4(0, 0, 0, 0);
+    if (iProbes <= 1) {
+        if (iProbes < 1) levelofdetail = maxLod;
+        end_result = read_mipmap(bg1, bg2, side, make_float2(sxf, syf), levelofdetail);
+    } else {
+        float lineLength = 2 * (majorRadius - minorRadius);
+        float du = cosf(theta) * lineLength / (iProbes - 1);
+        float dv = sinf(theta) * lineLength / (iProbes - 1);
+        float4 totalWeight = f4(0, 0, 0, 0);
+        float accumulatedProbes = 0;
+        int startN = (iProbes % 2) == 1 ? -2 * ((iProbes - 1) / 2) : -2 * (iProbes / 2) - 1;
+        int currentN = startN;
+        const float alpha = 2;
+        float sU = du / bg_width;
+        float sV = dv / bg_height;
+        for (int cnt = 0; cnt < iProbes; cnt++) {
+            float d_2 = (currentN * currentN / 4.f) * (du * du + dv * dv) / (majorRadius * majorRadius);
+            float relativeWeight = expf(-alpha * d_2);
+            float cu = sxf + (currentN / 2.f) * sU;
+            float cv = syf + (currentN / 2.f) * sV;
+            float4 fval = read_mipmap(bg1, bg2, side, make_float2(cu, cv), levelofdetail);
+            totalWeight = totalWeight + relativeWeight * fval;
+            accumulatedProbes += relativeWeight;
+            currentN += 2;
+        }
+        end_result = totalWeight / accumulatedProbes;
+    }
+
+    if (GET_FEATURE(redshift, dfg)) {
+        float z_shift = rdat.z_shift;
+        float3 lin_result = srgb_to_lin(f3(end_result.x, end_result.y, end_result.z));
+        const float real_sol = 299792458;
+        float test_wavelength = 555 / real_sol;
+        float local_wavelength = test_wavelength / (z_shift + 1);
+        float relative_luminance = 0.2126f * lin_result.x + 0.7152f * lin_result.y + 0.0722f * lin_result.z;
+        float new_relative_luminance = powf(local_wavelength, 3.f) * relative_luminance / powf(test_wavelength, 3.f);
+        new_relative_luminance = clampf(new_relative_luminance, 0.f, 1.f);
+        if ((double)relative_luminance > 0.00001) {
+            lin_result = (new_relative_luminance / relative_luminance) * lin_result;
+            lin_result = clamp3(lin_result, 0.f, 1.f);
+        }
+        lin_result = redshift_colour(lin_result, z_shift, dfg);
+        lin_result = clamp3(lin_result, 0.f, 1.f);
+#ifndef LINEAR_FRAMEBUFFER
+        lin_result = lin_to_srgb(lin_result);
+#endif
+        end_result.x = lin_result.x; end_result.y = lin_result.y; end_result.z = lin_result.z;
+    }
+#ifdef LINEAR_FRAMEBUFFER
+    if (!GET_FEATURE(redshift, dfg)) {
+        float3 l = srgb_to_lin(f3(end_result.x, end_result.y, end_result.z));
+        end_result.x = l.x; end_result.y = l.y; end_result.z = l.z;
+    }
+#endif
+    out[sy * width + sx] = end_result;
+}

@@ -1,0 +1,227 @@
+"""Thin object layer over the C ABI: Metric, Program, RenderState (host mirror of the reference's
+metric_manager / render_state roles).  All compute happens inside libgeodesic_hip.so."""
+import ctypes
+
+import numpy as np
+
+from . import (Camera, Features, FrameOptions, GeodesicError, MetricInfo, MODE_FUSED, STAGE_NAMES, c_float, c_int, c_size_t,
+               c_void_p, check, lib)
+
+LIGHTRAY_DTYPE = np.dtype([("position", "<f4", 4), ("velocity", "<f4", 4), ("initial_quat", "<f4", 4),
+                           ("acceleration", "<f4", 4), ("ku_uobsu", "<f4"), ("running_dlambda_dnew", "<f4"),
+                           ("terminated", "<i4"), ("sx", "<i4"), ("sy", "<i4"), ("pad", "<i4", 3)])
+RENDER_DATA_DTYPE = np.dtype([("tex_coord", "<f4", 2), ("z_shift", "<f4"), ("sx", "<i4"), ("sy", "<i4"),
+                              ("terminated", "<i4"), ("side", "<i4"), ("pad", "<i4")])
+assert LIGHTRAY_DTYPE.itemsize == 96 and RENDER_DATA_DTYPE.itemsize == 32
+
+
+def default_features(**overrides):
+    f = Features()
+    lib.gr_features_default(ctypes.byref(f))
+    for k, v in overrides.items():
+        setattr(f, k, v)
+    return f
+
+
+def default_camera(position=None, quat=None):
+    c = Camera()
+    lib.gr_camera_default(ctypes.byref(c))
+    if position is not None:
+        c.position = (c_float * 4)(*position)
+    if quat is not None:
+        c.quat = (c_float * 4)(*quat)
+    return c
+
+
+def frame_options(**overrides):
+    o = FrameOptions()
+    lib.gr_frame_options_default(ctypes.byref(o))
+    for k, v in overrides.items():
+        setattr(o, k, v)
+    return o
+
+
+class Metric:
+    """A loaded metric: config + symbolic descriptor (metrics::metric in the reference, metric.hpp:710-715)."""
+
+    def __init__(self, name, scripts_dir=None):
+        self.handle = c_void_p()
+        self.name = name
+        if scripts_dir is None:
+            check(lib.gr_metric_builtin(name.encode(), ctypes.byref(self.handle)))
+        else:
+            check(lib.gr_metric_load_script(str(scripts_dir).encode(), name.encode(), ctypes.byref(self.handle)))
+        self.info = MetricInfo()
+        check(lib.gr_metric_get_info(self.handle, ctypes.byref(self.info)))
+        n = self.info.num_dynamic_vars
+        self.dynamic_vars = [lib.gr_metric_dynamic_var_name(self.handle, i).decode() for i in range(n)]
+        self.dynamic_defaults = [lib.gr_metric_dynamic_var_default(self.handle, i) for i in range(n)]
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib.gr_metric_destroy(self.handle)
+            self.handle = None
+
+    def cfg_values(self, **params):
+        """$cfg values in declaration order, defaults overridden by name."""
+        vals = list(self.dynamic_defaults)
+        for k, v in params.items():
+            vals[self.dynamic_vars.index(k)] = float(v)
+        return vals
+
+    def features(self, **overrides):
+        """feature struct with this metric's error tolerance (metric_manager.hpp:50)."""
+        return default_features(max_acceleration_change=self.info.max_acceleration_change, **overrides)
+
+    def argument_string(self, features=None, static=False, cfg_values=None):
+        fptr = ctypes.byref(features) if features is not None else None
+        arr, n = None, 0
+        if cfg_values is not None:
+            n = len(cfg_values)
+            arr = (c_float * n)(*cfg_values)
+        need = c_size_t()
+        lib.gr_metric_argument_string(self.handle, fptr, int(static), arr, n, None, 0, ctypes.byref(need))
+        buf = ctypes.create_string_buffer(need.value)
+        check(lib.gr_metric_argument_string(self.handle, fptr, int(static), arr, n, buf, need.value, ctypes.byref(need)))
+        return buf.value.decode()
+
+
+class Program:
+    """Compiled gfx950 kernels for one argument string (cl::program in the reference)."""
+
+    def __init__(self, argument_string, device=0):
+        self.handle = c_void_p()
+        self.device = device
+        check(lib.gr_program_create(argument_string.encode(), device, ctypes.byref(self.handle)))
+
+    @staticmethod
+    def precompile(argument_string):
+        check(lib.gr_program_precompile(argument_string.encode()))
+
+    def kernel_info(self, name):
+        v, s, l = c_int(), c_int(), c_int()
+        check(lib.gr_program_kernel_info(self.handle, name.encode(), ctypes.byref(v), ctypes.byref(s), ctypes.byref(l)))
+        return {"vgprs": v.value, "scratch_bytes": l.value}
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib.gr_program_destroy(self.handle)
+            self.handle = None
+
+
+class DeviceBuffer:
+    def __init__(self, device, nbytes):
+        self.device, self.nbytes = device, nbytes
+        self.ptr = c_void_p()
+        check(lib.gr_device_alloc(device, nbytes, ctypes.byref(self.ptr)))
+
+    @classmethod
+    def from_numpy(cls, device, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(device, arr.nbytes)
+        check(lib.gr_device_upload(device, b.ptr, arr.ctypes.data_as(c_void_p), arr.nbytes))
+        return b
+
+    def to_numpy(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib.gr_device_download(self.device, out.ctypes.data_as(c_void_p), self.ptr, out.nbytes))
+        return out
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib.gr_device_free(self.device, self.ptr)
+            self.ptr = None
+
+
+def download(device, ptr, dtype, count):
+    out = np.empty(count, dtype=dtype)
+    check(lib.gr_device_download(device, out.ctypes.data_as(c_void_p), ptr, out.nbytes))
+    return out
+
+
+class RenderState:
+    """Per-frame device buffers + the frame sequence (render_state.hpp:97-197, main.cpp:2244-2526)."""
+
+    def __init__(self, width, height, device=0):
+        self.width, self.height, self.device = width, height, device
+        self.handle = c_void_p()
+        check(lib.gr_render_state_create(device, width, height, ctypes.byref(self.handle)))
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib.gr_render_state_destroy(self.handle)
+            self.handle = None
+
+    def render(self, program, metric, camera, out_ptr, background=None, features=None, cfg_values=None, options=None, stream=None):
+        """Enqueue one frame. `out_ptr`: device pointer to float4[width*height] (or None to stop after render-data);
+        `background`: (device_ptr, width, height, levels) or ((ptr1, ptr2), width, height, levels)."""
+        arr, n = None, 0
+        if cfg_values is not None:
+            n = len(cfg_values)
+            arr = (c_float * n)(*cfg_values)
+        bg1 = bg2 = None
+        bw = bh = bl = 0
+        if background is not None:
+            ptrs, bw, bh, bl = background
+            bg1, bg2 = ptrs if isinstance(ptrs, tuple) else (ptrs, ptrs)
+        if features is None:
+            features = metric.features()
+        check(lib.gr_render_frame(self.handle, program.handle, metric.handle, stream, ctypes.byref(camera),
+                                  ctypes.byref(features), arr, n, bg1, bg2, bw, bh, bl, out_ptr,
+                                  ctypes.byref(options) if options is not None else None))
+
+    def stage_ms(self):
+        out = {}
+        for i, name in enumerate(STAGE_NAMES):
+            ms = c_float()
+            check(lib.gr_render_state_stage_ms(self.handle, i, ctypes.byref(ms)))
+            out[name] = ms.value
+        return out
+
+    def attempts(self):
+        v = ctypes.c_ulonglong()
+        check(lib.gr_render_state_attempts(self.handle, ctypes.byref(v)))
+        return v.value
+
+    def buffer(self, which):
+        return lib.gr_render_state_buffer(self.handle, which)
+
+    def synchronize(self):
+        check(lib.gr_device_synchronize(self.device))
+
+
+def synthetic_background(width=1024, height=512, seed=0x5EED, stars=None):
+    """Deterministic equirectangular RGBA8 sky (the reference's PNG backgrounds are missing from the checkout):
+    smooth gradient + 10 degree latitude/longitude grid + point stars."""
+    rs = np.random.RandomState(seed)
+    y, x = np.mgrid[0:height, 0:width].astype(np.float32)
+    u, v = x / width, y / height
+    img = np.zeros((height, width, 4), dtype=np.float32)
+    img[..., 0] = 0.15 + 0.35 * (0.5 + 0.5 * np.sin(2 * np.pi * u))
+    img[..., 1] = 0.15 + 0.35 * v
+    img[..., 2] = 0.25 + 0.35 * (0.5 + 0.5 * np.cos(2 * np.pi * (u + v)))
+    lon = (u * 36.0) % 1.0
+    lat = (v * 18.0) % 1.0
+    line = (np.minimum(lon, 1 - lon) < 0.04) | (np.minimum(lat, 1 - lat) < 0.04)
+    img[line, :3] = 0.9
+    if stars is None:
+        stars = (width * height) // 400
+    sx = rs.randint(0, width, size=stars)
+    sy = rs.randint(0, height, size=stars)
+    bright = rs.uniform(0.5, 1.0, size=(stars, 1)).astype(np.float32) * rs.uniform(0.6, 1.0, size=(stars, 3)).astype(np.float32)
+    img[sy, sx, :3] = bright
+    img[..., 3] = 1.0
+    return (np.clip(img, 0, 1) * 255).astype(np.uint8)
+
+
+def pack_background(rgba):
+    """load_mipped_image (graphics_settings.cpp:152-212) -> (uint8 array [levels][h][w][4], levels)."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w = rgba.shape[:2]
+    levels = lib.gr_pack_mipped_background(None, w, h, None)
+    out = np.empty((levels, h, w, 4), dtype=np.uint8)
+    rc = lib.gr_pack_mipped_background(rgba.ctypes.data_as(c_void_p), w, h, out.ctypes.data_as(c_void_p))
+    if rc != levels:
+        raise GeodesicError("gr_pack_mipped_background failed")
+    return out, levels

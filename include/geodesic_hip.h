@@ -1,0 +1,293 @@
+/* geodesic_hip.h — C ABI of libgeodesic_hip.so, the MI355X (gfx950) implementation of the per-pixel
+ * geodesic ray pipeline of 20k/geodesic_raytracing.
+ *
+ * The reference has no C function API for this path; its boundary is
+ *   (1) the compile-time macro string  metrics::build_argument_string            metric.hpp:725-959
+ *       + dynamic_feature_config::generate_{dynamic,static}_argument_string       dynamic_feature_config.cpp:122-180
+ *       consumed by cl::build_program_with_cache({"cl.cl"}, ..., argument_string) metric_manager.hpp:88-108
+ *   (2) launches by kernel name: cl::command_queue::exec(name, args, global, local)
+ *       main.cpp:203, 2311, 2329, 2396, 2422, 2435, 2461, 2475, 2498, 2509, 2525
+ * Every entry point below replaces one of those; the replaced reference interface is cited at each
+ * declaration.  All device buffers are plain device pointers owned by the caller (the reference's
+ * cl::buffer ownership, render_state.hpp:172-196); kernels never allocate.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream); launches are asynchronous on it, like the
+ * reference's single in-order queue (main.cpp:1460).
+ *
+ * Every function returns 0 on success and a negative gr_status otherwise; gr_last_error() returns
+ * a thread-local message (the reference surfaces build errors through toolkit logging and
+ * script/JSON problems as std::runtime_error; kernels themselves report nothing).
+ */
+#ifndef GEODESIC_HIP_H
+#define GEODESIC_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gr_status {
+    GR_OK = 0,
+    GR_ERROR_INVALID_ARGUMENT = -1,
+    GR_ERROR_SCRIPT = -2,      /* metric script / JSON problem (std::runtime_error in the reference) */
+    GR_ERROR_COMPILE = -3,     /* device program build failure */
+    GR_ERROR_DEVICE = -4,      /* HIP runtime failure (no device, launch error, ...) */
+    GR_ERROR_BUFFER_TOO_SMALL = -5
+} gr_status;
+
+const char* gr_last_error(void);
+
+/* ---- data layouts shared with the device -------------------------------------------------- */
+
+/* struct lightray, cl.cl:813-824 / render_state.hpp:8-19; 96 bytes */
+typedef struct gr_lightray {
+    float position[4];
+    float velocity[4];
+    float initial_quat[4];
+    float acceleration[4];
+    float ku_uobsu;
+    float running_dlambda_dnew;
+    int terminated;            /* 0 = lost/absorbed, 1 = reached a boundary, 2 = skipped by the prepass */
+    int sx, sy;
+    int pad_[3];
+} gr_lightray;
+
+/* struct render_data, cl.cl:5066-5074 / render_state.hpp:21-29; 32 bytes */
+typedef struct gr_render_data {
+    float tex_coord[2];
+    float z_shift;
+    int sx, sy;
+    int terminated;
+    int side;
+    int pad_;
+} gr_render_data;
+
+/* struct dynamic_feature_config as packed by dynamic_feature_config::alloc_and_write_gpu_buffer
+ * (dynamic_feature_config.cpp:182-237): floats in alphabetical order, then bools as int. 48 bytes.
+ * Defaults: main.cpp:1123-1158. */
+typedef struct gr_features {
+    float adaptive_sampling_threshold;
+    float field_of_view;
+    float max_acceleration_change;
+    float max_precision_radius;
+    float min_step;
+    float ray_skip;
+    float universe_size;
+    int adaptive_sampling;
+    int redshift;
+    int reparameterisation;
+    int use_old_redshift;
+    int use_triangle_rendering;
+} gr_features;
+
+void gr_features_default(gr_features* out);
+
+/* ---- host side: metric -> macro string ----------------------------------------------------- */
+
+typedef struct gr_metric gr_metric;
+
+/* per-metric settings that steer the frame driver (metrics::metric_config, metric.hpp:330-357) */
+typedef struct gr_metric_info {
+    int is_big;                 /* GENERIC_BIG_METRIC */
+    int is_constant_theta;      /* GENERIC_CONSTANT_THETA */
+    int use_prepass;
+    int adaptive_precision;
+    float max_acceleration_change;
+    int num_dynamic_vars;       /* $cfg.NAME parameters */
+    int accel_ops;              /* DAG op count of GEO_ACCEL0..3 (VALU roofline accounting) */
+    int accel_transcendentals;
+    int coord_ops;              /* TO_COORDn + DISTANCE_FUNC */
+} gr_metric_info;
+
+/* One of the built-in metrics: "minkowski", "schwarzschild", "kerr_boyer", "alcubierre". */
+int gr_metric_builtin(const char* name, gr_metric** out);
+
+/* Loads <scripts_dir>/<name>.json (+ one level of inherit_settings) and the scripts it names, exactly
+ * as content_manager.cpp:9-112 does; the script dialect is the reference's (js_interop.cpp:665-959). */
+int gr_metric_load_script(const char* scripts_dir, const char* name, gr_metric** out);
+
+void gr_metric_destroy(gr_metric* m);
+int gr_metric_get_info(const gr_metric* m, gr_metric_info* out);
+const char* gr_metric_dynamic_var_name(const gr_metric* m, int index);
+float gr_metric_dynamic_var_default(const gr_metric* m, int index);
+
+/* metrics::build_argument_string (metric.hpp:725-959).
+ *   is_static = 0: "dynamic" program - expressions read cfg->NAME, features are read from the
+ *                  feature struct (KERNEL_IS_DYNAMIC);
+ *   is_static = 1: "substituted" program - cfg_values (NULL = defaults) and `features` are baked in
+ *                  as literals (KERNEL_IS_STATIC), metric_manager.hpp:153-166.
+ * Writes a NUL-terminated string; *needed receives the required capacity including the NUL. */
+int gr_metric_argument_string(const gr_metric* m, const gr_features* features, int is_static,
+                              const float* cfg_values, int num_cfg_values,
+                              char* buffer, size_t capacity, size_t* needed);
+
+/* ---- device program ------------------------------------------------------------------------- */
+
+typedef struct gr_program gr_program;
+
+/* cl::build_program_with_cache({"cl.cl"}, argument_string) (metric_manager.hpp:88-108): compiles the
+ * ray kernels for gfx950 specialised by `argument_string` (the macro set above; unknown macros such
+ * as CART_TO_POLn / FIX_LIGHTn / METRIC_TIME_G00 are accepted and ignored) and loads them on HIP
+ * device `device`.  Code objects are cached on disk keyed by a hash of source + arguments. */
+int gr_program_create(const char* argument_string, int device, gr_program** out);
+
+/* Compile only (no device needed): fills the on-disk cache; used by the build step. */
+int gr_program_precompile(const char* argument_string);
+
+void gr_program_destroy(gr_program* p);
+
+/* registers / scratch of a kernel as recorded in the code object (0 if unknown) */
+int gr_program_kernel_info(const gr_program* p, const char* kernel_name, int* vgprs, int* sgprs, int* scratch_bytes);
+
+/* ---- launchers: one per reference kernel, reference argument order -------------------------- */
+
+/* cart_to_generic_kernel, cl.cl:6018-6034; launched {1}/{1} at main.cpp:2311 */
+int gr_cart_to_generic(gr_program* p, void* stream, const void* position_cart_in, void* position_generic_out,
+                       int count, float flip, const void* cfg);
+
+/* init_basis_vectors, cl.cl:2483-2507; main.cpp:2329.  cartesian_basis_speed is a float3 there. */
+int gr_init_basis_vectors(gr_program* p, void* stream, const void* generic_in, int count,
+                          const float cartesian_basis_speed[3],
+                          void* e0_out, void* e1_out, void* e2_out, void* e3_out, const void* cfg);
+
+/* clear_termination_buffer, cl.cl:4997-5006; main.cpp:2396 */
+int gr_clear_termination_buffer(gr_program* p, void* stream, void* termination_buffer, int width, int height);
+
+/* init_rays_generic, cl.cl:3143-3251; main.cpp:2422 (prepass) and :2461.
+ * `tiled` (extension, pass 0 for reference behaviour): lay ray slots out in 8x8 pixel tiles; the ray
+ * buffer must then hold gr_tiled_slot_count(width, height) rays. */
+int gr_init_rays_generic(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
+                         void* rays, void* ray_count, int width, int height,
+                         const void* termination_buffer, int prepass_width, int prepass_height,
+                         int flip_geodesic_direction,
+                         const void* e0, const void* e1, const void* e2, const void* e3,
+                         const void* cfg, const void* dfg, int i_am_prepass, int tiled);
+int gr_tiled_slot_count(int width, int height);
+
+/* do_generic_rays, cl.cl:3954-4247; execute_kernel main.cpp:139-205.  `num_rays` sizes the grid
+ * (the reference launches width*height work-items); the device-side count is still honoured.
+ * ray_time_min/max, ray_write, mouse_x/y exist for signature parity (triangle path: unused here).
+ * attempt_counter (extension, may be NULL): device uint64 accumulating Verlet step attempts. */
+int gr_do_generic_rays(gr_program* p, void* stream, void* rays, const void* ray_count, int num_rays,
+                       void* ray_time_min, void* ray_time_max, const void* cfg, const void* dfg,
+                       int width, int height, int mouse_x, int mouse_y,
+                       void* ray_write, void* ray_write_counts, int max_write, void* attempt_counter);
+
+/* calculate_singularities, cl.cl:5008-5020; main.cpp:2435 */
+int gr_calculate_singularities(gr_program* p, void* stream, const void* finished_rays, const void* finished_count,
+                               int num_rays, void* termination_buffer, int width, int height);
+
+/* calculate_render_data, cl.cl:5135-5213; main.cpp:2475, 2509 */
+int gr_calculate_render_data(gr_program* p, void* stream, const void* rays, const void* ray_count, int num_rays,
+                             void* render_data, void* render_data_count, int width, int height,
+                             const void* cfg, const void* dfg);
+
+/* handle_adaptive_sampling, cl.cl:5223-5345; main.cpp:2498 */
+int gr_handle_adaptive_sampling(gr_program* p, void* stream, const void* rays, const void* ray_count,
+                                void* render_data, void* render_data_count,
+                                void* new_rays, void* new_ray_count,
+                                const void* camera_generic, const void* camera_quat,
+                                const void* e0, const void* e1, const void* e2, const void* e3,
+                                int width, int height, const void* cfg, const void* dfg);
+
+/* render, cl.cl:5453-5846; main.cpp:2525.  The image2d_t output becomes a float4[width*height] buffer,
+ * each image2d_array_t background becomes RGBA8 texels [levels][bg_height][bg_width] laid out as
+ * load_mipped_image does (graphics_settings.cpp:152-212). */
+int gr_render(gr_program* p, void* stream, const void* render_data, const void* render_data_count, int num_pixels,
+              void* out_rgba_f32, const void* background1, const void* background2,
+              int bg_width, int bg_height, int bg_levels,
+              int width, int height, int max_probes, const void* cfg, const void* dfg);
+
+/* render over image rows [row_begin,row_end) only (multi-GPU strips; render_data must be pixel-indexed) */
+int gr_render_rows(gr_program* p, void* stream, const void* render_data, void* out_rgba_f32,
+                   const void* background1, const void* background2, int bg_width, int bg_height, int bg_levels,
+                   int width, int height, int row_begin, int row_end, int max_probes, const void* cfg, const void* dfg);
+
+/* ---- fused MI355X path (no reference counterpart) ------------------------------------------- */
+
+/* Prepass termination flags from one fused trace at prepass resolution (replaces the sequence
+ * clear_termination_buffer / init_rays_generic / do_generic_rays / calculate_singularities,
+ * main.cpp:2387-2436). */
+int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
+                     void* termination_buffer, int prepass_width, int prepass_height,
+                     const void* e0, const void* e1, const void* e2, const void* e3,
+                     const void* cfg, const void* dfg);
+
+/* init -> integrate -> render-data for image rows [row_begin, row_end) in one launch; writes only
+ * render_data[sy*width+sx] (32 B per pixel).  termination_buffer may be NULL (no prepass). */
+int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
+                   void* render_data, int width, int height, int row_begin, int row_end,
+                   const void* termination_buffer, int prepass_width, int prepass_height,
+                   const void* e0, const void* e1, const void* e2, const void* e3,
+                   const void* cfg, const void* dfg, void* attempt_counter);
+
+/* ---- frame driver (the enqueue sequence of main.cpp:2244-2526) ------------------------------- */
+
+typedef struct gr_render_state gr_render_state;   /* render_state.hpp:97-197: all per-frame device buffers */
+
+/* camera, main.cpp:664-673: Cartesian (t,x,y,z) position, orientation quaternion (x,y,z,w) */
+typedef struct gr_camera {
+    float position[4];
+    float quat[4];
+    float basis_speed[3];   /* cartesian_basis_speed, main.cpp:2320-2327 */
+    float flip;             /* flip_sign > 0 puts the camera on the far side (negative r) */
+} gr_camera;
+void gr_camera_default(gr_camera* out);   /* pos (0,0,-4,0), axis-angle (1,0,0,-pi/2) */
+
+enum { GR_MODE_REFERENCE = 0,   /* one launch per reference kernel, 96-byte ray records in HBM */
+       GR_MODE_FUSED = 1 };     /* gr_prepass_fused + gr_trace_fused + gr_render */
+
+typedef struct gr_frame_options {
+    int mode;              /* GR_MODE_* */
+    int tiled;             /* reference mode only: 8x8-tile ray order (ignored when adaptive sampling is on) */
+    int use_prepass;       /* -1: per metric config (metric_cfg.use_prepass), 0/1 force */
+    int max_probes;        /* anisotropy, graphics_settings.hpp:34 (8) */
+    int row_begin, row_end;/* fused mode: rows traced and shaded by this device; 0,0 = whole image */
+    int time_kernels;      /* record HIP events around every stage (gr_render_state_stage_ms) */
+    int count_attempts;    /* accumulate Verlet step attempts (gr_render_state_attempts) */
+} gr_frame_options;
+void gr_frame_options_default(gr_frame_options* out);
+
+int gr_render_state_create(int device, int width, int height, gr_render_state** out);
+void gr_render_state_destroy(gr_render_state* s);
+
+/* Renders one frame into out_rgba_f32 (float4[width*height], device memory; in fused strip mode only
+ * rows [row_begin,row_end) are written).  cfg_values = the $cfg parameters (NULL = metric defaults). */
+int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void* stream,
+                    const gr_camera* camera, const gr_features* features,
+                    const float* cfg_values, int num_cfg_values,
+                    const void* background1, const void* background2, int bg_width, int bg_height, int bg_levels,
+                    void* out_rgba_f32, const gr_frame_options* options);
+
+/* stages for timing / buffer access */
+enum { GR_STAGE_CAMERA = 0, GR_STAGE_PREPASS = 1, GR_STAGE_INIT = 2, GR_STAGE_TRACE = 3, GR_STAGE_RENDER_DATA = 4,
+       GR_STAGE_ADAPTIVE = 5, GR_STAGE_RENDER = 6, GR_STAGE_COUNT = 7 };
+/* elapsed milliseconds of a stage of the last timed frame (synchronises on the stage's stop event) */
+int gr_render_state_stage_ms(gr_render_state* s, int stage, float* ms);
+/* total Verlet step attempts of the last frame rendered with count_attempts (synchronises the device) */
+int gr_render_state_attempts(gr_render_state* s, unsigned long long* attempts);
+
+enum { GR_BUF_RAYS_IN = 0, GR_BUF_RAYS_COUNT = 1, GR_BUF_RENDER_DATA = 2, GR_BUF_TERMINATION = 3, GR_BUF_CAMERA_GENERIC = 4,
+       GR_BUF_TETRAD0 = 5, GR_BUF_TETRAD1 = 6, GR_BUF_TETRAD2 = 7, GR_BUF_TETRAD3 = 8, GR_BUF_RAYS_ADAPTIVE = 9,
+       GR_BUF_RAYS_ADAPTIVE_COUNT = 10, GR_BUF_CFG = 11, GR_BUF_DFG = 12, GR_BUF_CAMERA_QUAT = 13 };
+/* device pointer of one of the state's buffers (NULL if not allocated) */
+void* gr_render_state_buffer(gr_render_state* s, int which);
+/* blocking copies for tests and tools */
+int gr_device_download(int device, void* host_dst, const void* device_src, size_t bytes);
+int gr_device_upload(int device, void* device_dst, const void* host_src, size_t bytes);
+int gr_device_alloc(int device, size_t bytes, void** out);
+int gr_device_free(int device, void* ptr);
+int gr_device_synchronize(int device);
+int gr_device_count(int* count);
+
+/* ---- host helper: background image ----------------------------------------------------------- */
+
+/* load_mipped_image (graphics_settings.cpp:152-212): packs an RGBA8 image and its box-filtered mip
+ * chain into `levels` same-size slices (mip i in the top-left corner of slice i, edge replicated).
+ * Returns the number of levels; `out` needs levels*width*height*4 bytes (call with out=NULL to query). */
+int gr_pack_mipped_background(const unsigned char* rgba, int width, int height, unsigned char* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
