@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mrays/s (and frames/s) of the geodesic ray pipeline at 3840x2160 Kerr.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete frame of BASELINE.json configs[2]: Kerr (Boyer-Lindquist, rs=1, a=0.45 i.e.
+a/M=0.9 - SURVEY.md section 8d), 3840x2160, adaptive sampling off (one primary ray per pixel), prepass
+as in the metric's config, all hot-path stages (camera tetrad, prepass, fused init+Verlet+render-data,
+anisotropic texture render) into a float4 HBM buffer.  Inputs (background, camera, cfg) are resident
+in HBM before the timed region.  With N > 1 the frame's rows are dealt to the ranks in 16-row blocks
+(block-cyclic), each rank renders its rows, and the final float4 rows are gathered on rank 0 over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
+TRACE_BYTES_PER_RAY = 32       # gr_trace_fused: one 32-byte render_data record per pixel
+STEP_OVERHEAD_FLOPS = 90       # integrator + step controller per Verlet attempt
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--metric", default="kerr_boyer")
+    ap.add_argument("--spin", type=float, default=0.45)
+    ap.add_argument("--mode", default="fused", choices=["fused", "reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(metric_name, cfg_values, features_kw, target_seconds):
+    """Times the CPU oracle (oracle/restate.cpp, all host cores) on a bounded sample of the same workload:
+    a low-resolution frame with the same camera and field of view (same ray distribution)."""
+    from oracle import build_restate
+    from oracle.refpipe import OraclePipeline, pack_features
+    import geodesic_raytracing_amd as gra
+    m = gra.Metric(metric_name)
+    so = build_restate.build(m.argument_string())
+    pipe = OraclePipeline(so)
+    cores = os.cpu_count() or 1
+    feats = pack_features(**features_kw)
+
+    def run(w, h):
+        t0 = time.perf_counter()
+        pipe.frame(w, h, cfg_values, feats, use_prepass=False, nthreads=cores, stages="trace")
+        return time.perf_counter() - t0
+
+    w, h = 96, 54
+    t = run(w, h)
+    rate = w * h / max(t, 1e-6)
+    # scale the sample (16:9) towards the target time, bounded
+    scale = (min(target_seconds, 30.0) * rate / (w * h)) ** 0.5
+    w2 = int(max(96, min(1920, round(96 * scale / 16) * 16)))
+    h2 = w2 * 9 // 16
+    t2 = run(w2, h2)
+    return {"value": round(w2 * h2 / t2 / 1e6, 6), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{w2}x{h2} frame of the same camera/metric (init + Verlet trace of every pixel, no prepass skip), "
+                      f"{t2:.1f} s on {cores} threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch
+    import torch.distributed as dist
+    import geodesic_raytracing_amd as gra
+    from geodesic_raytracing_amd import distributed as grd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    W, H = args.width, args.height
+    metric = gra.Metric(args.metric)
+    cfg_values = metric.cfg_values(a=args.spin) if "a" in metric.dynamic_vars else metric.cfg_values()
+    features = metric.features(adaptive_sampling=0)
+    program = gra.Program(metric.argument_string(), local_rank)
+    state = gra.RenderState(W, H, local_rank)
+    bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
+    bg = torch.from_numpy(bg_np).to(device)
+    camera = gra.default_camera()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    fused = args.mode == "fused"
+    plan = grd.StripPlan(H, world, block_rows=16)
+    out = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
+    gather = grd.FrameGather(plan, W, device, rank, world) if world > 1 else None
+
+    def frame(time_kernels=False, count_attempts=False):
+        if world == 1:
+            opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=int(time_kernels),
+                                     count_attempts=int(count_attempts))
+            state.render(program, metric, camera, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features, cfg_values, opts, stream)
+        else:
+            # this rank's row blocks (block-cyclic) -> compact strip buffer -> ONE gather to rank 0 + local un-permute
+            opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=rank, strip_count=world, block_rows=plan.block_rows, compact_out=1)
+            state.render(program, metric, camera, gather.local_buffer().data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features,
+                         cfg_values, opts, stream)
+            gather.run(out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    mrays = W * H / (elapsed / args.steps) / 1e6
+
+    # per-kernel timing (HIP events recorded on the launch stream) + step-attempt count, outside the headline timing
+    roofline = None
+    extra = {}
+    if world == 1:
+        trace_ms = []
+        stage_sum = {}
+        attempts = 0
+        for _ in range(max(3, min(args.steps, 10))):
+            frame(time_kernels=True, count_attempts=True)
+            torch.cuda.synchronize()
+            ms = state.stage_ms()
+            attempts = state.attempts()
+            trace_ms.append(ms["trace"])
+            for k, v in ms.items():
+                stage_sum.setdefault(k, []).append(v)
+        t_trace = float(np.mean(trace_ms)) * 1e-3
+        alg_bytes = TRACE_BYTES_PER_RAY * W * H if fused else 140 * W * H
+        achieved = alg_bytes / t_trace / 1e9
+        roofline = {"bound": "hbm", "kernel": "gr_trace_fused" if fused else "gr_do_generic_rays", "achieved": round(achieved, 3),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "avg_launch_ms": round(t_trace * 1e3, 4),
+                    "note": "register-resident ODE integrator: fp32 VALU bound, see valu_roofline (SURVEY.md 8d)"}
+        flops_per_attempt = metric.info.accel_ops + metric.info.coord_ops + STEP_OVERHEAD_FLOPS
+        tflops = flops_per_attempt * attempts / t_trace / 1e12
+        extra["valu_roofline"] = {"achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tflops / VALU_PEAK_TFLOPS, 4), "flops_per_attempt": flops_per_attempt,
+                                  "step_attempts_per_frame": int(attempts)}
+        extra["stage_ms"] = {k: round(float(np.mean(v)), 4) for k, v in stage_sum.items()}
+        extra["fps"] = round(1e3 / ms_per_step, 2)
+        rd = np.empty(W * H, dtype=gra.pipeline.RENDER_DATA_DTYPE)
+        gra.check(gra.lib.gr_device_download(local_rank, rd.ctypes.data_as(ctypes.c_void_p), state.buffer(gra.BUF_RENDER_DATA), rd.nbytes))
+        skipped = int((rd["terminated"] == 2).sum())
+        extra["traced_Mrays_per_s"] = round((W * H - skipped) / (elapsed / args.steps) / 1e6, 2)
+        extra["prepass_skipped_fraction"] = round(skipped / (W * H), 4)
+    else:
+        extra["fps"] = round(1e3 / ms_per_step, 2)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        feats_kw = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change)
+        cpu = cpu_baseline(args.metric, cfg_values, feats_kw, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "Mrays/sec at 3840x2160 Kerr (whole frame: prepass + init + adaptive Verlet + render-data + anisotropic render)",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.metric} (Boyer-Lindquist rs=1 a={args.spin}) {W}x{H}, camera (0,0,-4,0) fov 90, adaptive_sampling off, "
+                                   f"prepass {'on' if metric.info.use_prepass else 'off'}, tol {metric.info.max_acceleration_change:g}, "
+                                   f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
+                       "mode": args.mode, "parallelism": f"row-blocks x{world}" if world > 1 else "single"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,8 +44,9 @@ class Camera(ctypes.Structure):
 
 
 class FrameOptions(ctypes.Structure):
-    _fields_ = [("mode", c_int), ("tiled", c_int), ("use_prepass", c_int), ("max_probes", c_int), ("row_begin", c_int),
-                ("row_end", c_int), ("time_kernels", c_int), ("count_attempts", c_int)]
+    _fields_ = [("mode", c_int), ("tiled", c_int), ("use_prepass", c_int), ("max_probes", c_int), ("strip_rank", c_int),
+                ("strip_count", c_int), ("block_rows", c_int), ("compact_out", c_int), ("time_kernels", c_int),
+                ("count_attempts", c_int)]
 
 
 MODE_REFERENCE, MODE_FUSED = 0, 1
@@ -85,11 +86,12 @@ _SIGNATURES = {
     "gr_handle_adaptive_sampling": (c_int, [c_void_p] * 14 + [c_int, c_int, c_void_p, c_void_p]),
     "gr_render": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                           c_int, c_int, c_int, c_void_p, c_void_p]),
-    "gr_render_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                               c_int, c_int, c_int, c_void_p, c_void_p]),
+    "gr_render_strips": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "gr_strip_local_blocks": (c_int, [c_int, c_int, c_int, c_int]),
     "gr_prepass_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
-    "gr_trace_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+    "gr_trace_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gr_camera_default": (None, [ctypes.POINTER(Camera)]),
     "gr_frame_options_default": (None, [ctypes.POINTER(FrameOptions)]),

@@ -409,22 +409,30 @@ int gr_handle_adaptive_sampling(gr_program* p, void* stream, const void* rays, c
 int gr_render(gr_program* p, void* stream, const void* rdata, const void* rdata_count, int num_pixels, void* out,
               const void* bg1, const void* bg2, int bg_width, int bg_height, int bg_levels, int width, int height,
               int max_probes, const void* cfg, const void* dfg) {
-    int first = 0;
+    int block_pixels = num_pixels > 0 ? num_pixels : 1, rank = 0, count = 1, compact = 0;
     void* args[] = {&rdata, &rdata_count, &out, &bg1, &bg2, &bg_width, &bg_height, &bg_levels, &width, &height,
-                    &max_probes, &cfg, &dfg, &first, &num_pixels};
+                    &max_probes, &cfg, &dfg, &num_pixels, &block_pixels, &rank, &count, &compact};
     return launch(p, K_RENDER, stream, blocks(num_pixels, 256), 1, 256, 1, args);
 }
 
-// fused / strip mode: render_data is indexed by pixel, rows [row_begin,row_end) are one contiguous range
-int gr_render_rows(gr_program* p, void* stream, const void* rdata, void* out, const void* bg1, const void* bg2, int bg_width,
-                   int bg_height, int bg_levels, int width, int height, int row_begin, int row_end, int max_probes,
-                   const void* cfg, const void* dfg) {
-    if (row_begin < 0 || row_end > height || row_begin > row_end) return fail(GR_ERROR_INVALID_ARGUMENT, "bad row range");
-    int first = row_begin * width;
-    int num = (row_end - row_begin) * width;
+int gr_strip_local_blocks(int height, int block_rows, int strip_rank, int strip_count) {
+    if (block_rows <= 0 || strip_count <= 0) return 0;
+    int total = (height + block_rows - 1) / block_rows;
+    return strip_rank < total ? (total - strip_rank + strip_count - 1) / strip_count : 0;
+}
+
+// strip mode: render_data is indexed by pixel; shade this device's row blocks (block-cyclic)
+int gr_render_strips(gr_program* p, void* stream, const void* rdata, void* out, const void* bg1, const void* bg2, int bg_width,
+                     int bg_height, int bg_levels, int width, int height, int block_rows, int strip_rank, int strip_count,
+                     int compact_out, int max_probes, const void* cfg, const void* dfg) {
+    if (block_rows <= 0 || strip_count <= 0 || strip_rank < 0 || strip_rank >= strip_count)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip parameters");
+    int local_blocks = gr_strip_local_blocks(height, block_rows, strip_rank, strip_count);
+    int block_pixels = block_rows * width;
+    int num = local_blocks * block_pixels;
     const void* rdata_count = p ? p->huge_count : nullptr;
     void* args[] = {&rdata, &rdata_count, &out, &bg1, &bg2, &bg_width, &bg_height, &bg_levels, &width, &height,
-                    &max_probes, &cfg, &dfg, &first, &num};
+                    &max_probes, &cfg, &dfg, &num, &block_pixels, &strip_rank, &strip_count, &compact_out};
     return launch(p, K_RENDER, stream, blocks(num, 256), 1, 256, 1, args);
 }
 
@@ -438,15 +446,24 @@ int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, co
 }
 
 int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
-                   int height, int row_begin, int row_end, const void* term, int prepass_width, int prepass_height,
-                   const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg,
-                   void* attempt_counter) {
-    if (row_begin < 0 || row_end > height || row_begin > row_end) return fail(GR_ERROR_INVALID_ARGUMENT, "bad row range");
+                   int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
+                   int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
+                   const void* dfg, void* attempt_counter) {
     const int T = 8;
-    long long tiles = (long long)((width + T - 1) / T) * ((row_end - row_begin + T - 1) / T);
-    void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &row_begin, &row_end, &term, &prepass_width,
-                    &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter};
-    return launch(p, K_TRACE_FUSED, stream, (unsigned)tiles, 1, 64, 1, args);
+    if (strip_count <= 1) {   // one block covering the image
+        strip_count = 1;
+        strip_rank = 0;
+        block_rows = ((height + T - 1) / T) * T;
+    }
+    if (block_rows <= 0 || block_rows % T != 0 || strip_rank < 0 || strip_rank >= strip_count)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "block_rows must be a positive multiple of 8 and 0 <= strip_rank < strip_count");
+    if (strip_count > 1 && height > 1 && (height - 1) % block_rows == 0)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "the last image row must not start a block (its filter reads the row above)");
+    int local_blocks = gr_strip_local_blocks(height, block_rows, strip_rank, strip_count);
+    long long waves_per_block = (long long)((width + T - 1) / T) * (block_rows / T) + (strip_count > 1 ? (width + 63) / 64 : 0);
+    void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
+                    &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter};
+    return launch(p, K_TRACE_FUSED, stream, (unsigned)(waves_per_block * local_blocks), 1, 64, 1, args);
 }
 
 int gr_pack_mipped_background(const unsigned char* rgba, int width, int height, unsigned char* out) {

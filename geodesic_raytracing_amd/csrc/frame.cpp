@@ -74,8 +74,10 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->tiled = 1;
     o->use_prepass = -1;
     o->max_probes = 8;
-    o->row_begin = 0;
-    o->row_end = 0;
+    o->strip_rank = 0;
+    o->strip_count = 1;
+    o->block_rows = 16;
+    o->compact_out = 0;
     o->time_kernels = 0;
     o->count_attempts = 0;
 }
@@ -280,31 +282,27 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
 
     if (opt.mode == GR_MODE_FUSED) {
         if (adaptive) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused mode traces every pixel: turn adaptive_sampling off");
-        int row_begin = opt.row_begin, row_end = opt.row_end;
-        if (row_begin == 0 && row_end == 0) row_end = height;
+        int strip_count = opt.strip_count > 1 ? opt.strip_count : 1;
+        int strip_rank = strip_count > 1 ? opt.strip_rank : 0;
+        int block_rows = strip_count > 1 ? opt.block_rows : ((height + 7) / 8) * 8;
         if (use_prepass) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_prepass_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->termination_buffer, prepass_width,
                                       prepass_height, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg));
             GR_CHECK(end(GR_STAGE_PREPASS));
         }
-        // the texture filter reads the right/below neighbour (cl.cl:5509-5520): trace one halo row
-        int trace_end = row_end < height ? row_end + 1 : row_end;
-        int trace_begin = row_begin;
-        if (row_end == height && row_begin == height - 1 && row_begin > 0) trace_begin = row_begin - 1;   // last row looks up
+        // every device runs the (tiny) prepass itself; its own row blocks (+ one halo row each) are traced here
         GR_CHECK(begin(GR_STAGE_TRACE));
-        GR_CHECK(gr_trace_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, trace_begin,
-                                trace_end, use_prepass ? s->termination_buffer : nullptr,
+        GR_CHECK(gr_trace_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
+                                strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
                                 use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
                                 s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
         GR_CHECK(end(GR_STAGE_TRACE));
         if (out) {
-            // shade rows [row_begin,row_end): render_data is indexed by pixel, so a row range is a contiguous slice
-            int count_host = width * height;
-            HIP_CHECK(hipMemcpyAsync(s->render_data_count, &count_host, 4, hipMemcpyHostToDevice, stream));
             GR_CHECK(begin(GR_STAGE_RENDER));
-            GR_CHECK(gr_render_rows(p, stream, s->render_data, out, bg1, bg2, bg_width, bg_height, bg_levels, width, height,
-                                    row_begin, row_end, opt.max_probes, s->cfg, s->dfg));
+            GR_CHECK(gr_render_strips(p, stream, s->render_data, out, bg1, bg2, bg_width, bg_height, bg_levels, width, height,
+                                      strip_count > 1 ? block_rows : height, strip_rank, strip_count,
+                                      strip_count > 1 ? opt.compact_out : 0, opt.max_probes, s->cfg, s->dfg));
             GR_CHECK(end(GR_STAGE_RENDER));
         }
         return GR_OK;

@@ -968,18 +968,33 @@ extern "C" __global__ void gr_calculate_render_data(const lightray* __restrict__
 // init -> integrate -> render-data for one pixel per lane, 8x8 tiles, nothing but the 32-byte result is stored
 extern "C" __global__ void __launch_bounds__(64)
 gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
-               render_data* __restrict__ rdata, int width, int height, int row_begin, int row_end,
+               render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                cfg_t cfg, dfg_t dfg, unsigned long long* __restrict__ attempt_counter) {
+    // Image rows are dealt to devices in blocks of `block_rows` rows (block-cyclic: global block gb belongs to
+    // device gb % strip_count).  One workgroup = one wave = one 8x8 pixel tile of a block; when the image is
+    // split, each block is followed by 64x1 "halo" waves tracing the row just below it, which the texture filter
+    // of the block's last row reads (cl.cl:5509-5520).  strip_count == 1: one block covering the whole image.
     const int T = GR_TILE;
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    int tiles_x = (width + T - 1) / T;
-    int tile = id / (T * T);
-    int in = id % (T * T);
-    int cx = (tile % tiles_x) * T + in % T;
-    int cy = row_begin + (tile / tiles_x) * T + in / T;
-    if (cx >= width || cy >= row_end) return;
+    const int lane = threadIdx.x;
+    const int tiles_x = (width + T - 1) / T;
+    const int tile_rows = block_rows / T;
+    const int halo_waves = strip_count > 1 ? (width + 63) / 64 : 0;
+    const int waves_per_block = tiles_x * tile_rows + halo_waves;
+    const int local_block = blockIdx.x / waves_per_block;
+    const int within = blockIdx.x % waves_per_block;
+    const int r0 = (local_block * strip_count + strip_rank) * block_rows;
+    int cx, cy;
+    if (within < tiles_x * tile_rows) {
+        cx = (within % tiles_x) * T + lane % T;
+        cy = r0 + (within / tiles_x) * T + lane / T;
+        if (cy >= r0 + block_rows) return;
+    } else {
+        cx = (within - tiles_x * tile_rows) * 64 + lane;
+        cy = r0 + block_rows;
+    }
+    if (cx >= width || cy >= height) return;
 
     lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
     int terminated = 0;
@@ -1214,16 +1229,22 @@ extern "C" __global__ void gr_render(const render_data* __restrict__ rdata, cons
                                      const uchar4* __restrict__ bg1_texels, const uchar4* __restrict__ bg2_texels,
                                      int bg_width, int bg_height, int bg_levels,
                                      int width, int height, int maxProbes, cfg_t cfg, dfg_t dfg,
-                                     int first_pixel, int num_pixels) {
-    // first_pixel / num_pixels (extension): shade a contiguous pixel range; (0, width*height) = reference
+                                     int num_pixels, int block_pixels, int strip_rank, int strip_count, int compact_out) {
+    // Extension over the reference signature: shade only this device's row blocks.  Work-item gid covers pixel
+    // `off` of local block `lb`; the global block is lb*strip_count + strip_rank (block-cyclic rows).  With
+    // compact_out the device's blocks are written back to back (gather-friendly).  The reference launch is
+    // (num_pixels = block_pixels = width*height, strip_rank 0, strip_count 1, compact_out 0).
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= num_pixels) return;
-    int id = first_pixel + gid;
-    if (id >= *rdata_count) return;
+    int lb = gid / block_pixels;
+    int off = gid - lb * block_pixels;
+    int id = (lb * strip_count + strip_rank) * block_pixels + off;
+    if (id >= *rdata_count || id >= width * height) return;
     render_data rdat = rdata[id];
     int sx = rdat.sx, sy = rdat.sy, side = rdat.side;
+    const int out_index = compact_out ? lb * block_pixels + off : sy * width + sx;
     if (rdat.terminated != 1) {
-        out[sy * width + sx] = f4(0, 0, 0, 1);
+        out[out_index] = f4(0, 0, 0, 1);
         return;
     }
     background bg1{bg1_texels, bg_width, bg_height, bg_levels};
@@ -1321,5 +1342,5 @@ extern "C" __global__ void gr_render(const render_data* __restrict__ rdata, cons
         end_result.x = l.x; end_result.y = l.y; end_result.z = l.z;
     }
 #endif
-    out[sy * width + sx] = end_result;
+    out[out_index] = end_result;
 }

@@ -198,10 +198,15 @@ int gr_render(gr_program* p, void* stream, const void* render_data, const void* 
               int bg_width, int bg_height, int bg_levels,
               int width, int height, int max_probes, const void* cfg, const void* dfg);
 
-/* render over image rows [row_begin,row_end) only (multi-GPU strips; render_data must be pixel-indexed) */
-int gr_render_rows(gr_program* p, void* stream, const void* render_data, void* out_rgba_f32,
-                   const void* background1, const void* background2, int bg_width, int bg_height, int bg_levels,
-                   int width, int height, int row_begin, int row_end, int max_probes, const void* cfg, const void* dfg);
+/* render restricted to this device's row blocks (block-cyclic rows, see gr_trace_fused); render_data must be
+ * pixel-indexed.  compact_out = 1 writes the device's blocks back to back (block i of this device at
+ * out + i*block_rows*width float4), which is the layout the multi-GPU gather ships. */
+int gr_render_strips(gr_program* p, void* stream, const void* render_data, void* out_rgba_f32,
+                     const void* background1, const void* background2, int bg_width, int bg_height, int bg_levels,
+                     int width, int height, int block_rows, int strip_rank, int strip_count, int compact_out,
+                     int max_probes, const void* cfg, const void* dfg);
+/* number of row blocks device `strip_rank` owns */
+int gr_strip_local_blocks(int height, int block_rows, int strip_rank, int strip_count);
 
 /* ---- fused MI355X path (no reference counterpart) ------------------------------------------- */
 
@@ -213,10 +218,12 @@ int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, co
                      const void* e0, const void* e1, const void* e2, const void* e3,
                      const void* cfg, const void* dfg);
 
-/* init -> integrate -> render-data for image rows [row_begin, row_end) in one launch; writes only
- * render_data[sy*width+sx] (32 B per pixel).  termination_buffer may be NULL (no prepass). */
+/* init -> integrate -> render-data in one launch; writes only render_data[sy*width+sx] (32 B per pixel).
+ * Rows are dealt to devices block-cyclically: global block b (block_rows rows, multiple of 8) belongs to device
+ * b % strip_count; each block additionally traces the one row below it (texture-filter halo).  strip_count <= 1
+ * traces the whole image.  termination_buffer may be NULL (no prepass). */
 int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
-                   void* render_data, int width, int height, int row_begin, int row_end,
+                   void* render_data, int width, int height, int block_rows, int strip_rank, int strip_count,
                    const void* termination_buffer, int prepass_width, int prepass_height,
                    const void* e0, const void* e1, const void* e2, const void* e3,
                    const void* cfg, const void* dfg, void* attempt_counter);
@@ -242,7 +249,10 @@ typedef struct gr_frame_options {
     int tiled;             /* reference mode only: 8x8-tile ray order (ignored when adaptive sampling is on) */
     int use_prepass;       /* -1: per metric config (metric_cfg.use_prepass), 0/1 force */
     int max_probes;        /* anisotropy, graphics_settings.hpp:34 (8) */
-    int row_begin, row_end;/* fused mode: rows traced and shaded by this device; 0,0 = whole image */
+    int strip_rank;        /* fused mode, multi-GPU: image rows are dealt in blocks of block_rows rows,          */
+    int strip_count;       /*   global block b belongs to device b % strip_count (1 = whole image on this device) */
+    int block_rows;        /*   multiple of 8                                                                      */
+    int compact_out;       /*   1: write this device's blocks back to back into out (gather layout)               */
     int time_kernels;      /* record HIP events around every stage (gr_render_state_stage_ms) */
     int count_attempts;    /* accumulate Verlet step attempts (gr_render_state_attempts) */
 } gr_frame_options;

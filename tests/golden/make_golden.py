@@ -1,0 +1,94 @@
+"""Generates the golden vectors under tests/golden/ by running the REFERENCE's own device source
+(/root/reference/cl.cl compiled for x86-64, see oracle/build_ref.py) through the reference frame
+sequence on small images.  Runs only in the build container (needs /root/reference); the .npz files
+it writes are data: inputs (camera, cfg, features, background seed) and the reference's outputs
+(tetrad, initial rays, traced rays, render_data, pixels).
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import geodesic_raytracing_amd as gra  # noqa: E402
+from oracle import build_ref  # noqa: E402
+from oracle.refpipe import OraclePipeline, pack_features  # noqa: E402
+
+BG_SIZE = (256, 128)
+BG_SEED = 0x5EED
+
+
+def quat_axis_angle(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    s = np.sin(angle / 2)
+    return [float(axis[0] * s), float(axis[1] * s), float(axis[2] * s), float(np.cos(angle / 2))]
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return [aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw,
+            aw * bw - ax * bx - ay * by - az * bz]
+
+
+DEFAULT_QUAT = quat_axis_angle([1, 0, 0], -np.pi / 2)
+TILTED_QUAT = quat_mul(quat_axis_angle([0, 0, -1], 0.35), quat_mul(quat_axis_angle([0, 1, 0], 0.2), DEFAULT_QUAT))
+
+# name -> dict(metric, size, cfg overrides, features overrides, camera, prepass)
+CASES = {
+    "minkowski": dict(metric="minkowski", size=(48, 27)),
+    "minkowski_tilted": dict(metric="minkowski", size=(48, 27), camera_pos=[0.5, 3.0, -6.0, 2.0], camera_quat=TILTED_QUAT),
+    "schwarzschild": dict(metric="schwarzschild", size=(48, 27)),
+    "schwarzschild_tilted": dict(metric="schwarzschild", size=(48, 27), camera_pos=[0.0, 3.0, -6.0, 2.0], camera_quat=TILTED_QUAT),
+    "schwarzschild_redshift": dict(metric="schwarzschild", size=(48, 27), features=dict(redshift=1)),
+    "kerr": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45)),
+    "kerr_far": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), camera_pos=[0.0, 0.0, -15.0, 0.0]),
+    "kerr_tilted": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), camera_pos=[0.0, 3.0, -6.0, 2.0], camera_quat=TILTED_QUAT),
+    "kerr_superextremal": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.9)),
+    "kerr_prepass": dict(metric="kerr_boyer", size=(96, 64), cfg=dict(a=0.45), prepass=True),
+    "kerr_adaptive_sampling": dict(metric="kerr_boyer", size=(48, 28), cfg=dict(a=0.45), features=dict(adaptive_sampling=1, adaptive_sampling_threshold=32.0)),
+    "alcubierre": dict(metric="alcubierre", size=(48, 27), features=dict(redshift=1), camera_pos=[0.0, 0.0, -6.0, 0.5]),
+    "kerr_moving_observer": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.3, 0.0, 0.2], features=dict(redshift=1)),
+}
+
+
+def make_case(name, spec, scripts_dir=None):
+    metric = gra.Metric(spec["metric"], spec.get("scripts_dir", scripts_dir))
+    so = build_ref.build(spec["metric"] if not spec.get("tag") else spec["tag"], metric.argument_string())
+    cfg = metric.cfg_values(**spec.get("cfg", {}))
+    feats = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change)
+    feats.update(spec.get("features", {}))
+    w, h = spec["size"]
+    bg_rgba = gra.synthetic_background(*BG_SIZE, seed=BG_SEED)
+    bg, levels = gra.pack_background(bg_rgba)
+    pipe = OraclePipeline(so)
+    prepass = bool(spec.get("prepass", False))
+    res = pipe.frame(w, h, cfg, pack_features(**feats), camera_pos=spec.get("camera_pos", (0, 0, -4, 0)),
+                     camera_quat=spec.get("camera_quat", DEFAULT_QUAT), use_prepass=prepass, background=(bg, levels),
+                     basis_speed=spec.get("basis_speed", (0, 0, 0)))
+    meta = dict(metric=spec["metric"], width=w, height=h, cfg=cfg, features=feats, camera_pos=list(map(float, spec.get("camera_pos", (0, 0, -4, 0)))),
+                camera_quat=list(map(float, spec.get("camera_quat", DEFAULT_QUAT))), prepass=prepass, bg_size=BG_SIZE, bg_seed=BG_SEED,
+                basis_speed=list(map(float, spec.get("basis_speed", (0, 0, 0)))), max_probes=8,
+                argument_string_fnv=hex(hash(metric.argument_string()) & 0xffffffff))
+    arrays = {k: v for k, v in res.items() if isinstance(v, np.ndarray)}
+    if "adaptive_count" in res:
+        meta["adaptive_count"] = res["adaptive_count"]
+    arrays["pixels"] = arrays["pixels"].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=json.dumps(meta), **arrays)
+    term = np.bincount(res["rays"]["terminated"], minlength=3)
+    print(f"{name}: rays {len(res['rays'])} terminated {term.tolist()} pixel mean {arrays['pixels'][..., :3].mean():.4f}")
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for name, spec in CASES.items():
+        if only and name not in only:
+            continue
+        make_case(name, spec)

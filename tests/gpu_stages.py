@@ -1,0 +1,125 @@
+"""Helpers for the GPU parity tests: run single pipeline stages through the C ABI on explicit buffers."""
+import ctypes
+import json
+import os
+
+import numpy as np
+
+import geodesic_raytracing_amd as gra
+from geodesic_raytracing_amd.pipeline import DeviceBuffer, LIGHTRAY_DTYPE, RENDER_DATA_DTYPE
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+_programs = {}
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return meta, z
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+def program_for(metric_name):
+    if metric_name not in _programs:
+        m = gra.Metric(metric_name)
+        _programs[metric_name] = (m, gra.Program(m.argument_string(), 0))
+    return _programs[metric_name]
+
+
+def features_from(meta):
+    f = gra.default_features()
+    for k, v in meta["features"].items():
+        setattr(f, k, v)
+    return f
+
+
+def buf(arr):
+    return DeviceBuffer.from_numpy(0, np.ascontiguousarray(arr))
+
+
+class Stages:
+    """Device-side state for one golden case; each method runs exactly one reference kernel."""
+
+    def __init__(self, meta):
+        self.meta = meta
+        self.metric, self.program = program_for(meta["metric"])
+        self.w, self.h = meta["width"], meta["height"]
+        self.features = features_from(meta)
+        self.dfg = buf(np.frombuffer(bytes(self.features), dtype=np.uint8))
+        cfg = np.array(meta["cfg"] if meta["cfg"] else [0.0], dtype=np.float32)
+        self.cfg = buf(cfg)
+        self.quat = buf(np.array(meta["camera_quat"], dtype=np.float32))
+        self.p = self.program.handle
+
+    def camera(self):
+        cart = buf(np.array(self.meta["camera_pos"], dtype=np.float32))
+        generic = DeviceBuffer(0, 16)
+        gra.check(gra.lib.gr_cart_to_generic(self.p, None, cart.ptr, generic.ptr, 1, 0.0, self.cfg.ptr))
+        e = [DeviceBuffer(0, 16) for _ in range(4)]
+        speed = (ctypes.c_float * 3)(*self.meta["basis_speed"])
+        gra.check(gra.lib.gr_init_basis_vectors(self.p, None, generic.ptr, 1, speed, e[0].ptr, e[1].ptr, e[2].ptr, e[3].ptr, self.cfg.ptr))
+        return generic.to_numpy(np.float32, 4), np.stack([b.to_numpy(np.float32, 4) for b in e])
+
+    def init_rays(self, camera_generic, tetrad, termination=None, prepass_size=None, tiled=0, width=None, height=None, i_am_prepass=0):
+        w, h = width or self.w, height or self.h
+        cam = buf(camera_generic.astype(np.float32))
+        e = [buf(tetrad[i].astype(np.float32)) for i in range(4)]
+        slots = gra.lib.gr_tiled_slot_count(w, h) if tiled else w * h
+        rays = DeviceBuffer(0, slots * 96)
+        count = buf(np.zeros(1, dtype=np.int32))
+        term = buf(termination.astype(np.int32)) if termination is not None else buf(np.zeros(max(w * h, 1), dtype=np.int32))
+        pw, ph = prepass_size if prepass_size else (w, h)
+        gra.check(gra.lib.gr_init_rays_generic(self.p, None, cam.ptr, self.quat.ptr, rays.ptr, count.ptr, w, h, term.ptr, pw, ph, 0,
+                                               e[0].ptr, e[1].ptr, e[2].ptr, e[3].ptr, self.cfg.ptr, self.dfg.ptr, i_am_prepass, tiled))
+        n = int(count.to_numpy(np.int32, 1)[0])
+        return rays.to_numpy(LIGHTRAY_DTYPE, slots)[:n]
+
+    def trace(self, rays_init, count_attempts=False):
+        n = len(rays_init)
+        rays = buf(rays_init)
+        count = buf(np.array([n], dtype=np.int32))
+        wc = DeviceBuffer(0, max(n, 1) * 4)
+        att = buf(np.zeros(1, dtype=np.uint64))
+        gra.check(gra.lib.gr_do_generic_rays(self.p, None, rays.ptr, count.ptr, n, None, None, self.cfg.ptr, self.dfg.ptr, self.w, self.h,
+                                             0, 0, None, wc.ptr, 0, att.ptr))
+        out = rays.to_numpy(LIGHTRAY_DTYPE, n)
+        if count_attempts:
+            return out, int(att.to_numpy(np.uint64, 1)[0])
+        return out
+
+    def render_data(self, rays, base=None):
+        n = len(rays)
+        d_rays = buf(rays)
+        count = buf(np.array([n], dtype=np.int32))
+        init = np.zeros(self.w * self.h, dtype=RENDER_DATA_DTYPE) if base is None else base
+        rdata = buf(init)
+        rcount = buf(np.zeros(1, dtype=np.int32))
+        gra.check(gra.lib.gr_calculate_render_data(self.p, None, d_rays.ptr, count.ptr, n, rdata.ptr, rcount.ptr, self.w, self.h,
+                                                   self.cfg.ptr, self.dfg.ptr))
+        return rdata.to_numpy(RENDER_DATA_DTYPE, self.w * self.h)
+
+    def render(self, rdata, background, levels, max_probes=8):
+        d_r = buf(rdata)
+        count = buf(np.array([self.w * self.h], dtype=np.int32))
+        bg = buf(background)
+        out = buf(np.zeros((self.h, self.w, 4), dtype=np.float32))
+        bh, bw = background.shape[1], background.shape[2]
+        gra.check(gra.lib.gr_render(self.p, None, d_r.ptr, count.ptr, self.w * self.h, out.ptr, bg.ptr, bg.ptr, bw, bh, levels, self.w,
+                                    self.h, max_probes, self.cfg.ptr, self.dfg.ptr))
+        return out.to_numpy(np.float32, (self.h, self.w, 4))
+
+
+def circ_diff(a, b):
+    """difference of normalised texture coordinates with period 1"""
+    d = np.abs(a - b) % 1.0
+    return np.minimum(d, 1.0 - d)
+
+
+def rel_err(a, b, floor=1e-3):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)

@@ -1,0 +1,164 @@
+"""CPU tests of the host code generator: macro-set contract (metric.hpp:725-959) and the mathematics of the
+generated expressions (partials = finite differences of the metric, GEO_ACCEL = -Gamma v v)."""
+import math
+
+import numpy as np
+import pytest
+
+import geodesic_raytracing_amd as gra
+from macro_eval import MacroSet, parse_macros
+
+CASES = {
+    "minkowski": (dict(), [0.3, 1.0, -2.0, 0.5]),
+    "schwarzschild": (dict(), [0.0, 4.0, math.pi / 2, -0.7]),
+    "kerr_boyer": (dict(rs=1.0, a=0.45), [0.0, 3.5, 1.1, 0.4]),
+    "alcubierre": (dict(velocity=2.0, sigma=1.0, R=2.0), [0.4, 1.9, 0.6, -0.8]),
+}
+
+REQUIRED = (["RS_IMPL", "C_IMPL", "GENERIC_METRIC", "VERLET_INTEGRATION_GENERIC", "DISTANCE_FUNC", "TEMPORARIES0", "METRIC_TIME_G00",
+             "KERNEL_IS_DYNAMIC", "DYNAMIC_FLOAT_FEATURES", "DYNAMIC_BOOL_FEATURES", "LINEAR_FRAMEBUFFER"] +
+            [f"{p}{i}" for p in ("TO_COORD", "TO_DCOORD", "FROM_COORD", "FROM_DCOORD", "W_V") for i in range(1, 5)] +
+            [f"{p}{i}" for p in ("GEO_ACCEL", "FIX_LIGHT", "CART_TO_POL", "CART_TO_POL_D") for i in range(4)])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_macro_set_contract(name):
+    m = gra.Metric(name)
+    macros = parse_macros(m.argument_string())
+    for k in REQUIRED:
+        assert k in macros, k
+    n_i, n_p = (16, 64) if m.info.is_big else (4, 16)
+    assert ("GENERIC_BIG_METRIC" in macros) == bool(m.info.is_big)
+    for i in range(1, n_i + 1):
+        assert f"F{i}_I" in macros
+    for i in range(1, n_p + 1):
+        assert f"F{i}_P" in macros
+    assert ("GENERIC_CONSTANT_THETA" in macros) == bool(m.info.is_constant_theta)
+    assert ("DYNVARS" in macros) == (m.info.num_dynamic_vars > 0)
+    if m.info.num_dynamic_vars:
+        assert macros["DYNVARS"].split(",") == m.dynamic_vars
+    assert ("ADAPTIVE_PRECISION" in macros) == bool(m.info.adaptive_precision)
+    # the feature struct order is what dynamic_feature_config packs: alphabetical floats, then alphabetical bools
+    assert macros["DYNAMIC_FLOAT_FEATURES"].split(",") == sorted(macros["DYNAMIC_FLOAT_FEATURES"].split(","))
+    assert macros["DYNAMIC_BOOL_FEATURES"].split(",") == ["adaptive_sampling", "redshift", "reparameterisation", "use_old_redshift",
+                                                          "use_triangle_rendering"]
+    # no whitespace inside any value (the string is split on spaces by every consumer)
+    assert all(" " not in v for v in macros.values())
+
+
+def test_expected_kernel_variants():
+    """which metrics take which device path"""
+    info = {n: gra.Metric(n).info for n in CASES}
+    assert not info["minkowski"].is_big and not info["minkowski"].is_constant_theta and not info["minkowski"].adaptive_precision
+    assert not info["schwarzschild"].is_big and info["schwarzschild"].is_constant_theta
+    assert info["kerr_boyer"].is_big and not info["kerr_boyer"].is_constant_theta and info["kerr_boyer"].use_prepass
+    assert info["alcubierre"].is_big
+    m = parse_macros(gra.Metric("kerr_boyer").argument_string())
+    assert [m[f"W_V{i}"] for i in range(1, 5)] == ["1", "1", "8", "32"]
+    assert "SINGULARITY_DETECTION" in m
+    m = parse_macros(gra.Metric("schwarzschild").argument_string())
+    assert [m[f"W_V{i}"] for i in range(1, 5)] == ["1", "1", "8", "8"]
+    assert float(m["SINGULAR_TERMINATOR"].rstrip("f")) == pytest.approx(1.05, rel=1e-6)
+    assert parse_macros(gra.Metric("minkowski").argument_string())["GEO_ACCEL1"] in ("0.0f", "(-0.0f)")
+    assert "UNCONDITIONALLY_NONSINGULAR" in parse_macros(gra.Metric("alcubierre").argument_string())
+
+
+def test_static_argument_string_bakes_parameters():
+    m = gra.Metric("kerr_boyer")
+    s = m.argument_string(features=m.features(adaptive_sampling=0), static=True, cfg_values=m.cfg_values(a=0.45))
+    macros = parse_macros(s)
+    assert "KERNEL_IS_STATIC" in macros and "KERNEL_IS_DYNAMIC" not in macros
+    assert "cfg->" not in s.replace("-DDYNVARS", "")
+    assert macros["FEATURE_universe_size"] == "20.0f"
+    assert macros["FEATURE_adaptive_sampling"] == "0"
+    ms_dyn, ms_sta = MacroSet(m.argument_string()), MacroSet(s)
+    pos, vel = [0.0, 3.5, 1.1, 0.4], [-1.2, 0.3, 0.05, 0.1]
+    a = ms_dyn.accel(pos, vel, dict(rs=1.0, a=0.45))
+    b = ms_sta.accel(pos, vel, {})
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_partials_are_derivatives_of_the_metric(name):
+    cfg, pos = CASES[name]
+    ms = MacroSet(gra.Metric(name).argument_string())
+    h = 1e-5
+    for k in range(4):
+        p1, p0 = list(pos), list(pos)
+        p1[k] += h
+        p0[k] -= h
+        g1, g0 = ms.metric(p1, cfg), ms.metric(p0, cfg)
+        for i in range(4):
+            for j in range(4):
+                fd = (g1[i][j] - g0[i][j]) / (2 * h)
+                assert ms.partial(pos, k, i, j, cfg) == pytest.approx(fd, rel=2e-5, abs=2e-6), (k, i, j)
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n != "schwarzschild"])
+def test_geo_accel_is_minus_christoffel_v_v(name):
+    cfg, pos = CASES[name]
+    ms = MacroSet(gra.Metric(name).argument_string())
+    g = np.array(ms.metric(pos, cfg))
+    ginv = np.linalg.inv(g)
+    dg = np.array([[[ms.partial(pos, k, i, j, cfg) for j in range(4)] for i in range(4)] for k in range(4)])
+    gamma = np.zeros((4, 4, 4))
+    for i in range(4):
+        for k in range(4):
+            for l in range(4):
+                gamma[i, k, l] = 0.5 * sum(ginv[i, m] * (dg[l, m, k] + dg[k, m, l] - dg[m, k, l]) for m in range(4))
+    rng = np.random.RandomState(1)
+    for _ in range(4):
+        v = rng.uniform(-1, 1, 4)
+        want = -np.einsum("ikl,k,l->i", gamma, v, v)
+        got = np.array(ms.accel(pos, list(v), cfg))
+        assert np.allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
+def test_schwarzschild_equatorial_acceleration_known_answer():
+    """GEO_ACCEL of the constant-theta kernel: the textbook equatorial Schwarzschild geodesic equations (rs = 1)"""
+    ms = MacroSet(gra.Metric("schwarzschild").argument_string())
+    r = 4.0
+    pos, v = [0.0, r, math.pi / 2, 0.3], [1.3, -0.4, 0.0, 0.11]
+    f = 1 - 1 / r
+    want_t = -(1 / (r * r * f)) * v[0] * v[1]
+    want_r = -(f / (2 * r * r)) * v[0] ** 2 + (1 / (2 * r * r * f)) * v[1] ** 2 + r * f * v[3] ** 2
+    want_p = -(2 / r) * v[1] * v[3]
+    got = ms.accel(pos, v)
+    assert got[0] == pytest.approx(want_t, rel=1e-5)
+    assert got[1] == pytest.approx(want_r, rel=1e-5)
+    assert got[2] == 0.0
+    assert got[3] == pytest.approx(want_p, rel=1e-5)
+
+
+def test_kerr_reduces_to_schwarzschild_at_zero_spin():
+    kerr = MacroSet(gra.Metric("kerr_boyer").argument_string())
+    pos, v = [0.0, 5.0, 1.2, 0.3], [1.1, 0.2, -0.05, 0.07]
+    a = kerr.accel(pos, v, dict(rs=1.0, a=0.0))
+    r, th = pos[1], pos[2]
+    f = 1 - 1 / r
+    want_t = -(1 / (r * r * f)) * v[0] * v[1]
+    want_r = -(f / (2 * r * r)) * v[0] ** 2 + (1 / (2 * r * r * f)) * v[1] ** 2 + r * f * (v[2] ** 2 + math.sin(th) ** 2 * v[3] ** 2)
+    want_th = -(2 / r) * v[1] * v[2] + math.sin(th) * math.cos(th) * v[3] ** 2
+    want_ph = -(2 / r) * v[1] * v[3] - 2 * (math.cos(th) / math.sin(th)) * v[2] * v[3]
+    assert np.allclose(a, [want_t, want_r, want_th, want_ph], rtol=1e-5, atol=1e-7)
+
+
+def test_coordinate_differentials():
+    """TO_DCOORDn / FROM_DCOORDn are total differentials of TO_COORDn / FROM_COORDn (metric.hpp:247-274)"""
+    ms = MacroSet(gra.Metric("minkowski").argument_string())
+    pos, d = [0.2, 1.5, -2.5, 0.7], [0.1, -0.3, 0.2, 0.5]
+    h = 1e-6
+    for prefix in ("TO", "FROM"):
+        p = pos if prefix == "TO" else [0.2, 3.0, 1.1, -0.6]
+        e1 = ms.env([a + h * b for a, b in zip(p, d)])
+        e0 = ms.env([a - h * b for a, b in zip(p, d)])
+        ed = ms.env(p, dpos=d)
+        for i in range(1, 5):
+            fd = (ms.value(f"{prefix}_COORD{i}", e1) - ms.value(f"{prefix}_COORD{i}", e0)) / (2 * h)
+            assert ms.value(f"{prefix}_DCOORD{i}", ed) == pytest.approx(fd, rel=1e-5, abs=1e-7)
+
+
+def test_op_counts_reported():
+    i = gra.Metric("kerr_boyer").info
+    assert 100 < i.accel_ops < 260 and i.accel_transcendentals >= 2      # SURVEY: 214 ops after sympy CSE
+    assert gra.Metric("minkowski").info.accel_ops == 0

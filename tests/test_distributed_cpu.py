@@ -1,0 +1,82 @@
+"""CPU tests (gloo, world_size 2) of the multi-GPU frame decomposition: block-cyclic row plan + the single gather +
+un-permute.  The GPU side of a rank is replaced by slicing a known frame, so the collective path is exactly the one
+bench.py uses with backend "nccl"."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from geodesic_raytracing_amd.distributed import FrameGather, StripPlan
+
+
+def test_plan_partitions_every_row_once():
+    for height, world, block in [(2160, 8, 16), (1080, 4, 16), (54, 2, 8), (100, 3, 8), (2160, 1, 16)]:
+        plan = StripPlan(height, world, block)
+        rows = []
+        for r in range(world):
+            for a, b in plan.blocks_of(r):
+                assert (a // block) % world == r
+                rows.extend(range(a, b))
+            assert plan.local_blocks(r) <= plan.blocks_per_rank
+        assert sorted(rows) == list(range(height))
+        assert all(plan.owner_of_row(y) == (y // block) % world for y in (0, height // 2, height - 1))
+
+
+def test_plan_balances_the_shadow():
+    """a centred disc (the black-hole shadow, skipped by the prepass) is spread evenly over ranks"""
+    h, w = 2160, 3840
+    yy = np.arange(h)[:, None]
+    xx = np.arange(w)[None, :]
+    work = ((yy - h / 2) ** 2 + (xx - w / 2) ** 2 > (0.35 * h) ** 2).sum(axis=1)   # traced rays per row
+    plan = StripPlan(h, 8, 16)
+    per_rank = [sum(work[a:b].sum() for a, b in plan.blocks_of(r)) for r in range(8)]
+    assert max(per_rank) / min(per_rank) < 1.10    # 135 blocks over 8 ranks: one rank has 16 blocks, the others 17
+    contiguous = [work[r * h // 8:(r + 1) * h // 8].sum() for r in range(8)]
+    assert max(contiguous) / min(contiguous) > 1.3
+
+
+def test_plan_rejects_bad_blocks():
+    with pytest.raises(ValueError):
+        StripPlan(100, 2, 12)
+    with pytest.raises(ValueError):
+        StripPlan(17, 2, 16)      # last row would start a block
+
+
+def _worker(rank, world, port, height, width, block, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    frame = torch.rand((height, width, 4))            # the same "rendered frame" on every rank
+    plan = StripPlan(height, world, block)
+    g = FrameGather(plan, width, torch.device("cpu"), rank, world)
+    local = g.local_buffer()
+    for i, (a, b) in enumerate(plan.blocks_of(rank)):  # what gr_render_frame(compact_out=1) writes on this rank
+        local[i, :b - a] = frame[a:b]
+    t0 = torch.zeros(1)
+    dist.all_reduce(t0)                               # barrier-like use of the group
+    got = g.run()
+    if rank == 0:
+        assert torch.equal(got, frame)
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([1]))
+    else:
+        assert got is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height,width,block", [(54, 12, 8), (100, 7, 16)])
+def test_gather_assembles_the_frame_world_size_2(tmp_path, height, width, block):
+    port = 29500 + (os.getpid() % 2000) + height
+    mp.spawn(_worker, args=(2, port, height, width, block, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok.npy")
+
+
+def test_single_rank_gather_is_identity():
+    plan = StripPlan(40, 1, 8)
+    g = FrameGather(plan, 5, torch.device("cpu"), 0, 1)
+    frame = torch.rand((40, 5, 4))
+    g.local_buffer().copy_(frame.view(5, 8, 5, 4))
+    assert torch.equal(g.run(), frame)

@@ -1,0 +1,122 @@
+"""GPU tests (-m gpu) at BASELINE.json's full sizes through size-independent properties: known answers, symmetry,
+determinism, decomposition invariance.  These exercise the exact frame path bench.py times."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import geodesic_raytracing_amd as gra  # noqa: E402
+from geodesic_raytracing_amd.pipeline import DeviceBuffer, RENDER_DATA_DTYPE, download  # noqa: E402
+from gpu_stages import circ_diff  # noqa: E402
+
+_bg = {}
+
+
+def background():
+    if "bg" not in _bg:
+        packed, levels = gra.pack_background(gra.synthetic_background(1024, 512))
+        _bg["bg"] = (DeviceBuffer.from_numpy(0, packed), levels)
+    return _bg["bg"]
+
+
+def render(name, w, h, cfg=None, options=None, features=None, camera=None, out_rows=None):
+    metric = gra.Metric(name)
+    prog = gra.Program(metric.argument_string(), 0)
+    state = gra.RenderState(w, h, 0)
+    dbg, levels = background()
+    out = DeviceBuffer(0, (out_rows or h) * w * 16)
+    feats = metric.features(adaptive_sampling=0, **(features or {}))
+    opts = gra.frame_options(**(options or {}))
+    state.render(prog, metric, camera or gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats,
+                 metric.cfg_values(**(cfg or {})), opts)
+    state.synchronize()
+    rd = download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h).reshape(h, w)
+    return out.to_numpy(np.float32, (out_rows or h, w, 4)), rd, state
+
+
+def test_minkowski_256_known_answer():
+    """config 0: flat space, rays are straight lines - sky coordinates follow from geometry alone"""
+    w = h = 256
+    px, rd, _ = render("minkowski", w, h)
+    assert (rd["terminated"] == 1).all()
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    f = (w / 2) / np.tan(np.radians(90.0) / 2)
+    d = np.stack([xx - w / 2, yy - h / 2, np.full_like(xx, f)], axis=-1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    q = np.array(list(gra.default_camera().quat), dtype=np.float64)
+    qv, qw = q[:3], q[3]
+    t = 2 * np.cross(qv, d)
+    d = d + qw * t + np.cross(qv, t)
+    p0 = np.array([0.0, -4.0, 0.0])
+    b = d @ p0
+    s = -b + np.sqrt(b * b - (p0 @ p0 - 400.0))
+    hit = p0 + s[..., None] * d
+    theta = np.arccos(hit[..., 2] / 20.0)
+    phi = np.arctan2(hit[..., 1], hit[..., 0])
+    want = np.stack([np.fmod(phi, 2 * np.pi) / (2 * np.pi) + 0.5, theta / np.pi], axis=-1)
+    assert circ_diff(rd["tex_coord"], want).max() <= 3e-5
+    assert np.isfinite(px).all() and px[..., :3].max() <= 1.0 and px[..., :3].min() >= 0.0
+
+
+def test_schwarzschild_1080p_mirror_symmetry():
+    """spherical symmetry + a camera on the y axis looking at the hole: the capture pattern is mirror symmetric"""
+    w, h = 1920, 1080
+    _, rd, _ = render("schwarzschild", w, h)
+    t = rd["terminated"]
+    assert 0.005 < (t != 1).mean() < 0.2
+    lr = (t[:, 1:] != t[:, :0:-1]).mean()           # pixel offsets are cx - w/2: mirror of cx is w - cx
+    ud = (t[1:, :] != t[:0:-1, :]).mean()
+    assert lr <= 1e-3 and ud <= 1e-3
+    # the theta coordinate of the sky position is mirrored top-bottom (equatorial camera)
+    ok = (t[1:, :] == 1) & (t[:0:-1, :] == 1)
+    assert np.abs(rd["tex_coord"][1:, :, 1][ok] - (1 - rd["tex_coord"][:0:-1, :, 1][ok])).max() <= 2e-3
+
+
+def test_kerr_4k_frame_properties():
+    """the bench configuration: shadow fraction, prepass consistency, determinism, finite pixels"""
+    w, h = 3840, 2160
+    px, rd, state = render("kerr_boyer", w, h, cfg=dict(a=0.45), options=dict(mode=gra.MODE_FUSED, count_attempts=1))
+    t = rd["terminated"]
+    assert np.isfinite(px).all()
+    frac = {k: float((t == k).mean()) for k in (0, 1, 2)}
+    assert 0.35 < frac[1] < 0.50 and 0.50 < frac[0] + frac[2] < 0.65      # 59 % of a 16:9 fov-90 frame is shadow
+    assert frac[2] > 0.4
+    assert (px[t != 1][:, :3] == 0).all() and (px[t != 1][:, 3] == 1).all()
+    attempts = state.attempts()
+    assert 100 < attempts / (w * h) < 400
+    px2, rd2, _ = render("kerr_boyer", w, h, cfg=dict(a=0.45), options=dict(mode=gra.MODE_FUSED))
+    assert np.array_equal(px, px2)                                          # bit-reproducible
+    # a ray skipped by the prepass stencil must be one the full trace would not have finished either
+    _, rd_full, _ = render("kerr_boyer", w, h, cfg=dict(a=0.45), options=dict(mode=gra.MODE_FUSED, use_prepass=0))
+    skipped = t == 2
+    assert (rd_full["terminated"][skipped] == 1).mean() <= 2e-3
+    same = (rd_full["terminated"] == 1) == (t == 1)
+    assert same.mean() >= 0.998
+
+
+@pytest.mark.parametrize("world,block", [(2, 16), (8, 16), (3, 24)])
+def test_row_block_decomposition_equals_full_frame(world, block):
+    """what rank r of N computes in strip mode is bit-identical to the same rows of the single-GPU frame"""
+    from geodesic_raytracing_amd.distributed import StripPlan
+    w, h = 1920, 1080
+    full, _, _ = render("kerr_boyer", w, h, cfg=dict(a=0.45), options=dict(mode=gra.MODE_FUSED))
+    plan = StripPlan(h, world, block)
+    assembled = np.zeros_like(full)
+    for r in range(world):
+        rows = plan.blocks_per_rank * block
+        part, _, _ = render("kerr_boyer", w, h, cfg=dict(a=0.45), out_rows=rows,
+                            options=dict(mode=gra.MODE_FUSED, strip_rank=r, strip_count=world, block_rows=block, compact_out=1))
+        for i, (a, b) in enumerate(plan.blocks_of(r)):
+            assembled[a:b] = part[i * block:i * block + (b - a)]
+    assert np.array_equal(assembled, full)
+
+
+def test_alcubierre_8k_rows_sample():
+    """config 4 shape (7680x4320, redshift on): trace a band of rows in strip mode and check it is sane"""
+    w, h = 7680, 4320
+    part, rd, _ = render("alcubierre", w, h, features=dict(redshift=1), out_rows=16,
+                         options=dict(mode=gra.MODE_FUSED, strip_rank=135, strip_count=270, block_rows=16, compact_out=1))
+    assert np.isfinite(part).all()
+    band = rd[135 * 16:136 * 16]
+    assert (band["terminated"] == 1).all()
+    assert np.abs(band["z_shift"]).max() < 5 and np.abs(band["z_shift"]).max() > 0
