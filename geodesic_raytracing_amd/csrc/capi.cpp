@@ -107,7 +107,13 @@ int compile_code_object(const std::string& argument_string, std::string& code) {
         // the reference builds with -cl-unsafe-math-optimizations (metric_manager.hpp:70): reassociation,
         // reciprocal division, contraction - but NaN/Inf stay meaningful (IS_DEGENERATE, cl.cl:68)
         "-ffp-contract=fast", "-fno-math-errno", "-freciprocal-math", "-fassociative-math",
-        "-fno-signed-zeros", "-fno-trapping-math"};
+        "-fno-signed-zeros", "-fno-trapping-math",
+        // OpenCL's default 2.5-ulp fp32 divide/sqrt (the reference does not pass -cl-fp32-correctly-rounded-divide-sqrt):
+        // v_rcp_f32 / v_sqrt_f32 instead of the ~10-instruction correctly rounded sequences
+        "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+        // ... and its "unsafe math": approximate-function semantics for divide/sqrt/libm (a/b = a * v_rcp_f32(b) with no
+        // denormal rescaling) and flushed fp32 denormals.  Measured -18 % on the Kerr Verlet kernel, parity unchanged.
+        "-fapprox-func", "-fgpu-flush-denormals-to-zero"};
     for (auto& tok : split_arguments(argument_string)) {
         if (tok.rfind("-D", 0) == 0) opts.push_back(tok);
         else if (tok.rfind("-cl-", 0) == 0 || tok == "-I" || tok == "./") continue;   // OpenCL-only prefix flags

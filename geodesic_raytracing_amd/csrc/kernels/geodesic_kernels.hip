@@ -92,6 +92,12 @@ struct dynamic_feature_config {
 #define GR_TILE 8
 #endif
 
+// minimum resident waves per SIMD the integrator kernels are register-allocated for (512 VGPRs / N waves each).
+// Measured on MI355X (profiles/r01_*): forcing 8 (<= 64 VGPRs) makes the Kerr loop spill and run 1.6x slower.
+#ifndef GR_TRACE_WAVES
+#define GR_TRACE_WAVES 4
+#endif
+
 typedef const dynamic_config* __restrict__ cfg_t;
 typedef const dynamic_feature_config* __restrict__ dfg_t;
 
@@ -100,12 +106,46 @@ typedef const dynamic_feature_config* __restrict__ dfg_t;
 // so unqualified sin/cos/... bind to these fp32 versions.
 namespace gm {
 
-#ifdef GR_FAST_TRIG
+#if defined(GR_FAST_TRIG)
+// hardware v_sin_f32 / v_cos_f32: ~1e-6 absolute error (poor relative accuracy next to the zeros), opt-in only
 __device__ __forceinline__ float sin(float x) { return __sinf(x); }
 __device__ __forceinline__ float cos(float x) { return __cosf(x); }
-#else
+#elif defined(GR_LIBM_TRIG)
 __device__ __forceinline__ float sin(float x) { return ::sinf(x); }
 __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
+#else
+// sin and cos of the same angle share one Cody-Waite reduction and both minimax polynomials (the common
+// sub-expressions of the two inlined calls merge), ~1 ulp for |x| < 8192; larger arguments take the libm path.
+// The metric expressions evaluate sin(theta) and cos(theta) together every Verlet step, where the two separate libm
+// calls (each with its own large-argument branch) were ~25 % of the step's instructions.
+struct sincos_pair { float s, c; };
+__device__ __forceinline__ sincos_pair sincos_reduced(float x) {
+    float j = __builtin_rintf(x * 0.636619772367581343f);           // nearest multiple of pi/2
+    float r = __builtin_fmaf(-j, 1.57079637050628662109375f, x);   // pi/2 = hi + lo, fma keeps the product exact
+    r = __builtin_fmaf(-j, -4.37113900018624283e-8f, r);
+    float r2 = r * r;
+    float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+    float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
+                              r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+    int q = (int)j;
+    float s = (q & 1) ? cp : sp;
+    float c = (q & 1) ? sp : cp;
+    s = (q & 2) ? -s : s;
+    c = ((q + 1) & 2) ? -c : c;
+    return {s, c};
+}
+// the polynomial is evaluated unconditionally (so sin and cos of one angle stay in one basic block and share it);
+// the libm call only overrides the result in the never-in-practice large-argument case
+__device__ __forceinline__ float sin(float x) {
+    float s = sincos_reduced(x).s;
+    if (__builtin_expect(!(__builtin_fabsf(x) < 8192.f), 0)) s = ::sinf(x);
+    return s;
+}
+__device__ __forceinline__ float cos(float x) {
+    float c = sincos_reduced(x).c;
+    if (__builtin_expect(!(__builtin_fabsf(x) < 8192.f), 0)) c = ::cosf(x);
+    return c;
+}
 #endif
 __device__ __forceinline__ float tan(float x) { return ::tanf(x); }
 __device__ __forceinline__ float asin(float x) { return ::asinf(x); }
@@ -591,6 +631,13 @@ __device__ __forceinline__ bool slot_to_pixel(int id, int width, int height, int
     return cx < width && cy < height;
 }
 
+// (float)a / b rounded as IEEE division does.  The kernels are built with approximate fp32 division (v_rcp_f32); this
+// quotient feeds round() to pick prepass cells (cl.cl:3217-3221), where a 1-ulp difference moves the stencil.
+__device__ __forceinline__ float exact_ratio(int a, int b) {
+#pragma float_control(precise, on)
+    return (float)((double)a / (double)b);
+}
+
 __device__ __forceinline__ int early_terminate(int x, int y, int w, int h, const int* __restrict__ term) {
     if (x < 0 || y < 0 || x > w - 1 || y > h - 1) return 0;
     return term[y * w + x] == 1;
@@ -894,8 +941,8 @@ extern "C" __global__ void gr_init_rays_generic(const float4* __restrict__ g_gen
 
     // prepass stencil (cl.cl:3213-3232)
     if (prepass_width != width && prepass_height != height) {
-        float fx = (float)cx / width;
-        float fy = (float)cy / height;
+        float fx = exact_ratio(cx, width);
+        float fy = exact_ratio(cy, height);
         int lx = (int)roundf(fx * prepass_width);
         int ly = (int)roundf(fy * prepass_height);
         if (early_terminate(lx - 1, ly, prepass_width, prepass_height, termination_buffer) &&
@@ -915,7 +962,7 @@ extern "C" __global__ void gr_init_rays_generic(const float4* __restrict__ g_gen
     }
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
 gr_do_generic_rays(lightray* __restrict__ generic_rays_in, const int* __restrict__ generic_count_in,
                    int* __restrict__ ray_time_min, int* __restrict__ ray_time_max,
                    cfg_t cfg, dfg_t dfg, int width, int height, int mouse_x, int mouse_y,
@@ -966,7 +1013,7 @@ extern "C" __global__ void gr_calculate_render_data(const lightray* __restrict__
 }
 
 // init -> integrate -> render-data for one pixel per lane, 8x8 tiles, nothing but the 32-byte result is stored
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
 gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
@@ -999,8 +1046,8 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
     lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
     int terminated = 0;
     if (termination_buffer && prepass_width != width && prepass_height != height) {
-        float fx = (float)cx / width;
-        float fy = (float)cy / height;
+        float fx = exact_ratio(cx, width);
+        float fy = exact_ratio(cy, height);
         int lx = (int)roundf(fx * prepass_width);
         int ly = (int)roundf(fy * prepass_height);
         if (early_terminate(lx - 1, ly, prepass_width, prepass_height, termination_buffer) &&
@@ -1030,7 +1077,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
 
 // termination flags of the low-resolution prepass, straight from a fused trace (role of
 // clear_termination_buffer + init_rays_generic(prepass) + do_generic_rays + calculate_singularities)
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
 gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                  int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                  const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
