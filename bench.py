@@ -51,7 +51,7 @@ def cpu_baseline(metric_name, cfg_values, features_kw, target_seconds):
     from oracle import build_restate
     from oracle.refpipe import OraclePipeline, pack_features
     import geodesic_raytracing_amd as gra
-    m = gra.Metric(metric_name)
+    m = gra.Metric(metric_name, os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"))
     so = build_restate.build(m.argument_string())
     pipe = OraclePipeline(so)
     cores = os.cpu_count() or 1
@@ -97,7 +97,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     W, H = args.width, args.height
-    metric = gra.Metric(args.metric)
+    # the metric comes from the script front-end (scripts/kerr_boyer.js + .json), as in the reference
+    metric = gra.Metric(args.metric, os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"))
     cfg_values = metric.cfg_values(a=args.spin) if "a" in metric.dynamic_vars else metric.cfg_values()
     features = metric.features(adaptive_sampling=0)
     program = gra.Program(metric.argument_string(), local_rank)

@@ -131,6 +131,8 @@ double apply2(Fn f, double x, double y) {
         case F_FMOD: return std::fmod(x, y);
         case F_MIN: return std::min(x, y);
         case F_MAX: return std::max(x, y);
+        case F_CSQRT_RE: return std::sqrt(std::max(0.5 * (std::hypot(x, y) + x), 0.0));
+        case F_CSQRT_IM: return (y < 0 ? -1.0 : 1.0) * std::sqrt(std::max(0.5 * (std::hypot(x, y) - x), 0.0));
         case F_LT: return x < y ? 1.0 : 0.0;
         case F_LE: return x <= y ? 1.0 : 0.0;
         case F_EQ: return x == y ? 1.0 : 0.0;
@@ -408,6 +410,15 @@ E diff(E e, const std::string& wrt) {
                     }
                     break;
                 case F_FMOD: r = da; break;
+                case F_CSQRT_RE:
+                case F_CSQRT_IM: {
+                    // w = sqrt(a + i b):  dw = (da + i db) conj(w) / (2 |w|^2),  |w|^2 = |a + i b|
+                    E wr = fn2(F_CSQRT_RE, a, b), wi = fn2(F_CSQRT_IM, a, b);
+                    E den = mul(constant(2.0), fn1(F_SQRT, add(mul(a, a), mul(b, b))));
+                    if (e->fn == F_CSQRT_RE) r = div(add(mul(da, wr), mul(db, wi)), den);
+                    else r = div(sub(mul(db, wr), mul(da, wi)), den);
+                    break;
+                }
                 case F_MIN: r = select(fn2(F_LT, a, b), da, db); break;
                 case F_MAX: r = select(fn2(F_GT, a, b), da, db); break;
                 default: r = constant(0.0); break;  // comparisons
@@ -538,7 +549,14 @@ void to_c_rec(E e, const std::unordered_map<E, std::string>* names, std::string&
             out += ")";
             break;
         case FN2:
-            if (is_cmp(e->fn)) {
+            if (e->fn == F_CSQRT_RE || e->fn == F_CSQRT_IM) {
+                std::string a, b;
+                to_c_rec(e->a, names, a, false);
+                to_c_rec(e->b, names, b, false);
+                std::string mod = "sqrt(((" + a + "*" + a + ")+(" + b + "*" + b + ")))";
+                if (e->fn == F_CSQRT_RE) out += "sqrt(fmax((0.5f*(" + mod + "+" + a + ")),0.0f))";
+                else out += "(((" + b + "<0.0f)?(-1.0f):1.0f)*sqrt(fmax((0.5f*(" + mod + "-" + a + ")),0.0f)))";
+            } else if (is_cmp(e->fn)) {
                 const char* o = e->fn == F_LT ? "<" : e->fn == F_LE ? "<=" : e->fn == F_EQ ? "==" : e->fn == F_GT ? ">" : ">=";
                 out += "((";
                 to_c_rec(e->a, names, out, false);
@@ -592,6 +610,7 @@ OpCount count_ops(const std::vector<E>& roots) {
             case FN2:
                 oc.ops++;
                 if (e->fn == F_ATAN2 || e->fn == F_POW || e->fn == F_FMOD) oc.transcendental++;
+                if (e->fn == F_CSQRT_RE || e->fn == F_CSQRT_IM) { oc.ops += 7; oc.transcendental += 2; }
                 break;
             default: oc.ops++; break;
         }
@@ -676,12 +695,8 @@ Cx csqrt_real(E a) {
 }
 Cx csqrt_principal(Cx a) {
     if (is_zero(a.im)) return csqrt_real(a.re);
-    // principal branch: sqrt((|z|+re)/2) + i*sign(im)*sqrt((|z|-re)/2)
-    E m = cabs(a);
-    E re = fn1(F_SQRT, fn2(F_MAX, mul(constant(0.5), add(m, a.re)), constant(0.0)));
-    E imag = fn1(F_SQRT, fn2(F_MAX, mul(constant(0.5), sub(m, a.re)), constant(0.0)));
-    E sgn = select(fn2(F_LT, a.im, constant(0.0)), constant(-1.0), constant(1.0));
-    return Cx{re, mul(sgn, imag)};
+    // principal branch: sqrt((|z|+re)/2) + i*sign(im)*sqrt((|z|-re)/2), as a differentiable primitive pair
+    return Cx{fn2(F_CSQRT_RE, a.re, a.im), fn2(F_CSQRT_IM, a.re, a.im)};
 }
 Cx csin(Cx a) {
     if (is_zero(a.im)) return cx(fn1(F_SIN, a.re));

@@ -26,6 +26,10 @@ enum Fn : uint8_t {
     F_TANH, F_SIGN,
     // binary
     F_ATAN2, F_POW, F_FMOD, F_MIN, F_MAX,
+    // real / imaginary part of the principal square root of the complex number (a + i b).  Primitive so that its
+    // derivative can follow d sqrt(z) = dz / (2 sqrt(z)) (finite for z != 0) instead of differentiating the
+    // component formulas, which are 0/0 on the real axis.  Printed inline, no run-time support function needed.
+    F_CSQRT_RE, F_CSQRT_IM,
     // comparisons (binary, value is 1.0f / 0.0f)
     F_LT, F_LE, F_EQ, F_GT, F_GE,
     F_NONE

@@ -55,13 +55,16 @@ CASES = {
     "kerr_prepass": dict(metric="kerr_boyer", size=(96, 64), cfg=dict(a=0.45), prepass=True),
     "kerr_adaptive_sampling": dict(metric="kerr_boyer", size=(48, 28), cfg=dict(a=0.45), features=dict(adaptive_sampling=1, adaptive_sampling_threshold=32.0)),
     "alcubierre": dict(metric="alcubierre", size=(48, 27), features=dict(redshift=1), camera_pos=[0.0, 0.0, -6.0, 0.5]),
+    "double_unequal_kerr": dict(metric="double_unequal_kerr", scripts=True, size=(48, 27), camera_pos=[0.0, 0.0, -6.0, 0.5]),
+    "kerr_script": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(48, 27), cfg=dict(a=0.45)),
     "kerr_moving_observer": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.3, 0.0, 0.2], features=dict(redshift=1)),
 }
 
 
 def make_case(name, spec, scripts_dir=None):
-    metric = gra.Metric(spec["metric"], spec.get("scripts_dir", scripts_dir))
-    so = build_ref.build(spec["metric"] if not spec.get("tag") else spec["tag"], metric.argument_string())
+    own_scripts = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
+    metric = gra.Metric(spec["metric"], own_scripts if spec.get("scripts") else None)
+    so = build_ref.build(spec.get("tag", spec["metric"]), metric.argument_string())
     cfg = metric.cfg_values(**spec.get("cfg", {}))
     feats = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change)
     feats.update(spec.get("features", {}))
@@ -73,7 +76,7 @@ def make_case(name, spec, scripts_dir=None):
     res = pipe.frame(w, h, cfg, pack_features(**feats), camera_pos=spec.get("camera_pos", (0, 0, -4, 0)),
                      camera_quat=spec.get("camera_quat", DEFAULT_QUAT), use_prepass=prepass, background=(bg, levels),
                      basis_speed=spec.get("basis_speed", (0, 0, 0)))
-    meta = dict(metric=spec["metric"], width=w, height=h, cfg=cfg, features=feats, camera_pos=list(map(float, spec.get("camera_pos", (0, 0, -4, 0)))),
+    meta = dict(metric=spec["metric"], scripts=bool(spec.get("scripts")), width=w, height=h, cfg=cfg, features=feats, camera_pos=list(map(float, spec.get("camera_pos", (0, 0, -4, 0)))),
                 camera_quat=list(map(float, spec.get("camera_quat", DEFAULT_QUAT))), prepass=prepass, bg_size=BG_SIZE, bg_seed=BG_SEED,
                 basis_speed=list(map(float, spec.get("basis_speed", (0, 0, 0)))), max_probes=8,
                 argument_string_fnv=hex(hash(metric.argument_string()) & 0xffffffff))

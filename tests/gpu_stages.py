@@ -23,11 +23,20 @@ def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
 
 
-def program_for(metric_name):
-    if metric_name not in _programs:
-        m = gra.Metric(metric_name)
-        _programs[metric_name] = (m, gra.Program(m.argument_string(), 0))
-    return _programs[metric_name]
+SCRIPTS_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geodesic_raytracing_amd", "scripts")
+
+
+def metric_for(meta):
+    """the metric of a golden case: built-in, or loaded from this repository's scripts/ folder"""
+    return gra.Metric(meta["metric"], SCRIPTS_DIR if meta.get("scripts") else None)
+
+
+def program_for(meta):
+    key = (meta["metric"], bool(meta.get("scripts")))
+    if key not in _programs:
+        m = metric_for(meta)
+        _programs[key] = (m, gra.Program(m.argument_string(), 0))
+    return _programs[key]
 
 
 def features_from(meta):
@@ -46,7 +55,7 @@ class Stages:
 
     def __init__(self, meta):
         self.meta = meta
-        self.metric, self.program = program_for(meta["metric"])
+        self.metric, self.program = program_for(meta)
         self.w, self.h = meta["width"], meta["height"]
         self.features = features_from(meta)
         self.dfg = buf(np.frombuffer(bytes(self.features), dtype=np.uint8))

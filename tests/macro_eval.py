@@ -19,11 +19,43 @@ def parse_macros(argument_string):
     return out
 
 
+def _ternaries(s):
+    """C `(c ? a : b)` (always fully parenthesised by the generator) -> Python conditional expression"""
+    out, i = [], 0
+    while i < len(s):
+        if s[i] != "(":
+            out.append(s[i])
+            i += 1
+            continue
+        depth, j = 0, i
+        while True:
+            depth += s[j] == "("
+            depth -= s[j] == ")"
+            if depth == 0:
+                break
+            j += 1
+        inner = s[i + 1:j]
+        depth, q, c = 0, -1, -1
+        for k, ch in enumerate(inner):
+            depth += ch == "("
+            depth -= ch == ")"
+            if depth == 0 and ch == "?" and q < 0:
+                q = k
+            elif depth == 0 and ch == ":" and q >= 0 and c < 0:
+                c = k
+        if q >= 0:
+            out.append("((" + _ternaries(inner[q + 1:c]) + ") if (" + _ternaries(inner[:q]) + ") else (" + _ternaries(inner[c + 1:]) + "))")
+        else:
+            out.append("(" + _ternaries(inner) + ")")
+        i = j + 1
+    return "".join(out)
+
+
 def to_python(expr):
-    if _TERNARY.search(expr):
-        raise ValueError("ternary expressions are not supported by the test evaluator")
-    e = _LITERAL.sub(r"\1", expr)
-    return e.replace("cfg->", "cfg_")
+    e = _LITERAL.sub(r"\1", expr).replace("cfg->", "cfg_")
+    if _TERNARY.search(e):
+        e = _ternaries(e)
+    return e
 
 
 class MacroSet:

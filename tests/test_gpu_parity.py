@@ -21,7 +21,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import geodesic_raytracing_amd as gra  # noqa: E402
-from gpu_stages import Stages, circ_diff, golden_names, load_golden, rel_err  # noqa: E402
+from gpu_stages import Stages, circ_diff, golden_names, load_golden, metric_for, rel_err  # noqa: E402
 
 PLAIN = [n for n in golden_names() if n not in ("kerr_prepass", "kerr_adaptive_sampling")]
 CHAOTIC = {"kerr_superextremal"}
@@ -112,7 +112,7 @@ def test_end_to_end(name):
 def _frame(meta, mode, tiled=0, options=None):
     """whole frame through gr_render_frame"""
     from geodesic_raytracing_amd.pipeline import DeviceBuffer
-    metric = gra.Metric(meta["metric"])
+    metric = metric_for(meta)
     prog = gra.Program(metric.argument_string(), 0)
     w, h = meta["width"], meta["height"]
     state = gra.RenderState(w, h, 0)

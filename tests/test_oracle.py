@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import geodesic_raytracing_amd as gra
-from gpu_stages import circ_diff, golden_names, load_golden, rel_err
+from gpu_stages import circ_diff, golden_names, load_golden, metric_for, rel_err
 from oracle import build_ref, build_restate
 from oracle.refpipe import OraclePipeline, pack_features
 
@@ -22,7 +22,7 @@ def run_oracle(so, meta):
 @pytest.mark.parametrize("name", golden_names())
 def test_restatement_reproduces_reference_golden_vectors(name):
     meta, z = load_golden(name)
-    so = build_restate.build(gra.Metric(meta["metric"]).argument_string())
+    so = build_restate.build(metric_for(meta).argument_string())
     r = run_oracle(so, meta)
     assert np.abs(r["camera_generic"] - z["camera_generic"]).max() <= 2e-6
     assert np.abs(r["tetrad"] - z["tetrad"]).max() <= 2e-6
@@ -51,7 +51,7 @@ def test_restatement_reproduces_reference_golden_vectors(name):
 def test_fixtures_are_what_the_reference_computes(name):
     """re-runs /root/reference/cl.cl (x86-64 build) and checks the committed fixtures are its output, bit for bit"""
     meta, z = load_golden(name)
-    so = build_ref.build(meta["metric"], gra.Metric(meta["metric"]).argument_string())
+    so = build_ref.build(meta["metric"], metric_for(meta).argument_string())
     r = run_oracle(so, meta)
     for f in ("position", "velocity", "terminated"):
         assert np.array_equal(r["rays"][f], z["rays"][f]), f

@@ -1,0 +1,200 @@
+"""CPU tests of the script front-end (geodesic_raytracing_amd/csrc/jsfront.cpp): the repository's own metric scripts,
+drop-in loading of the reference's unmodified scripts folder (build container only), and the mathematics of what
+the scripts generate."""
+import os
+
+import numpy as np
+import pytest
+
+import geodesic_raytracing_amd as gra
+from macro_eval import MacroSet, parse_macros
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OWN = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
+REF = "/root/reference/scripts"
+CONFIG_METRICS = ["minkowski", "schwarzschild", "kerr_boyer", "double_unequal_kerr", "alcubierre"]
+
+needs_reference = pytest.mark.skipif(not os.path.isdir(REF), reason="reference scripts only exist in the build container")
+
+
+def sample_point(metric, rng):
+    cyl = metric.name == "double_unequal_kerr"
+    if cyl:
+        return [0.1, rng.uniform(0.5, 5), rng.uniform(0, 6), rng.uniform(-4, 4)]
+    if metric.name in ("minkowski", "alcubierre"):
+        return list(rng.uniform(-3, 3, 4))
+    return [0.2, rng.uniform(2.5, 6), rng.uniform(0.4, 2.7), rng.uniform(-3, 3)]
+
+
+@pytest.mark.parametrize("name", CONFIG_METRICS)
+def test_own_scripts_load_and_match_expected_variant(name):
+    m = gra.Metric(name, OWN)
+    macros = parse_macros(m.argument_string())
+    expected = {
+        "minkowski": dict(big=0, ctheta=0, adaptive=0, prepass=0, vars=[]),
+        "schwarzschild": dict(big=0, ctheta=1, adaptive=0, prepass=0, vars=[]),
+        "kerr_boyer": dict(big=1, ctheta=0, adaptive=1, prepass=1, vars=["rs", "a"]),
+        "double_unequal_kerr": dict(big=1, ctheta=0, adaptive=1, prepass=0, vars=["m1", "m2", "fa1", "fa2", "R"]),
+        "alcubierre": dict(big=1, ctheta=0, adaptive=1, prepass=0, vars=["velocity", "sigma", "R"]),
+    }[name]
+    assert (m.info.is_big, m.info.is_constant_theta, m.info.adaptive_precision, m.info.use_prepass) == (
+        expected["big"], expected["ctheta"], expected["adaptive"], expected["prepass"])
+    assert m.dynamic_vars == expected["vars"]
+    if name == "double_unequal_kerr":
+        assert [macros[f"W_V{i}"] for i in range(1, 5)] == ["1", "1", "8", "1"]        # CYLINDRICAL, metric.hpp:861-865
+        assert macros["COORDINATE_PERIODICITY3"].startswith("6.28")
+        assert m.dynamic_defaults == pytest.approx([0.15, 0.3, 1.0, -0.3, 4.0])
+        assert m.info.max_acceleration_change == pytest.approx(1e-5)
+    if name == "alcubierre":
+        assert "UNCONDITIONALLY_NONSINGULAR" in macros and "cfg->velocity" in macros["DISTANCE_FUNC"]
+    if name == "schwarzschild":
+        assert "SINGULAR" in macros and "ADAPTIVE_PRECISION" not in macros
+
+
+@pytest.mark.parametrize("name", ["minkowski", "schwarzschild", "kerr_boyer", "alcubierre"])
+def test_scripts_and_builtins_define_the_same_metric(name):
+    a, b = gra.Metric(name, OWN), gra.Metric(name)
+    ma, mb = MacroSet(a.argument_string()), MacroSet(b.argument_string())
+    cfg = dict(zip(a.dynamic_vars, a.dynamic_defaults))
+    rng = np.random.RandomState(3)
+    for _ in range(3):
+        pos, vel = sample_point(a, rng), list(rng.uniform(-1, 1, 4))
+        assert np.allclose(ma.metric(pos, cfg), mb.metric(pos, cfg), rtol=1e-6, atol=1e-9)
+        assert np.allclose(ma.accel(pos, vel, cfg), mb.accel(pos, vel, cfg), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", CONFIG_METRICS)
+def test_script_metric_calculus(name):
+    """F*_P are the derivatives of F*_I, and GEO_ACCELn = -Gamma v v built from them (complex-valued scripts included)"""
+    m = gra.Metric(name, OWN)
+    ms = MacroSet(m.argument_string())
+    cfg = dict(zip(m.dynamic_vars, m.dynamic_defaults))
+    rng = np.random.RandomState(5)
+    h = 1e-6
+    for _ in range(2):
+        pos, vel = sample_point(m, rng), list(rng.uniform(-1, 1, 4))
+        if m.info.is_constant_theta:
+            pos[2], vel[2] = float(np.float32(np.pi / 2)), 0.0
+        g = np.array(ms.metric(pos, cfg))
+        assert np.allclose(g, g.T) and np.linalg.det(g) < 0          # real symmetric, Lorentzian
+        dg = np.zeros((4, 4, 4))
+        for k in range(4):
+            p1, p0 = list(pos), list(pos)
+            p1[k] += h
+            p0[k] -= h
+            fd = (np.array(ms.metric(p1, cfg)) - np.array(ms.metric(p0, cfg))) / (2 * h)
+            dg[k] = [[ms.partial(pos, k, i, j, cfg) for j in range(4)] for i in range(4)]
+            assert np.allclose(dg[k], fd, rtol=1e-4, atol=1e-6), (name, k)
+        ginv = np.linalg.inv(g)
+        gamma = 0.5 * (np.einsum("im,lmk->ikl", ginv, dg) + np.einsum("im,kml->ikl", ginv, dg) - np.einsum("im,mkl->ikl", ginv, dg))
+        want = -np.einsum("ikl,k,l->i", gamma, vel, vel)
+        got = np.array(ms.accel(pos, vel, cfg))
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-7), name
+
+
+def test_double_kerr_is_asymptotically_flat():
+    m = gra.Metric("double_unequal_kerr", OWN)
+    ms = MacroSet(m.argument_string())
+    g = np.array(ms.metric([0.0, 3000.0, 0.3, 1000.0], dict(zip(m.dynamic_vars, m.dynamic_defaults))))
+    assert g[0, 0] == pytest.approx(-1, abs=2e-3) and g[2, 2] / 3000.0 ** 2 == pytest.approx(1, abs=2e-3)
+    # e^{2 gamma} tends to a constant close to (not exactly) 1 with the reference's normalisation K0; the two
+    # meridional components are equal, the frame dragging term dies out
+    assert g[1, 1] == pytest.approx(g[3, 3], rel=1e-12) and 0.9 < g[1, 1] < 1.1
+    assert abs(g[0, 2]) / 3000.0 < 1e-4
+
+
+def test_config_metrics_compile_for_gfx950():
+    for name in ("double_unequal_kerr",):
+        gra.Program.precompile(gra.Metric(name, OWN).argument_string())
+
+
+def test_script_errors_are_reported(tmp_path):
+    (tmp_path / "bad.json").write_text('{"name": "bad", "to_polar": "polar_to_polar", "from_polar": "polar_to_polar", "origin_distance": "at_origin"}')
+    (tmp_path / "bad.js").write_text("function f(t, r, theta, phi) { return [1, 2, undefined_symbol, 4]; }\nf\n")
+    for n in ("polar_to_polar", "at_origin"):
+        sub = "coordinates" if "polar" in n else "origins"
+        (tmp_path / sub).mkdir(exist_ok=True)
+        (tmp_path / sub / (n + ".js")).write_text(open(os.path.join(OWN, sub, n + ".js")).read())
+    with pytest.raises(gra.GeodesicError, match="undefined_symbol"):
+        gra.Metric("bad", tmp_path)
+    with pytest.raises(gra.GeodesicError):
+        gra.Metric("does_not_exist", tmp_path)
+    (tmp_path / "three.json").write_text((tmp_path / "bad.json").read_text())
+    (tmp_path / "three.js").write_text("function f(t, r, theta, phi) { return [1, 2, 3]; }\nf\n")
+    with pytest.raises(gra.GeodesicError, match="4 or 16"):
+        gra.Metric("three", tmp_path)
+
+
+def test_script_language_features(tmp_path):
+    """closures, function-scoped var, loops, ASI, ++, arrays with holes, nested functions"""
+    for sub, n in (("coordinates", "polar_to_polar"), ("origins", "at_origin")):
+        (tmp_path / sub).mkdir(exist_ok=True)
+        (tmp_path / sub / (n + ".js")).write_text(open(os.path.join(OWN, sub, n + ".js")).read())
+    (tmp_path / "m.json").write_text('{"name": "m", "to_polar": "polar_to_polar", "from_polar": "polar_to_polar", "origin_distance": "at_origin", "coordinate_system": "OTHER"}')
+    (tmp_path / "m.js").write_text("""
+/* block comment */
+function m(t, x, y, z)
+{
+    $cfg.k.$default = 1/3.
+    var k = $cfg.k      // no semicolons: line ends terminate statements
+    function pw(v, n) { var r = 1; for (var i = 0; i < n; i++) { r = r * v } return r }
+    var eta = [-1, 0, 0, 0,
+                0, 1, 0, 0,
+                0, 0, 1, 0,
+                0, 0, 0, 1];
+    var l = [1, x / 10, y / 10, z / 10]
+    var g = []
+    g.length = 16
+    for (var k = 0; k < 4; k++)        // shadows the $cfg symbol, as `var` does
+        for (var j = 0; j < 4; j++)
+            g[k * 4 + j] = eta[k * 4 + j] + (k == j ? 0.5 : 0.25) * pw(l[k], 1) * l[j] * $cfg.k;
+    if (k == 4 && g.length == 16) { g[5] = g[5] + CMath.select(CMath.lt(x, 0), 1, 2) * 0 }
+    return g
+};
+
+m
+""")
+    m = gra.Metric("m", tmp_path)
+    assert m.dynamic_vars == ["k"] and m.dynamic_defaults == pytest.approx([1 / 3.0])
+    ms = MacroSet(m.argument_string())
+    g = np.array(ms.metric([0.0, 1.0, 2.0, 3.0], dict(k=1 / 3.0)))
+    l = np.array([1, 0.1, 0.2, 0.3])
+    want = np.diag([-1.0, 1, 1, 1]) + (np.full((4, 4), 0.25) + 0.25 * np.eye(4)) * np.outer(l, l) / 3.0
+    want = np.triu(want) + np.triu(want, 1).T       # the device reads the upper triangle
+    assert np.allclose(g, want, rtol=1e-6)
+
+
+@needs_reference
+def test_every_reference_script_loads_unmodified():
+    names = sorted(f[:-5] for f in os.listdir(REF) if f.endswith(".json") and os.path.exists(os.path.join(REF, f[:-5] + ".js")))
+    assert len(names) == 31
+    constant_theta = set()
+    for n in names:
+        m = gra.Metric(n, REF)
+        macros = parse_macros(m.argument_string())
+        assert "GEO_ACCEL3" in macros and "TEMPORARIES0" in macros
+        if m.info.is_constant_theta:
+            constant_theta.add(n)
+    # spherically symmetric polar metrics take the equatorial-plane kernel, Kerr does not
+    assert {"schwarzschild", "schwarzschild_accurate", "wormhole", "de_sitter", "configurable_wormhole"} <= constant_theta
+    assert not ({"kerr_boyer", "kerr_newman_boyer", "minkowski", "alcubierre", "double_kerr"} & constant_theta)
+
+
+@needs_reference
+@pytest.mark.parametrize("name", CONFIG_METRICS)
+def test_own_scripts_equal_the_reference_scripts(name):
+    a, b = gra.Metric(name, OWN), gra.Metric(name, REF)
+    assert a.dynamic_vars == b.dynamic_vars and a.dynamic_defaults == pytest.approx(b.dynamic_defaults)
+    assert (a.info.is_big, a.info.is_constant_theta, a.info.use_prepass, a.info.adaptive_precision) == (
+        b.info.is_big, b.info.is_constant_theta, b.info.use_prepass, b.info.adaptive_precision)
+    assert a.info.max_acceleration_change == pytest.approx(b.info.max_acceleration_change)
+    ma, mb = MacroSet(a.argument_string()), MacroSet(b.argument_string())
+    pa, pb = parse_macros(a.argument_string()), parse_macros(b.argument_string())
+    for k in ("W_V1", "W_V2", "W_V3", "W_V4", "DYNVARS", "TO_COORD2", "FROM_COORD3", "DISTANCE_FUNC"):
+        assert pa.get(k) == pb.get(k), k
+    cfg = dict(zip(a.dynamic_vars, a.dynamic_defaults))
+    rng = np.random.RandomState(11)
+    for _ in range(3):
+        pos, vel = sample_point(a, rng), list(rng.uniform(-1, 1, 4))
+        assert np.allclose(ma.metric(pos, cfg), mb.metric(pos, cfg), rtol=1e-9, atol=1e-12)
+        assert np.allclose(ma.accel(pos, vel, cfg), mb.accel(pos, vel, cfg), rtol=1e-6, atol=1e-9)
