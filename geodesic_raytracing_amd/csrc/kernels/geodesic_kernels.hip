@@ -93,9 +93,11 @@ struct dynamic_feature_config {
 #endif
 
 // minimum resident waves per SIMD the integrator kernels are register-allocated for (512 VGPRs / N waves each).
-// Measured on MI355X (profiles/r01_*): forcing 8 (<= 64 VGPRs) makes the Kerr loop spill and run 1.6x slower.
+// 1 = no cap: the allocator takes what the metric's expressions need and occupancy follows (Kerr: ~100 VGPRs ->
+// 4 waves/SIMD; the complex-valued double-Kerr metric: ~370 VGPRs -> 1 wave/SIMD but no spills).  Measured on
+// MI355X: capping Kerr at 64 VGPRs makes its loop spill (1.6x slower); capping double Kerr at 128 costs 5.3x.
 #ifndef GR_TRACE_WAVES
-#define GR_TRACE_WAVES 4
+#define GR_TRACE_WAVES 1
 #endif
 
 typedef const dynamic_config* __restrict__ cfg_t;
