@@ -103,6 +103,15 @@ struct dynamic_feature_config {
 typedef const dynamic_config* __restrict__ cfg_t;
 typedef const dynamic_feature_config* __restrict__ dfg_t;
 
+// The integrator kernels copy the (wave-uniform) $cfg and feature blocks into registers once: the generated
+// expressions say `cfg->NAME` inside the Verlet loop, and re-reading them through the pointer costs a scalar load
+// plus an lgkmcnt wait per step.
+#define GR_PARAMETERS_IN_REGISTERS                                   \
+    const dynamic_config gr_cfg_registers = *cfg_in;                 \
+    const dynamic_feature_config gr_dfg_registers = *dfg_in;         \
+    const dynamic_config* const cfg = &gr_cfg_registers;             \
+    const dynamic_feature_config* const dfg = &gr_dfg_registers;
+
 // ------------------------------------------------------------------------------------------------
 // math used by the generated expressions.  Everything generated is evaluated inside namespace gm,
 // so unqualified sin/cos/... bind to these fp32 versions.
@@ -967,9 +976,10 @@ extern "C" __global__ void gr_init_rays_generic(const float4* __restrict__ g_gen
 extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
 gr_do_generic_rays(lightray* __restrict__ generic_rays_in, const int* __restrict__ generic_count_in,
                    int* __restrict__ ray_time_min, int* __restrict__ ray_time_max,
-                   cfg_t cfg, dfg_t dfg, int width, int height, int mouse_x, int mouse_y,
+                   cfg_t cfg_in, dfg_t dfg_in, int width, int height, int mouse_x, int mouse_y,
                    float4* __restrict__ ray_write, int* __restrict__ ray_write_counts, int max_write,
                    unsigned long long* __restrict__ attempt_counter) {
+    GR_PARAMETERS_IN_REGISTERS
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= *generic_count_in) return;
     if (ray_write_counts) ray_write_counts[id] = 0;
@@ -1020,7 +1030,8 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
-               cfg_t cfg, dfg_t dfg, unsigned long long* __restrict__ attempt_counter) {
+               cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter) {
+    GR_PARAMETERS_IN_REGISTERS
     // Image rows are dealt to devices in blocks of `block_rows` rows (block-cyclic: global block gb belongs to
     // device gb % strip_count).  One workgroup = one wave = one 8x8 pixel tile of a block; when the image is
     // split, each block is followed by 64x1 "halo" waves tracing the row just below it, which the texture filter
@@ -1083,7 +1094,8 @@ extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
 gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                  int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                  const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
-                 cfg_t cfg, dfg_t dfg) {
+                 cfg_t cfg_in, dfg_t dfg_in) {
+    GR_PARAMETERS_IN_REGISTERS
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= prepass_width * prepass_height) return;
     int cx = id % prepass_width, cy = id / prepass_width;
