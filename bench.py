@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--metric", default="kerr_boyer")
     ap.add_argument("--spin", type=float, default=0.45)
     ap.add_argument("--mode", default="fused", choices=["fused", "reference"])
+    ap.add_argument("--program", default="static", choices=["static", "dynamic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -92,8 +93,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # GR_BENCH_FORCE_DISTRIBUTED=1 drives the multi-GPU code path (process group, strip mode, gather) with one rank
+    multi = world > 1 or os.environ.get("GR_BENCH_FORCE_DISTRIBUTED") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     W, H = args.width, args.height
@@ -101,7 +105,12 @@ def main():
     metric = gra.Metric(args.metric, os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"))
     cfg_values = metric.cfg_values(a=args.spin) if "a" in metric.dynamic_vars else metric.cfg_values()
     features = metric.features(adaptive_sampling=0)
-    program = gra.Program(metric.argument_string(), local_rank)
+    # metric_manager.hpp:19-219: dynamic program first, substituted program (parameters baked in) built in the
+    # background and swapped in; the steady state the reference runs in - and the one timed here - is the substituted one
+    manager = gra.pipeline.ProgramManager(metric, local_rank, features, cfg_values)
+    program = manager.current(wait=(args.program == "static"))
+    if args.program == "dynamic":
+        program = manager.dynamic
     state = gra.RenderState(W, H, local_rank)
     bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
     bg = torch.from_numpy(bg_np).to(device)
@@ -111,10 +120,10 @@ def main():
     fused = args.mode == "fused"
     plan = grd.StripPlan(H, world, block_rows=16)
     out = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
-    gather = grd.FrameGather(plan, W, device, rank, world) if world > 1 else None
+    gather = grd.FrameGather(plan, W, device, rank, world) if multi else None
 
     def frame(time_kernels=False, count_attempts=False):
-        if world == 1:
+        if not multi:
             opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=int(time_kernels),
                                      count_attempts=int(count_attempts))
             state.render(program, metric, camera, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features, cfg_values, opts, stream)
@@ -126,7 +135,7 @@ def main():
             gather.run(out)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +147,7 @@ def main():
         frame()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -148,7 +157,7 @@ def main():
     # per-kernel timing (HIP events recorded on the launch stream) + step-attempt count, outside the headline timing
     roofline = None
     extra = {}
-    if world == 1:
+    if not multi:
         trace_ms = []
         stage_sum = {}
         attempts = 0
@@ -163,8 +172,15 @@ def main():
         t_trace = float(np.mean(trace_ms)) * 1e-3
         alg_bytes = TRACE_BYTES_PER_RAY * W * H if fused else 140 * W * H
         achieved = alg_bytes / t_trace / 1e9
+        # HBM bytes per launch from the PMC passes of the same command (FETCH_SIZE and WRITE_SIZE in separate rocprofv3
+        # --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); committed summary, not live
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_trace_kernel.json")
+        if fused and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "kernel": "gr_trace_fused" if fused else "gr_do_generic_rays", "achieved": round(achieved, 3),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "avg_launch_ms": round(t_trace * 1e3, 4),
                     "note": "register-resident ODE integrator: fp32 VALU bound, see valu_roofline (SURVEY.md 8d)"}
         flops_per_attempt = metric.info.accel_ops + metric.info.coord_ops + STEP_OVERHEAD_FLOPS
@@ -179,6 +195,30 @@ def main():
         skipped = int((rd["terminated"] == 2).sum())
         extra["traced_Mrays_per_s"] = round((W * H - skipped) / (elapsed / args.steps) / 1e6, 2)
         extra["prepass_skipped_fraction"] = round(skipped / (W * H), 4)
+
+        # secondary figures SURVEY.md 8d asks for (same resolution, outside the headline timing)
+        def timed(cam, feats, cfg, prog, mode, n=5):
+            opts = gra.frame_options(mode=mode, tiled=1)
+            for _ in range(2):
+                state.render(prog, metric, cam, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), feats, cfg, opts, stream)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                state.render(prog, metric, cam, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), feats, cfg, opts, stream)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+
+        secondary = {}
+        if "a" in metric.dynamic_vars:
+            t = timed(gra.default_camera([0, 0, -15, 0]), features, cfg_values, manager.dynamic, gra.MODE_FUSED)
+            secondary["far_pose_camera_r15_Mrays_per_s"] = round(W * H / t / 1e6, 1)
+            t = timed(camera, features, metric.cfg_values(a=0.9), manager.dynamic, gra.MODE_FUSED)
+            secondary["superextremal_a0.9_Mrays_per_s"] = round(W * H / t / 1e6, 1)
+        t = timed(camera, metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0), cfg_values, manager.dynamic, gra.MODE_REFERENCE)
+        secondary["adaptive_sampling_on_threshold32_fps"] = round(1 / t, 1)
+        t = timed(camera, features, cfg_values, manager.dynamic, gra.MODE_REFERENCE)
+        secondary["reference_kernel_sequence_dynamic_program_fps"] = round(1 / t, 1)
+        extra["secondary"] = secondary
     else:
         extra["fps"] = round(1e3 / ms_per_step, 2)
 
@@ -196,12 +236,13 @@ def main():
             "config": {"workload": f"{args.metric} (Boyer-Lindquist rs=1 a={args.spin}) {W}x{H}, camera (0,0,-4,0) fov 90, adaptive_sampling off, "
                                    f"prepass {'on' if metric.info.use_prepass else 'off'}, tol {metric.info.max_acceleration_change:g}, "
                                    f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
-                       "mode": args.mode, "parallelism": f"row-blocks x{world}" if world > 1 else "single"},
+                       "mode": args.mode, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
+                       "parallelism": f"16-row blocks, block-cyclic over {world} GPUs + one RCCL gather" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -69,6 +69,9 @@ _SIGNATURES = {
                                           c_char_p, c_size_t, ctypes.POINTER(c_size_t)]),
     "gr_program_create": (c_int, [c_char_p, c_int, ctypes.POINTER(c_void_p)]),
     "gr_program_precompile": (c_int, [c_char_p]),
+    "gr_program_create_async": (c_int, [c_char_p, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_program_future_poll": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "gr_program_future_destroy": (None, [c_void_p]),
     "gr_program_destroy": (None, [c_void_p]),
     "gr_program_kernel_info": (c_int, [c_void_p, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gr_cart_to_generic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),

@@ -22,6 +22,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "builtin_metrics.hpp"
@@ -320,6 +321,55 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
     HIP_CHECK(hipMemcpy(p->huge_count, &huge, sizeof(int), hipMemcpyHostToDevice));
     *out = p.release();
     return GR_OK;
+}
+
+// ---- background build of the substituted program (metric_manager.hpp:153-219) ---------------------------------
+
+struct gr_program_future {
+    std::string arguments;
+    int device = 0;
+    std::thread worker;
+    std::mutex mu;
+    bool done = false;
+    int rc = GR_OK;
+    std::string error;
+    std::string code;
+};
+
+int gr_program_create_async(const char* argument_string, int device, gr_program_future** out) {
+    if (!argument_string || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    auto* f = new gr_program_future();
+    f->arguments = argument_string;
+    f->device = device;
+    f->worker = std::thread([f]() {
+        std::string code;
+        int rc = compile_code_object(f->arguments, code);   // hiprtc only: no device work on this thread
+        std::lock_guard<std::mutex> lock(f->mu);
+        f->rc = rc;
+        if (rc != GR_OK) f->error = g_error;
+        f->code.swap(code);
+        f->done = true;
+    });
+    *out = f;
+    return GR_OK;
+}
+
+int gr_program_future_poll(gr_program_future* f, gr_program** out) {
+    if (!f || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(f->mu);
+        if (!f->done) return 0;
+        if (f->rc != GR_OK) return fail((gr_status)f->rc, f->error);
+    }
+    int rc = gr_program_create(f->arguments.c_str(), f->device, out);   // code object now comes from the cache
+    return rc == GR_OK ? 1 : rc;
+}
+
+void gr_program_future_destroy(gr_program_future* f) {
+    if (!f) return;
+    if (f->worker.joinable()) f->worker.join();
+    delete f;
 }
 
 void gr_program_destroy(gr_program* p) {

@@ -55,7 +55,7 @@ class FrameGather:
 
     def run(self, frame_out=None):
         """one collective: gather to rank 0; returns the assembled [H, W, 4] frame on rank 0, None elsewhere"""
-        if self.world > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.gather(self.local, self.parts, dst=0, group=self.group)
         else:
             self.parts = [self.local]

@@ -109,6 +109,55 @@ class Program:
             self.handle = None
 
 
+class ProgramManager:
+    """metric_manager (metric_manager.hpp:19-219): the "dynamic" program (reads $cfg / features from memory) is usable at
+    once; the "substituted" program with every parameter baked in is built in the background and swapped in when ready.
+    Changing a parameter (`update`) falls back to the dynamic program until the new substituted one is built."""
+
+    def __init__(self, metric, device=0, features=None, cfg_values=None):
+        self.metric, self.device = metric, device
+        self.dynamic = Program(metric.argument_string(), device)
+        self.static = None
+        self._future = None
+        self.update(features, cfg_values)
+
+    def update(self, features=None, cfg_values=None):
+        self.features = features if features is not None else self.metric.features()
+        self.cfg_values = list(cfg_values) if cfg_values is not None else self.metric.cfg_values()
+        self.static = None
+        self._drop_future()
+        args = self.metric.argument_string(features=self.features, static=True, cfg_values=self.cfg_values)
+        self._future = c_void_p()
+        check(lib.gr_program_create_async(args.encode(), self.device, ctypes.byref(self._future)))
+
+    def _drop_future(self):
+        if self._future:
+            lib.gr_program_future_destroy(self._future)
+            self._future = None
+
+    def current(self, wait=False):
+        """the program to launch this frame"""
+        while self.static is None and self._future:
+            handle = c_void_p()
+            rc = lib.gr_program_future_poll(self._future, ctypes.byref(handle))
+            if rc < 0:
+                check(rc)
+            if rc == 1:
+                p = Program.__new__(Program)
+                p.handle, p.device = handle, self.device
+                self.static = p
+                self._drop_future()
+                break
+            if not wait:
+                break
+            import time
+            time.sleep(0.01)
+        return self.static if self.static is not None else self.dynamic
+
+    def __del__(self):
+        self._drop_future()
+
+
 class DeviceBuffer:
     def __init__(self, device, nbytes):
         self.device, self.nbytes = device, nbytes

@@ -134,6 +134,14 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
 /* Compile only (no device needed): fills the on-disk cache; used by the build step. */
 int gr_program_precompile(const char* argument_string);
 
+/* Background build + swap of the "substituted" program (metric_manager.hpp:153-166 builds it asynchronously,
+ * check_substitution :172-219 swaps it in once is_built()).  create_async starts the compile on a worker thread and
+ * returns at once; poll returns 1 and a loaded program when it is ready, 0 while pending, < 0 on a build error. */
+typedef struct gr_program_future gr_program_future;
+int gr_program_create_async(const char* argument_string, int device, gr_program_future** out);
+int gr_program_future_poll(gr_program_future* f, gr_program** out);
+void gr_program_future_destroy(gr_program_future* f);
+
 void gr_program_destroy(gr_program* p);
 
 /* registers / scratch of a kernel as recorded in the code object (0 if unknown) */
