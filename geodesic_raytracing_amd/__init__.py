@@ -46,7 +46,7 @@ class Camera(ctypes.Structure):
 class FrameOptions(ctypes.Structure):
     _fields_ = [("mode", c_int), ("tiled", c_int), ("use_prepass", c_int), ("max_probes", c_int), ("strip_rank", c_int),
                 ("strip_count", c_int), ("block_rows", c_int), ("compact_out", c_int), ("time_kernels", c_int),
-                ("count_attempts", c_int)]
+                ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera))]
 
 
 MODE_REFERENCE, MODE_FUSED = 0, 1

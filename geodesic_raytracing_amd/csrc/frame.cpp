@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -52,6 +53,30 @@ struct gr_render_state {
     std::vector<float> host_cfg;
     gr_features host_features{};
     bool features_valid = false;
+    // second camera/tetrad/termination set + side stream: the next frame's camera set-up and prepass (a latency-bound
+    // launch of only W/16 x H/16 rays) run concurrently with this frame's trace (gr_frame_options.next_camera)
+    struct camera_set {
+        void* camera_pos_cart = nullptr;
+        void* camera_quat = nullptr;
+        void* camera_pos_generic = nullptr;
+        void* tetrad[4] = {};
+        void* termination_buffer = nullptr;
+    } alt;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t main_mark = nullptr, alt_ready = nullptr;
+    bool alt_prefetched = false;
+    gr_camera alt_camera{};
+    std::vector<float> alt_cfg;
+    gr_features alt_features{};
+    const void* alt_program = nullptr;
+
+    void swap_sets() {
+        std::swap(camera_pos_cart, alt.camera_pos_cart);
+        std::swap(camera_quat, alt.camera_quat);
+        std::swap(camera_pos_generic, alt.camera_pos_generic);
+        for (int i = 0; i < 4; i++) std::swap(tetrad[i], alt.tetrad[i]);
+        std::swap(termination_buffer, alt.termination_buffer);
+    }
 };
 
 static const int CFG_MAX = 64;
@@ -80,6 +105,7 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->compact_out = 0;
     o->time_kernels = 0;
     o->count_attempts = 0;
+    o->next_camera = nullptr;
 }
 
 int gr_device_count(int* count) {
@@ -140,6 +166,14 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
     size_t px = (size_t)width * height;
     A(&s->render_data, px * sizeof(gr_render_data));
     A(&s->termination_buffer, px * sizeof(int));
+    A(&s->alt.camera_pos_cart, 16);
+    A(&s->alt.camera_quat, 16);
+    A(&s->alt.camera_pos_generic, 16);
+    for (auto& t : s->alt.tetrad) A(&t, 16);
+    A(&s->alt.termination_buffer, px * sizeof(int));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->main_mark, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->alt_ready, hipEventDisableTiming);
     for (int i = 0; i < GR_STAGE_COUNT && e == hipSuccess; i++) {
         e = hipEventCreate(&s->ev_start[i]);
         if (e == hipSuccess) e = hipEventCreate(&s->ev_stop[i]);
@@ -157,7 +191,12 @@ void gr_render_state_destroy(gr_render_state* s) {
     (void)hipSetDevice(s->device);
     void* ptrs[] = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
                     s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
-                    s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer};
+                    s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->alt.camera_pos_cart,
+                    s->alt.camera_quat, s->alt.camera_pos_generic, s->alt.tetrad[0], s->alt.tetrad[1], s->alt.tetrad[2],
+                    s->alt.tetrad[3], s->alt.termination_buffer};
+    if (s->side_stream) { (void)hipStreamSynchronize(s->side_stream); (void)hipStreamDestroy(s->side_stream); }
+    if (s->main_mark) (void)hipEventDestroy(s->main_mark);
+    if (s->alt_ready) (void)hipEventDestroy(s->alt_ready);
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < GR_STAGE_COUNT; i++) {
@@ -252,8 +291,21 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         s->host_features = features;
         s->features_valid = true;
     }
-    HIP_CHECK(hipMemcpyAsync(s->camera_pos_cart, camera->position, 16, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(s->camera_quat, camera->quat, 16, hipMemcpyHostToDevice, stream));
+    int prepass_width = width / 16, prepass_height = height / 16;   // main.cpp:2380-2381
+    if (prepass_width < 1 || prepass_height < 1) use_prepass = false;
+
+    // was this frame's camera set-up + prepass already done on the side stream during the previous frame?
+    bool prefetched = opt.mode == GR_MODE_FUSED && use_prepass && s->alt_prefetched && s->alt_program == (const void*)p &&
+                      memcmp(&s->alt_camera, camera, sizeof(gr_camera)) == 0 && s->alt_cfg == cfg &&
+                      memcmp(&s->alt_features, &features, sizeof(features)) == 0;
+    s->alt_prefetched = false;
+    if (prefetched) {
+        s->swap_sets();
+        HIP_CHECK(hipStreamWaitEvent(stream, s->alt_ready, 0));
+    } else {
+        HIP_CHECK(hipMemcpyAsync(s->camera_pos_cart, camera->position, 16, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(s->camera_quat, camera->quat, 16, hipMemcpyHostToDevice, stream));
+    }
 
     for (int i = 0; i < GR_STAGE_COUNT; i++) s->stage_timed[i] = false;
     auto begin = [&](int st) -> int {
@@ -271,26 +323,27 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     }
 
     // camera position and tetrad (main.cpp:2311, 2329)
-    GR_CHECK(begin(GR_STAGE_CAMERA));
-    GR_CHECK(gr_cart_to_generic(p, stream, s->camera_pos_cart, s->camera_pos_generic, 1, camera->flip, s->cfg));
-    GR_CHECK(gr_init_basis_vectors(p, stream, s->camera_pos_generic, 1, camera->basis_speed, s->tetrad[0], s->tetrad[1],
-                                   s->tetrad[2], s->tetrad[3], s->cfg));
-    GR_CHECK(end(GR_STAGE_CAMERA));
-
-    int prepass_width = width / 16, prepass_height = height / 16;   // main.cpp:2380-2381
-    if (prepass_width < 1 || prepass_height < 1) use_prepass = false;
+    if (!prefetched) {
+        GR_CHECK(begin(GR_STAGE_CAMERA));
+        GR_CHECK(gr_cart_to_generic(p, stream, s->camera_pos_cart, s->camera_pos_generic, 1, camera->flip, s->cfg));
+        GR_CHECK(gr_init_basis_vectors(p, stream, s->camera_pos_generic, 1, camera->basis_speed, s->tetrad[0], s->tetrad[1],
+                                       s->tetrad[2], s->tetrad[3], s->cfg));
+        GR_CHECK(end(GR_STAGE_CAMERA));
+    }
 
     if (opt.mode == GR_MODE_FUSED) {
         if (adaptive) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused mode traces every pixel: turn adaptive_sampling off");
         int strip_count = opt.strip_count > 1 ? opt.strip_count : 1;
         int strip_rank = strip_count > 1 ? opt.strip_rank : 0;
         int block_rows = strip_count > 1 ? opt.block_rows : ((height + 7) / 8) * 8;
-        if (use_prepass) {
+        if (use_prepass && !prefetched) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_prepass_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->termination_buffer, prepass_width,
                                       prepass_height, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg));
             GR_CHECK(end(GR_STAGE_PREPASS));
         }
+        const bool prefetch_next = use_prepass && opt.next_camera != nullptr;
+        if (prefetch_next) HIP_CHECK(hipEventRecord(s->main_mark, stream));   // everything up to here is older than the prefetch
         // every device runs the (tiny) prepass itself; its own row blocks (+ one halo row each) are traced here
         GR_CHECK(begin(GR_STAGE_TRACE));
         GR_CHECK(gr_trace_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
@@ -298,6 +351,25 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                 use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
                                 s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
         GR_CHECK(end(GR_STAGE_TRACE));
+        if (prefetch_next) {
+            // next frame's camera set-up and prepass on the side stream, into the other buffer set, while the trace runs
+            const gr_camera* next = opt.next_camera;
+            HIP_CHECK(hipStreamWaitEvent(s->side_stream, s->main_mark, 0));
+            HIP_CHECK(hipMemcpyAsync(s->alt.camera_pos_cart, next->position, 16, hipMemcpyHostToDevice, s->side_stream));
+            HIP_CHECK(hipMemcpyAsync(s->alt.camera_quat, next->quat, 16, hipMemcpyHostToDevice, s->side_stream));
+            GR_CHECK(gr_cart_to_generic(p, s->side_stream, s->alt.camera_pos_cart, s->alt.camera_pos_generic, 1, next->flip, s->cfg));
+            GR_CHECK(gr_init_basis_vectors(p, s->side_stream, s->alt.camera_pos_generic, 1, next->basis_speed, s->alt.tetrad[0],
+                                           s->alt.tetrad[1], s->alt.tetrad[2], s->alt.tetrad[3], s->cfg));
+            GR_CHECK(gr_prepass_fused(p, s->side_stream, s->alt.camera_pos_generic, s->alt.camera_quat, s->alt.termination_buffer,
+                                      prepass_width, prepass_height, s->alt.tetrad[0], s->alt.tetrad[1], s->alt.tetrad[2],
+                                      s->alt.tetrad[3], s->cfg, s->dfg));
+            HIP_CHECK(hipEventRecord(s->alt_ready, s->side_stream));
+            s->alt_prefetched = true;
+            s->alt_camera = *next;
+            s->alt_cfg = cfg;
+            s->alt_features = features;
+            s->alt_program = (const void*)p;
+        }
         if (out) {
             GR_CHECK(begin(GR_STAGE_RENDER));
             GR_CHECK(gr_render_strips(p, stream, s->render_data, out, bg1, bg2, bg_width, bg_height, bg_levels, width, height,

@@ -241,12 +241,13 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
 typedef struct gr_render_state gr_render_state;   /* render_state.hpp:97-197: all per-frame device buffers */
 
 /* camera, main.cpp:664-673: Cartesian (t,x,y,z) position, orientation quaternion (x,y,z,w) */
-typedef struct gr_camera {
+typedef struct gr_camera gr_camera;
+struct gr_camera {
     float position[4];
     float quat[4];
     float basis_speed[3];   /* cartesian_basis_speed, main.cpp:2320-2327 */
     float flip;             /* flip_sign > 0 puts the camera on the far side (negative r) */
-} gr_camera;
+};
 void gr_camera_default(gr_camera* out);   /* pos (0,0,-4,0), axis-angle (1,0,0,-pi/2) */
 
 enum { GR_MODE_REFERENCE = 0,   /* one launch per reference kernel, 96-byte ray records in HBM */
@@ -263,6 +264,9 @@ typedef struct gr_frame_options {
     int compact_out;       /*   1: write this device's blocks back to back into out (gather layout)               */
     int time_kernels;      /* record HIP events around every stage (gr_render_state_stage_ms) */
     int count_attempts;    /* accumulate Verlet step attempts (gr_render_state_attempts) */
+    const struct gr_camera* next_camera;   /* fused mode, optional: the camera of the NEXT gr_render_frame call.  Its tetrad and
+                            * prepass are then computed on a second stream while this frame traces, and the next call
+                            * (same program / cfg / features / camera) skips them.  NULL = no look-ahead. */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 

@@ -123,3 +123,41 @@ def test_alcubierre_8k_rows_sample():
     band = rd[135 * 16:136 * 16]
     assert (band["terminated"] == 1).all()
     assert np.abs(band["z_shift"]).max() < 5 and np.abs(band["z_shift"]).max() > 0
+
+
+def test_prepass_lookahead_is_bit_identical():
+    """frames rendered with the next camera's prepass overlapped on the side stream equal frames rendered one by one"""
+    import ctypes
+    w, h = 1280, 720
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    dbg, levels = background()
+    feats = metric.features(adaptive_sampling=0)
+    cfg = metric.cfg_values(a=0.45)
+    cams = [gra.default_camera([0, 0.2 * i, -4 - 0.5 * i, 0.1 * i]) for i in range(4)]
+    out = DeviceBuffer(0, w * h * 16)
+
+    def render_all(lookahead):
+        state = gra.RenderState(w, h, 0)
+        frames = []
+        for i, cam in enumerate(cams):
+            opts = gra.frame_options(mode=gra.MODE_FUSED)
+            if lookahead and i + 1 < len(cams):
+                opts.next_camera = ctypes.pointer(cams[i + 1])
+            state.render(prog, metric, cam, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfg, opts)
+            state.synchronize()
+            frames.append(out.to_numpy(np.float32, (h, w, 4)))
+        return frames
+
+    plain, piped = render_all(False), render_all(True)
+    for a, b in zip(plain, piped):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(plain[0], plain[1])
+    # a look-ahead that turns out wrong (different camera next) is simply discarded
+    state = gra.RenderState(w, h, 0)
+    opts = gra.frame_options(mode=gra.MODE_FUSED)
+    opts.next_camera = ctypes.pointer(cams[3])
+    state.render(prog, metric, cams[0], out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfg, opts)
+    state.render(prog, metric, cams[1], out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfg, gra.frame_options(mode=gra.MODE_FUSED))
+    state.synchronize()
+    assert np.array_equal(out.to_numpy(np.float32, (h, w, 4)), plain[1])
