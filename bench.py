@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--mode", default="fused", choices=["fused", "reference"])
     ap.add_argument("--program", default="static", choices=["static", "dynamic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (other poses / modes); used for profiling runs")
     ap.add_argument("--no-lookahead", action="store_true", help="do not overlap the next frame's prepass with this frame's trace")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -218,16 +219,19 @@ def main():
             return (time.perf_counter() - t) / n
 
         secondary = {}
-        if "a" in metric.dynamic_vars:
+        if args.no_secondary:
+            timed = None
+        if timed and "a" in metric.dynamic_vars:
             t = timed(gra.default_camera([0, 0, -15, 0]), features, cfg_values, manager.dynamic, gra.MODE_FUSED)
             secondary["far_pose_camera_r15_Mrays_per_s"] = round(W * H / t / 1e6, 1)
             t = timed(camera, features, metric.cfg_values(a=0.9), manager.dynamic, gra.MODE_FUSED)
             secondary["superextremal_a0.9_Mrays_per_s"] = round(W * H / t / 1e6, 1)
-        t = timed(camera, metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0), cfg_values, manager.dynamic, gra.MODE_REFERENCE)
-        secondary["adaptive_sampling_on_threshold32_fps"] = round(1 / t, 1)
-        t = timed(camera, features, cfg_values, manager.dynamic, gra.MODE_REFERENCE)
-        secondary["reference_kernel_sequence_dynamic_program_fps"] = round(1 / t, 1)
-        extra["secondary"] = secondary
+        if timed:
+            t = timed(camera, metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0), cfg_values, manager.dynamic, gra.MODE_REFERENCE)
+            secondary["adaptive_sampling_on_threshold32_fps"] = round(1 / t, 1)
+            t = timed(camera, features, cfg_values, manager.dynamic, gra.MODE_REFERENCE)
+            secondary["reference_kernel_sequence_dynamic_program_fps"] = round(1 / t, 1)
+            extra["secondary"] = secondary
     else:
         extra["fps"] = round(1e3 / ms_per_step, 2)
 

@@ -1,0 +1,39 @@
+"""Summarises rocprofv3 --pmc CSV passes (gpurun_out/<dir>/pmc_counter_collection.csv) into a text table and the
+profiles/pmc_trace_kernel.json that bench.py reads for roofline.traffic."""
+import collections, csv, json, os, sys
+
+def load(dirs):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        f = os.path.join(d, "pmc_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if k.startswith("gr_"):
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {n: sum(v) / len(v) for n, v in c.items()} for k, c in agg.items()}
+
+if __name__ == "__main__":
+    out_txt, out_json = sys.argv[1], sys.argv[2]
+    data = load(sys.argv[3:])
+    lines = ["# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-lookahead   (one pass per counter set)",
+             "# 3840x2160 Kerr a=0.45, fused mode, substituted program; per-dispatch means; FETCH_SIZE / WRITE_SIZE in KiB"]
+    for k in sorted(data):
+        for n in sorted(data[k]):
+            lines.append(f"{k:22s} {n:26s} {data[k][n]:16.6g}")
+    t = data.get("gr_trace_fused", {})
+    if t:
+        lane_util = t["SQ_THREAD_CYCLES_VALU"] / (t["SQ_ACTIVE_INST_VALU"] * 64)
+        fetch, write = t.get("FETCH_SIZE", 0) * 1024, t.get("WRITE_SIZE", 0) * 1024
+        hbm = 2 * fetch + write       # gfx950: FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM)
+        lines += ["", "# derived, gr_trace_fused:",
+                  f"#   VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64) = {lane_util:.3f}",
+                  f"#   SQ_INSTS_VALU = {t['SQ_INSTS_VALU']:.4g} wave-instructions per launch",
+                  f"#   wave time: WAIT_INST_ANY {t['SQ_WAIT_INST_ANY'] / t['SQ_WAVE_CYCLES']:.2f}, WAIT_ANY {t['SQ_WAIT_ANY'] / t['SQ_WAVE_CYCLES']:.2f} of SQ_WAVE_CYCLES",
+                  f"#   HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE = 2 x {fetch:.4g} + {write:.4g} = {hbm:.4g} B  (algorithmic: 32 B x 8294400 = 2.654e8 B)"]
+        json.dump({"kernel": "gr_trace_fused", "hbm_bytes_per_launch": round(hbm), "fetch_size_bytes": round(fetch), "write_size_bytes": round(write),
+                   "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)", "valu_lane_utilisation": round(lane_util, 4),
+                   "source": "profiles/" + os.path.basename(out_txt)}, open(out_json, "w"), indent=1)
+    open(out_txt, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[-6:]))
