@@ -57,6 +57,12 @@ CASES = {
     "alcubierre": dict(metric="alcubierre", size=(48, 27), features=dict(redshift=1), camera_pos=[0.0, 0.0, -6.0, 0.5]),
     "double_unequal_kerr": dict(metric="double_unequal_kerr", scripts=True, size=(48, 27), camera_pos=[0.0, 0.0, -6.0, 0.5]),
     "kerr_script": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(48, 27), cfg=dict(a=0.45)),
+    "ingoing_ef": dict(metric="schwarzschild_ingoing_ef", scripts=True, size=(48, 27)),
+    "wormhole_through": dict(metric="wormhole", scripts=True, size=(48, 27), camera_pos=[0.0, 0.0, -2.5, 0.3]),
+    "wormhole_far_side": dict(metric="wormhole", scripts=True, size=(48, 27), camera_pos=[0.0, 1.0, -3.0, 0.5], flip=1.0),
+    "kerr_reparameterised": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), features=dict(reparameterisation=1)),
+    "schwarzschild_wide_universe": dict(metric="schwarzschild", size=(48, 27),
+                                        features=dict(field_of_view=60.0, universe_size=40.0, max_precision_radius=15.0)),
     "kerr_moving_observer": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.3, 0.0, 0.2], features=dict(redshift=1)),
 }
 
@@ -75,8 +81,8 @@ def make_case(name, spec, scripts_dir=None):
     prepass = bool(spec.get("prepass", False))
     res = pipe.frame(w, h, cfg, pack_features(**feats), camera_pos=spec.get("camera_pos", (0, 0, -4, 0)),
                      camera_quat=spec.get("camera_quat", DEFAULT_QUAT), use_prepass=prepass, background=(bg, levels),
-                     basis_speed=spec.get("basis_speed", (0, 0, 0)))
-    meta = dict(metric=spec["metric"], scripts=bool(spec.get("scripts")), width=w, height=h, cfg=cfg, features=feats, camera_pos=list(map(float, spec.get("camera_pos", (0, 0, -4, 0)))),
+                     basis_speed=spec.get("basis_speed", (0, 0, 0)), flip=float(spec.get("flip", 0.0)))
+    meta = dict(flip=float(spec.get("flip", 0.0)), metric=spec["metric"], scripts=bool(spec.get("scripts")), width=w, height=h, cfg=cfg, features=feats, camera_pos=list(map(float, spec.get("camera_pos", (0, 0, -4, 0)))),
                 camera_quat=list(map(float, spec.get("camera_quat", DEFAULT_QUAT))), prepass=prepass, bg_size=BG_SIZE, bg_seed=BG_SEED,
                 basis_speed=list(map(float, spec.get("basis_speed", (0, 0, 0)))), max_probes=8,
                 argument_string_fnv=hex(hash(metric.argument_string()) & 0xffffffff))

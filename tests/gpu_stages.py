@@ -67,7 +67,7 @@ class Stages:
     def camera(self):
         cart = buf(np.array(self.meta["camera_pos"], dtype=np.float32))
         generic = DeviceBuffer(0, 16)
-        gra.check(gra.lib.gr_cart_to_generic(self.p, None, cart.ptr, generic.ptr, 1, 0.0, self.cfg.ptr))
+        gra.check(gra.lib.gr_cart_to_generic(self.p, None, cart.ptr, generic.ptr, 1, float(self.meta.get("flip", 0.0)), self.cfg.ptr))
         e = [DeviceBuffer(0, 16) for _ in range(4)]
         speed = (ctypes.c_float * 3)(*self.meta["basis_speed"])
         gra.check(gra.lib.gr_init_basis_vectors(self.p, None, generic.ptr, 1, speed, e[0].ptr, e[1].ptr, e[2].ptr, e[3].ptr, self.cfg.ptr))

@@ -122,6 +122,7 @@ def _frame(meta, mode, tiled=0, options=None):
     out = DeviceBuffer(0, w * h * 16)
     cam = gra.default_camera(meta["camera_pos"], meta["camera_quat"])
     cam.basis_speed = (gra.c_float * 3)(*meta["basis_speed"])
+    cam.flip = float(meta.get("flip", 0.0))
     opts = gra.frame_options(mode=mode, tiled=tiled, use_prepass=int(meta["prepass"]), **(options or {}))
     state.render(prog, metric, cam, out.ptr, (dbg.ptr, bg.shape[2], bg.shape[1], levels), feats, meta["cfg"], opts)
     state.synchronize()

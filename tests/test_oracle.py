@@ -16,7 +16,7 @@ def run_oracle(so, meta):
     bg, levels = gra.pack_background(gra.synthetic_background(*meta["bg_size"], seed=meta["bg_seed"]))
     return OraclePipeline(so).frame(meta["width"], meta["height"], meta["cfg"], pack_features(**meta["features"]),
                                     camera_pos=meta["camera_pos"], camera_quat=meta["camera_quat"], use_prepass=meta["prepass"],
-                                    background=(bg, levels), basis_speed=meta["basis_speed"], nthreads=4)
+                                    background=(bg, levels), basis_speed=meta["basis_speed"], nthreads=4, flip=float(meta.get("flip", 0.0)))
 
 
 @pytest.mark.parametrize("name", golden_names())
