@@ -253,20 +253,25 @@ void MetricDescriptor::load(const MetricFunctions& f, const MetricConfig& cfg) {
     E vv[4][4];
     for (int k = 0; k < 4; k++)
         for (int l = k; l < 4; l++) vv[k][l] = mul(vel[k], vel[l]);
-    raw.accel.clear();
-    for (int i = 0; i < 4; i++) {
+    // Same contraction as the reference's Gamma^i_kl v^k v^l, associated the cheap way round: first the covariant
+    // components  w_m = Gamma_{m,kl} v^k v^l = sum_{k<=l} (d_l g_mk + d_k g_ml - d_m g_kl) [1/2 if k == l] v^k v^l,
+    // whose coefficients are plain partial derivatives, then one raise  a^i = -g^{im} w_m.  Forming the 40 mixed
+    // Christoffel symbols g^{im} Gamma_{m,kl} first costs ~25 more multiplications per Verlet step for Kerr.
+    E lowered[4];
+    for (int m = 0; m < 4; m++) {
         E sum = constant(0.0);
         for (int k = 0; k < 4; k++)
             for (int l = k; l < 4; l++) {
-                E coeff = constant(0.0);
-                for (int m = 0; m < 4; m++) {
-                    if (is_zero(ginv[i][m])) continue;
-                    E bracket = sub(add(dg[l][m][k], dg[k][m][l]), dg[m][k][l]);
-                    coeff = add(coeff, mul(ginv[i][m], bracket));
-                }
-                if (k == l) coeff = mul(constant(0.5), coeff);   // off-diagonal pairs appear twice
-                sum = add(sum, mul(coeff, vv[k][l]));
+                E bracket = sub(add(dg[l][m][k], dg[k][m][l]), dg[m][k][l]);
+                if (k == l) bracket = mul(constant(0.5), bracket);   // off-diagonal pairs appear twice
+                sum = add(sum, mul(bracket, vv[k][l]));
             }
+        lowered[m] = sum;
+    }
+    raw.accel.clear();
+    for (int i = 0; i < 4; i++) {
+        E sum = constant(0.0);
+        for (int m = 0; m < 4; m++) sum = add(sum, mul(ginv[i][m], lowered[m]));
         raw.accel.push_back(neg(sum));
     }
 
