@@ -142,10 +142,11 @@ def main():
                 opts.next_camera = lookahead
             state.render(program, metric, camera, gather.local_buffer().data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features,
                          cfg_values, opts, stream)
-            gather.run(out)
+            gather.submit(out)      # the gather of this frame overlaps the next frame's trace (double-buffered strips)
 
     def barrier():
         if multi:
+            gather.drain(out)       # every frame submitted so far is gathered and assembled on rank 0
             dist.barrier()
         torch.cuda.synchronize()
 

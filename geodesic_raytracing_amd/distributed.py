@@ -6,7 +6,8 @@ are mostly skipped by the prepass, is spread over all ranks instead of landing o
 Every rank traces one extra "halo" row under each of its blocks (the texture filter reads the pixel
 below, cl.cl:5509-5520) instead of exchanging render_data rows.  The only collective is ONE gather of
 the finished float4 rows to rank 0 (direct fan-in over the 7 xGMI links), followed by a local
-un-permute of the block-cyclic layout.  The reference itself is single-GPU.
+un-permute of the block-cyclic layout.  The gather of frame n runs on RCCL's stream while frame n+1 is
+traced (`submit` / `drain`, double-buffered strips).  The reference itself is single-GPU.
 """
 import torch
 import torch.distributed as dist
@@ -40,32 +41,81 @@ class StripPlan:
 
 class FrameGather:
     """Gathers every rank's compact strip buffer ([blocks_per_rank, block_rows, W, 4] float32) on rank 0 and
-    un-permutes it into the [H, W, 4] frame."""
+    un-permutes it into the [H, W, 4] frame.
 
-    def __init__(self, plan, width, device, rank, world, group=None):
+    run():              synchronous - gather + assemble, returns the frame on rank 0.
+    submit() / drain(): pipelined - the gather of the strips just rendered is issued asynchronously and completes
+                        while the next frame is traced into the other strip buffer; a frame is assembled on rank 0
+                        when its buffer comes round again (or at drain())."""
+
+    def __init__(self, plan, width, device, rank, world, group=None, depth=2):
         self.plan, self.width, self.rank, self.world, self.group = plan, width, rank, world, group
         shape = (plan.blocks_per_rank, plan.block_rows, width, 4)
-        self.local = torch.zeros(shape, dtype=torch.float32, device=device)
-        self.parts = [torch.zeros(shape, dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
-        self.frame = None
+        self.locals = [torch.zeros(shape, dtype=torch.float32, device=device) for _ in range(depth)]
+        self.parts = [[torch.zeros(shape, dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
+                      for _ in range(depth)]
+        self.pending = [None] * depth
+        self.slot = 0
+        self.frames_done = 0
 
     def local_buffer(self):
         """the compact buffer gr_render_frame writes into (options.compact_out = 1)"""
-        return self.local
+        return self.locals[self.slot]
 
-    def run(self, frame_out=None):
-        """one collective: gather to rank 0; returns the assembled [H, W, 4] frame on rank 0, None elsewhere"""
-        if dist.is_available() and dist.is_initialized():
-            dist.gather(self.local, self.parts, dst=0, group=self.group)
-        else:
-            self.parts = [self.local]
-        if self.rank != 0:
-            return None
+    def _collective(self):
+        return dist.is_available() and dist.is_initialized()
+
+    def _assemble(self, parts, frame_out):
         p = self.plan
-        # parts[r][i] is global block i*world + r  ->  stack to [blocks_per_rank, world, block_rows, W, 4]
-        stacked = torch.stack(self.parts, dim=1).reshape(p.blocks_per_rank * self.world * p.block_rows, self.width, 4)
+        # parts[r][i] is global block i*world + r  ->  [blocks_per_rank, world, block_rows, W, 4] -> rows
+        stacked = torch.stack(parts, dim=1).reshape(p.blocks_per_rank * self.world * p.block_rows, self.width, 4)
         frame = stacked[:p.height]
         if frame_out is not None:
             frame_out.copy_(frame)
             return frame_out
         return frame
+
+    def run(self, frame_out=None):
+        """one collective: gather to rank 0; returns the assembled [H, W, 4] frame on rank 0, None elsewhere"""
+        i = self.slot
+        if self._collective():
+            dist.gather(self.locals[i], self.parts[i], dst=0, group=self.group)
+            parts = self.parts[i]
+        else:
+            parts = [self.locals[i]]
+        if self.rank != 0:
+            return None
+        return self._assemble(parts, frame_out)
+
+    def _finish(self, j, frame_out):
+        work = self.pending[j]
+        if work is None:
+            return None
+        self.pending[j] = None
+        if work is not True:
+            work.wait()          # orders the current stream after the collective; the host does not block
+        self.frames_done += 1
+        if self.rank != 0:
+            return None
+        return self._assemble(self.parts[j] if self._collective() else [self.locals[j]], frame_out)
+
+    def submit(self, frame_out=None):
+        """call after rendering into local_buffer(): starts its gather and moves on to the other buffer.  Returns the
+        frame (rank 0) whose buffer is about to be reused, if one was in flight, else None."""
+        i = self.slot
+        if self._collective():
+            self.pending[i] = dist.gather(self.locals[i], self.parts[i], dst=0, group=self.group, async_op=True)
+        else:
+            self.pending[i] = True
+        self.slot = (i + 1) % len(self.locals)
+        return self._finish(self.slot, frame_out)
+
+    def drain(self, frame_out=None):
+        """completes every gather still in flight; returns the last assembled frame on rank 0"""
+        last = None
+        n = len(self.locals)
+        for k in range(n):
+            r = self._finish((self.slot + k) % n, frame_out)
+            if r is not None:
+                last = r
+        return last

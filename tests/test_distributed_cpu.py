@@ -74,6 +74,58 @@ def test_gather_assembles_the_frame_world_size_2(tmp_path, height, width, block)
     assert os.path.exists(tmp_path / "ok.npy")
 
 
+def _pipelined_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    height, width, block = 54, 6, 8
+    plan = StripPlan(height, world, block)
+    g = FrameGather(plan, width, torch.device("cpu"), rank, world)
+    torch.manual_seed(1)
+    frames = [torch.rand((height, width, 4)) for _ in range(5)]
+    got = []
+    out = torch.zeros((height, width, 4)) if rank == 0 else None
+    for f in frames:                       # bench.py's loop: render into local_buffer(), submit, next frame
+        local = g.local_buffer()
+        local.zero_()
+        for i, (a, b) in enumerate(plan.blocks_of(rank)):
+            local[i, :b - a] = f[a:b]
+        r = g.submit(out)
+        if r is not None:
+            got.append(r.clone())
+    r = g.drain(out)
+    if r is not None:
+        got.append(r.clone())
+    assert g.frames_done == len(frames)
+    if rank == 0:
+        # every frame comes out exactly once, in order (the drain returns the last one)
+        assert len(got) >= 1 and torch.equal(got[-1], frames[-1])
+        for k, fr in enumerate(got[:-1]):
+            assert any(torch.equal(fr, f) for f in frames)
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([len(got)]))
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_world_size_2(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_pipelined_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok.npy")
+
+
+def test_pipelined_gather_without_process_group():
+    plan = StripPlan(40, 1, 8)
+    g = FrameGather(plan, 5, torch.device("cpu"), 0, 1)
+    frames = [torch.rand((40, 5, 4)) for _ in range(3)]
+    outs = []
+    for f in frames:
+        g.local_buffer().copy_(f.view(5, 8, 5, 4))
+        r = g.submit()
+        if r is not None:
+            outs.append(r.clone())
+    outs.append(g.drain().clone())
+    assert torch.equal(outs[-1], frames[-1]) and torch.equal(outs[0], frames[0])
+
+
 def test_single_rank_gather_is_identity():
     plan = StripPlan(40, 1, 8)
     g = FrameGather(plan, 5, torch.device("cpu"), 0, 1)
