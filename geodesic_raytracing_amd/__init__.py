@@ -113,6 +113,10 @@ _SIGNATURES = {
     "gr_device_synchronize": (c_int, [c_int]),
     "gr_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "gr_pack_mipped_background": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "gr_frame_to_rgba8": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "gr_write_frame_png": (c_int, [c_char_p, c_void_p, c_int, c_int]),
+    "gr_write_png_rgba8": (c_int, [c_char_p, c_void_p, c_int, c_int]),
+    "gr_read_png_rgba8": (c_int, [c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_size_t]),
 }
 
 for _name, (_res, _args) in _SIGNATURES.items():

@@ -309,6 +309,16 @@ int gr_device_count(int* count);
  * Returns the number of levels; `out` needs levels*width*height*4 bytes (call with out=NULL to query). */
 int gr_pack_mipped_background(const unsigned char* rgba, int width, int height, unsigned char* out);
 
+/* ---- host helpers: PNG in/out (headless counterpart of the screenshot path main.cpp:2762-2808 and of the
+ *      sf::Image background loader graphics_settings.cpp:214-243) ------------------------------------------- */
+
+/* clamp -> linear-to-sRGB -> clamp -> 8 bit, as the reference's screenshot loop does (main.cpp:2791-2800) */
+int gr_frame_to_rgba8(const float* frame_rgba_f32, int width, int height, unsigned char* out_rgba8);
+int gr_write_frame_png(const char* path, const float* frame_rgba_f32, int width, int height);
+int gr_write_png_rgba8(const char* path, const unsigned char* rgba, int width, int height);
+/* 8-bit non-interlaced PNG -> RGBA8; call with out = NULL to query the size */
+int gr_read_png_rgba8(const char* path, int* width, int* height, unsigned char* out, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

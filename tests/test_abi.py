@@ -109,3 +109,26 @@ def test_strip_block_helpers():
     assert sum(gra.lib.gr_strip_local_blocks(2160, 16, r, 8) for r in range(8)) == 135
     assert gra.lib.gr_tiled_slot_count(3840, 2160) == 3840 * 2160
     assert gra.lib.gr_tiled_slot_count(10, 9) == 16 * 16
+
+
+def test_png_round_trip_and_screenshot_conversion(tmp_path):
+    """gr_write_frame_png = the reference's screenshot loop (main.cpp:2791-2800): clamp, linear -> sRGB, clamp, 8 bit"""
+    from geodesic_raytracing_amd.render import read_png, write_frame_png
+    rng = np.random.RandomState(2)
+    frame = rng.uniform(-0.2, 1.3, size=(19, 31, 4)).astype(np.float32)
+    path = str(tmp_path / "f.png")
+    write_frame_png(path, frame)
+    got = read_png(path)
+    c = np.clip(frame, 0, 1)
+    srgb = np.where(c <= 0.0031308, c * 12.92, 1.055 * np.power(c, 1 / 2.4) - 0.055)
+    want = (np.clip(srgb, 0, 1) * 255).astype(np.uint8)
+    assert got.shape == (19, 31, 4) and np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    # a PNG written by another encoder (all filter types, RGB) reads back exactly
+    pil = pytest.importorskip("PIL.Image")
+    img = rng.randint(0, 256, size=(23, 17, 3)).astype(np.uint8)
+    img[5:15, 3:9] = np.linspace(0, 255, 6).astype(np.uint8)[None, :, None]
+    pil.fromarray(img).save(str(tmp_path / "g.png"), optimize=True)
+    back = read_png(str(tmp_path / "g.png"))
+    assert np.array_equal(back[..., :3], img) and (back[..., 3] == 255).all()
+    with pytest.raises(gra.GeodesicError):
+        read_png(str(tmp_path / "missing.png"))

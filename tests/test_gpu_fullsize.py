@@ -161,3 +161,19 @@ def test_prepass_lookahead_is_bit_identical():
     state.render(prog, metric, cams[1], out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfg, gra.frame_options(mode=gra.MODE_FUSED))
     state.synchronize()
     assert np.array_equal(out.to_numpy(np.float32, (h, w, 4)), plain[1])
+
+
+def test_headless_render_to_png(tmp_path):
+    """script -> program (substituted, built in the background) -> frame -> PNG, as a user would run it"""
+    from geodesic_raytracing_amd import render as R
+    frame = R.render("kerr_boyer", 640, 360, cfg=dict(a=0.45))
+    assert frame.shape == (360, 640, 4) and np.isfinite(frame).all()
+    shadow = (frame[..., :3].sum(axis=2) == 0).mean()
+    assert 0.4 < shadow < 0.7
+    R.write_frame_png(str(tmp_path / "kerr.png"), frame)
+    back = R.read_png(str(tmp_path / "kerr.png"))
+    assert back.shape == (360, 640, 4) and back[..., :3].max() > 100
+    # adaptive sampling (reference kernel sequence) gives nearly the same picture
+    frame2 = R.render("kerr_boyer", 640, 360, cfg=dict(a=0.45), adaptive=True)
+    d = frame2[..., :3] - frame[..., :3]
+    assert (np.abs(d).max(axis=2) > 0.05).mean() < 0.05
