@@ -96,6 +96,14 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "gr_trace_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gr_boost_tetrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gr_init_inertial_ray": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
+    "gr_get_geodesic_path": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_void_p]),
+    "gr_parallel_transport_quantity": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                               c_void_p]),
+    "gr_handle_interpolating_geodesic": (c_int, [c_void_p] * 14 + [c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gr_camera_default": (None, [ctypes.POINTER(Camera)]),
     "gr_frame_options_default": (None, [ctypes.POINTER(FrameOptions)]),
     "gr_render_state_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),

@@ -81,10 +81,12 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_prepass_fused"};
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_prepass_fused", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_PREPASS_FUSED, K_COUNT
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_PREPASS_FUSED, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
 std::vector<std::string> split_arguments(const std::string& s) {
@@ -524,6 +526,44 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter};
     return launch(p, K_TRACE_FUSED, stream, (unsigned)(waves_per_block * local_blocks), 1, 64, 1, args);
+}
+
+// ---- camera on a timelike geodesic (cl.cl:2441-2481, 3117-3141, 4735-4940, 2569-2620, 2738-2872) --------------------
+
+int gr_boost_tetrad(gr_program* p, void* stream, const void* generic_in, int count, const void* basis_speed, void* e0, void* e1,
+                    void* e2, void* e3, const void* cfg) {
+    void* args[] = {&generic_in, &count, &basis_speed, &e0, &e1, &e2, &e3, &cfg};
+    return launch(p, K_BOOST_TETRAD, stream, blocks(count, 64), 1, 64, 1, args);
+}
+
+int gr_init_inertial_ray(gr_program* p, void* stream, const void* generic_position_in, int ray_count, void* rays, void* ray_count_out,
+                         const void* e0, const void* e1, const void* e2, const void* e3, const void* basis_speed, const void* cfg) {
+    void* args[] = {&generic_position_in, &ray_count, &rays, &ray_count_out, &e0, &e1, &e2, &e3, &basis_speed, &cfg};
+    return launch(p, K_INIT_INERTIAL, stream, blocks(ray_count, 64), 1, 64, 1, args);
+}
+
+int gr_get_geodesic_path(gr_program* p, void* stream, const void* rays, int num_rays, void* positions_out, void* velocities_out,
+                         void* ds_out, const void* ray_count, int max_path_length, const void* cfg, const void* dfg, void* count_out) {
+    void* args[] = {&rays, &positions_out, &velocities_out, &ds_out, &ray_count, &max_path_length, &cfg, &dfg, &count_out};
+    return launch(p, K_GEODESIC_PATH, stream, blocks(num_rays, 64), 1, 64, 1, args);
+}
+
+int gr_parallel_transport_quantity(gr_program* p, void* stream, const void* geodesic_path, const void* geodesic_velocity,
+                                   const void* ds_in, const void* quantity, const void* count_in, int count, void* quantity_out,
+                                   const void* cfg) {
+    void* args[] = {&geodesic_path, &geodesic_velocity, &ds_in, &quantity, &count_in, &count, &quantity_out, &cfg};
+    return launch(p, K_PARALLEL_TRANSPORT, stream, blocks(count, 64), 1, 64, 1, args);
+}
+
+int gr_handle_interpolating_geodesic(gr_program* p, void* stream, const void* geodesic_path, const void* geodesic_velocity,
+                                     const void* ds_in, void* camera_generic_out, const void* t_e0, const void* t_e1,
+                                     const void* t_e2, const void* t_e3, void* e0_out, void* e1_out, void* e2_out, void* e3_out,
+                                     float target_time, const void* count_in, int parallel_transport_observer,
+                                     const void* basis_speed, void* interpolated_velocity, const void* cfg) {
+    void* args[] = {&geodesic_path, &geodesic_velocity, &ds_in, &camera_generic_out, &t_e0, &t_e1, &t_e2, &t_e3, &e0_out, &e1_out,
+                    &e2_out, &e3_out, &target_time, &count_in, &parallel_transport_observer, &basis_speed, &interpolated_velocity,
+                    &cfg};
+    return launch(p, K_INTERPOLATE_GEODESIC, stream, 1, 1, 64, 1, args);
 }
 
 int gr_pack_mipped_background(const unsigned char* rgba, int width, int height, unsigned char* out) {

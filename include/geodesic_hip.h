@@ -216,6 +216,30 @@ int gr_render_strips(gr_program* p, void* stream, const void* render_data, void*
 /* number of row blocks device `strip_rank` owns */
 int gr_strip_local_blocks(int height, int block_rows, int strip_rank, int strip_count);
 
+/* ---- camera riding a timelike geodesic (the snapshot sequence of main.cpp:2675-2760 and the
+ *      per-frame interpolation of main.cpp:2265-2297).  Path buffers are step-major: element k of observer id is at
+ *      [k*count + id].  basis_speed buffers hold float4 per observer (the reference's float3 has the same 16-byte stride). */
+
+/* boost_tetrad, cl.cl:2441-2481; main.cpp:2700 */
+int gr_boost_tetrad(gr_program* p, void* stream, const void* generic_in, int count, const void* basis_speed,
+                    void* e0_io, void* e1_io, void* e2_io, void* e3_io, const void* cfg);
+/* init_inertial_ray, cl.cl:3117-3141; main.cpp:2722 */
+int gr_init_inertial_ray(gr_program* p, void* stream, const void* generic_position_in, int ray_count, void* rays, void* ray_count_out,
+                         const void* e0, const void* e1, const void* e2, const void* e3, const void* basis_speed, const void* cfg);
+/* get_geodesic_path, cl.cl:4735-4940; main.cpp:2742.  velocities_out / ds_out may be NULL. */
+int gr_get_geodesic_path(gr_program* p, void* stream, const void* rays, int num_rays, void* positions_out, void* velocities_out,
+                         void* ds_out, const void* ray_count, int max_path_length, const void* cfg, const void* dfg, void* count_out);
+/* parallel_transport_quantity, cl.cl:2569-2620; main.cpp:2758 (once per tetrad leg) */
+int gr_parallel_transport_quantity(gr_program* p, void* stream, const void* geodesic_path, const void* geodesic_velocity,
+                                   const void* ds_in, const void* quantity, const void* count_in, int count, void* quantity_out,
+                                   const void* cfg);
+/* handle_interpolating_geodesic, cl.cl:2738-2872; main.cpp:2293: camera position + tetrad at proper time target_time */
+int gr_handle_interpolating_geodesic(gr_program* p, void* stream, const void* geodesic_path, const void* geodesic_velocity,
+                                     const void* ds_in, void* camera_generic_out, const void* t_e0, const void* t_e1,
+                                     const void* t_e2, const void* t_e3, void* e0_out, void* e1_out, void* e2_out, void* e3_out,
+                                     float target_time, const void* count_in, int parallel_transport_observer,
+                                     const void* basis_speed, void* interpolated_velocity, const void* cfg);
+
 /* ---- fused MI355X path (no reference counterpart) ------------------------------------------- */
 
 /* Prepass termination flags from one fused trace at prepass resolution (replaces the sequence

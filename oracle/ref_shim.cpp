@@ -220,6 +220,13 @@ void calculate_render_data(const void*, const int*, void*, int*, int, int, const
 void handle_adaptive_sampling(const void*, const int*, void*, int*, void*, int*, float4*, float4*, const float4*, const float4*,
                               const float4*, const float4*, int, int, const void*, const void*);
 void render(const void*, const int*, ref_image*, ref_image*, ref_image*, int, int, int, const void*, const void*);
+void boost_tetrad(float4*, int, float3*, float4*, float4*, float4*, float4*, const void*);
+void init_inertial_ray(float4*, int, void*, int*, float4*, float4*, float4*, float4*, float3*, const void*);
+void get_geodesic_path(void*, float4*, float4*, float*, int*, int, const void*, const void*, int*);
+void parallel_transport_quantity(float4*, float4*, float*, float4*, int*, int, float4*, const void*);
+void handle_interpolating_geodesic(const float4*, const float4*, const float*, float4*, const float4*, const float4*, const float4*,
+                                   const float4*, float4*, float4*, float4*, float4*, float, const int*, int, const float3*, float4*,
+                                   const void*);
 }
 
 template <typename F>
@@ -299,6 +306,34 @@ void ref_render(const void* rdata, const int* count, int n_items, float* out, co
     ref_image b1{bgw, bgh, levels, bg1, nullptr};
     ref_image b2{bgw, bgh, levels, bg2, nullptr};
     run_items(n_items, nthreads, [&]() { render(rdata, count, &o, &b1, &b2, w, h, max_probes, cfg, dfg); });
+}
+
+// camera on a timelike geodesic: single observer (count = 1), cl.cl:2441-2481, 3117-3141, 4735-4940, 2569-2620, 2738-2872
+void ref_boost_tetrad(float* generic, float* speed4, float* e0, float* e1, float* e2, float* e3, const void* cfg) {
+    t_gid[0] = 0;
+    boost_tetrad((float4*)generic, 1, (float3*)speed4, (float4*)e0, (float4*)e1, (float4*)e2, (float4*)e3, cfg);
+}
+void ref_init_inertial_ray(float* generic, void* rays, int* count, float* e0, float* e1, float* e2, float* e3, float* speed4, const void* cfg) {
+    t_gid[0] = 0;
+    init_inertial_ray((float4*)generic, 1, rays, count, (float4*)e0, (float4*)e1, (float4*)e2, (float4*)e3, (float3*)speed4, cfg);
+}
+void ref_get_geodesic_path(void* rays, float* positions, float* velocities, float* ds, int* count_in, int max_len, const void* cfg,
+                           const void* dfg, int* count_out) {
+    t_gid[0] = 0;
+    get_geodesic_path(rays, (float4*)positions, (float4*)velocities, ds, count_in, max_len, cfg, dfg, count_out);
+}
+void ref_parallel_transport_quantity(float* path, float* vel, float* ds, float* quantity, int* count_in, float* out, const void* cfg) {
+    t_gid[0] = 0;
+    parallel_transport_quantity((float4*)path, (float4*)vel, ds, (float4*)quantity, count_in, 1, (float4*)out, cfg);
+}
+void ref_handle_interpolating_geodesic(const float* path, const float* vel, const float* ds, float* cam_out, const float* te0,
+                                       const float* te1, const float* te2, const float* te3, float* e0, float* e1, float* e2, float* e3,
+                                       float target_time, const int* count_in, int parallel_transport_observer, const float* speed4,
+                                       float* interp_vel, const void* cfg) {
+    t_gid[0] = 0;
+    handle_interpolating_geodesic((const float4*)path, (const float4*)vel, ds, (float4*)cam_out, (const float4*)te0, (const float4*)te1,
+                                  (const float4*)te2, (const float4*)te3, (float4*)e0, (float4*)e1, (float4*)e2, (float4*)e3, target_time,
+                                  count_in, parallel_transport_observer, (const float3*)speed4, (float4*)interp_vel, cfg);
 }
 
 }  // extern "C"

@@ -111,3 +111,47 @@ class OraclePipeline:
                          _p(dfg), nthreads)
             out["pixels"] = pixels
         return out
+
+    def geodesic_camera(self, cfg_values, features_bytes, camera_pos=(0, 0, -4, 0), basis_speed=(0, 0, 0), max_len=4096,
+                        target_times=(), parallel_transport=True, flip=0.0):
+        """Snapshot of the camera's timelike geodesic, main.cpp:2675-2760, then one handle_interpolating_geodesic call per
+        target proper time (main.cpp:2264-2293).  Returns dict: tetrad_boosted[4,4], ray, path[n,4], velocity[n,4], ds[n],
+        count, transported[4,n,4], interpolated: list of dicts (camera, tetrad[4,4], velocity)."""
+        L = self.lib
+        cfg = np.array(list(cfg_values) if len(cfg_values) else [0.0], dtype="<f4")
+        dfg = np.frombuffer(features_bytes, dtype=np.uint8).copy()
+        cam = np.array(camera_pos, dtype="<f4")
+        generic = np.zeros(4, dtype="<f4")
+        L.ref_cart_to_generic(_p(cam), _p(generic), ctypes.c_float(flip), _p(cfg))
+        zero_speed = np.zeros(4, dtype="<f4")
+        speed = np.zeros(4, dtype="<f4")
+        speed[:3] = basis_speed
+        e = [np.zeros(4, dtype="<f4") for _ in range(4)]
+        L.ref_init_basis_vectors(_p(generic), _p(zero_speed), _p(e[0]), _p(e[1]), _p(e[2]), _p(e[3]), _p(cfg))
+        out = {"camera_generic": generic.copy(), "tetrad": np.stack(e)}
+        L.ref_boost_tetrad(_p(generic), _p(speed), _p(e[0]), _p(e[1]), _p(e[2]), _p(e[3]), _p(cfg))
+        out["tetrad_boosted"] = np.stack(e)
+        ray = np.zeros(1, dtype=LIGHTRAY_DTYPE)
+        rcount = np.zeros(1, dtype="<i4")
+        L.ref_init_inertial_ray(_p(generic), _p(ray), _p(rcount), _p(e[0]), _p(e[1]), _p(e[2]), _p(e[3]), _p(speed), _p(cfg))
+        out["ray"] = ray.copy()
+        path = np.zeros((max_len, 4), dtype="<f4")
+        vel = np.zeros((max_len, 4), dtype="<f4")
+        ds = np.zeros(max_len, dtype="<f4")
+        count = np.zeros(1, dtype="<i4")
+        L.ref_get_geodesic_path(_p(ray), _p(path), _p(vel), _p(ds), _p(rcount), max_len, _p(cfg), _p(dfg), _p(count))
+        n = int(count[0])
+        transported = np.zeros((4, max_len, 4), dtype="<f4")
+        for i in range(4):
+            L.ref_parallel_transport_quantity(_p(path), _p(vel), _p(ds), _p(e[i]), _p(count), _p(transported[i]), _p(cfg))
+        out.update(path=path[:n].copy(), velocity=vel[:n].copy(), ds=ds[:n].copy(), count=n, transported=transported[:, :n].copy())
+        out["interpolated"] = []
+        for t in target_times:
+            cam_out = np.zeros(4, dtype="<f4")
+            eo = [np.zeros(4, dtype="<f4") for _ in range(4)]
+            v = np.zeros(4, dtype="<f4")
+            L.ref_handle_interpolating_geodesic(_p(path), _p(vel), _p(ds), _p(cam_out), _p(transported[0]), _p(transported[1]),
+                                                _p(transported[2]), _p(transported[3]), _p(eo[0]), _p(eo[1]), _p(eo[2]), _p(eo[3]),
+                                                ctypes.c_float(t), _p(count), int(bool(parallel_transport)), _p(speed), _p(v), _p(cfg))
+            out["interpolated"].append({"time": float(t), "camera": cam_out, "tetrad": np.stack(eo), "velocity": v})
+        return out

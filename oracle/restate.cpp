@@ -1013,4 +1013,273 @@ void ref_render(const void* rdata_v, const int* count, int n_items, float* out, 
     parallel_for(n, nthreads, [&](long id) { shade_pixel((const render_data*)rdata_v, (int)id, out, b1, b2, w, h, max_probes, (dfg_t)dfg); });
 }
 
+// ---- camera on a timelike geodesic (single observer) ------------------------------------------------
+// get_timelike_vector, cl.cl:1974-1990
+static v4 timelike_vector(v3 speed, const v4 e[4]) {
+    float Y = 1 / std::sqrt(1 - dot(speed, speed));
+    return Y * e[0] + (Y * speed.x) * e[1] + (Y * speed.y) * e[2] + (Y * speed.z) * e[3];
+}
+static inline v4 ld4(const float* p) { return {p[0], p[1], p[2], p[3]}; }
+static inline void st4(float* p, v4 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
+
+// boost_tetrad, cl.cl:2441-2481 (calculate_lorentz_boost_big :1919-1972)
+void ref_boost_tetrad(float* generic, float* speed4, float* e0, float* e1, float* e2, float* e3, const void* cfg_v) {
+    cfg_t cfg = (cfg_t)cfg_v;
+    v4 e[4] = {ld4(e0), ld4(e1), ld4(e2), ld4(e3)};
+    v4 observer = timelike_vector({speed4[0], speed4[1], speed4[2]}, e);
+    float g[16];
+    gen::metric_big(ld4(generic), g, cfg);
+    v4 lT4 = lower_index(e[0], g), lu4 = lower_index(observer, g);
+    float T[4] = {e[0].x, e[0].y, e[0].z, e[0].w}, lT[4] = {lT4.x, lT4.y, lT4.z, lT4.w};
+    float uo[4] = {observer.x, observer.y, observer.z, observer.w}, luo[4] = {lu4.x, lu4.y, lu4.z, lu4.w};
+    float gamma = -dot(lT4, observer);
+    float L[16];
+    for (int u = 0; u < 4; u++)
+        for (int v = 0; v < 4; v++)
+            L[u * 4 + v] = (u == v ? 1.f : 0.f) + (1 / (1 + gamma)) * (T[u] + uo[u]) * (lT[v] + luo[v]) - 2 * uo[u] * lT[v];
+    auto apply = [&](v4 x) {
+        float xi[4] = {x.x, x.y, x.z, x.w}, o[4];
+        for (int u = 0; u < 4; u++) o[u] = L[u * 4 + 0] * xi[0] + L[u * 4 + 1] * xi[1] + L[u * 4 + 2] * xi[2] + L[u * 4 + 3] * xi[3];
+        return v4{o[0], o[1], o[2], o[3]};
+    };
+    st4(e0, observer); st4(e1, apply(e[1])); st4(e2, apply(e[2])); st4(e3, apply(e[3]));
+}
+
+// init_inertial_ray, cl.cl:3117-3141 (geodesic_to_trace_ray :3066-3115)
+void ref_init_inertial_ray(float* generic, void* rays_v, int* count, float* e0, float* e1, float* e2, float* e3, float* speed4,
+                           const void* cfg_v) {
+    cfg_t cfg = (cfg_t)cfg_v;
+    v4 e[4] = {ld4(e0), ld4(e1), ld4(e2), ld4(e3)};
+    v4 velocity = timelike_vector({speed4[0], speed4[1], speed4[2]}, e);
+    lightray ray = render_ray(0, 0, ld4(generic), velocity, e[0], cfg);
+    ray.ku_uobsu = 1;
+    ((lightray*)rays_v)[0] = ray;
+    *count = 1;
+}
+
+// circular_diff / periodic_diff, cl.cl:3598-3630
+static float circular_diff_period(float f1, float f2, float period) {
+    float g1 = (float)((double)f1 * (2 * PId / (double)period));
+    float g2 = (float)((double)f2 * (2 * PId / (double)period));
+    float d = g2 - g1;
+    return (float)((double)(period * std::atan2(std::sin(d), std::cos(d))) / (2 * PId));
+}
+static v4 periodic_diff(v4 in1, v4 in2, v4 periods) {
+    v4 ret = in1 - in2;
+    if (periods.x != 0) ret.x = circular_diff_period(in2.x, in1.x, periods.x);
+    if (periods.y != 0) ret.y = circular_diff_period(in2.y, in1.y, periods.y);
+    if (periods.z != 0) ret.z = circular_diff_period(in2.z, in1.z, periods.z);
+    if (periods.w != 0) ret.w = circular_diff_period(in2.w, in1.w, periods.w);
+    return ret;
+}
+// get_coordinate_period, cl.cl:1338-1355
+static v4 coordinate_period(cfg_t cfg) {
+#ifdef HAS_COORDINATE_PERIODICITY
+    v4 zero{0, 0, 0, 0};
+    POSITION_VARS(zero)
+    return {(float)(COORDINATE_PERIODICITY1), (float)(COORDINATE_PERIODICITY2), (float)(COORDINATE_PERIODICITY3),
+            (float)(COORDINATE_PERIODICITY4)};
+#else
+    (void)cfg;
+    return {0, 0, 0, 0};
+#endif
+}
+
+// get_geodesic_path, cl.cl:4735-4940
+void ref_get_geodesic_path(void* rays_v, float* positions, float* velocities, float* ds_out, int* count_in, int max_len,
+                           const void* cfg_v, const void* dfg_v, int* count_out) {
+    cfg_t cfg = (cfg_t)cfg_v;
+    dfg_t dfg = (dfg_t)dfg_v;
+    if (*count_in < 1) return;
+    const lightray* ray = (const lightray*)rays_v;
+    v4 position = ray->position, velocity = ray->velocity, acceleration = ray->acceleration;
+    const v4 quat = ray->initial_quat;
+    const float f_in_x = std::fabs(velocity.x);
+#ifdef IS_CONSTANT_THETA
+    position.z = PIf / 2; velocity.z = 0; acceleration.z = 0;
+#endif
+    float next_ds = 0.00001f;
+#ifdef ADAPTIVE_PRECISION
+    const float max_accel = std::fmin(0.00001000f, GET_FEATURE(max_acceleration_change, dfg));
+    const float min_step = GET_FEATURE(min_step, dfg);
+    (void)acceleration_to_precision(acceleration, max_accel, &next_ds);
+#endif
+    const float subambient = 0.5f, ambient = 0.2f;
+    const float new_max = GET_FEATURE(max_precision_radius, dfg), new_min = 3;
+    int bufc = 0;
+    const v4 periods = coordinate_period(cfg);
+    v4 last_pos_generic{0, 0, 0, 0};
+    float running = 1;
+    (void)quat; (void)periods; (void)last_pos_generic;
+    for (int i = 0; i < max_len; i++) {
+#ifdef IS_CONSTANT_THETA
+        position.z = PIf / 2; velocity.z = 0; acceleration.z = 0;
+#endif
+        v4 polar = gen::to_spherical(position, cfg);
+#ifdef IS_CONSTANT_THETA
+        polar.z = PIf / 2;
+#endif
+        float ar = std::fabs(gen::distance_to_object(polar, cfg));
+        float ds = mixf(ambient, subambient, (clampf(ar, new_min, new_max) - new_min) / (new_max - new_min));
+#ifdef ADAPTIVE_PRECISION
+        ds = next_ds;
+#endif
+        if (ar < new_max) ds = std::fmin(ds, ambient);
+        else ds = (float)(0.1 * (double)(ar - new_max) + (double)ambient);   // double-typed literal at cl.cl:4815
+        bool should_break = std::fabs(polar.y) >= GET_FEATURE(universe_size, dfg);
+#ifdef SINGULAR
+        should_break |= std::fabs(polar.y) < SINGULAR_TERMINATOR;
+#endif
+        v4 next_position = position + velocity * ds + 0.5f * acceleration * ds * ds;
+        v4 half_velocity = velocity + acceleration * ds;
+        v4 next_acceleration = gen::geo_accel(next_position, half_velocity, cfg);
+        v4 next_velocity = velocity + 0.5f * (acceleration + next_acceleration) * ds;
+        float K = 1;
+        if (GET_FEATURE(reparameterisation, dfg)) {
+            K = 1 / std::fmax(std::fmax(std::fabs(next_velocity.x), std::fabs(next_velocity.y)),
+                              std::fmax(std::fabs(next_velocity.z), std::fabs(next_velocity.w)));
+            next_velocity = next_velocity * K;
+            next_acceleration = next_acceleration * K * K;
+        }
+        const float old_dlambda = running;
+        running *= K;
+#ifdef ADAPTIVE_PRECISION
+        if (ar < new_max) {
+            float suggested = 0;
+            float diff = acceleration_to_precision(next_acceleration, max_accel, &suggested);
+            float nds = 0.99f * ds * clampf(suggested / ds, 0.3f, 2.f);
+            nds = std::fmax(nds, min_step);
+            next_ds = nds;
+#ifdef SINGULARITY_DETECTION
+            if (nds == min_step && (diff / (256 * 256)) > max_accel * 10000) should_break = true;
+#endif
+            if (nds < ds / 1.95f) continue;   // the rejected step still consumes an iteration here (cl.cl:4849-4850)
+        }
+#endif
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        if (std::fabs(velocity.x / running) > 1000 + f_in_x && std::fabs(acceleration.x / running) > 100) should_break = true;
+#endif
+        v4 pos_out = position, vel_out = velocity / old_dlambda;
+#ifdef GENERIC_CONSTANT_THETA
+        {   // undo the equatorial rotation, cl.cl:4864-4902
+            v4 pos_sph = gen::to_spherical(position, cfg);
+            v4 vel_sph = gen::velocity_to_spherical(position, velocity / old_dlambda, cfg);
+            float sgn = signf(pos_sph.y);
+            pos_sph.y = std::fabs(pos_sph.y);
+            v3 pos_cart = rot_quat(polar_to_cartesian(yzw(pos_sph)), quat);
+            v3 vel_cart = rot_quat(spherical_velocity_to_cartesian_velocity(yzw(pos_sph), yzw(vel_sph)), quat);
+            v3 npos = cartesian_to_polar(pos_cart);
+            v3 nvel = cartesian_velocity_to_polar_velocity(pos_cart, vel_cart);
+            if (sgn < 0) npos.x = -npos.x;
+            v4 next_pos_generic = gen::from_spherical(mk4(pos_sph.x, npos), cfg);
+            v4 next_vel_generic = gen::velocity_from_spherical(mk4(pos_sph.x, npos), mk4(vel_sph.x, nvel), cfg);
+            if (i != 0) next_pos_generic = periodic_diff(next_pos_generic, last_pos_generic, periods) + last_pos_generic;
+            last_pos_generic = next_pos_generic;
+            pos_out = next_pos_generic;
+            vel_out = next_vel_generic;
+        }
+#endif
+        if (degenerate(next_position) || degenerate(next_velocity) || degenerate(next_acceleration)) break;
+        position = next_position;
+        velocity = next_velocity;
+        acceleration = next_acceleration;
+        st4(positions + 4 * bufc, pos_out);
+        if (velocities) st4(velocities + 4 * bufc, vel_out);
+        if (ds_out) ds_out[bufc] = ds * old_dlambda;
+        bufc++;
+        if (should_break) break;
+    }
+    count_out[0] = bufc;
+}
+
+// parallel_transport_get_velocity, cl.cl:2164-2207
+static v4 parallel_transport_velocity(v4 X, v4 position, v4 velocity, cfg_t cfg) {
+    float g[16], dg[64], ginv[16];
+    gen::metric_big(position, g, cfg);
+    gen::partials_big(position, dg, cfg);
+    inverse4(g, ginv);
+    float Xa[4] = {X.x, X.y, X.z, X.w}, Ya[4] = {velocity.x, velocity.y, velocity.z, velocity.w}, out[4];
+    for (int a = 0; a < 4; a++) {
+        float sum = 0;
+        for (int b = 0; b < 4; b++)
+            for (int s = 0; s < 4; s++) {
+                float gam = 0;
+                for (int m = 0; m < 4; m++)
+                    gam += ginv[a * 4 + m] * (dg[s * 16 + m * 4 + b] + dg[b * 16 + m * 4 + s] - dg[m * 16 + b * 4 + s]);
+                sum += 0.5f * gam * Xa[b] * Ya[s];
+            }
+        out[a] = -sum;
+    }
+    return {out[0], out[1], out[2], out[3]};
+}
+
+// parallel_transport_quantity, cl.cl:2569-2620
+void ref_parallel_transport_quantity(float* path, float* vel, float* ds_in, float* quantity, int* count_in, float* out, const void* cfg_v) {
+    cfg_t cfg = (cfg_t)cfg_v;
+    int cnt = count_in[0];
+    if (cnt == 0) return;
+    v4 current = ld4(quantity);
+    st4(out, current);
+    if (cnt == 1) return;
+    for (int k = 0; k < cnt - 1; k++) {
+        float ds = ds_in[k];
+        v4 f_x = parallel_transport_velocity(current, ld4(path + 4 * k), ld4(vel + 4 * k), cfg);
+        v4 predictor = current + f_x * ds;
+        v4 next = current + (0.5f * ds) * (f_x + parallel_transport_velocity(predictor, ld4(path + 4 * (k + 1)), ld4(vel + 4 * (k + 1)), cfg));
+        st4(out + 4 * k, current);
+        current = next;
+    }
+    st4(out + 4 * (cnt - 1), current);
+}
+
+// handle_interpolating_geodesic, cl.cl:2738-2872
+void ref_handle_interpolating_geodesic(const float* path, const float* vel, const float* ds_in, float* cam_out, const float* te0,
+                                       const float* te1, const float* te2, const float* te3, float* e0, float* e1, float* e2, float* e3,
+                                       float target_time, const int* count_in, int parallel_transport_observer, const float* speed4,
+                                       float* interp_vel, const void* cfg_v) {
+    cfg_t cfg = (cfg_t)cfg_v;
+    int cnt = *count_in;
+    if (cnt == 0) return;
+    v3 speed{speed4[0], speed4[1], speed4[2]};
+    auto store = [&](const v4 t[4]) { st4(e0, t[0]); st4(e1, t[1]); st4(e2, t[2]); st4(e3, t[3]); };
+    auto stored = [&](int i) { v4 t[4] = {ld4(te0 + 4 * i), ld4(te1 + 4 * i), ld4(te2 + 4 * i), ld4(te3 + 4 * i)}; store(t); };
+    auto mix = [](v4 a, v4 b, float t) { return a + (b - a) * t; };
+    if (!parallel_transport_observer) {
+        v4 t[4];
+        calculate_tetrads(ld4(path), speed, t, cfg, 1);
+        store(t);
+    } else {
+        stored(0);
+    }
+    float proper_time = 0;
+    st4(cam_out, ld4(path));
+    st4(interp_vel, ld4(vel));
+    if (cnt == 1) return;
+    for (int i = 0; i < cnt - 1; i++) {
+        float next_proper_time = proper_time + ds_in[i];
+        if ((target_time >= proper_time && target_time < next_proper_time) || target_time < proper_time) {
+            float dx = (target_time - proper_time) / (next_proper_time - proper_time);
+            if (target_time < proper_time) dx = 0;
+            v4 fin = mix(ld4(path + 4 * i), ld4(path + 4 * (i + 1)), dx);
+            st4(cam_out, fin);
+            v4 t[4] = {mix(ld4(te0 + 4 * i), ld4(te0 + 4 * (i + 1)), dx), mix(ld4(te1 + 4 * i), ld4(te1 + 4 * (i + 1)), dx),
+                       mix(ld4(te2 + 4 * i), ld4(te2 + 4 * (i + 1)), dx), mix(ld4(te3 + 4 * i), ld4(te3 + 4 * (i + 1)), dx)};
+            if (!parallel_transport_observer) calculate_tetrads(fin, speed, t, cfg, 1);
+            st4(interp_vel, mix(ld4(vel + 4 * i), ld4(vel + 4 * (i + 1)), dx));
+            store(t);
+            return;
+        }
+        proper_time = next_proper_time;
+    }
+    st4(cam_out, ld4(path + 4 * (cnt - 1)));
+    st4(interp_vel, ld4(vel + 4 * (cnt - 1)));
+    if (!parallel_transport_observer) {
+        v4 t[4];
+        calculate_tetrads(ld4(path + 4 * (cnt - 1)), speed, t, cfg, 1);
+        store(t);
+    } else {
+        stored(cnt - 1);
+    }
+}
+
 }  // extern "C"

@@ -2,9 +2,11 @@
 (/root/reference/cl.cl compiled for x86-64, see oracle/build_ref.py) through the reference frame
 sequence on small images.  Runs only in the build container (needs /root/reference); the .npz files
 it writes are data: inputs (camera, cfg, features, background seed) and the reference's outputs
-(tetrad, initial rays, traced rays, render_data, pixels).
+(tetrad, initial rays, traced rays, render_data, pixels); tests/golden/paths/ holds the camera-on-a-geodesic
+cases (boosted tetrad, path, velocities, step lengths, transported tetrads, interpolated cameras).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py            # everything
+    python tests/golden/make_golden.py paths      # only the geodesic-camera cases
 """
 import json
 import os
@@ -67,6 +69,47 @@ CASES = {
 }
 
 
+# camera riding a timelike geodesic (boost_tetrad .. handle_interpolating_geodesic): name -> spec
+PATH_TIMES = (0.0, 0.37, 1.5, 7.3, 19.0, 1.0e6)
+PATH_CASES = {
+    "minkowski_drift": dict(metric="minkowski", camera_pos=[0.5, 3.0, -6.0, 2.0], basis_speed=[0.1, -0.2, 0.4]),
+    "schwarzschild_outward": dict(metric="schwarzschild", camera_pos=[0.0, 0.0, -8.0, 0.0], basis_speed=[0.0, -0.3, 0.1]),
+    "schwarzschild_infall": dict(metric="schwarzschild", camera_pos=[0.0, 2.0, -7.0, 1.0], basis_speed=[-0.05, 0.3, 0.0]),
+    "schwarzschild_at_rest": dict(metric="schwarzschild", camera_pos=[0.0, 0.0, -5.0, 0.0], basis_speed=[0.0, 0.0, 0.0]),
+    "kerr_flyby": dict(metric="kerr_boyer", cfg=dict(a=0.45), camera_pos=[0.0, 1.0, -8.0, 0.5], basis_speed=[0.2, 0.0, 0.3]),
+    "kerr_infall": dict(metric="kerr_boyer", cfg=dict(a=0.45), camera_pos=[0.0, 1.0, -6.0, 0.5], basis_speed=[0.1, 0.35, -0.05]),
+    "kerr_recomputed_tetrads": dict(metric="kerr_boyer", cfg=dict(a=0.45), camera_pos=[0.0, 1.0, -8.0, 0.5], basis_speed=[0.2, 0.0, 0.3],
+                                    parallel_transport=False),
+    "kerr_script_reparameterised": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", cfg=dict(a=0.45),
+                                        camera_pos=[0.0, 1.0, -8.0, 0.5], basis_speed=[0.2, 0.0, 0.3], features=dict(reparameterisation=1)),
+    "alcubierre_passenger": dict(metric="alcubierre", camera_pos=[0.0, 0.0, -3.0, 0.5], basis_speed=[0.0, 0.0, 0.1]),
+    "wormhole_crossing": dict(metric="wormhole", scripts=True, camera_pos=[0.0, 0.3, -2.5, 0.3], basis_speed=[0.05, 0.5, -0.02]),
+}
+
+
+def make_path_case(name, spec):
+    own_scripts = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
+    metric = gra.Metric(spec["metric"], own_scripts if spec.get("scripts") else None)
+    so = build_ref.build(spec.get("tag", spec["metric"]), metric.argument_string())
+    cfg = metric.cfg_values(**spec.get("cfg", {}))
+    feats = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change)
+    feats.update(spec.get("features", {}))
+    max_len = int(spec.get("max_len", 2048))
+    transport = bool(spec.get("parallel_transport", True))
+    res = OraclePipeline(so).geodesic_camera(cfg, pack_features(**feats), camera_pos=spec["camera_pos"], basis_speed=spec["basis_speed"],
+                                             max_len=max_len, target_times=PATH_TIMES, parallel_transport=transport)
+    meta = dict(metric=spec["metric"], scripts=bool(spec.get("scripts")), cfg=cfg, features=feats, camera_pos=list(map(float, spec["camera_pos"])),
+                basis_speed=list(map(float, spec["basis_speed"])), max_len=max_len, parallel_transport=transport,
+                target_times=list(map(float, PATH_TIMES)), count=res["count"], width=1, height=1, camera_quat=[0.0, 0.0, 0.0, 1.0])
+    arrays = {k: v for k, v in res.items() if isinstance(v, np.ndarray)}
+    arrays["interp_camera"] = np.stack([i["camera"] for i in res["interpolated"]])
+    arrays["interp_tetrad"] = np.stack([i["tetrad"] for i in res["interpolated"]])
+    arrays["interp_velocity"] = np.stack([i["velocity"] for i in res["interpolated"]])
+    os.makedirs(os.path.join(HERE, "paths"), exist_ok=True)
+    np.savez_compressed(os.path.join(HERE, "paths", name + ".npz"), meta=json.dumps(meta), **arrays)
+    print(f"path {name}: {res['count']} steps, proper time {res['ds'].sum():.3f}, end {res['path'][-1].round(3).tolist()}")
+
+
 def make_case(name, spec, scripts_dir=None):
     own_scripts = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
     metric = gra.Metric(spec["metric"], own_scripts if spec.get("scripts") else None)
@@ -101,3 +144,7 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         make_case(name, spec)
+    for name, spec in PATH_CASES.items():
+        if only and ("path_" + name) not in only and "paths" not in only:
+            continue
+        make_path_case(name, spec)

@@ -23,6 +23,15 @@ def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
 
 
+def path_golden_names():
+    d = os.path.join(GOLDEN_DIR, "paths")
+    return sorted(f[:-4] for f in os.listdir(d) if f.endswith(".npz"))
+
+
+def load_path_golden(name):
+    return load_golden(os.path.join("paths", name))
+
+
 SCRIPTS_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geodesic_raytracing_amd", "scripts")
 
 
@@ -132,3 +141,65 @@ def rel_err(a, b, floor=1e-3):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+class GeodesicCamera:
+    """Device-side run of the camera-on-a-geodesic kernels (one observer) through the C ABI, in the reference's order
+    (main.cpp:2675-2760, 2264-2293)."""
+
+    def __init__(self, meta):
+        self.meta = meta
+        self.st = Stages(meta)
+        self.p, self.cfg, self.dfg = self.st.p, self.st.cfg, self.st.dfg
+        speed = np.zeros(4, dtype=np.float32)
+        speed[:3] = meta["basis_speed"]
+        self.speed = buf(speed)
+
+    def snapshot(self):
+        L, p, cfg = gra.lib, self.p, self.cfg
+        m = dict(self.meta, basis_speed=[0.0, 0.0, 0.0])
+        self.st.meta = m
+        generic, tetrad = self.st.camera()
+        self.generic = buf(generic)
+        e = [buf(tetrad[i]) for i in range(4)]
+        gra.check(L.gr_boost_tetrad(p, None, self.generic.ptr, 1, self.speed.ptr, e[0].ptr, e[1].ptr, e[2].ptr, e[3].ptr, cfg.ptr))
+        out = {"camera_generic": generic, "tetrad": tetrad, "tetrad_boosted": np.stack([b.to_numpy(np.float32, 4) for b in e])}
+        ray = DeviceBuffer(0, 96)
+        rcount = buf(np.zeros(1, dtype=np.int32))
+        gra.check(L.gr_init_inertial_ray(p, None, self.generic.ptr, 1, ray.ptr, rcount.ptr, e[0].ptr, e[1].ptr, e[2].ptr, e[3].ptr,
+                                         self.speed.ptr, cfg.ptr))
+        out["ray"] = ray.to_numpy(LIGHTRAY_DTYPE, 1)
+        n_max = self.meta["max_len"]
+        self.path, self.vel = DeviceBuffer(0, n_max * 16), DeviceBuffer(0, n_max * 16)
+        self.ds = DeviceBuffer(0, n_max * 4)
+        self.count = buf(np.zeros(1, dtype=np.int32))
+        gra.check(L.gr_get_geodesic_path(p, None, ray.ptr, 1, self.path.ptr, self.vel.ptr, self.ds.ptr, rcount.ptr, n_max, cfg.ptr,
+                                         self.dfg.ptr, self.count.ptr))
+        n = int(self.count.to_numpy(np.int32, 1)[0])
+        self.transported = [buf(np.zeros((n_max, 4), dtype=np.float32)) for _ in range(4)]
+        for i in range(4):
+            gra.check(L.gr_parallel_transport_quantity(p, None, self.path.ptr, self.vel.ptr, self.ds.ptr, e[i].ptr, self.count.ptr, 1,
+                                                       self.transported[i].ptr, cfg.ptr))
+        out.update(count=n, path=self.path.to_numpy(np.float32, (n_max, 4))[:n], velocity=self.vel.to_numpy(np.float32, (n_max, 4))[:n],
+                   ds=self.ds.to_numpy(np.float32, n_max)[:n],
+                   transported=np.stack([t.to_numpy(np.float32, (n_max, 4))[:n] for t in self.transported]))
+        return out
+
+    def interpolate(self, target_time):
+        cam, vel = DeviceBuffer(0, 16), DeviceBuffer(0, 16)
+        e = [DeviceBuffer(0, 16) for _ in range(4)]
+        t = self.transported
+        gra.check(gra.lib.gr_handle_interpolating_geodesic(self.p, None, self.path.ptr, self.vel.ptr, self.ds.ptr, cam.ptr, t[0].ptr,
+                                                           t[1].ptr, t[2].ptr, t[3].ptr, e[0].ptr, e[1].ptr, e[2].ptr, e[3].ptr,
+                                                           float(target_time), self.count.ptr, int(self.meta["parallel_transport"]),
+                                                           self.speed.ptr, vel.ptr, self.cfg.ptr))
+        return cam.to_numpy(np.float32, 4), np.stack([b.to_numpy(np.float32, 4) for b in e]), vel.to_numpy(np.float32, 4)
+
+
+def vec_err(a, b, floor=1e-3):
+    """|a - b| relative to the largest component of each reference 4-vector (components that cancel to ~0 carry no
+    relative information)"""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.maximum(np.abs(b).max(axis=-1, keepdims=True), floor)
+    return np.abs(a - b) / scale

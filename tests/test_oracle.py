@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import geodesic_raytracing_amd as gra
-from gpu_stages import circ_diff, golden_names, load_golden, metric_for, rel_err
+from gpu_stages import circ_diff, golden_names, load_golden, load_path_golden, metric_for, path_golden_names, rel_err, vec_err
 from oracle import build_ref, build_restate
 from oracle.refpipe import OraclePipeline, pack_features
 
@@ -57,6 +57,62 @@ def test_fixtures_are_what_the_reference_computes(name):
         assert np.array_equal(r["rays"][f], z["rays"][f]), f
     assert np.array_equal(r["render_data"]["tex_coord"], z["render_data"]["tex_coord"])
     assert np.array_equal(r["pixels"], z["pixels"])
+
+
+def run_path_oracle(so, meta):
+    return OraclePipeline(so).geodesic_camera(meta["cfg"], pack_features(**meta["features"]), camera_pos=meta["camera_pos"],
+                                              basis_speed=meta["basis_speed"], max_len=meta["max_len"],
+                                              target_times=meta["target_times"], parallel_transport=meta["parallel_transport"])
+
+
+@pytest.mark.parametrize("name", path_golden_names())
+def test_restatement_reproduces_reference_geodesic_camera(name):
+    """boost_tetrad .. handle_interpolating_geodesic: the restatement against the reference's own kernels' output"""
+    meta, z = load_path_golden(name)
+    r = run_path_oracle(build_restate.build(metric_for(meta).argument_string()), meta)
+    assert np.abs(r["tetrad_boosted"] - z["tetrad_boosted"]).max() <= 2e-6
+    for f in ("position", "velocity", "acceleration", "initial_quat"):
+        assert np.abs(r["ray"][f] - z["ray"][f]).max() <= 2e-6, f
+    assert r["ray"]["ku_uobsu"][0] == 1.0
+    assert r["count"] == meta["count"]
+    assert vec_err(r["path"], z["path"]).max() <= 1e-4
+    assert vec_err(r["velocity"], z["velocity"]).max() <= 3e-4   # wormhole_crossing grazes the polar axis (theta -> 3.09)
+    assert rel_err(r["ds"], z["ds"], floor=1e-6).max() <= 1e-4
+    assert np.abs(r["transported"] - z["transported"]).max() <= 1e-4 * max(1.0, np.abs(z["transported"]).max())
+    for k, it in enumerate(r["interpolated"]):
+        assert vec_err(it["camera"], z["interp_camera"][k]).max() <= 1e-4
+        assert np.abs(it["tetrad"] - z["interp_tetrad"][k]).max() <= 1e-4 * max(1.0, np.abs(z["interp_tetrad"][k]).max())
+        assert vec_err(it["velocity"], z["interp_velocity"][k]).max() <= 1e-4
+
+
+@pytest.mark.skipif(not build_ref.reference_available(), reason="reference sources only exist in the build container")
+@pytest.mark.parametrize("name", ["schwarzschild_infall", "kerr_flyby"])
+def test_path_fixtures_are_what_the_reference_computes(name):
+    meta, z = load_path_golden(name)
+    r = run_path_oracle(build_ref.build(meta["metric"], metric_for(meta).argument_string()), meta)
+    for f in ("path", "velocity", "ds", "transported", "tetrad_boosted"):
+        assert np.array_equal(r[f], z[f]), f
+
+
+def test_transported_tetrad_stays_orthonormal():
+    """property of the golden data itself: parallel transport preserves inner products, so the transported frame stays
+    orthonormal under the metric evaluated by the independent float64 macro evaluator (tests/macro_eval.py), and the
+    path tangent keeps its norm.  (e0 is not the tangent: the reference boosts by the basis speed in boost_tetrad and
+    again in init_inertial_ray, main.cpp:2689-2722.)"""
+    from macro_eval import MacroSet
+    meta, z = load_path_golden("kerr_flyby")
+    metric = metric_for(meta)
+    ms = MacroSet(metric.argument_string())
+    cfg = dict(zip(metric.dynamic_vars, meta["cfg"]))
+    eta = np.diag([-1.0, 1.0, 1.0, 1.0])
+    worst = 0.0
+    for k in range(0, meta["count"], 7):
+        g = np.array(ms.metric([float(x) for x in z["path"][k]], cfg))
+        E = z["transported"][:, k].astype(np.float64)
+        worst = max(worst, np.abs(E @ g @ E.T - eta).max())
+        u = z["velocity"][k].astype(np.float64)
+        assert abs(u @ g @ u + 1.0) <= 5e-3
+    assert worst <= 5e-3
 
 
 def test_minkowski_rays_are_straight_lines():
