@@ -46,7 +46,8 @@ class Camera(ctypes.Structure):
 class FrameOptions(ctypes.Structure):
     _fields_ = [("mode", c_int), ("tiled", c_int), ("use_prepass", c_int), ("max_probes", c_int), ("strip_rank", c_int),
                 ("strip_count", c_int), ("block_rows", c_int), ("compact_out", c_int), ("time_kernels", c_int),
-                ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera))]
+                ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera)), ("geodesic", c_void_p),
+                ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("parallel_transport_observer", c_int)]
 
 
 MODE_REFERENCE, MODE_FUSED = 0, 1
@@ -111,6 +112,14 @@ _SIGNATURES = {
     "gr_render_frame": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Camera), ctypes.POINTER(Features),
                                 ctypes.POINTER(c_float), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                 ctypes.POINTER(FrameOptions)]),
+    "gr_geodesic_camera_create": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_geodesic_camera_destroy": (None, [c_void_p]),
+    "gr_geodesic_camera_snapshot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Camera), ctypes.POINTER(c_float),
+                                            ctypes.POINTER(Features), ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int),
+                                            ctypes.POINTER(c_float)]),
+    "gr_geodesic_camera_interpolate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, ctypes.POINTER(c_float),
+                                               ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
+    "gr_geodesic_camera_buffer": (c_void_p, [c_void_p, c_int]),
     "gr_render_state_stage_ms": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float)]),
     "gr_render_state_attempts": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gr_render_state_buffer": (c_void_p, [c_void_p, c_int]),
@@ -145,5 +154,5 @@ def check(rc):
         raise GeodesicError(f"libgeodesic_hip error {rc}: {msg.decode(errors='replace') if msg else ''}")
 
 
-from .pipeline import (Metric, Program, RenderState, default_camera, default_features, frame_options,  # noqa: E402,F401
+from .pipeline import (GeodesicCamera, Metric, Program, RenderState, default_camera, default_features, frame_options,  # noqa: E402,F401
                        synthetic_background, pack_background)

@@ -69,6 +69,9 @@ struct gr_render_state {
     std::vector<float> alt_cfg;
     gr_features alt_features{};
     const void* alt_program = nullptr;
+    const void* alt_geodesic = nullptr;
+    float alt_geodesic_time = 0;
+    int alt_transport = 0;
 
     void swap_sets() {
         std::swap(camera_pos_cart, alt.camera_pos_cart);
@@ -80,6 +83,29 @@ struct gr_render_state {
 };
 
 static const int CFG_MAX = 64;
+
+// A snapshot of the camera's own timelike geodesic (main.cpp:1232-1242 buffers, :2675-2760 snapshot): path, velocity and
+// proper-time step per sample, the four tetrad legs parallel transported along it, all resident on the device.
+struct gr_geodesic_camera {
+    int device = 0;
+    int max_path_length = 0;
+    void* path = nullptr;        // float4[max]
+    void* velocity = nullptr;    // float4[max]
+    void* ds = nullptr;          // float[max]
+    void* count = nullptr;       // int
+    void* transported[4] = {};   // float4[max] each
+    void* ray = nullptr;         // lightray
+    void* ray_count = nullptr;   // int
+    void* basis_speed = nullptr; // float4
+    void* camera_generic = nullptr;
+    void* tetrad[4] = {};
+    void* interpolated_velocity = nullptr;
+    void* alt_interpolated_velocity = nullptr;
+    void* cfg = nullptr;
+    void* dfg = nullptr;
+    int steps = 0;
+    float proper_time = 0;
+};
 
 extern "C" {
 
@@ -106,6 +132,10 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->time_kernels = 0;
     o->count_attempts = 0;
     o->next_camera = nullptr;
+    o->geodesic = nullptr;
+    o->geodesic_time = 0;
+    o->next_geodesic_time = 0;
+    o->parallel_transport_observer = 1;   // main.cpp:1259
 }
 
 int gr_device_count(int* count) {
@@ -256,6 +286,128 @@ static int ensure_rays(gr_render_state* s, size_t slots, bool adaptive) {
     return GR_OK;
 }
 
+// ---- camera on a timelike geodesic ------------------------------------------------------------------
+int gr_geodesic_camera_create(int device, int max_path_length, gr_geodesic_camera** out) {
+    if (!out || max_path_length < 2) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "bad geodesic camera size");
+    HIP_CHECK(hipSetDevice(device));
+    gr_geodesic_camera* g = new gr_geodesic_camera();
+    g->device = device;
+    g->max_path_length = max_path_length;
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, bytes);
+        if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
+    };
+    size_t n = (size_t)max_path_length;
+    A(&g->path, n * 16); A(&g->velocity, n * 16); A(&g->ds, n * 4); A(&g->count, 4);
+    for (auto& t : g->transported) A(&t, n * 16);
+    A(&g->ray, sizeof(gr_lightray)); A(&g->ray_count, 4); A(&g->basis_speed, 16); A(&g->camera_generic, 16);
+    for (auto& t : g->tetrad) A(&t, 16);
+    A(&g->interpolated_velocity, 16); A(&g->alt_interpolated_velocity, 16);
+    A(&g->cfg, CFG_MAX * sizeof(float)); A(&g->dfg, sizeof(gr_features));
+    if (e != hipSuccess) {
+        gr_geodesic_camera_destroy(g);
+        return gr_internal_fail(GR_ERROR_DEVICE, (std::string("geodesic camera allocation: ") + hipGetErrorString(e)).c_str());
+    }
+    *out = g;
+    return GR_OK;
+}
+
+void gr_geodesic_camera_destroy(gr_geodesic_camera* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    void* ptrs[] = {g->path, g->velocity, g->ds, g->count, g->transported[0], g->transported[1], g->transported[2], g->transported[3],
+                    g->ray, g->ray_count, g->basis_speed, g->camera_generic, g->tetrad[0], g->tetrad[1], g->tetrad[2], g->tetrad[3],
+                    g->interpolated_velocity, g->alt_interpolated_velocity, g->cfg, g->dfg};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+}
+
+int gr_geodesic_camera_snapshot(gr_geodesic_camera* g, gr_program* p, const gr_metric* m, void* stream_v, const gr_camera* camera,
+                                const float geodesic_basis_speed[3], const gr_features* features_in, const float* cfg_values,
+                                int num_cfg_values, int* steps_out, float* proper_time_out) {
+    if (!g || !p || !m || !camera || !geodesic_basis_speed) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_CHECK(hipSetDevice(g->device));
+    gr_metric_info info;
+    GR_CHECK(gr_metric_get_info(m, &info));
+    gr_features features;
+    gr_features_default(&features);
+    if (features_in) features = *features_in;
+    else features.max_acceleration_change = info.max_acceleration_change;
+    std::vector<float> cfg(info.num_dynamic_vars > 0 ? info.num_dynamic_vars : 1, 0.f);
+    for (int i = 0; i < info.num_dynamic_vars; i++)
+        cfg[i] = (cfg_values && i < num_cfg_values) ? cfg_values[i] : gr_metric_dynamic_var_default(m, i);
+    if ((int)cfg.size() > CFG_MAX) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "too many dynamic variables");
+    float speed4[4] = {geodesic_basis_speed[0], geodesic_basis_speed[1], geodesic_basis_speed[2], 0.f};
+    if (speed4[0] * speed4[0] + speed4[1] * speed4[1] + speed4[2] * speed4[2] >= 1.f)
+        return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "geodesic basis speed must be below c");
+    void* cart = g->interpolated_velocity;   // scratch until the first interpolation
+    HIP_CHECK(hipMemcpyAsync(g->cfg, cfg.data(), cfg.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(g->dfg, &features, sizeof(features), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(g->basis_speed, speed4, 16, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(cart, camera->position, 16, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemsetAsync(g->count, 0, 4, stream));
+    HIP_CHECK(hipMemsetAsync(g->ray_count, 0, 4, stream));
+    // main.cpp:2311-2329 (this frame's camera), then :2689-2758
+    GR_CHECK(gr_cart_to_generic(p, stream, cart, g->camera_generic, 1, camera->flip, g->cfg));
+    GR_CHECK(gr_init_basis_vectors(p, stream, g->camera_generic, 1, camera->basis_speed, g->tetrad[0], g->tetrad[1], g->tetrad[2],
+                                   g->tetrad[3], g->cfg));
+    GR_CHECK(gr_boost_tetrad(p, stream, g->camera_generic, 1, g->basis_speed, g->tetrad[0], g->tetrad[1], g->tetrad[2], g->tetrad[3],
+                             g->cfg));
+    GR_CHECK(gr_init_inertial_ray(p, stream, g->camera_generic, 1, g->ray, g->ray_count, g->tetrad[0], g->tetrad[1], g->tetrad[2],
+                                  g->tetrad[3], g->basis_speed, g->cfg));
+    GR_CHECK(gr_get_geodesic_path(p, stream, g->ray, 1, g->path, g->velocity, g->ds, g->ray_count, g->max_path_length, g->cfg, g->dfg,
+                                  g->count));
+    for (int i = 0; i < 4; i++)
+        GR_CHECK(gr_parallel_transport_quantity(p, stream, g->path, g->velocity, g->ds, g->tetrad[i], g->count, 1, g->transported[i],
+                                                g->cfg));
+    HIP_CHECK(hipMemcpyAsync(&g->steps, g->count, 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<float> ds((size_t)std::max(g->steps, 1));
+    if (g->steps > 0) HIP_CHECK(hipMemcpy(ds.data(), g->ds, (size_t)g->steps * 4, hipMemcpyDeviceToHost));
+    double total = 0;
+    for (int i = 0; i + 1 < g->steps; i++) total += ds[i];   // the last sample has no successor (cl.cl:2808-2845)
+    g->proper_time = (float)total;
+    if (steps_out) *steps_out = g->steps;
+    if (proper_time_out) *proper_time_out = g->proper_time;
+    return GR_OK;
+}
+
+int gr_geodesic_camera_interpolate(gr_geodesic_camera* g, gr_program* p, void* stream_v, float proper_time,
+                                   int parallel_transport_observer, float camera_generic_out[4], float tetrad_out[16],
+                                   float velocity_out[4]) {
+    if (!g || !p) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_CHECK(hipSetDevice(g->device));
+    GR_CHECK(gr_handle_interpolating_geodesic(p, stream, g->path, g->velocity, g->ds, g->camera_generic, g->transported[0],
+                                              g->transported[1], g->transported[2], g->transported[3], g->tetrad[0], g->tetrad[1],
+                                              g->tetrad[2], g->tetrad[3], proper_time, g->count, parallel_transport_observer,
+                                              g->basis_speed, g->interpolated_velocity, g->cfg));
+    if (camera_generic_out) HIP_CHECK(hipMemcpyAsync(camera_generic_out, g->camera_generic, 16, hipMemcpyDeviceToHost, stream));
+    if (velocity_out) HIP_CHECK(hipMemcpyAsync(velocity_out, g->interpolated_velocity, 16, hipMemcpyDeviceToHost, stream));
+    if (tetrad_out)
+        for (int i = 0; i < 4; i++) HIP_CHECK(hipMemcpyAsync(tetrad_out + 4 * i, g->tetrad[i], 16, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return GR_OK;
+}
+
+void* gr_geodesic_camera_buffer(gr_geodesic_camera* g, int which) {
+    if (!g) return nullptr;
+    switch (which) {
+        case GR_GEOBUF_PATH: return g->path;
+        case GR_GEOBUF_VELOCITY: return g->velocity;
+        case GR_GEOBUF_DS: return g->ds;
+        case GR_GEOBUF_COUNT: return g->count;
+        case GR_GEOBUF_TRANSPORTED0: return g->transported[0];
+        case GR_GEOBUF_TRANSPORTED1: return g->transported[1];
+        case GR_GEOBUF_TRANSPORTED2: return g->transported[2];
+        case GR_GEOBUF_TRANSPORTED3: return g->transported[3];
+    }
+    return nullptr;
+}
+
 int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void* stream_v, const gr_camera* camera,
                     const gr_features* features_in, const float* cfg_values, int num_cfg_values, const void* bg1,
                     const void* bg2, int bg_width, int bg_height, int bg_levels, void* out, const gr_frame_options* opt_in) {
@@ -297,7 +449,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     // was this frame's camera set-up + prepass already done on the side stream during the previous frame?
     bool prefetched = opt.mode == GR_MODE_FUSED && use_prepass && s->alt_prefetched && s->alt_program == (const void*)p &&
                       memcmp(&s->alt_camera, camera, sizeof(gr_camera)) == 0 && s->alt_cfg == cfg &&
-                      memcmp(&s->alt_features, &features, sizeof(features)) == 0;
+                      memcmp(&s->alt_features, &features, sizeof(features)) == 0 && s->alt_geodesic == (const void*)opt.geodesic &&
+                      (!opt.geodesic || (s->alt_geodesic_time == opt.geodesic_time && s->alt_transport == opt.parallel_transport_observer));
     s->alt_prefetched = false;
     if (prefetched) {
         s->swap_sets();
@@ -322,12 +475,24 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         attempts = s->attempts;
     }
 
-    // camera position and tetrad (main.cpp:2311, 2329)
+    // camera position and tetrad: from the cartesian camera (main.cpp:2311, 2329), or - camera on a geodesic - interpolated
+    // from the snapshot at the requested proper time (main.cpp:2264-2293)
+    const gr_geodesic_camera* gc = opt.geodesic;
+    if (gc && gc->device != s->device) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "geodesic camera lives on another device");
+    auto camera_setup = [&](hipStream_t st, void* cart, void* generic, void* const* tetrad, const gr_camera* cam, float time,
+                            void* velocity_out) -> int {
+        if (gc)
+            return gr_handle_interpolating_geodesic(p, st, gc->path, gc->velocity, gc->ds, generic, gc->transported[0], gc->transported[1],
+                                                    gc->transported[2], gc->transported[3], tetrad[0], tetrad[1], tetrad[2], tetrad[3],
+                                                    time, gc->count, opt.parallel_transport_observer, gc->basis_speed, velocity_out,
+                                                    s->cfg);
+        GR_CHECK(gr_cart_to_generic(p, st, cart, generic, 1, cam->flip, s->cfg));
+        return gr_init_basis_vectors(p, st, generic, 1, cam->basis_speed, tetrad[0], tetrad[1], tetrad[2], tetrad[3], s->cfg);
+    };
     if (!prefetched) {
         GR_CHECK(begin(GR_STAGE_CAMERA));
-        GR_CHECK(gr_cart_to_generic(p, stream, s->camera_pos_cart, s->camera_pos_generic, 1, camera->flip, s->cfg));
-        GR_CHECK(gr_init_basis_vectors(p, stream, s->camera_pos_generic, 1, camera->basis_speed, s->tetrad[0], s->tetrad[1],
-                                       s->tetrad[2], s->tetrad[3], s->cfg));
+        GR_CHECK(camera_setup(stream, s->camera_pos_cart, s->camera_pos_generic, s->tetrad, camera, opt.geodesic_time,
+                              gc ? gc->interpolated_velocity : nullptr));
         GR_CHECK(end(GR_STAGE_CAMERA));
     }
 
@@ -357,9 +522,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             HIP_CHECK(hipStreamWaitEvent(s->side_stream, s->main_mark, 0));
             HIP_CHECK(hipMemcpyAsync(s->alt.camera_pos_cart, next->position, 16, hipMemcpyHostToDevice, s->side_stream));
             HIP_CHECK(hipMemcpyAsync(s->alt.camera_quat, next->quat, 16, hipMemcpyHostToDevice, s->side_stream));
-            GR_CHECK(gr_cart_to_generic(p, s->side_stream, s->alt.camera_pos_cart, s->alt.camera_pos_generic, 1, next->flip, s->cfg));
-            GR_CHECK(gr_init_basis_vectors(p, s->side_stream, s->alt.camera_pos_generic, 1, next->basis_speed, s->alt.tetrad[0],
-                                           s->alt.tetrad[1], s->alt.tetrad[2], s->alt.tetrad[3], s->cfg));
+            GR_CHECK(camera_setup(s->side_stream, s->alt.camera_pos_cart, s->alt.camera_pos_generic, s->alt.tetrad, next,
+                                  opt.next_geodesic_time, gc ? gc->alt_interpolated_velocity : nullptr));
             GR_CHECK(gr_prepass_fused(p, s->side_stream, s->alt.camera_pos_generic, s->alt.camera_quat, s->alt.termination_buffer,
                                       prepass_width, prepass_height, s->alt.tetrad[0], s->alt.tetrad[1], s->alt.tetrad[2],
                                       s->alt.tetrad[3], s->cfg, s->dfg));
@@ -369,6 +533,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             s->alt_cfg = cfg;
             s->alt_features = features;
             s->alt_program = (const void*)p;
+            s->alt_geodesic = (const void*)gc;
+            s->alt_geodesic_time = opt.next_geodesic_time;
+            s->alt_transport = opt.parallel_transport_observer;
         }
         if (out) {
             GR_CHECK(begin(GR_STAGE_RENDER));

@@ -240,6 +240,48 @@ class RenderState:
         check(lib.gr_device_synchronize(self.device))
 
 
+class GeodesicCamera:
+    """Snapshot of the camera's timelike geodesic (main.cpp:2675-2760); pass `handle` as frame_options(geodesic=...)
+    together with geodesic_time to render from a point on it."""
+
+    def __init__(self, max_path_length=16384, device=0):
+        self.device, self.max_path_length = device, max_path_length
+        self.handle = c_void_p()
+        check(lib.gr_geodesic_camera_create(device, max_path_length, ctypes.byref(self.handle)))
+        self.steps, self.proper_time = 0, 0.0
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib.gr_geodesic_camera_destroy(self.handle)
+            self.handle = None
+
+    def snapshot(self, program, metric, camera, geodesic_basis_speed, features=None, cfg_values=None, stream=None):
+        arr, n = None, 0
+        if cfg_values is not None:
+            n = len(cfg_values)
+            arr = (c_float * n)(*cfg_values)
+        if features is None:
+            features = metric.features()
+        steps, tau = ctypes.c_int(), c_float()
+        check(lib.gr_geodesic_camera_snapshot(self.handle, program.handle, metric.handle, stream, ctypes.byref(camera),
+                                              (c_float * 3)(*geodesic_basis_speed), ctypes.byref(features), arr, n,
+                                              ctypes.byref(steps), ctypes.byref(tau)))
+        self.steps, self.proper_time = steps.value, tau.value
+        return self.steps, self.proper_time
+
+    def interpolate(self, program, proper_time, parallel_transport=True, stream=None):
+        cam, tet, vel = (c_float * 4)(), (c_float * 16)(), (c_float * 4)()
+        check(lib.gr_geodesic_camera_interpolate(self.handle, program.handle, stream, float(proper_time), int(parallel_transport), cam,
+                                                 tet, vel))
+        return np.array(cam, dtype=np.float32), np.array(tet, dtype=np.float32).reshape(4, 4), np.array(vel, dtype=np.float32)
+
+    def path(self):
+        """(positions[n,4], velocities[n,4], ds[n]) of the current snapshot"""
+        n = self.steps
+        get = lambda which, dtype, count: download(self.device, lib.gr_geodesic_camera_buffer(self.handle, which), dtype, count)
+        return get(0, np.float32, n * 4).reshape(n, 4), get(1, np.float32, n * 4).reshape(n, 4), get(2, np.float32, n)
+
+
 def synthetic_background(width=1024, height=512, seed=0x5EED, stars=None):
     """Deterministic equirectangular RGBA8 sky (the reference's PNG backgrounds are missing from the checkout):
     smooth gradient + 10 degree latitude/longitude grid + point stars."""

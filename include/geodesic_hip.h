@@ -277,6 +277,10 @@ void gr_camera_default(gr_camera* out);   /* pos (0,0,-4,0), axis-angle (1,0,0,-
 enum { GR_MODE_REFERENCE = 0,   /* one launch per reference kernel, 96-byte ray records in HBM */
        GR_MODE_FUSED = 1 };     /* gr_prepass_fused + gr_trace_fused + gr_render */
 
+/* Snapshot of the camera's own timelike geodesic, resident on the device: the buffers of main.cpp:1232-1242
+ * (geodesic_trace / vel / ds / count) and the four parallel-transported tetrad legs. */
+typedef struct gr_geodesic_camera gr_geodesic_camera;
+
 typedef struct gr_frame_options {
     int mode;              /* GR_MODE_* */
     int tiled;             /* reference mode only: 8x8-tile ray order (ignored when adaptive sampling is on) */
@@ -291,6 +295,11 @@ typedef struct gr_frame_options {
     const struct gr_camera* next_camera;   /* fused mode, optional: the camera of the NEXT gr_render_frame call.  Its tetrad and
                             * prepass are then computed on a second stream while this frame traces, and the next call
                             * (same program / cfg / features / camera) skips them.  NULL = no look-ahead. */
+    const gr_geodesic_camera* geodesic;   /* camera_on_geodesic (main.cpp:2264-2293): position and tetrad come from this snapshot
+                            * at proper time geodesic_time instead of camera->position; camera->quat still orients the view */
+    float geodesic_time;          /* current_geodesic_time of this frame */
+    float next_geodesic_time;     /* ... of the next frame, used with next_camera (look-ahead) */
+    int parallel_transport_observer;   /* 1 (default, main.cpp:1259): interpolate the transported tetrads; 0: rebuild them */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 
@@ -304,6 +313,24 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                     const float* cfg_values, int num_cfg_values,
                     const void* background1, const void* background2, int bg_width, int bg_height, int bg_levels,
                     void* out_rgba_f32, const gr_frame_options* options);
+
+/* Camera on a timelike geodesic: object form of main.cpp:2675-2760.  gr_geodesic_camera_snapshot launches
+ * cart_to_generic, init_basis_vectors (camera->basis_speed), boost_tetrad, init_inertial_ray, get_geodesic_path and four
+ * parallel_transport_quantity on `stream`, then synchronises once to report the number of samples and the proper time the
+ * path covers.  geodesic_basis_speed is g_geodesic_basis_speed (main.cpp:2253-2261), |v| < 1. */
+int gr_geodesic_camera_create(int device, int max_path_length, gr_geodesic_camera** out);
+void gr_geodesic_camera_destroy(gr_geodesic_camera* g);
+int gr_geodesic_camera_snapshot(gr_geodesic_camera* g, gr_program* p, const gr_metric* m, void* stream, const gr_camera* camera,
+                                const float geodesic_basis_speed[3], const gr_features* features, const float* cfg_values,
+                                int num_cfg_values, int* steps_out, float* proper_time_out);
+/* handle_interpolating_geodesic + read-back (the reference's geodesic_q / camera_q async reads, main.cpp:2295-2296):
+ * generic camera position, tetrad (4 rows of 4) and 4-velocity at `proper_time`; any output may be NULL */
+int gr_geodesic_camera_interpolate(gr_geodesic_camera* g, gr_program* p, void* stream, float proper_time,
+                                   int parallel_transport_observer, float camera_generic_out[4], float tetrad_out[16],
+                                   float velocity_out[4]);
+enum { GR_GEOBUF_PATH = 0, GR_GEOBUF_VELOCITY = 1, GR_GEOBUF_DS = 2, GR_GEOBUF_COUNT = 3, GR_GEOBUF_TRANSPORTED0 = 4,
+       GR_GEOBUF_TRANSPORTED1 = 5, GR_GEOBUF_TRANSPORTED2 = 6, GR_GEOBUF_TRANSPORTED3 = 7 };
+void* gr_geodesic_camera_buffer(gr_geodesic_camera* g, int which);
 
 /* stages for timing / buffer access */
 enum { GR_STAGE_CAMERA = 0, GR_STAGE_PREPASS = 1, GR_STAGE_INIT = 2, GR_STAGE_TRACE = 3, GR_STAGE_RENDER_DATA = 4,

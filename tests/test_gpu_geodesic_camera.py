@@ -76,3 +76,77 @@ def test_many_observers_share_one_launch():
     p = path.to_numpy(np.float32, (n_max, n, 4))[:single["count"]]
     for lane in (0, 1, 63, 64, 69):
         assert np.array_equal(p[:, lane], single["path"])
+
+
+@pytest.mark.parametrize("name", ["schwarzschild_infall", "kerr_flyby", "kerr_recomputed_tetrads"])
+def test_frame_from_a_point_on_the_geodesic(name):
+    """gr_geodesic_camera + gr_render_frame(options.geodesic): the frame rendered from proper time tau must equal the frame
+    rendered through the plain stage kernels from the golden interpolated camera/tetrad, in fused, look-ahead and reference modes"""
+    import ctypes
+    import geodesic_raytracing_amd as gra
+    from gpu_stages import Stages, program_for, features_from
+    from geodesic_raytracing_amd.pipeline import DeviceBuffer, RENDER_DATA_DTYPE
+    meta, z = load_path_golden(name)
+    metric, program = program_for(meta)
+    feats = features_from(meta)
+    camera = gra.default_camera(position=meta["camera_pos"])
+    gc = gra.GeodesicCamera(meta["max_len"])
+    steps, tau_total = gc.snapshot(program, metric, camera, meta["basis_speed"], features=feats, cfg_values=meta["cfg"])
+    assert steps == meta["count"]
+    assert abs(tau_total - float(z["ds"][:-1].astype(np.float64).sum())) <= 1e-3 * max(1.0, tau_total)
+    path, vel, ds = gc.path()
+    assert vec_err(path, z["path"]).max() <= 1e-3
+    k = 3
+    tau = meta["target_times"][k]
+    cam_i, tet_i, vel_i = gc.interpolate(program, tau, meta["parallel_transport"])
+    assert vec_err(cam_i, z["interp_camera"][k]).max() <= 1e-3
+    assert np.abs(tet_i - z["interp_tetrad"][k]).max() <= 1e-3 * max(1.0, np.abs(z["interp_tetrad"][k]).max())
+
+    w, h = 64, 40
+    m2 = dict(meta, width=w, height=h, camera_quat=list(camera.quat))
+    st = Stages(m2)
+    rays = st.trace(st.init_rays(cam_i, tet_i))
+    want = st.render_data(rays).reshape(h, w)
+
+    state = gra.RenderState(w, h)
+    frames = {}
+    for label, kw in [("fused", dict(mode=gra.MODE_FUSED, use_prepass=0)),
+                      ("reference", dict(mode=gra.MODE_REFERENCE, use_prepass=0, tiled=0))]:
+        opt = gra.frame_options(geodesic=gc.handle.value, geodesic_time=tau, parallel_transport_observer=int(meta["parallel_transport"]), **kw)
+        state.render(program, metric, camera, None, features=feats, cfg_values=meta["cfg"], options=opt)
+        state.synchronize()
+        got = gra.pipeline.download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h).reshape(h, w)
+        frames[label] = got
+        assert (got["terminated"] == want["terminated"]).mean() >= 0.995
+        both = (got["terminated"] == 1) & (want["terminated"] == 1)
+        assert np.percentile(np.abs(got["tex_coord"][both] - want["tex_coord"][both]), 95) <= 1e-4
+    # look-ahead: frame A prefetches the camera of proper time tau, frame B must then equal the directly rendered one
+    opt = gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1, geodesic=gc.handle.value, geodesic_time=0.0, next_geodesic_time=tau,
+                            next_camera=ctypes.pointer(camera), parallel_transport_observer=int(meta["parallel_transport"]))
+    state.render(program, metric, camera, None, features=feats, cfg_values=meta["cfg"], options=opt)
+    opt2 = gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1, geodesic=gc.handle.value, geodesic_time=tau,
+                             parallel_transport_observer=int(meta["parallel_transport"]))
+    state.render(program, metric, camera, None, features=feats, cfg_values=meta["cfg"], options=opt2)
+    state.synchronize()
+    ahead = gra.pipeline.download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h).reshape(h, w)
+    state2 = gra.RenderState(w, h)
+    state2.render(program, metric, camera, None, features=feats, cfg_values=meta["cfg"], options=opt2)
+    state2.synchronize()
+    direct = gra.pipeline.download(0, state2.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h).reshape(h, w)
+    assert np.array_equal(ahead["tex_coord"], direct["tex_coord"]) and np.array_equal(ahead["terminated"], direct["terminated"])
+
+
+def test_cli_renders_a_sequence_along_the_geodesic(tmp_path):
+    """python -m geodesic_raytracing_amd.render --geodesic-speed ...: frames are written, differ from each other (the camera
+    moves) and the first one equals the plain render from the same camera when the geodesic speed is zero-time/zero-offset"""
+    from geodesic_raytracing_amd import render as cli
+    out = tmp_path / "fall.png"
+    rc = cli.main(["--metric", "schwarzschild", "--size", "96x64", "--camera", "0,0,-8,0", "--geodesic-speed", "0,0.3,0",
+                   "--geodesic-dt", "4.0", "--frames", "3", "--out", str(out)])
+    assert rc == 0
+    frames = [cli.read_png(str(tmp_path / f"fall_{i:03d}.png")) for i in range(3)]
+    assert frames[0].shape == (64, 96, 4)
+    assert (frames[0] != frames[1]).mean() > 0.05 and (frames[1] != frames[2]).mean() > 0.05
+    # the hole grows as the camera falls towards it: more black (captured) pixels in later frames
+    dark = [int((f[..., :3].max(axis=2) == 0).sum()) for f in frames]
+    assert dark[0] < dark[1] < dark[2]
