@@ -131,18 +131,25 @@ __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
 // calls (each with its own large-argument branch) were ~25 % of the step's instructions.
 struct sincos_pair { float s, c; };
 __device__ __forceinline__ sincos_pair sincos_reduced(float x) {
-    float j = __builtin_rintf(x * 0.636619772367581343f);           // nearest multiple of pi/2
+#pragma clang fp reassociate(off)
+    // nearest multiple of pi/2 by the 1.5 * 2^23 trick: the rounded quotient lands in the low mantissa bits of t (so the
+    // quadrant needs no v_cvt_i32_f32) and j = t - magic is exact; both are full-rate ops where v_rndne_f32 and
+    // v_cvt_i32_f32 issue at half rate.  Valid for |x| < 2^21 (callers only trust the result below 8192).  Re-association
+    // (allowed by the build flags elsewhere) is off in this function so that the two constants are not cancelled.
+    float t = __builtin_fmaf(x, 0.636619772367581343f, 12582912.f);
+    float j = t - 12582912.f;
+    unsigned int q = __builtin_bit_cast(unsigned int, t);
     float r = __builtin_fmaf(-j, 1.57079637050628662109375f, x);   // pi/2 = hi + lo, fma keeps the product exact
     r = __builtin_fmaf(-j, -4.37113900018624283e-8f, r);
     float r2 = r * r;
     float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
     float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
                               r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
-    int q = (int)j;
     float s = (q & 1) ? cp : sp;
     float c = (q & 1) ? sp : cp;
-    s = (q & 2) ? -s : s;
-    c = ((q + 1) & 2) ? -c : c;
+    // quadrant signs applied to the sign bit directly (xor is full rate, compare + select are not)
+    s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, s) ^ ((q & 2u) << 30));
+    c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, c) ^ (((q + 1u) & 2u) << 30));
     return {s, c};
 }
 // the polynomial is evaluated unconditionally (so sin and cos of one angle stay in one basic block and share it);
@@ -328,6 +335,12 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return __
 __device__ __forceinline__ float mixf(float a, float b, float t) { return a + (b - a) * t; }
 __device__ __forceinline__ bool degenerate(float x) { return !(__builtin_fabsf(x) <= 3.402823466e+38f); }   // NaN or Inf
 __device__ __forceinline__ bool degenerate4(float4 v) { return degenerate(v.x) || degenerate(v.y) || degenerate(v.z) || degenerate(v.w); }
+// x * 0 is 0 for finite x and NaN for +-inf / NaN, so the accumulated sum is NaN exactly when a component is degenerate.
+// Inside the Verlet loop this replaces four half-rate v_cmp_class per vector (plus the mask plumbing) by four full-rate
+// v_fma and one compare for all vectors together.  (No -ffinite-math-only: the compiler may not fold x * 0.)
+__device__ __forceinline__ float degenerate_accumulate(float4 v, float acc) {
+    return __builtin_fmaf(v.x, 0.f, __builtin_fmaf(v.y, 0.f, __builtin_fmaf(v.z, 0.f, __builtin_fmaf(v.w, 0.f, acc))));
+}
 __device__ __forceinline__ float get4(float4 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 __device__ __forceinline__ void swap4(float4& a, float4& b) { float4 t = a; a = b; b = t; }
 
@@ -705,7 +718,7 @@ __device__ __forceinline__ float acceleration_to_precision(float4 acc, float max
     float diff = current * scale;
     float floor_diff = err * scale / 1e10f;      // pow(max_timestep = 100000, 2)
     if (diff < floor_diff) diff = floor_diff;
-    next_ds = __builtin_sqrtf((err * scale) / diff);
+    next_ds = __builtin_sqrtf(err * scale) * __builtin_amdgcn_rsqf(diff);   // sqrt((err * scale) / diff); first factor is loop-invariant
     return diff;
 }
 #endif
@@ -798,7 +811,8 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
             // calculate_ds_error
             float suggested;
             float diff = acceleration_to_precision(next_acceleration, max_accel, suggested);
-            float nds = 0.99f * ds * clampf(suggested / ds, 0.3f, 2.f);
+            // 0.99 * ds * clamp(suggested / ds, 0.3, 2) with ds > 0, without forming the quotient
+            float nds = clampf(0.99f * suggested, (0.99f * 0.3f) * ds, (0.99f * 2.f) * ds);
             nds = __builtin_fmaxf(nds, min_step);
             next_ds = nds;
 #ifdef SINGULARITY_DETECTION
@@ -811,7 +825,11 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
         velocity = next_velocity;
         acceleration = next_acceleration;
         i++;
-        if (degenerate4(position) || degenerate4(velocity) || degenerate4(acceleration)) break;
+        // IS_DEGENERATE of position, velocity, acceleration (cl.cl:4235-4244).  Without reparameterisation a
+        // degenerate acceleration always makes the velocity computed from it degenerate, so two vectors suffice.
+        float poison = degenerate_accumulate(position, degenerate_accumulate(velocity, 0.f));
+        if (reparam) poison = degenerate_accumulate(acceleration, poison);
+        if (!(poison == 0.f)) break;
     }
     s.position = position;
     s.velocity = velocity;

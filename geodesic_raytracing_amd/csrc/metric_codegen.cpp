@@ -403,9 +403,16 @@ std::vector<unsigned char> FeatureConfig::pack() const {
 // ----------------------------------------------------------------------------------------------
 // macro string
 
-std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl& impl,
+std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl& impl_in,
                                   const MetricConfig& cfg, const DynamicVars& vars, bool is_static,
                                   const FeatureConfig& features, bool linear_framebuffer) {
+    // the expressions evaluated every Verlet step trade reciprocals of squares for squares of reciprocals
+    MetricImpl impl = impl_in;
+    {
+        std::unordered_map<E, E> memo;
+        for (auto* v : {&impl.real_eq, &impl.derivatives, &impl.accel})
+            for (auto& e : *v) e = share_reciprocals(e, memo);
+    }
     // position-only common sub-expressions of everything evaluated in TEMPORARIES0 scope
     std::vector<E> scoped;
     scoped.insert(scoped.end(), impl.real_eq.begin(), impl.real_eq.end());

@@ -460,6 +460,36 @@ E subst_rec(E e, const std::map<std::string, E>& m, std::unordered_map<E, E>& me
 }
 }  // namespace
 
+E share_reciprocals(E e, std::unordered_map<E, E>& memo) {
+    if (e->op == CONST || e->op == VAR) return e;
+    auto it = memo.find(e);
+    if (it != memo.end()) return it->second;
+    auto R = [&](E x) { return share_reciprocals(x, memo); };
+    E r = nullptr;
+    switch (e->op) {
+        case ADD: r = add(R(e->a), R(e->b)); break;
+        case SUB: r = sub(R(e->a), R(e->b)); break;
+        case MUL: r = mul(R(e->a), R(e->b)); break;
+        case DIV: {
+            E n = R(e->a), d = R(e->b);
+            if (d->op == MUL && d->a == d->b) {
+                E inv = div(constant(1.0), d->a);
+                r = mul(n, mul(inv, inv));
+            } else {
+                r = div(n, d);
+            }
+            break;
+        }
+        case NEG: r = neg(R(e->a)); break;
+        case FN1: r = fn1(e->fn, R(e->a)); break;
+        case FN2: r = fn2(e->fn, R(e->a), R(e->b)); break;
+        case SELECT: r = select(R(e->a), R(e->b), R(e->s)); break;
+        default: throw std::runtime_error("share_reciprocals: bad op");
+    }
+    memo.emplace(e, r);
+    return r;
+}
+
 E subst(E e, const std::map<std::string, E>& m) {
     std::unordered_map<E, E> memo;
     return subst_rec(e, m, memo);

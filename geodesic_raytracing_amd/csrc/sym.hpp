@@ -78,6 +78,11 @@ E diff(E e, const std::string& wrt);
 E subst(E e, const std::map<std::string, E>& m);
 double eval(E e, const std::map<std::string, double>& env);
 
+// n / (x*x) -> n * ((1/x) * (1/x)): the reciprocal of x is (almost always) needed anyway, and on gfx950 v_rcp_f32
+// issues at a quarter of the v_mul_f32 rate.  `memo` carries the rewritten nodes across calls so that several roots
+// keep sharing sub-expressions.
+E share_reciprocals(E e, std::unordered_map<E, E>& memo);
+
 // fully parenthesised C expression (valid OpenCL C, HIP device C++ and host C++); float literals.
 // `names` maps node -> identifier for nodes that were hoisted into temporaries.
 // `is_definition` prints the body of `e` even when `e` itself has a name (used for "pvN=<body>").
