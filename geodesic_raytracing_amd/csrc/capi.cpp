@@ -525,7 +525,12 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
     long long waves_per_block = (long long)((width + T - 1) / T) * (block_rows / T) + (strip_count > 1 ? (width + 63) / 64 : 0);
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter};
-    return launch(p, K_TRACE_FUSED, stream, (unsigned)(waves_per_block * local_blocks), 1, 64, 1, args);
+    // four tile-waves per workgroup (measured on MI355X, 4K Kerr: 64 -> 7.59 ms, 128 -> 7.43, 256 -> 7.24; one wave per SIMD
+    // still leaves the full 512-VGPR budget to the heaviest metrics).  Experiment hook: GR_TRACE_BLOCK=64|128|256 with the
+    // kernel built with the same -DGR_TRACE_BLOCK through GR_EXTRA_FLAGS.
+    static const int wg = [] { const char* e = getenv("GR_TRACE_BLOCK"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128) ? v : 256; }();
+    long long waves = waves_per_block * local_blocks;
+    return launch(p, K_TRACE_FUSED, stream, (unsigned)((waves * 64 + wg - 1) / wg), 1, wg, 1, args);
 }
 
 // ---- camera on a timelike geodesic (cl.cl:2441-2481, 3117-3141, 4735-4940, 2569-2620, 2738-2872) --------------------

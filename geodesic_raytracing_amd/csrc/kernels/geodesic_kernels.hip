@@ -1078,7 +1078,11 @@ extern "C" __global__ void gr_calculate_render_data(const lightray* __restrict__
 }
 
 // init -> integrate -> render-data for one pixel per lane, 8x8 tiles, nothing but the 32-byte result is stored
-extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
+// workgroup size of the fused trace kernel: 4 tile-waves, one per SIMD of a CU (capi.cpp launches with the same number)
+#ifndef GR_TRACE_BLOCK
+#define GR_TRACE_BLOCK 256
+#endif
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
 gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
@@ -1090,13 +1094,14 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
     // split, each block is followed by 64x1 "halo" waves tracing the row just below it, which the texture filter
     // of the block's last row reads (cl.cl:5509-5520).  strip_count == 1: one block covering the whole image.
     const int T = GR_TILE;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x % 64;
+    const int wave = blockIdx.x * (GR_TRACE_BLOCK / 64) + threadIdx.x / 64;   // waves past the last tile fall off the image below
     const int tiles_x = (width + T - 1) / T;
     const int tile_rows = block_rows / T;
     const int halo_waves = strip_count > 1 ? (width + 63) / 64 : 0;
     const int waves_per_block = tiles_x * tile_rows + halo_waves;
-    const int local_block = blockIdx.x / waves_per_block;
-    const int within = blockIdx.x % waves_per_block;
+    const int local_block = wave / waves_per_block;
+    const int within = wave % waves_per_block;
     const int r0 = (local_block * strip_count + strip_rank) * block_rows;
     int cx, cy;
     if (within < tiles_x * tile_rows) {
