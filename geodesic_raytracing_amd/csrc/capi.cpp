@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -188,6 +189,12 @@ struct gr_program {
     hipModule_t module = nullptr;
     hipFunction_t fn[K_COUNT] = {};
     void* huge_count = nullptr;   // device int = INT_MAX: "no device-side count" for range launches
+    // tile tickets of the persistent fused trace: one counter per launch, taken round robin from a small ring so that
+    // launches in flight on different streams never share one
+    static const int TICKET_RING = 64;
+    unsigned int* tickets = nullptr;
+    std::atomic<unsigned> next_ticket{0};
+    int compute_units = 256;
     std::string arguments;
 };
 
@@ -319,6 +326,8 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
     HIP_CHECK(hipModuleLoadData(&p->module, code.data()));
     for (int k = 0; k < K_COUNT; k++) HIP_CHECK(hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]));
     const int huge = 0x7fffffff;
+    HIP_CHECK(hipMalloc((void**)&p->tickets, gr_program::TICKET_RING * sizeof(unsigned int)));
+    HIP_CHECK(hipDeviceGetAttribute(&p->compute_units, hipDeviceAttributeMultiprocessorCount, p->device));
     HIP_CHECK(hipMalloc(&p->huge_count, sizeof(int)));
     HIP_CHECK(hipMemcpy(p->huge_count, &huge, sizeof(int), hipMemcpyHostToDevice));
     *out = p.release();
@@ -377,6 +386,7 @@ void gr_program_future_destroy(gr_program_future* f) {
 void gr_program_destroy(gr_program* p) {
     if (!p) return;
     if (p->huge_count) (void)hipFree(p->huge_count);
+    if (p->tickets) (void)hipFree(p->tickets);
     if (p->module) (void)hipModuleUnload(p->module);
     delete p;
 }
@@ -523,14 +533,28 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
         return fail(GR_ERROR_INVALID_ARGUMENT, "the last image row must not start a block (its filter reads the row above)");
     int local_blocks = gr_strip_local_blocks(height, block_rows, strip_rank, strip_count);
     long long waves_per_block = (long long)((width + T - 1) / T) * (block_rows / T) + (strip_count > 1 ? (width + 63) / 64 : 0);
-    void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
-                    &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter};
     // four tile-waves per workgroup (measured on MI355X, 4K Kerr: 64 -> 7.59 ms, 128 -> 7.43, 256 -> 7.24; one wave per SIMD
-    // still leaves the full 512-VGPR budget to the heaviest metrics).  Experiment hook: GR_TRACE_BLOCK=64|128|256 with the
-    // kernel built with the same -DGR_TRACE_BLOCK through GR_EXTRA_FLAGS.
+    // still leaves the full 512-VGPR budget to the heaviest metrics).  Experiment hooks: GR_TRACE_BLOCK=64|128|256 with the
+    // kernel built with the same -DGR_TRACE_BLOCK through GR_EXTRA_FLAGS; GR_TRACE_PERSISTENT=0 launches one wave per tile.
     static const int wg = [] { const char* e = getenv("GR_TRACE_BLOCK"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128) ? v : 256; }();
+    static const bool persistent = [] { const char* e = getenv("GR_TRACE_PERSISTENT"); return !(e && e[0] == '0'); }();
     long long waves = waves_per_block * local_blocks;
-    return launch(p, K_TRACE_FUSED, stream, (unsigned)((waves * 64 + wg - 1) / wg), 1, wg, 1, args);
+    if (waves <= 0) return GR_OK;
+    if (waves > 0x7fffffff) return fail(GR_ERROR_INVALID_ARGUMENT, "too many tiles");
+    int total_waves = (int)waves;
+    long long groups = (waves * 64 + wg - 1) / wg;
+    unsigned int* tickets = nullptr;
+    // persistent mode only pays when there are more tiles than wave slots (8 per SIMD, 4 SIMDs per CU)
+    long long resident_groups = (long long)p->compute_units * 32 * 64 / wg;
+    if (persistent && groups > resident_groups) {
+        tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
+        HIP_CHECK(hipSetDevice(p->device));
+        HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
+        groups = resident_groups;
+    }
+    void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
+                    &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves};
+    return launch(p, K_TRACE_FUSED, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
 // ---- camera on a timelike geodesic (cl.cl:2441-2481, 3117-3141, 4735-4940, 2569-2620, 2738-2872) --------------------

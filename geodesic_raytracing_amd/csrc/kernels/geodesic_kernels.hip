@@ -1077,25 +1077,18 @@ extern "C" __global__ void gr_calculate_render_data(const lightray* __restrict__
     rdata[sy * width + sx] = dat;
 }
 
-// init -> integrate -> render-data for one pixel per lane, 8x8 tiles, nothing but the 32-byte result is stored
-// workgroup size of the fused trace kernel: 4 tile-waves, one per SIMD of a CU (capi.cpp launches with the same number)
-#ifndef GR_TRACE_BLOCK
-#define GR_TRACE_BLOCK 256
-#endif
-extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
-gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
-               render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
-               const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
-               const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
-               cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter) {
-    GR_PARAMETERS_IN_REGISTERS
-    // Image rows are dealt to devices in blocks of `block_rows` rows (block-cyclic: global block gb belongs to
-    // device gb % strip_count).  One workgroup = one wave = one 8x8 pixel tile of a block; when the image is
-    // split, each block is followed by 64x1 "halo" waves tracing the row just below it, which the texture filter
-    // of the block's last row reads (cl.cl:5509-5520).  strip_count == 1: one block covering the whole image.
+// init -> integrate -> render-data for one pixel per lane, 8x8 tiles, nothing but the 32-byte result is stored.
+// `wave` numbers the tile-waves of this device: image rows are dealt to devices in blocks of `block_rows` rows (block-cyclic:
+// global block gb belongs to device gb % strip_count); a block is tiles_x * block_rows/8 tile-waves, and, when the image is
+// split, 64x1 "halo" waves tracing the row just below it, which the texture filter of the block's last row reads
+// (cl.cl:5509-5520).  strip_count == 1: one block covering the whole image.
+__device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __restrict__ camera, const float4* __restrict__ camera_quat,
+                                           render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank,
+                                           int strip_count, const int* __restrict__ termination_buffer, int prepass_width,
+                                           int prepass_height, const float4* __restrict__ e0, const float4* __restrict__ e1,
+                                           const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
+                                           unsigned long long* __restrict__ attempt_counter) {
     const int T = GR_TILE;
-    const int lane = threadIdx.x % 64;
-    const int wave = blockIdx.x * (GR_TRACE_BLOCK / 64) + threadIdx.x / 64;   // waves past the last tile fall off the image below
     const int tiles_x = (width + T - 1) / T;
     const int tile_rows = block_rows / T;
     const int halo_waves = strip_count > 1 ? (width + 63) / 64 : 0;
@@ -1114,7 +1107,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
     }
     if (cx >= width || cy >= height) return;
 
-    lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+    // the prepass verdict first: a skipped pixel (58 % of the 4K Kerr frame) needs no ray at all
     int terminated = 0;
     if (termination_buffer && prepass_width != width && prepass_height != height) {
         float fx = exact_ratio(cx, width);
@@ -1129,21 +1122,69 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
             terminated = 2;
         }
     }
-    ray_state s;
-    s.position = ray.position;
-    s.velocity = ray.velocity;
-    s.acceleration = ray.acceleration;
-    s.running_dlambda_dnew = 1;
+    render_data dat;
     unsigned int tries = 0;
-    if (terminated != 2) {
+    if (terminated == 2) {
+        dat.tex_coord = make_float2(0, 0);
+        dat.z_shift = 0;
+        dat.sx = cx;
+        dat.sy = cy;
+        dat.terminated = 2;
+        dat.side = 1;
+    } else {
+        // camera and tetrad are re-read (scalar loads) for every tile: 24 wave-uniform values held across the integrator
+        // loop would spill scalar registers
+        lightray ray = make_pixel_ray(cx, cy, width, height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        ray_state s;
+        s.position = ray.position;
+        s.velocity = ray.velocity;
+        s.acceleration = ray.acceleration;
+        s.running_dlambda_dnew = 1;
         int res = integrate_ray(s, cfg, dfg, &tries);
         if (res == RAY_TERMINATED) terminated = 1;
         else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
+        dat = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated, cx, cy, cfg,
+                               dfg, GET_FEATURE(redshift, dfg) != 0);
     }
-    render_data dat = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew,
-                                       terminated, cx, cy, cfg, dfg, GET_FEATURE(redshift, dfg) != 0);
     rdata[cy * width + cx] = dat;
     if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);
+}
+
+// workgroup size of the fused trace kernel: 4 tile-waves, one per SIMD of a CU (capi.cpp launches with the same number)
+#ifndef GR_TRACE_BLOCK
+#define GR_TRACE_BLOCK 256
+#endif
+// Two scheduling modes.  tile_counter == NULL: wave w of the launch traces tile w (grid = all tiles).  tile_counter != NULL:
+// persistent waves - the launch only fills the machine and every wave keeps drawing the next tile from the device-side
+// counter until total_waves are handed out, so a SIMD slot never idles between the end of a short tile (prepass-skipped
+// tiles finish in a few hundred cycles) and the dispatcher's next workgroup.
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
+gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+               render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
+               const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+               const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+               cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
+               int total_waves) {
+    GR_PARAMETERS_IN_REGISTERS
+    const int lane = threadIdx.x % 64;
+    // one call site for both modes: the two schedules must run the very same instructions per pixel (strip renders are
+    // compared bit for bit with whole-frame renders)
+    int wave = blockIdx.x * (GR_TRACE_BLOCK / 64) + threadIdx.x / 64;
+    for (;;) {
+        if (tile_counter) {
+            unsigned int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(tile_counter, 1u);
+            wave = (int)__builtin_amdgcn_readfirstlane(ticket);
+        }
+        if (wave >= total_waves) break;
+        // Launder the camera / tetrad pointers once per tile: otherwise everything in the ray set-up that depends only on
+        // them is hoisted out of the tile loop and held in registers across the integrator (94 instead of 64 VGPRs, i.e.
+        // 5 instead of 8 waves per SIMD).  Re-reading 96 bytes through the scalar cache per tile is free by comparison.
+        asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
+        trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
+                   termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter);
+        if (!tile_counter) break;
+    }
 }
 
 // termination flags of the low-resolution prepass, straight from a fused trace (role of
