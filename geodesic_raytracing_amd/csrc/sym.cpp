@@ -98,11 +98,28 @@ E intern(Op op, Fn fn, double c, const std::string& name, E a, E b, E s) {
     if (b) { n.deps |= b->deps; size += b->size; }
     if (s) { n.deps |= s->deps; size += s->size; }
     n.size = size > 0x7fffffffu ? 0x7fffffffu : (uint32_t)size;
+    {
+        auto mix = [](uint64_t h, uint64_t v) {
+            h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+            h *= 0xff51afd7ed558ccdull;
+            return h ^ (h >> 33);
+        };
+        uint64_t h = mix(0x243f6a8885a308d3ull, (uint64_t)op * 131 + (uint64_t)fn);
+        h = mix(h, bits);
+        for (unsigned char ch : name) h = mix(h, ch);
+        h = mix(h, a ? a->shape : 1);
+        h = mix(h, b ? b->shape : 2);
+        h = mix(h, s ? s->shape : 3);
+        n.shape = h;
+    }
     p.nodes.push_back(n);
     E e = &p.nodes.back();
     p.table.emplace(k, e);
     return e;
 }
+
+// canonical order of the operands of a commutative node
+inline bool ordered_before(E x, E y) { return x->shape != y->shape ? x->shape < y->shape : x->id < y->id; }
 
 double apply1(Fn f, double x) {
     switch (f) {
@@ -207,7 +224,7 @@ E add(E a, E b) {
         split_coef(b, cb, tb);
         if (ta == tb && ta->op != CONST) return mul(constant(ca + cb), ta);
     }
-    if (a->id > b->id) std::swap(a, b);
+    if (ordered_before(b, a)) std::swap(a, b);
     return intern(ADD, F_NONE, 0, "", a, b, nullptr);
 }
 
@@ -248,7 +265,7 @@ E mul(E a, E b) {
     // float constants migrate outwards: (c*x)*y -> c*(x*y)
     if (a->op == MUL && a->a->op == CONST) return mul(a->a, mul(a->b, b));
     if (b->op == MUL && b->a->op == CONST) return mul(b->a, mul(a, b->b));
-    if (a->id > b->id) std::swap(a, b);
+    if (ordered_before(b, a)) std::swap(a, b);
     return intern(MUL, F_NONE, 0, "", a, b, nullptr);
 }
 

@@ -46,6 +46,8 @@ struct Node {
     uint32_t id;         // creation index, deterministic within a process
     uint32_t deps;       // dependency mask, see dep_* below
     uint32_t size;       // tree size estimate (saturating)
+    uint64_t shape;      // structural hash (operator, constants, names, operand shapes): orders commutative operands the same
+                         // way whatever was built earlier in the process, so a metric's macro string never depends on history
 };
 typedef const Node* E;
 

@@ -162,3 +162,25 @@ def test_op_counts_reported():
     i = gra.Metric("kerr_boyer").info
     assert 100 < i.accel_ops < 260 and i.accel_transcendentals >= 2      # SURVEY: 214 ops after sympy CSE
     assert gra.Metric("minkowski").info.accel_ops == 0
+
+
+def test_argument_string_does_not_depend_on_process_history():
+    """the macro string of a metric is the cache key of its code object and the input of the golden fixtures: it must be the
+    same whichever metrics were built earlier in the process (commutative operands are ordered by structure, not by age)"""
+    import hashlib
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, hashlib; sys.path.insert(0, %r); import geodesic_raytracing_amd as gra\n"
+            "sc = %r\n"
+            "for n in sys.argv[1:]:\n"
+            "    name, _, scripted = n.partition(':')\n"
+            "    print(name, hashlib.md5(gra.Metric(name, sc if scripted else None).argument_string().encode()).hexdigest())\n"
+            % (root, os.path.join(root, "geodesic_raytracing_amd", "scripts")))
+    names = ["alcubierre", "kerr_boyer:s", "wormhole:s", "schwarzschild"]
+    out = []
+    for order in (names, names[::-1]):
+        r = subprocess.run([sys.executable, "-c", prog] + order, capture_output=True, text=True, check=True)
+        out.append(dict(line.split() for line in r.stdout.strip().splitlines()))
+    assert out[0] == out[1]
