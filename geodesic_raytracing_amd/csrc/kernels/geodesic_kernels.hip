@@ -792,10 +792,11 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
 
         // velocity Verlet (step_verlet)
         tries++;
-        float4 next_position = position + velocity * ds + (0.5f * acceleration) * (ds * ds);
+        const float half_ds = 0.5f * ds, half_ds2 = half_ds * ds;
+        float4 next_position = position + velocity * ds + acceleration * half_ds2;
         float4 half_velocity = velocity + acceleration * ds;
         float4 next_acceleration = gm::geodesic_acceleration(next_position, half_velocity, cfg);
-        float4 next_velocity = velocity + (0.5f * (acceleration + next_acceleration)) * ds;
+        float4 next_velocity = velocity + (acceleration + next_acceleration) * half_ds;
         float K = 1;
         if (reparam) {
             float md = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(next_velocity.x), __builtin_fabsf(next_velocity.y)),
@@ -806,6 +807,7 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
         }
         running *= K;
 
+        bool accept = true;
 #ifdef ADAPTIVE_PRECISION
         if (ar < new_max) {
             // calculate_ds_error
@@ -818,18 +820,20 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
 #ifdef SINGULARITY_DETECTION
             if (nds == min_step && (diff / 65536.f) > max_accel * 10000) break;
 #endif
-            if (nds < ds / 1.95f) continue;   // back-step: retry from the same state with the smaller step
+            accept = !(nds < ds / 1.95f);   // back-step: retry from the same state with the smaller step
         }
 #endif
-        position = next_position;
-        velocity = next_velocity;
-        acceleration = next_acceleration;
-        i++;
-        // IS_DEGENERATE of position, velocity, acceleration (cl.cl:4235-4244).  Without reparameterisation a
-        // degenerate acceleration always makes the velocity computed from it degenerate, so two vectors suffice.
-        float poison = degenerate_accumulate(position, degenerate_accumulate(velocity, 0.f));
-        if (reparam) poison = degenerate_accumulate(acceleration, poison);
-        if (!(poison == 0.f)) break;
+        if (accept) {
+            position = next_position;
+            velocity = next_velocity;
+            acceleration = next_acceleration;
+            i++;
+            // IS_DEGENERATE of position, velocity, acceleration (cl.cl:4235-4244).  Without reparameterisation a
+            // degenerate acceleration always makes the velocity computed from it degenerate, so two vectors suffice.
+            float poison = degenerate_accumulate(position, degenerate_accumulate(velocity, 0.f));
+            if (reparam) poison = degenerate_accumulate(acceleration, poison);
+            if (!(poison == 0.f)) break;
+        }
     }
     s.position = position;
     s.velocity = velocity;
@@ -1183,7 +1187,11 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
         asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
         trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
                    termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter);
+#ifdef GR_TRACE_SINGLE_TILE   // experiment: one tile per wave only (launch with GR_TRACE_PERSISTENT=0)
+        break;
+#else
         if (!tile_counter) break;
+#endif
     }
 }
 
