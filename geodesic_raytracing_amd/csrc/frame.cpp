@@ -201,7 +201,15 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
     A(&s->alt.camera_pos_generic, 16);
     for (auto& t : s->alt.tetrad) A(&t, 16);
     A(&s->alt.termination_buffer, px * sizeof(int));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // High priority: the look-ahead prepass is a latency-bound launch of a few hundred waves that must make progress
+        // while the trace kernel occupies every CU, and priority streams get hardware queues of their own (with the
+        // default priority the stream can share a queue with the caller's stream once a framework - torch + RCCL - has
+        // created a few streams of its own, which serialises the overlap: measured 6.66 -> 7.98 ms per 4K frame).
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->side_stream, hipStreamNonBlocking, greatest);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->main_mark, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->alt_ready, hipEventDisableTiming);
     for (int i = 0; i < GR_STAGE_COUNT && e == hipSuccess; i++) {
