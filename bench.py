@@ -10,7 +10,10 @@ as in the metric's config, all hot-path stages (camera tetrad, prepass, fused in
 anisotropic texture render) into a float4 HBM buffer.  Inputs (background, camera, cfg) are resident
 in HBM before the timed region.  With N > 1 the frame's rows are dealt to the ranks in 16-row blocks
 (block-cyclic), each rank renders its rows, and the final float4 rows are gathered on rank 0 over RCCL.
-Prints ONE JSON line on rank 0.
+Frames are rendered the way the reference's main loop does it (a ring of render_state objects, each frame on the next one: main.cpp:1463-1469, 1505-1510):
+--frames-in-flight F states, each with its own HIP stream and output buffer, so that the low-occupancy tail of one
+frame's trace, its texture pass and (N > 1) its gather overlap the next frame's trace.  Every one of the K timed frames
+is complete (and gathered) when the clock stops.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
@@ -44,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (other poses / modes); used for profiling runs")
     ap.add_argument("--no-lookahead", action="store_true", help="do not overlap the next frame's prepass with this frame's trace")
+    ap.add_argument("--lookahead-depth", type=int, default=0, help="frames of prepass look-ahead (1 or 2); default 1 on one GPU, "
+                    "2 when the frame is split over several (a strip traces faster than one prepass runs)")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="render states / streams cycled through (1 = strictly one frame at a time)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -113,46 +119,66 @@ def main():
     program = manager.current(wait=(args.program == "static"))
     if args.program == "dynamic":
         program = manager.dynamic
-    state = gra.RenderState(W, H, local_rank)
     bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
     bg = torch.from_numpy(bg_np).to(device)
     camera = gra.default_camera()
-    stream = torch.cuda.current_stream().cuda_stream
 
     fused = args.mode == "fused"
     plan = grd.StripPlan(H, world, block_rows=16)
-    out = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
-    gather = grd.FrameGather(plan, W, device, rank, world) if multi else None
+    in_flight = max(1, min(args.frames_in_flight, 8)) if fused else 1
 
-    # a batch renderer knows the next frame's camera: its tetrad + prepass (1.5 ms of pure latency, 507 waves) run on a
-    # second stream while the current frame traces (gr_frame_options.next_camera).  Here every frame uses one camera.
+    class Slot:   # one frame in flight: render state (per-frame device buffers), stream, output, gather buffers
+        def __init__(self, first):
+            self.state = gra.RenderState(W, H, local_rank)
+            self.stream = torch.cuda.current_stream() if first and in_flight == 1 else torch.cuda.Stream(device=device)
+            self.out = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
+            self.gather = grd.FrameGather(plan, W, device, rank, world) if multi else None
+
+    ring = [Slot(i == 0) for i in range(in_flight)]
+    state, out, stream = ring[0].state, ring[0].out, ring[0].stream.cuda_stream
+    frame_index = [0]
+
+    # a batch renderer knows the next frames' cameras: their tetrad + prepass (1.2 ms of pure latency, 507 waves) run on
+    # high-priority side streams while the current frame traces (gr_frame_options.next_camera / next_camera2).  Here every
+    # frame uses one camera.
     lookahead = ctypes.pointer(camera) if (fused and not args.no_lookahead) else None
+    depth = 0 if lookahead is None else (args.lookahead_depth if args.lookahead_depth in (1, 2) else (2 if world > 1 else 1))
 
-    def frame(time_kernels=False, count_attempts=False):
-        if not multi:
-            opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=int(time_kernels),
-                                     count_attempts=int(count_attempts))
-            if lookahead is not None and not time_kernels:
-                opts.next_camera = lookahead
-            state.render(program, metric, camera, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features, cfg_values, opts, stream)
-        else:
-            # this rank's row blocks (block-cyclic) -> compact strip buffer -> ONE gather to rank 0 + local un-permute
-            opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=rank, strip_count=world, block_rows=plan.block_rows, compact_out=1)
+    def frame():
+        slot = ring[frame_index[0] % in_flight]
+        frame_index[0] += 1
+        with torch.cuda.stream(slot.stream):
+            if not multi:
+                opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=2)
+                target = slot.out.data_ptr()
+            else:
+                # this rank's row blocks (block-cyclic) -> compact strip buffer -> ONE gather to rank 0 + local un-permute
+                opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=rank, strip_count=world, block_rows=plan.block_rows, compact_out=1,
+                                         time_kernels=2)
+                target = slot.gather.local_buffer().data_ptr()
             if lookahead is not None:
                 opts.next_camera = lookahead
-            state.render(program, metric, camera, gather.local_buffer().data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features,
-                         cfg_values, opts, stream)
-            gather.submit(out)      # the gather of this frame overlaps the next frame's trace (double-buffered strips)
+                if depth == 2:
+                    opts.next_camera2 = lookahead
+            slot.state.render(program, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfg_values, opts,
+                              slot.stream.cuda_stream)
+            if multi:
+                slot.gather.submit(slot.out)   # asynchronous: overlaps the following frames (double-buffered strips)
 
     def barrier():
         if multi:
-            gather.drain(out)       # every frame submitted so far is gathered and assembled on rank 0
+            for slot in ring:
+                with torch.cuda.stream(slot.stream):
+                    slot.gather.drain(slot.out)   # every frame submitted so far is gathered and assembled on rank 0
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         frame()
     barrier()
+    for slot in ring:
+        slot.state.trace_log(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
@@ -164,43 +190,47 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     mrays = W * H / (elapsed / args.steps) / 1e6
+    # every trace launch of the timed region, HIP events on the stream it was launched on
+    logged = [slot.state.trace_log(reset=True) for slot in ring]
+    launches = sum(n for _, n in logged)
+    avg_launch_s = sum(ms for ms, _ in logged) / max(launches, 1) * 1e-3
 
-    # per-kernel timing (HIP events recorded on the launch stream) + step-attempt count, outside the headline timing
-    roofline = None
+    # roofline of the dominant kernel from the launches of the timed region; stage breakdown and step-attempt count from a
+    # few strictly sequential frames afterwards (stages of overlapping frames cannot be told apart)
     extra = {}
+    local_pixels = W * H if world == 1 else sum(b - a for a, b in plan.blocks_of(rank)) * W + plan.local_blocks(rank) * W
+    alg_bytes = (TRACE_BYTES_PER_RAY if fused else 140) * local_pixels
+    achieved = alg_bytes / avg_launch_s / 1e9
+    # HBM bytes per launch from the PMC passes of the same command (FETCH_SIZE and WRITE_SIZE in separate rocprofv3
+    # --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); committed summary, not live
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_trace_kernel.json")
+    if fused and world == 1 and os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+    roofline = {"bound": "hbm", "kernel": "gr_trace_fused" if fused else "gr_do_generic_rays", "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches_timed": launches, "concurrent_launches": in_flight,
+                "note": "register-resident ODE integrator: fp32 VALU bound, see valu_roofline (SURVEY.md 8d); launches of "
+                        "frames in flight overlap, so one launch's duration is longer than a frame's share of the wall clock"}
+    extra["fps"] = round(1e3 / ms_per_step, 2)
     if not multi:
-        trace_ms = []
         stage_sum = {}
         attempts = 0
-        for _ in range(max(3, min(args.steps, 10))):
-            frame(time_kernels=True, count_attempts=True)
+        for _ in range(3):
+            opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=1, count_attempts=1)
+            state.render(program, metric, camera, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features, cfg_values, opts, stream)
             torch.cuda.synchronize()
-            ms = state.stage_ms()
             attempts = state.attempts()
-            trace_ms.append(ms["trace"])
-            for k, v in ms.items():
+            for k, v in state.stage_ms().items():
                 stage_sum.setdefault(k, []).append(v)
-        t_trace = float(np.mean(trace_ms)) * 1e-3
-        alg_bytes = TRACE_BYTES_PER_RAY * W * H if fused else 140 * W * H
-        achieved = alg_bytes / t_trace / 1e9
-        # HBM bytes per launch from the PMC passes of the same command (FETCH_SIZE and WRITE_SIZE in separate rocprofv3
-        # --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); committed summary, not live
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_trace_kernel.json")
-        if fused and os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-        roofline = {"bound": "hbm", "kernel": "gr_trace_fused" if fused else "gr_do_generic_rays", "achieved": round(achieved, 3),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                    "avg_launch_ms": round(t_trace * 1e3, 4),
-                    "note": "register-resident ODE integrator: fp32 VALU bound, see valu_roofline (SURVEY.md 8d)"}
         flops_per_attempt = metric.info.accel_ops + metric.info.coord_ops + STEP_OVERHEAD_FLOPS
-        tflops = flops_per_attempt * attempts / t_trace / 1e12
+        tflops = flops_per_attempt * attempts * args.steps / elapsed / 1e12     # whole timed region, all stages included
         extra["valu_roofline"] = {"achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(tflops / VALU_PEAK_TFLOPS, 4), "flops_per_attempt": flops_per_attempt,
-                                  "step_attempts_per_frame": int(attempts)}
-        extra["stage_ms"] = {k: round(float(np.mean(v)), 4) for k, v in stage_sum.items()}
-        extra["fps"] = round(1e3 / ms_per_step, 2)
+                                  "step_attempts_per_frame": int(attempts),
+                                  "basis": "flops_per_attempt x attempts x frames / wall clock of the timed region"}
+        extra["stage_ms_sequential_frame"] = {k: round(float(np.mean(v)), 4) for k, v in stage_sum.items()}
         rd = np.empty(W * H, dtype=gra.pipeline.RENDER_DATA_DTYPE)
         gra.check(gra.lib.gr_device_download(local_rank, rd.ctypes.data_as(ctypes.c_void_p), state.buffer(gra.BUF_RENDER_DATA), rd.nbytes))
         skipped = int((rd["terminated"] == 2).sum())
@@ -233,8 +263,6 @@ def main():
             t = timed(camera, features, cfg_values, manager.dynamic, gra.MODE_REFERENCE)
             secondary["reference_kernel_sequence_dynamic_program_fps"] = round(1 / t, 1)
             extra["secondary"] = secondary
-    else:
-        extra["fps"] = round(1e3 / ms_per_step, 2)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -250,7 +278,8 @@ def main():
             "config": {"workload": f"{args.metric} (Boyer-Lindquist rs=1 a={args.spin}) {W}x{H}, camera (0,0,-4,0) fov 90, adaptive_sampling off, "
                                    f"prepass {'on' if metric.info.use_prepass else 'off'}, tol {metric.info.max_acceleration_change:g}, "
                                    f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
-                       "mode": args.mode, "prepass_lookahead": bool(fused and not args.no_lookahead), "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
+                       "mode": args.mode, "prepass_lookahead": bool(fused and not args.no_lookahead), "prepass_lookahead_depth": depth,
+                       "frames_in_flight": in_flight, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
                        "parallelism": f"16-row blocks, block-cyclic over {world} GPUs + one RCCL gather" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

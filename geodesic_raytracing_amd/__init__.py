@@ -47,7 +47,8 @@ class FrameOptions(ctypes.Structure):
     _fields_ = [("mode", c_int), ("tiled", c_int), ("use_prepass", c_int), ("max_probes", c_int), ("strip_rank", c_int),
                 ("strip_count", c_int), ("block_rows", c_int), ("compact_out", c_int), ("time_kernels", c_int),
                 ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera)), ("geodesic", c_void_p),
-                ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("parallel_transport_observer", c_int)]
+                ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("parallel_transport_observer", c_int),
+                ("next_camera2", ctypes.POINTER(Camera)), ("next_geodesic_time2", c_float)]
 
 
 MODE_REFERENCE, MODE_FUSED = 0, 1
@@ -121,6 +122,7 @@ _SIGNATURES = {
                                                ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
     "gr_geodesic_camera_buffer": (c_void_p, [c_void_p, c_int]),
     "gr_render_state_stage_ms": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float)]),
+    "gr_render_state_trace_log": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int), c_int]),
     "gr_render_state_attempts": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gr_render_state_buffer": (c_void_p, [c_void_p, c_int]),
     "gr_device_download": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),

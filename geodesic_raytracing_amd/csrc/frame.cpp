@@ -53,32 +53,53 @@ struct gr_render_state {
     std::vector<float> host_cfg;
     gr_features host_features{};
     bool features_valid = false;
-    // second camera/tetrad/termination set + side stream: the next frame's camera set-up and prepass (a latency-bound
-    // launch of only W/16 x H/16 rays) run concurrently with this frame's trace (gr_frame_options.next_camera)
+    // Look-ahead (gr_frame_options.next_camera / next_camera2): the camera set-up and the prepass of the next one or two
+    // frames - latency-bound launches of only W/16 x H/16 rays - run on high-priority side streams into buffer sets of
+    // their own while this frame traces.  A frame that finds its own request in a slot swaps that set in and skips both.
     struct camera_set {
         void* camera_pos_cart = nullptr;
         void* camera_quat = nullptr;
         void* camera_pos_generic = nullptr;
         void* tetrad[4] = {};
         void* termination_buffer = nullptr;
-    } alt;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t main_mark = nullptr, alt_ready = nullptr;
-    bool alt_prefetched = false;
-    gr_camera alt_camera{};
-    std::vector<float> alt_cfg;
-    gr_features alt_features{};
-    const void* alt_program = nullptr;
-    const void* alt_geodesic = nullptr;
-    float alt_geodesic_time = 0;
-    int alt_transport = 0;
+    };
+    struct prefetch_key {
+        gr_camera camera{};
+        std::vector<float> cfg;
+        gr_features features{};
+        const void* program = nullptr;
+        const void* geodesic = nullptr;
+        float geodesic_time = 0;
+        int transport = 0;
+        bool operator==(const prefetch_key& o) const {
+            return memcmp(&camera, &o.camera, sizeof(camera)) == 0 && cfg == o.cfg && memcmp(&features, &o.features, sizeof(features)) == 0 &&
+                   program == o.program && geodesic == o.geodesic && (!geodesic || (geodesic_time == o.geodesic_time && transport == o.transport));
+        }
+    };
+    struct prefetch_slot {
+        camera_set set;
+        void* velocity = nullptr;   // interpolated 4-velocity written by handle_interpolating_geodesic (unused here)
+        hipStream_t stream = nullptr;
+        hipEvent_t ready = nullptr;
+        bool valid = false;
+        unsigned long long age = 0;
+        prefetch_key key;
+    };
+    static const int LOOKAHEAD = 2;
+    prefetch_slot pre[LOOKAHEAD];
+    hipEvent_t main_mark = nullptr;
+    unsigned long long frame_counter = 0;
+    // time_kernels == 2: one event pair per trace launch, kept until gr_render_state_trace_log collects them (frames of
+    // several states overlap on the GPU in pipelined rendering, so "the last frame" is not a representative sample)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_log;
+    size_t trace_log_used = 0;
 
-    void swap_sets() {
-        std::swap(camera_pos_cart, alt.camera_pos_cart);
-        std::swap(camera_quat, alt.camera_quat);
-        std::swap(camera_pos_generic, alt.camera_pos_generic);
-        for (int i = 0; i < 4; i++) std::swap(tetrad[i], alt.tetrad[i]);
-        std::swap(termination_buffer, alt.termination_buffer);
+    void swap_in(camera_set& o) {
+        std::swap(camera_pos_cart, o.camera_pos_cart);
+        std::swap(camera_quat, o.camera_quat);
+        std::swap(camera_pos_generic, o.camera_pos_generic);
+        for (int i = 0; i < 4; i++) std::swap(tetrad[i], o.tetrad[i]);
+        std::swap(termination_buffer, o.termination_buffer);
     }
 };
 
@@ -100,7 +121,6 @@ struct gr_geodesic_camera {
     void* camera_generic = nullptr;
     void* tetrad[4] = {};
     void* interpolated_velocity = nullptr;
-    void* alt_interpolated_velocity = nullptr;
     void* cfg = nullptr;
     void* dfg = nullptr;
     int steps = 0;
@@ -136,6 +156,8 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->geodesic_time = 0;
     o->next_geodesic_time = 0;
     o->parallel_transport_observer = 1;   // main.cpp:1259
+    o->next_camera2 = nullptr;
+    o->next_geodesic_time2 = 0;
 }
 
 int gr_device_count(int* count) {
@@ -196,11 +218,14 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
     size_t px = (size_t)width * height;
     A(&s->render_data, px * sizeof(gr_render_data));
     A(&s->termination_buffer, px * sizeof(int));
-    A(&s->alt.camera_pos_cart, 16);
-    A(&s->alt.camera_quat, 16);
-    A(&s->alt.camera_pos_generic, 16);
-    for (auto& t : s->alt.tetrad) A(&t, 16);
-    A(&s->alt.termination_buffer, px * sizeof(int));
+    for (auto& slot : s->pre) {
+        A(&slot.set.camera_pos_cart, 16);
+        A(&slot.set.camera_quat, 16);
+        A(&slot.set.camera_pos_generic, 16);
+        for (auto& t : slot.set.tetrad) A(&t, 16);
+        A(&slot.set.termination_buffer, px * sizeof(int));
+        A(&slot.velocity, 16);
+    }
     if (e == hipSuccess) {
         // High priority: the look-ahead prepass is a latency-bound launch of a few hundred waves that must make progress
         // while the trace kernel occupies every CU, and priority streams get hardware queues of their own (with the
@@ -208,10 +233,12 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
         // created a few streams of its own, which serialises the overlap: measured 6.66 -> 7.98 ms per 4K frame).
         int least = 0, greatest = 0;
         e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->side_stream, hipStreamNonBlocking, greatest);
+        for (auto& slot : s->pre) {
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&slot.stream, hipStreamNonBlocking, greatest);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&slot.ready, hipEventDisableTiming);
+        }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->main_mark, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->alt_ready, hipEventDisableTiming);
     for (int i = 0; i < GR_STAGE_COUNT && e == hipSuccess; i++) {
         e = hipEventCreate(&s->ev_start[i]);
         if (e == hipSuccess) e = hipEventCreate(&s->ev_stop[i]);
@@ -227,14 +254,17 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
 void gr_render_state_destroy(gr_render_state* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* ptrs[] = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
-                    s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
-                    s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->alt.camera_pos_cart,
-                    s->alt.camera_quat, s->alt.camera_pos_generic, s->alt.tetrad[0], s->alt.tetrad[1], s->alt.tetrad[2],
-                    s->alt.tetrad[3], s->alt.termination_buffer};
-    if (s->side_stream) { (void)hipStreamSynchronize(s->side_stream); (void)hipStreamDestroy(s->side_stream); }
+    std::vector<void*> ptrs = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
+                               s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
+                               s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer};
+    for (auto& slot : s->pre) {
+        if (slot.stream) { (void)hipStreamSynchronize(slot.stream); (void)hipStreamDestroy(slot.stream); }
+        if (slot.ready) (void)hipEventDestroy(slot.ready);
+        ptrs.insert(ptrs.end(), {slot.set.camera_pos_cart, slot.set.camera_quat, slot.set.camera_pos_generic, slot.set.tetrad[0],
+                                 slot.set.tetrad[1], slot.set.tetrad[2], slot.set.tetrad[3], slot.set.termination_buffer, slot.velocity});
+    }
     if (s->main_mark) (void)hipEventDestroy(s->main_mark);
-    if (s->alt_ready) (void)hipEventDestroy(s->alt_ready);
+    for (auto& pr : s->trace_log) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < GR_STAGE_COUNT; i++) {
@@ -271,6 +301,22 @@ int gr_render_state_stage_ms(gr_render_state* s, int stage, float* ms) {
     if (!s->stage_timed[stage]) return GR_OK;
     HIP_CHECK(hipEventSynchronize(s->ev_stop[stage]));
     HIP_CHECK(hipEventElapsedTime(ms, s->ev_start[stage], s->ev_stop[stage]));
+    return GR_OK;
+}
+
+int gr_render_state_trace_log(gr_render_state* s, float* total_ms, int* launches, int reset) {
+    if (!s) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    HIP_CHECK(hipSetDevice(s->device));
+    double sum = 0;
+    for (size_t i = 0; i < s->trace_log_used; i++) {
+        float ms = 0;
+        HIP_CHECK(hipEventSynchronize(s->trace_log[i].second));
+        HIP_CHECK(hipEventElapsedTime(&ms, s->trace_log[i].first, s->trace_log[i].second));
+        sum += ms;
+    }
+    if (total_ms) *total_ms = (float)sum;
+    if (launches) *launches = (int)s->trace_log_used;
+    if (reset) s->trace_log_used = 0;
     return GR_OK;
 }
 
@@ -311,7 +357,7 @@ int gr_geodesic_camera_create(int device, int max_path_length, gr_geodesic_camer
     for (auto& t : g->transported) A(&t, n * 16);
     A(&g->ray, sizeof(gr_lightray)); A(&g->ray_count, 4); A(&g->basis_speed, 16); A(&g->camera_generic, 16);
     for (auto& t : g->tetrad) A(&t, 16);
-    A(&g->interpolated_velocity, 16); A(&g->alt_interpolated_velocity, 16);
+    A(&g->interpolated_velocity, 16);
     A(&g->cfg, CFG_MAX * sizeof(float)); A(&g->dfg, sizeof(gr_features));
     if (e != hipSuccess) {
         gr_geodesic_camera_destroy(g);
@@ -326,7 +372,7 @@ void gr_geodesic_camera_destroy(gr_geodesic_camera* g) {
     (void)hipSetDevice(g->device);
     void* ptrs[] = {g->path, g->velocity, g->ds, g->count, g->transported[0], g->transported[1], g->transported[2], g->transported[3],
                     g->ray, g->ray_count, g->basis_speed, g->camera_generic, g->tetrad[0], g->tetrad[1], g->tetrad[2], g->tetrad[3],
-                    g->interpolated_velocity, g->alt_interpolated_velocity, g->cfg, g->dfg};
+                    g->interpolated_velocity, g->cfg, g->dfg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -454,27 +500,53 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     int prepass_width = width / 16, prepass_height = height / 16;   // main.cpp:2380-2381
     if (prepass_width < 1 || prepass_height < 1) use_prepass = false;
 
-    // was this frame's camera set-up + prepass already done on the side stream during the previous frame?
-    bool prefetched = opt.mode == GR_MODE_FUSED && use_prepass && s->alt_prefetched && s->alt_program == (const void*)p &&
-                      memcmp(&s->alt_camera, camera, sizeof(gr_camera)) == 0 && s->alt_cfg == cfg &&
-                      memcmp(&s->alt_features, &features, sizeof(features)) == 0 && s->alt_geodesic == (const void*)opt.geodesic &&
-                      (!opt.geodesic || (s->alt_geodesic_time == opt.geodesic_time && s->alt_transport == opt.parallel_transport_observer));
-    s->alt_prefetched = false;
-    if (prefetched) {
-        s->swap_sets();
-        HIP_CHECK(hipStreamWaitEvent(stream, s->alt_ready, 0));
-    } else {
+    // was this frame's camera set-up + prepass already done on a side stream during an earlier frame?
+    auto make_key = [&](const gr_camera* c, float time) {
+        gr_render_state::prefetch_key k;
+        k.camera = *c;
+        k.cfg = cfg;
+        k.features = features;
+        k.program = (const void*)p;
+        k.geodesic = (const void*)opt.geodesic;
+        k.geodesic_time = time;
+        k.transport = opt.parallel_transport_observer;
+        return k;
+    };
+    s->frame_counter++;
+    bool prefetched = false;
+    if (opt.mode == GR_MODE_FUSED && use_prepass) {
+        const auto want = make_key(camera, opt.geodesic_time);
+        gr_render_state::prefetch_slot* hit = nullptr;   // the oldest matching prefetch: it has had the most time to finish
+        for (auto& slot : s->pre)
+            if (slot.valid && slot.key == want && (!hit || slot.age < hit->age)) hit = &slot;
+        if (hit) {
+            s->swap_in(hit->set);
+            HIP_CHECK(hipStreamWaitEvent(stream, hit->ready, 0));
+            hit->valid = false;
+            prefetched = true;
+        }
+    }
+    if (!prefetched) {
         HIP_CHECK(hipMemcpyAsync(s->camera_pos_cart, camera->position, 16, hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(s->camera_quat, camera->quat, 16, hipMemcpyHostToDevice, stream));
     }
 
     for (int i = 0; i < GR_STAGE_COUNT; i++) s->stage_timed[i] = false;
+    const bool log_trace = opt.time_kernels == 2;
+    if (log_trace && s->trace_log_used == s->trace_log.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_CHECK(hipEventCreate(&a));
+        HIP_CHECK(hipEventCreate(&b));
+        s->trace_log.emplace_back(a, b);
+    }
     auto begin = [&](int st) -> int {
-        if (opt.time_kernels) { HIP_CHECK(hipEventRecord(s->ev_start[st], stream)); }
+        if (log_trace) { if (st == GR_STAGE_TRACE) HIP_CHECK(hipEventRecord(s->trace_log[s->trace_log_used].first, stream)); }
+        else if (opt.time_kernels) { HIP_CHECK(hipEventRecord(s->ev_start[st], stream)); }
         return GR_OK;
     };
     auto end = [&](int st) -> int {
-        if (opt.time_kernels) { HIP_CHECK(hipEventRecord(s->ev_stop[st], stream)); s->stage_timed[st] = true; }
+        if (log_trace) { if (st == GR_STAGE_TRACE) { HIP_CHECK(hipEventRecord(s->trace_log[s->trace_log_used].second, stream)); s->trace_log_used++; } }
+        else if (opt.time_kernels) { HIP_CHECK(hipEventRecord(s->ev_stop[st], stream)); s->stage_timed[st] = true; }
         return GR_OK;
     };
     void* attempts = nullptr;
@@ -515,8 +587,22 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                       prepass_height, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg));
             GR_CHECK(end(GR_STAGE_PREPASS));
         }
-        const bool prefetch_next = use_prepass && opt.next_camera != nullptr;
-        if (prefetch_next) HIP_CHECK(hipEventRecord(s->main_mark, stream));   // everything up to here is older than the prefetch
+        // look-ahead requests that are not already sitting in a slot
+        struct request { const gr_camera* camera; float time; };
+        std::vector<request> todo;
+        bool claimed[gr_render_state::LOOKAHEAD] = {};   // a slot serves one request (two frames may share one camera)
+        if (use_prepass) {
+            const request asked[2] = {{opt.next_camera, opt.next_geodesic_time}, {opt.next_camera2, opt.next_geodesic_time2}};
+            for (const auto& r : asked) {
+                if (!r.camera) continue;
+                const auto k = make_key(r.camera, r.time);
+                bool have = false;
+                for (int i = 0; i < gr_render_state::LOOKAHEAD && !have; i++)
+                    if (!claimed[i] && s->pre[i].valid && s->pre[i].key == k) claimed[i] = have = true;
+                if (!have) todo.push_back(r);
+            }
+        }
+        if (!todo.empty()) HIP_CHECK(hipEventRecord(s->main_mark, stream));   // everything up to here is older than the prefetches
         // every device runs the (tiny) prepass itself; its own row blocks (+ one halo row each) are traced here
         GR_CHECK(begin(GR_STAGE_TRACE));
         GR_CHECK(gr_trace_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
@@ -524,26 +610,31 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                 use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
                                 s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
         GR_CHECK(end(GR_STAGE_TRACE));
-        if (prefetch_next) {
-            // next frame's camera set-up and prepass on the side stream, into the other buffer set, while the trace runs
-            const gr_camera* next = opt.next_camera;
-            HIP_CHECK(hipStreamWaitEvent(s->side_stream, s->main_mark, 0));
-            HIP_CHECK(hipMemcpyAsync(s->alt.camera_pos_cart, next->position, 16, hipMemcpyHostToDevice, s->side_stream));
-            HIP_CHECK(hipMemcpyAsync(s->alt.camera_quat, next->quat, 16, hipMemcpyHostToDevice, s->side_stream));
-            GR_CHECK(camera_setup(s->side_stream, s->alt.camera_pos_cart, s->alt.camera_pos_generic, s->alt.tetrad, next,
-                                  opt.next_geodesic_time, gc ? gc->alt_interpolated_velocity : nullptr));
-            GR_CHECK(gr_prepass_fused(p, s->side_stream, s->alt.camera_pos_generic, s->alt.camera_quat, s->alt.termination_buffer,
-                                      prepass_width, prepass_height, s->alt.tetrad[0], s->alt.tetrad[1], s->alt.tetrad[2],
-                                      s->alt.tetrad[3], s->cfg, s->dfg));
-            HIP_CHECK(hipEventRecord(s->alt_ready, s->side_stream));
-            s->alt_prefetched = true;
-            s->alt_camera = *next;
-            s->alt_cfg = cfg;
-            s->alt_features = features;
-            s->alt_program = (const void*)p;
-            s->alt_geodesic = (const void*)gc;
-            s->alt_geodesic_time = opt.next_geodesic_time;
-            s->alt_transport = opt.parallel_transport_observer;
+        for (const auto& r : todo) {
+            // a free slot, else the stalest one no current request claims (a camera that was announced but never came)
+            gr_render_state::prefetch_slot* slot = nullptr;
+            int chosen = -1;
+            for (int i = 0; i < gr_render_state::LOOKAHEAD; i++)
+                if (!claimed[i] && (chosen < 0 || (!s->pre[i].valid && s->pre[chosen].valid) ||
+                                    (s->pre[i].valid == s->pre[chosen].valid && s->pre[i].age < s->pre[chosen].age)))
+                    chosen = i;
+            if (chosen >= 0) { slot = &s->pre[chosen]; claimed[chosen] = true; }
+            if (!slot) break;
+            // camera set-up and prepass on the slot's stream, into the slot's buffer set, while the trace runs.  The set may
+            // have belonged to the previous frame (swapped out above): the stream first waits for everything the caller's
+            // stream had queued before this frame's trace.
+            HIP_CHECK(hipStreamWaitEvent(slot->stream, s->main_mark, 0));
+            HIP_CHECK(hipMemcpyAsync(slot->set.camera_pos_cart, r.camera->position, 16, hipMemcpyHostToDevice, slot->stream));
+            HIP_CHECK(hipMemcpyAsync(slot->set.camera_quat, r.camera->quat, 16, hipMemcpyHostToDevice, slot->stream));
+            GR_CHECK(camera_setup(slot->stream, slot->set.camera_pos_cart, slot->set.camera_pos_generic, slot->set.tetrad, r.camera, r.time,
+                                  slot->velocity));
+            GR_CHECK(gr_prepass_fused(p, slot->stream, slot->set.camera_pos_generic, slot->set.camera_quat, slot->set.termination_buffer,
+                                      prepass_width, prepass_height, slot->set.tetrad[0], slot->set.tetrad[1], slot->set.tetrad[2],
+                                      slot->set.tetrad[3], s->cfg, s->dfg));
+            HIP_CHECK(hipEventRecord(slot->ready, slot->stream));
+            slot->valid = true;
+            slot->age = s->frame_counter;
+            slot->key = make_key(r.camera, r.time);
         }
         if (out) {
             GR_CHECK(begin(GR_STAGE_RENDER));

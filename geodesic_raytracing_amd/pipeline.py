@@ -228,6 +228,12 @@ class RenderState:
             out[name] = ms.value
         return out
 
+    def trace_log(self, reset=True):
+        """(sum of durations in ms, number) of the trace launches logged with frame_options(time_kernels=2)"""
+        total, n = c_float(), ctypes.c_int()
+        check(lib.gr_render_state_trace_log(self.handle, ctypes.byref(total), ctypes.byref(n), int(reset)))
+        return total.value, n.value
+
     def attempts(self):
         v = ctypes.c_ulonglong()
         check(lib.gr_render_state_attempts(self.handle, ctypes.byref(v)))

@@ -290,7 +290,8 @@ typedef struct gr_frame_options {
     int strip_count;       /*   global block b belongs to device b % strip_count (1 = whole image on this device) */
     int block_rows;        /*   multiple of 8                                                                      */
     int compact_out;       /*   1: write this device's blocks back to back into out (gather layout)               */
-    int time_kernels;      /* record HIP events around every stage (gr_render_state_stage_ms) */
+    int time_kernels;      /* 1: record HIP events around every stage of this frame (gr_render_state_stage_ms);
+                            * 2: log one event pair per trace launch until gr_render_state_trace_log collects them */
     int count_attempts;    /* accumulate Verlet step attempts (gr_render_state_attempts) */
     const struct gr_camera* next_camera;   /* fused mode, optional: the camera of the NEXT gr_render_frame call.  Its tetrad and
                             * prepass are then computed on a second stream while this frame traces, and the next call
@@ -300,6 +301,10 @@ typedef struct gr_frame_options {
     float geodesic_time;          /* current_geodesic_time of this frame */
     float next_geodesic_time;     /* ... of the next frame, used with next_camera (look-ahead) */
     int parallel_transport_observer;   /* 1 (default, main.cpp:1259): interpolate the transported tetrads; 0: rebuild them */
+    const struct gr_camera* next_camera2;   /* optional: the camera of the call AFTER next_camera's.  Two prepasses are then in
+                            * flight on two streams, which hides their latency even when a frame traces faster than one
+                            * prepass runs (row-split frames on several GPUs). */
+    float next_geodesic_time2;
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 
@@ -337,6 +342,9 @@ enum { GR_STAGE_CAMERA = 0, GR_STAGE_PREPASS = 1, GR_STAGE_INIT = 2, GR_STAGE_TR
        GR_STAGE_ADAPTIVE = 5, GR_STAGE_RENDER = 6, GR_STAGE_COUNT = 7 };
 /* elapsed milliseconds of a stage of the last timed frame (synchronises on the stage's stop event) */
 int gr_render_state_stage_ms(gr_render_state* s, int stage, float* ms);
+/* sum of the durations and number of the trace launches (gr_trace_fused / gr_do_generic_rays) logged with time_kernels = 2
+ * since the last reset; waits for the logged launches to finish */
+int gr_render_state_trace_log(gr_render_state* s, float* total_ms, int* launches, int reset);
 /* total Verlet step attempts of the last frame rendered with count_attempts (synchronises the device) */
 int gr_render_state_attempts(gr_render_state* s, unsigned long long* attempts);
 

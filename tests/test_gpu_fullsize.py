@@ -137,22 +137,37 @@ def test_prepass_lookahead_is_bit_identical():
     cams = [gra.default_camera([0, 0.2 * i, -4 - 0.5 * i, 0.1 * i]) for i in range(4)]
     out = DeviceBuffer(0, w * h * 16)
 
-    def render_all(lookahead):
+    def render_all(lookahead, sequence=cams, sync=True):
         state = gra.RenderState(w, h, 0)
         frames = []
-        for i, cam in enumerate(cams):
+        outs = [DeviceBuffer(0, w * h * 16) for _ in sequence]
+        for i, cam in enumerate(sequence):
             opts = gra.frame_options(mode=gra.MODE_FUSED)
-            if lookahead and i + 1 < len(cams):
-                opts.next_camera = ctypes.pointer(cams[i + 1])
-            state.render(prog, metric, cam, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfg, opts)
-            state.synchronize()
-            frames.append(out.to_numpy(np.float32, (h, w, 4)))
-        return frames
+            if lookahead >= 1 and i + 1 < len(sequence):
+                opts.next_camera = ctypes.pointer(sequence[i + 1])
+            if lookahead >= 2 and i + 2 < len(sequence):
+                opts.next_camera2 = ctypes.pointer(sequence[i + 2])
+            state.render(prog, metric, cam, outs[i].ptr, (dbg.ptr, 1024, 512, levels), feats, cfg, opts)
+            if sync:
+                state.synchronize()
+        state.synchronize()
+        return [o.to_numpy(np.float32, (h, w, 4)) for o in outs]
 
-    plain, piped = render_all(False), render_all(True)
+    plain, piped = render_all(0), render_all(1)
     for a, b in zip(plain, piped):
         assert np.array_equal(a, b)
     assert not np.array_equal(plain[0], plain[1])
+    # two frames of look-ahead (two prepasses in flight on two streams), with and without a host sync between frames
+    for sync in (True, False):
+        for a, b in zip(plain, render_all(2, sync=sync)):
+            assert np.array_equal(a, b)
+    # repeated cameras (two outstanding requests with one key) and a sequence that revisits a pose
+    seq = [cams[0], cams[0], cams[1], cams[0], cams[0], cams[2], cams[1]]
+    want = {0: plain[0], 1: plain[1], 2: plain[2]}
+    index = [0, 0, 1, 0, 0, 2, 1]
+    for depth in (1, 2):
+        for k, frame in enumerate(render_all(depth, sequence=seq, sync=False)):
+            assert np.array_equal(frame, want[index[k]]), (depth, k)
     # a look-ahead that turns out wrong (different camera next) is simply discarded
     state = gra.RenderState(w, h, 0)
     opts = gra.frame_options(mode=gra.MODE_FUSED)

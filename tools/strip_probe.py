@@ -1,0 +1,45 @@
+"""Per-frame time of ONE rank's share of a frame split N ways (no communication), by look-ahead depth: what an N-GPU run
+can reach per frame.   usage: python tools/strip_probe.py [N ...]"""
+import ctypes, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import geodesic_raytracing_amd as gra
+
+W, H = 3840, 2160
+metric = gra.Metric("kerr_boyer", os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"))
+cfg = metric.cfg_values(a=0.45)
+feats = metric.features(adaptive_sampling=0)
+program = gra.pipeline.ProgramManager(metric, 0, feats, cfg).current(wait=True)
+states = [gra.RenderState(W, H, 0) for _ in range(3)]
+streams = [torch.cuda.Stream() for _ in range(3)]
+bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
+bg = torch.from_numpy(bg_np).cuda()
+outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+camera = gra.default_camera()
+look = ctypes.pointer(camera)
+for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+  for inflight in (1, 2, 3):
+    for depth in (1, 2):
+        counter = [0]
+
+        def frame():
+            k = counter[0] % inflight
+            counter[0] += 1
+            state, out, stream = states[k], outs[k], streams[k].cuda_stream
+            o = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=0, strip_count=world, block_rows=16, compact_out=1)
+            if depth >= 1:
+                o.next_camera = look
+            if depth >= 2:
+                o.next_camera2 = look
+            state.render(program, metric, camera, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), feats, cfg, o, stream)
+        for _ in range(5):
+            frame()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        n = 40
+        for _ in range(n):
+            frame()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / n * 1e3
+        print(f"1 of {world} ranks, {inflight} frames in flight, look-ahead depth {depth}: {ms:6.3f} ms/frame  -> {W * H / ms / 1e3:8.1f} Mrays/s if every rank keeps up", flush=True)
