@@ -224,12 +224,25 @@ def main():
             attempts = state.attempts()
             for k, v in state.stage_ms().items():
                 stage_sum.setdefault(k, []).append(v)
-        flops_per_attempt = metric.info.accel_ops + metric.info.coord_ops + STEP_OVERHEAD_FLOPS
-        tflops = flops_per_attempt * attempts * args.steps / elapsed / 1e12     # whole timed region, all stages included
+        # fp32 FLOP of one trace launch: counted by the hardware for the default workload (SQ_INSTS_VALU_{ADD,MUL,FMA x2,TRANS}_F32
+        # x 64 lanes, profiles/pmc_trace_kernel.json); the code generator's operation count is the fallback and is reported next
+        # to it (it counts every DAG node and a fixed 90 for integrator + controller, more than the compiled loop executes)
+        model_flops_per_attempt = metric.info.accel_ops + metric.info.coord_ops + STEP_OVERHEAD_FLOPS
+        default_workload = (args.metric == "kerr_boyer" and abs(args.spin - 0.45) < 1e-9 and (W, H) == (3840, 2160) and fused
+                            and args.program == "static")
+        counted = None
+        if default_workload and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                counted = json.load(f).get("fp32_flop_per_launch")
+        flop_per_frame = counted if counted else model_flops_per_attempt * attempts
+        tflops = flop_per_frame * args.steps / elapsed / 1e12     # whole timed region, all stages included
         extra["valu_roofline"] = {"achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(tflops / VALU_PEAK_TFLOPS, 4), "flops_per_attempt": flops_per_attempt,
+                                  "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
+                                  "flop_per_frame": int(flop_per_frame), "flop_source": "hardware counters (profiles/)" if counted else "code generator model",
+                                  "flops_per_attempt": round(flop_per_frame / max(attempts, 1), 1),
+                                  "flops_per_attempt_codegen_model": model_flops_per_attempt,
                                   "step_attempts_per_frame": int(attempts),
-                                  "basis": "flops_per_attempt x attempts x frames / wall clock of the timed region"}
+                                  "basis": "fp32 FLOP of the trace launches / wall clock of the timed region (all stages)"}
         extra["stage_ms_sequential_frame"] = {k: round(float(np.mean(v)), 4) for k, v in stage_sum.items()}
         rd = np.empty(W * H, dtype=gra.pipeline.RENDER_DATA_DTYPE)
         gra.check(gra.lib.gr_device_download(local_rank, rd.ctypes.data_as(ctypes.c_void_p), state.buffer(gra.BUF_RENDER_DATA), rd.nbytes))

@@ -17,7 +17,7 @@ def load(dirs):
 if __name__ == "__main__":
     out_txt, out_json = sys.argv[1], sys.argv[2]
     data = load(sys.argv[3:])
-    lines = ["# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-lookahead --no-secondary   (one pass per counter set)",
+    lines = ["# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --frames-in-flight 1 --no-lookahead   (tools/final_profiles.sh; one pass per counter set)",
              "# 3840x2160 Kerr a=0.45, fused mode, substituted program; per-dispatch means; FETCH_SIZE / WRITE_SIZE in KiB"]
     for k in sorted(data):
         for n in sorted(data[k]):
@@ -41,7 +41,11 @@ if __name__ == "__main__":
                       f"TRANS {t['SQ_INSTS_VALU_TRANS_F32']:.4g}, INT32 {t['SQ_INSTS_VALU_INT32']:.4g}, CVT {t['SQ_INSTS_VALU_CVT']:.4g}, "
                       f"other (mov/cmp/cndmask/min/max/bit ops) {other:.4g}",
                       f"#   instruction issue: SALU {t['SQ_INSTS_SALU']:.4g}, branches {t.get('SQ_INSTS_BRANCH', 0):.4g}, waves {t['SQ_WAVES']:.6g}"]
-        json.dump({"kernel": "gr_trace_fused", "hbm_bytes_per_launch": round(hbm), "fetch_size_bytes": round(fetch), "write_size_bytes": round(write),
+        flop_counters = None
+        if "SQ_INSTS_VALU_FMA_F32" in t:
+            flop_counters = round(64 * (t["SQ_INSTS_VALU_ADD_F32"] + t["SQ_INSTS_VALU_MUL_F32"] + 2 * t["SQ_INSTS_VALU_FMA_F32"] + t["SQ_INSTS_VALU_TRANS_F32"]))
+        json.dump({"kernel": "gr_trace_fused", "workload": "kerr_boyer a=0.45 3840x2160 substituted program",
+                   "fp32_flop_per_launch": flop_counters, "valu_wave_instructions_per_launch": round(t["SQ_INSTS_VALU"]), "hbm_bytes_per_launch": round(hbm), "fetch_size_bytes": round(fetch), "write_size_bytes": round(write),
                    "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)", "valu_lane_utilisation": round(lane_util, 4),
                    "source": "profiles/" + os.path.basename(out_txt)}, open(out_json, "w"), indent=1)
     open(out_txt, "w").write("\n".join(lines) + "\n")
