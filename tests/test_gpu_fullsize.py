@@ -19,8 +19,11 @@ def background():
     return _bg["bg"]
 
 
-def render(name, w, h, cfg=None, options=None, features=None, camera=None, out_rows=None):
-    metric = gra.Metric(name)
+SCRIPTS = __import__("os").path.join(__import__("os").path.dirname(gra.__file__), "scripts")
+
+
+def render(name, w, h, cfg=None, options=None, features=None, camera=None, out_rows=None, scripts=None):
+    metric = gra.Metric(name, scripts)
     prog = gra.Program(metric.argument_string(), 0)
     state = gra.RenderState(w, h, 0)
     dbg, levels = background()
@@ -112,6 +115,27 @@ def test_row_block_decomposition_equals_full_frame(world, block):
         for i, (a, b) in enumerate(plan.blocks_of(r)):
             assembled[a:b] = part[i * block:i * block + (b - a)]
     assert np.array_equal(assembled, full)
+
+
+def test_double_unequal_kerr_4k_bands():
+    """config 3 shape (scripts/double_unequal_kerr.js, 3840x2160, row-tiled): two 16-row bands traced in strip mode as ranks of
+    a 135-way split must be bit-identical to the same rows of a low-cost reference - the same bands traced as ranks of a
+    different split (270-way, 8-row blocks) - and every traced pixel must be finite with a sane hit rate"""
+    w, h = 3840, 2160
+    cam = gra.default_camera([0, 0, -6, 0.5])
+    bands = {}
+    for block, count, ranks in ((16, 135, (40, 67)), (8, 270, (80, 81, 134, 135))):
+        for r in ranks:
+            part, rd, _ = render("double_unequal_kerr", w, h, camera=cam, out_rows=block, scripts=SCRIPTS,
+                                 options=dict(mode=gra.MODE_FUSED, strip_rank=r, strip_count=count, block_rows=block, compact_out=1))
+            bands[(block, r)] = (part, rd[r * block:(r + 1) * block])
+    for r16, (a, b) in ((40, (80, 81)), (67, (134, 135))):
+        whole = bands[(16, r16)][0]
+        halves = np.concatenate([bands[(8, a)][0], bands[(8, b)][0]])
+        assert np.array_equal(whole, halves)
+        rd = bands[(16, r16)][1]
+        assert np.isfinite(whole).all()
+        assert 0.5 < (rd["terminated"] == 1).mean() <= 1.0
 
 
 def test_alcubierre_8k_rows_sample():
