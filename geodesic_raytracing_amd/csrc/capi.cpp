@@ -545,7 +545,9 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
     long long groups = (waves * 64 + wg - 1) / wg;
     unsigned int* tickets = nullptr;
     // persistent mode only pays when there are more tiles than wave slots (8 per SIMD, 4 SIMDs per CU)
-    long long resident_groups = (long long)p->compute_units * 32 * 64 / wg;
+    // experiment hook: GR_TRACE_WAVES_PER_SIMD=k launches only k persistent waves per SIMD (occupancy scaling studies)
+    static const int waves_per_simd = [] { const char* e = getenv("GR_TRACE_WAVES_PER_SIMD"); int v = e ? atoi(e) : 8; return (v >= 1 && v <= 8) ? v : 8; }();
+    long long resident_groups = (long long)p->compute_units * 4 * waves_per_simd * 64 / wg;
     if (persistent && groups > resident_groups) {
         tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
         HIP_CHECK(hipSetDevice(p->device));
