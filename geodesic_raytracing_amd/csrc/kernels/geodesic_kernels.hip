@@ -761,13 +761,7 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
     unsigned int tries = 0;
     int result = RAY_LOST;
 
-    // Everything the termination tests and the step length read from the state changes only when a step is accepted,
-    // so it is evaluated once before the loop and then after every commit (the reference evaluates it at the top of
-    // every iteration, cl.cl:3990-4060, which is the same sequence of tests on the same states); a rejected attempt
-    // goes straight back to the Verlet step, and the loop has one place where rays leave it.
-    float ar = 0;
-    bool stop_lost = false, stop_terminated = false;
-    auto examine = [&]() {
+    for (int i = 0; i < loop_limit;) {
 #ifdef IS_CONSTANT_THETA
         position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
 #endif
@@ -775,30 +769,26 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
 #ifdef IS_CONSTANT_THETA
         polar.z = GR_PIf / 2;
 #endif
-        ar = __builtin_fabsf(gm::distance_to_object(polar, cfg));
-        stop_terminated = __builtin_fabsf(polar.y) >= universe;
-#ifdef SINGULAR
-        stop_terminated |= __builtin_fabsf(polar.y) < SINGULAR_TERMINATOR;
-#endif
-        stop_lost = false;
-#ifdef HAS_CYLINDRICAL_SINGULARITY
-        stop_lost |= position.y < CYLINDRICAL_TERMINATOR;
-#endif
-#ifndef UNCONDITIONALLY_NONSINGULAR
-        stop_lost |= __builtin_fabsf(velocity.x / running) > 1000 + f_in_x && __builtin_fabsf(acceleration.x / running) > 100;
-#endif
-    };
-    examine();
-    int i = 0;
-    bool alive = !(stop_lost || stop_terminated);
-    if (!stop_lost && stop_terminated) result = RAY_TERMINATED;
-    while (alive) {
+        float r_value = gm::distance_to_object(polar, cfg);
+        float ar = __builtin_fabsf(r_value);
         float ds = mixf(ambient_precision, subambient_precision, (clampf(ar, new_min, new_max) - new_min) / (new_max - new_min));
 #ifdef ADAPTIVE_PRECISION
         ds = next_ds;
 #endif
         if (ar < new_max) ds = __builtin_fminf(ds, ambient_precision);
         else ds = 0.1f * (ar - new_max) + ambient_precision;
+
+        bool should_terminate = __builtin_fabsf(polar.y) >= universe;
+#ifdef SINGULAR
+        should_terminate |= __builtin_fabsf(polar.y) < SINGULAR_TERMINATOR;
+#endif
+#ifdef HAS_CYLINDRICAL_SINGULARITY
+        if (position.y < CYLINDRICAL_TERMINATOR) break;
+#endif
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        if (__builtin_fabsf(velocity.x / running) > 1000 + f_in_x && __builtin_fabsf(acceleration.x / running) > 100) break;
+#endif
+        if (should_terminate) { result = RAY_TERMINATED; break; }
 
         // velocity Verlet (step_verlet)
         tries++;
@@ -842,9 +832,7 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
             // degenerate acceleration always makes the velocity computed from it degenerate, so two vectors suffice.
             float poison = degenerate_accumulate(position, degenerate_accumulate(velocity, 0.f));
             if (reparam) poison = degenerate_accumulate(acceleration, poison);
-            examine();
-            if (!(poison == 0.f) || i >= loop_limit || stop_lost) alive = false;
-            else if (stop_terminated) { alive = false; result = RAY_TERMINATED; }
+            if (!(poison == 0.f)) break;
         }
     }
     s.position = position;

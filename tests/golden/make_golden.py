@@ -65,6 +65,9 @@ CASES = {
     "kerr_reparameterised": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), features=dict(reparameterisation=1)),
     "schwarzschild_wide_universe": dict(metric="schwarzschild", size=(48, 27),
                                         features=dict(field_of_view=60.0, universe_size=40.0, max_precision_radius=15.0)),
+    "cosmic_string": dict(metric="cosmic_string", scripts=True, size=(48, 27), cfg=dict(mu=0.05), camera_pos=[0.0, 0.3, -6.0, 0.5]),
+    "cosmic_string_hit": dict(metric="cosmic_string", scripts=True, size=(48, 27), cfg=dict(mu=0.02), camera_pos=[0.0, 0.0, -3.0, 0.0],
+                              features=dict(redshift=1)),
     "kerr_moving_observer": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.3, 0.0, 0.2], features=dict(redshift=1)),
 }
 
@@ -83,6 +86,7 @@ PATH_CASES = {
     "kerr_script_reparameterised": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", cfg=dict(a=0.45),
                                         camera_pos=[0.0, 1.0, -8.0, 0.5], basis_speed=[0.2, 0.0, 0.3], features=dict(reparameterisation=1)),
     "alcubierre_passenger": dict(metric="alcubierre", camera_pos=[0.0, 0.0, -3.0, 0.5], basis_speed=[0.0, 0.0, 0.1]),
+    "cosmic_string_flyby": dict(metric="cosmic_string", scripts=True, cfg=dict(mu=0.05), camera_pos=[0.0, 1.0, -6.0, 0.5], basis_speed=[0.0, 0.4, 0.05]),
     "wormhole_crossing": dict(metric="wormhole", scripts=True, camera_pos=[0.0, 0.3, -2.5, 0.3], basis_speed=[0.05, 0.5, -0.02]),
 }
 
