@@ -114,14 +114,18 @@ def test_end_to_end(name):
     assert np.sqrt((d[~bad] ** 2).mean()) <= (3e-4 if name in CHAOTIC else 1e-4)
 
 
-def _frame(meta, mode, tiled=0, options=None):
-    """whole frame through gr_render_frame"""
+def _frame(meta, mode, tiled=0, options=None, substituted=False):
+    """whole frame through gr_render_frame; substituted = the program with $cfg values and features baked in (the one
+    bench.py times, metric_manager.hpp:153-166) instead of the dynamic one"""
     from geodesic_raytracing_amd.pipeline import DeviceBuffer
     metric = metric_for(meta)
-    prog = gra.Program(metric.argument_string(), 0)
+    feats = gra.default_features(**meta["features"])
+    if substituted:
+        prog = gra.Program(metric.argument_string(features=feats, static=True, cfg_values=meta["cfg"]), 0)
+    else:
+        prog = gra.Program(metric.argument_string(), 0)
     w, h = meta["width"], meta["height"]
     state = gra.RenderState(w, h, 0)
-    feats = gra.default_features(**meta["features"])
     bg, levels = background(meta)
     dbg = DeviceBuffer.from_numpy(0, bg)
     out = DeviceBuffer(0, w * h * 16)
@@ -187,3 +191,45 @@ def test_fused_and_tiled_paths_equal_reference_sequence(name):
         bad = np.abs(d).max(axis=2) > 1e-3
         assert bad.mean() <= 0.005
         assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
+
+
+SUBSTITUTED = ["kerr", "kerr_tilted", "kerr_far", "kerr_prepass", "kerr_moving_observer", "kerr_reparameterised", "schwarzschild_redshift",
+               "alcubierre", "ingoing_ef", "double_unequal_kerr", "cosmic_string", "wormhole_through"]
+
+
+@pytest.mark.parametrize("name", SUBSTITUTED)
+@pytest.mark.parametrize("mode", ["fused", "reference"])
+def test_substituted_program_matches_reference(name, mode):
+    """the program bench.py times (parameters and features folded into literals) against the reference's pixels, through the
+    fused kernel and through the reference-shaped kernel sequence"""
+    meta, z = load_golden(name)
+    px, _ = _frame(meta, gra.MODE_FUSED if mode == "fused" else gra.MODE_REFERENCE, substituted=True)
+    d = px[..., :3] - z["pixels"][..., :3]
+    bad = np.abs(d).max(axis=2) > 1e-3
+    assert bad.mean() <= 0.005
+    assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["kerr", "kerr_far", "kerr_tilted", "alcubierre", "schwarzschild", "ingoing_ef", "cosmic_string"])
+def test_step_attempts_match_oracle(name):
+    """the number of Verlet attempts is a sensitive summary of the step-size controller (a wrong precision-radius test or a
+    lagging step length changes it by percent while end pixels barely move): GPU kernels - dynamic and substituted, fused
+    and reference-shaped - against the CPU restatement, which is pinned to the reference's own kernels"""
+    import ctypes
+    from oracle import build_restate
+    from oracle.refpipe import OraclePipeline, pack_features
+    meta, z = load_golden(name)
+    metric = metric_for(meta)
+    pipe = OraclePipeline(build_restate.build(metric.argument_string()))
+    pipe.frame(meta["width"], meta["height"], meta["cfg"], pack_features(**meta["features"]), camera_pos=meta["camera_pos"],
+               camera_quat=meta["camera_quat"], basis_speed=meta["basis_speed"], flip=float(meta.get("flip", 0.0)), stages="trace", nthreads=4)
+    pipe.lib.ref_last_attempts.restype = ctypes.c_uint64
+    want = int(pipe.lib.ref_last_attempts())
+    got = {}
+    _, att = Stages(meta).trace(z["rays_init"], count_attempts=True)
+    got["dynamic reference-shaped"] = att
+    for substituted in (False, True):
+        _, state = _frame(meta, gra.MODE_FUSED, options=dict(count_attempts=1), substituted=substituted)
+        got["substituted fused" if substituted else "dynamic fused"] = state.attempts()
+    for label, att in got.items():
+        assert abs(att - want) <= 0.003 * want, (label, att, want)
