@@ -100,6 +100,33 @@ def test_kerr_4k_frame_properties():
     assert same.mean() >= 0.998
 
 
+def test_kerr_4k_bench_frame_against_the_oracle():
+    """The exact frame bench.py times (scripts/kerr_boyer.js, a = 0.45, 3840x2160, substituted program, fused kernel, prepass on)
+    against the CPU oracle: pixel (8k, 8j) of the 4K frame looks along exactly the direction of pixel (k, j) of a 480x270 frame
+    with the same camera and field of view, so every 8th pixel in x and y must land on the oracle's sky coordinates."""
+    import os
+    from oracle import build_restate
+    from oracle.refpipe import OraclePipeline, pack_features
+    w, h, stride = 3840, 2160, 8
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfg = metric.cfg_values(a=0.45)
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(features=feats, static=True, cfg_values=cfg), 0)
+    state = gra.RenderState(w, h, 0)
+    state.render(prog, metric, gra.default_camera(), None, None, feats, cfg, gra.frame_options(mode=gra.MODE_FUSED, count_attempts=1))
+    state.synchronize()
+    rd = download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h).reshape(h, w)[::stride, ::stride]
+    pipe = OraclePipeline(build_restate.build(metric.argument_string()))
+    ref = pipe.frame(w // stride, h // stride, cfg, pack_features(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change),
+                     use_prepass=False, nthreads=os.cpu_count() or 4)["render_data"].reshape(h // stride, w // stride)
+    hit_gpu, hit_ref = rd["terminated"] == 1, ref["terminated"] == 1
+    assert (hit_gpu != hit_ref).mean() <= 0.003                      # rays on the shadow edge may fall either way
+    assert ((rd["terminated"] == 2) & hit_ref).mean() <= 0.001         # the prepass only skips rays that are captured
+    both = hit_gpu & hit_ref
+    err = circ_diff(rd["tex_coord"][both], ref["tex_coord"][both]).max(axis=1)
+    assert np.percentile(err, 99) <= 1e-4 and np.percentile(err, 50) <= 2e-6
+
+
 @pytest.mark.parametrize("world,block", [(2, 16), (8, 16), (3, 24)])
 def test_row_block_decomposition_equals_full_frame(world, block):
     """what rank r of N computes in strip mode is bit-identical to the same rows of the single-GPU frame"""
