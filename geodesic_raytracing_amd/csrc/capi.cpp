@@ -510,11 +510,22 @@ int gr_render_strips(gr_program* p, void* stream, const void* rdata, void* out, 
 
 int gr_internal_fail(int code, const char* msg) { return fail((gr_status)code, msg ? msg : ""); }
 
+int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* term,
+                            int prepass_width, int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3,
+                            const void* cfg, const void* dfg, int image_height, int block_rows, int strip_rank, int strip_count) {
+    if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = 8; }
+    if (block_rows <= 0 || strip_rank < 0 || strip_rank >= strip_count || image_height <= 0)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
+    void* args[] = {&camera_generic, &camera_quat, &term, &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg,
+                    &image_height, &block_rows, &strip_rank, &strip_count};
+    return launch(p, K_PREPASS_FUSED, stream, blocks((long long)prepass_width * prepass_height, 64), 1, 64, 1, args);
+}
+
 int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* term,
                      int prepass_width, int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3,
                      const void* cfg, const void* dfg) {
-    void* args[] = {&camera_generic, &camera_quat, &term, &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg};
-    return launch(p, K_PREPASS_FUSED, stream, blocks((long long)prepass_width * prepass_height, 64), 1, 64, 1, args);
+    return gr_prepass_fused_strips(p, stream, camera_generic, camera_quat, term, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg,
+                                   prepass_height * 16, 8, 0, 1);
 }
 
 int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

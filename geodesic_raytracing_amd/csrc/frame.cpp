@@ -71,9 +71,11 @@ struct gr_render_state {
         const void* geodesic = nullptr;
         float geodesic_time = 0;
         int transport = 0;
+        int strip[3] = {0, 0, 0};   // block_rows, strip_rank, strip_count: the prepass only covers the cells these rows look at
         bool operator==(const prefetch_key& o) const {
             return memcmp(&camera, &o.camera, sizeof(camera)) == 0 && cfg == o.cfg && memcmp(&features, &o.features, sizeof(features)) == 0 &&
-                   program == o.program && geodesic == o.geodesic && (!geodesic || (geodesic_time == o.geodesic_time && transport == o.transport));
+                   program == o.program && geodesic == o.geodesic && (!geodesic || (geodesic_time == o.geodesic_time && transport == o.transport)) &&
+                   memcmp(strip, o.strip, sizeof(strip)) == 0;
         }
     };
     struct prefetch_slot {
@@ -510,6 +512,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         k.geodesic = (const void*)opt.geodesic;
         k.geodesic_time = time;
         k.transport = opt.parallel_transport_observer;
+        k.strip[2] = opt.strip_count > 1 ? opt.strip_count : 1;
+        k.strip[1] = k.strip[2] > 1 ? opt.strip_rank : 0;
+        k.strip[0] = k.strip[2] > 1 ? opt.block_rows : 0;
         return k;
     };
     s->frame_counter++;
@@ -583,8 +588,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         int block_rows = strip_count > 1 ? opt.block_rows : ((height + 7) / 8) * 8;
         if (use_prepass && !prefetched) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
-            GR_CHECK(gr_prepass_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->termination_buffer, prepass_width,
-                                      prepass_height, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg));
+            GR_CHECK(gr_prepass_fused_strips(p, stream, s->camera_pos_generic, s->camera_quat, s->termination_buffer, prepass_width,
+                                             prepass_height, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg,
+                                             height, block_rows, strip_rank, strip_count));
             GR_CHECK(end(GR_STAGE_PREPASS));
         }
         // look-ahead requests that are not already sitting in a slot
@@ -628,9 +634,10 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             HIP_CHECK(hipMemcpyAsync(slot->set.camera_quat, r.camera->quat, 16, hipMemcpyHostToDevice, slot->stream));
             GR_CHECK(camera_setup(slot->stream, slot->set.camera_pos_cart, slot->set.camera_pos_generic, slot->set.tetrad, r.camera, r.time,
                                   slot->velocity));
-            GR_CHECK(gr_prepass_fused(p, slot->stream, slot->set.camera_pos_generic, slot->set.camera_quat, slot->set.termination_buffer,
-                                      prepass_width, prepass_height, slot->set.tetrad[0], slot->set.tetrad[1], slot->set.tetrad[2],
-                                      slot->set.tetrad[3], s->cfg, s->dfg));
+            GR_CHECK(gr_prepass_fused_strips(p, slot->stream, slot->set.camera_pos_generic, slot->set.camera_quat,
+                                             slot->set.termination_buffer, prepass_width, prepass_height, slot->set.tetrad[0],
+                                             slot->set.tetrad[1], slot->set.tetrad[2], slot->set.tetrad[3], s->cfg, s->dfg, height,
+                                             block_rows, strip_rank, strip_count));
             HIP_CHECK(hipEventRecord(slot->ready, slot->stream));
             slot->valid = true;
             slot->age = s->frame_counter;

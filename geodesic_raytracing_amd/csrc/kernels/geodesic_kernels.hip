@@ -1196,16 +1196,32 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
 }
 
 // termination flags of the low-resolution prepass, straight from a fused trace (role of
-// clear_termination_buffer + init_rays_generic(prepass) + do_generic_rays + calculate_singularities)
+// clear_termination_buffer + init_rays_generic(prepass) + do_generic_rays + calculate_singularities).
+// When the image is split over devices (strip_count > 1) a device only traces the cells its own rows can look at: a pixel
+// row cy reads the cell rows round(cy * ph / H) - 1 .. + 1 (init_rays_generic's 5-point stencil, cl.cl:3213-3232), so
+// cell row cp matters to this device only if one of its blocks (or the halo row under it) intersects the pixel rows
+// that map to cp - 1 .. cp + 1.  The prepass is otherwise replicated work: 11 % of a device's frame at 8 devices.
 extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
 gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                  int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                  const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
-                 cfg_t cfg_in, dfg_t dfg_in) {
+                 cfg_t cfg_in, dfg_t dfg_in, int image_height, int block_rows, int strip_rank, int strip_count) {
     GR_PARAMETERS_IN_REGISTERS
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= prepass_width * prepass_height) return;
     int cx = id % prepass_width, cy = id / prepass_width;
+    if (strip_count > 1) {
+        // pixel rows whose stencil can touch cell row cy, bounded generously (an extra cell costs nothing but time)
+        long long lo = ((long long)(2 * cy - 3) * image_height) / (2 * prepass_height) - 2;
+        long long hi = ((long long)(2 * cy + 3) * image_height + 2 * prepass_height - 1) / (2 * prepass_height) + 2;
+        if (lo < 0) lo = 0;
+        if (hi > image_height - 1) hi = image_height - 1;
+        // blocks b (rows b*B .. (b+1)*B inclusive of the halo row) that meet [lo, hi]
+        long long b_lo = lo / block_rows - 1, b_hi = hi / block_rows;
+        if (b_lo < 0) b_lo = 0;
+        long long first = b_lo + (((long long)strip_rank - b_lo) % strip_count + strip_count) % strip_count;   // first own block >= b_lo
+        if (first > b_hi) return;
+    }
     lightray ray = make_pixel_ray(cx, cy, prepass_width, prepass_height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
     ray_state s;
     s.position = ray.position;

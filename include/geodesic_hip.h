@@ -249,6 +249,12 @@ int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, co
                      void* termination_buffer, int prepass_width, int prepass_height,
                      const void* e0, const void* e1, const void* e2, const void* e3,
                      const void* cfg, const void* dfg);
+/* the same for a device that owns only the row blocks strip_rank, strip_rank + strip_count, ... of an image of
+ * image_height rows (see gr_trace_fused): cells none of its rows can look at are not traced and keep their old value */
+int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
+                            void* termination_buffer, int prepass_width, int prepass_height,
+                            const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg,
+                            int image_height, int block_rows, int strip_rank, int strip_count);
 
 /* init -> integrate -> render-data in one launch; writes only render_data[sy*width+sx] (32 B per pixel).
  * Rows are dealt to devices block-cyclically: global block b (block_rows rows, multiple of 8) belongs to device

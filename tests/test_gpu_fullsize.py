@@ -132,15 +132,19 @@ def test_row_block_decomposition_equals_full_frame(world, block):
     """what rank r of N computes in strip mode is bit-identical to the same rows of the single-GPU frame"""
     from geodesic_raytracing_amd.distributed import StripPlan
     w, h = 1920, 1080
-    full, _, _ = render("kerr_boyer", w, h, cfg=dict(a=0.45), options=dict(mode=gra.MODE_FUSED))
+    full, rd_full, _ = render("kerr_boyer", w, h, cfg=dict(a=0.45), options=dict(mode=gra.MODE_FUSED))
     plan = StripPlan(h, world, block)
     assembled = np.zeros_like(full)
     for r in range(world):
         rows = plan.blocks_per_rank * block
-        part, _, _ = render("kerr_boyer", w, h, cfg=dict(a=0.45), out_rows=rows,
-                            options=dict(mode=gra.MODE_FUSED, strip_rank=r, strip_count=world, block_rows=block, compact_out=1))
+        part, rd, _ = render("kerr_boyer", w, h, cfg=dict(a=0.45), out_rows=rows,
+                             options=dict(mode=gra.MODE_FUSED, strip_rank=r, strip_count=world, block_rows=block, compact_out=1))
         for i, (a, b) in enumerate(plan.blocks_of(r)):
             assembled[a:b] = part[i * block:i * block + (b - a)]
+            # the rank traced only the prepass cells its rows can see: every verdict its rows used must be the full frame's
+            # (a missing cell would show as terminated 0 instead of 2 - both render black, so the pixels alone cannot tell)
+            assert np.array_equal(rd["terminated"][a:b], rd_full["terminated"][a:b])
+            assert np.array_equal(rd["tex_coord"][a:b], rd_full["tex_coord"][a:b])
     assert np.array_equal(assembled, full)
 
 

@@ -11,16 +11,16 @@ metric = gra.Metric("kerr_boyer", os.path.join(ROOT, "geodesic_raytracing_amd", 
 cfg = metric.cfg_values(a=0.45)
 feats = metric.features(adaptive_sampling=0)
 program = gra.pipeline.ProgramManager(metric, 0, feats, cfg).current(wait=True)
-states = [gra.RenderState(W, H, 0) for _ in range(3)]
-streams = [torch.cuda.Stream() for _ in range(3)]
+states = [gra.RenderState(W, H, 0) for _ in range(6)]
+streams = [torch.cuda.Stream() for _ in range(6)]
 bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
 bg = torch.from_numpy(bg_np).cuda()
-outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(6)]
 camera = gra.default_camera()
 look = ctypes.pointer(camera)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
-  for inflight in (1, 2, 3):
-    for depth in (1, 2):
+  for inflight in (1, 2, 3, 4, 6):
+    for depth in (2,):
         counter = [0]
 
         def frame():
