@@ -275,6 +275,31 @@ def main():
             secondary["adaptive_sampling_on_threshold32_fps"] = round(1 / t, 1)
             t = timed(camera, features, cfg_values, manager.dynamic, gra.MODE_REFERENCE)
             secondary["reference_kernel_sequence_dynamic_program_fps"] = round(1 / t, 1)
+            # the other BASELINE.json configurations, one frame at a time on this one GPU (dynamic programs, fused kernel)
+            scripts_dir = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
+            for label, name, (cw, ch), cam_pos, feats_kw in (
+                    ("config1_schwarzschild_1920x1080", "schwarzschild", (1920, 1080), None, {}),
+                    ("config3_double_unequal_kerr_3840x2160", "double_unequal_kerr", (3840, 2160), [0, 0, -6, 0.5], {}),
+                    ("config4_alcubierre_7680x4320_redshift", "alcubierre", (7680, 4320), [0, 0, -6, 0.5], {"redshift": 1})):
+                m2 = gra.Metric(name, scripts_dir)
+                f2 = m2.features(adaptive_sampling=0, **feats_kw)
+                p2 = gra.Program(m2.argument_string(), local_rank)
+                st2 = gra.RenderState(cw, ch, local_rank)
+                out2 = torch.zeros((ch, cw, 4), dtype=torch.float32, device=device)
+                c2 = gra.default_camera(cam_pos)
+                o2 = gra.frame_options(mode=gra.MODE_FUSED)
+
+                def once():
+                    st2.render(p2, m2, c2, out2.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), f2, m2.cfg_values(), o2, stream)
+                once()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(3):
+                    once()
+                torch.cuda.synchronize()
+                t = (time.perf_counter() - t) / 3
+                secondary[label] = {"Mrays_per_s": round(cw * ch / t / 1e6, 1), "fps": round(1 / t, 1)}
+                del st2, out2
             extra["secondary"] = secondary
 
     cpu = None
