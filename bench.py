@@ -131,8 +131,11 @@ def main():
         def __init__(self, first):
             self.state = gra.RenderState(W, H, local_rank)
             self.stream = torch.cuda.current_stream() if first and in_flight == 1 else torch.cuda.Stream(device=device)
-            self.out = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
             self.gather = grd.FrameGather(plan, W, device, rank, world) if multi else None
+            # rank 0's frame; in the multi-GPU path padded to whole blocks so that the un-permute writes it directly
+            self.out = None
+            if rank == 0:
+                self.out = self.gather.frame_buffer(device) if multi else torch.zeros((H, W, 4), dtype=torch.float32, device=device)
 
     ring = [Slot(i == 0) for i in range(in_flight)]
     state, out, stream = ring[0].state, ring[0].out, ring[0].stream.cuda_stream

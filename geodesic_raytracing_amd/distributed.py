@@ -65,10 +65,21 @@ class FrameGather:
     def _collective(self):
         return dist.is_available() and dist.is_initialized()
 
+    def frame_buffer(self, device=None):
+        """a frame buffer padded to whole blocks for every rank ([blocks_per_rank * world * block_rows, W, 4]): passed as
+        frame_out it lets the un-permute write the frame directly (one copy instead of two); rows [0, H) are the image"""
+        p = self.plan
+        return torch.zeros((p.blocks_per_rank * self.world * p.block_rows, self.width, 4), dtype=torch.float32,
+                           device=device if device is not None else self.locals[0].device)
+
     def _assemble(self, parts, frame_out):
         p = self.plan
+        padded_rows = p.blocks_per_rank * self.world * p.block_rows
         # parts[r][i] is global block i*world + r  ->  [blocks_per_rank, world, block_rows, W, 4] -> rows
-        stacked = torch.stack(parts, dim=1).reshape(p.blocks_per_rank * self.world * p.block_rows, self.width, 4)
+        if frame_out is not None and frame_out.shape[0] == padded_rows and frame_out.is_contiguous():
+            torch.stack(parts, dim=1, out=frame_out.view(p.blocks_per_rank, self.world, p.block_rows, self.width, 4))
+            return frame_out[:p.height]
+        stacked = torch.stack(parts, dim=1).reshape(padded_rows, self.width, 4)
         frame = stacked[:p.height]
         if frame_out is not None:
             frame_out.copy_(frame)
