@@ -17,7 +17,13 @@
 //   gr_handle_adaptive_sampling handle_adaptive_sampling  cl.cl:5223-5345
 //   gr_render                   render                    cl.cl:5453-5846 (read_mipmap 5421-5449)
 //   gr_trace_fused              (no counterpart) init -> integrate -> render-data in one launch,
-//                               ray state never leaves registers
+//                               ray state never leaves registers; persistent tile-waves
+//   gr_prepass_fused            (no counterpart) the W/16 x H/16 prepass as one launch -> termination flags
+//   gr_boost_tetrad             boost_tetrad              cl.cl:2441-2481
+//   gr_init_inertial_ray        init_inertial_ray         cl.cl:3117-3141
+//   gr_get_geodesic_path        get_geodesic_path         cl.cl:4735-4940
+//   gr_parallel_transport_quantity  parallel_transport_quantity  cl.cl:2569-2620
+//   gr_handle_interpolating_geodesic  handle_interpolating_geodesic  cl.cl:2738-2872
 //
 // MI355X design notes
 //   * one ray per lane, one wave64 per 64 consecutive ray slots; ray slots are laid out in 8x8
@@ -29,6 +35,9 @@
 //   * accept / reject of an adaptive step is a per-lane select - both outcomes ran the same
 //     step_verlet, so rejection costs no divergence; a wave leaves the loop on a ballot of
 //     finished lanes;
+//   * the Verlet loop is written against the issue rates measured on this GPU (tools/ubench/valu_rate.hip): full rate
+//     for fma/mul/add/mov/bit ops, half rate for compares, selects, min/max, conversions, quarter rate for
+//     rcp/rsq/sqrt - see degenerate_accumulate, acceleration_to_precision, sincos_reduced;
 //   * no MFMA: the work is a 4x4 per-ray ODE, bound by fp32 VALU issue, not by HBM or matrix rate.
 //
 // No double-precision arithmetic on the hot path; the few double expressions of the reference's
@@ -93,9 +102,10 @@ struct dynamic_feature_config {
 #endif
 
 // minimum resident waves per SIMD the integrator kernels are register-allocated for (512 VGPRs / N waves each).
-// 1 = no cap: the allocator takes what the metric's expressions need and occupancy follows (Kerr: ~100 VGPRs ->
-// 4 waves/SIMD; the complex-valued double-Kerr metric: ~370 VGPRs -> 1 wave/SIMD but no spills).  Measured on
-// MI355X: capping Kerr at 64 VGPRs makes its loop spill (1.6x slower); capping double Kerr at 128 costs 5.3x.
+// 1 = no cap: the allocator takes what the metric's expressions need and occupancy follows (substituted Kerr: 92 VGPRs
+// in the persistent fused kernel -> 5 waves/SIMD, which already saturates the VALU; the complex-valued double-Kerr
+// metric: 186-370 VGPRs -> 1-2 waves/SIMD but no spills).  Measured on MI355X: forcing 6-8 waves on Kerr does not make it
+// faster; capping double Kerr at 128 VGPRs costs 5.3x.
 #ifndef GR_TRACE_WAVES
 #define GR_TRACE_WAVES 1
 #endif
