@@ -48,7 +48,7 @@ class FrameOptions(ctypes.Structure):
                 ("strip_count", c_int), ("block_rows", c_int), ("compact_out", c_int), ("time_kernels", c_int),
                 ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera)), ("geodesic", c_void_p),
                 ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("parallel_transport_observer", c_int),
-                ("next_camera2", ctypes.POINTER(Camera)), ("next_geodesic_time2", c_float)]
+                ("ray_compaction", c_int), ("next_camera2", ctypes.POINTER(Camera)), ("next_geodesic_time2", c_float)]
 
 
 MODE_REFERENCE, MODE_FUSED = 0, 1
@@ -100,6 +100,8 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "gr_trace_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gr_trace_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "gr_boost_tetrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gr_init_inertial_ray": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -82,11 +83,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_prepass_fused", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_compact", "gr_prepass_fused", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_PREPASS_FUSED, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_COMPACT, K_PREPASS_FUSED, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -568,6 +569,37 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves};
     return launch(p, K_TRACE_FUSED, stream, (unsigned)groups, 1, wg, 1, args);
+}
+
+int gr_trace_compact(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
+                     int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
+                     int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
+                     const void* dfg, void* attempt_counter, int keep_lanes) {
+    const int T = 8;
+    if (keep_lanes < 1 || keep_lanes > 64) return fail(GR_ERROR_INVALID_ARGUMENT, "keep_lanes must be 1..64");
+    if (strip_count <= 1) {
+        strip_count = 1;
+        strip_rank = 0;
+        block_rows = ((height + T - 1) / T) * T;
+    }
+    if (block_rows <= 0 || block_rows % T != 0 || strip_rank < 0 || strip_rank >= strip_count)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "block_rows must be a positive multiple of 8 and 0 <= strip_rank < strip_count");
+    if (strip_count > 1 && height > 1 && (height - 1) % block_rows == 0)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "the last image row must not start a block (its filter reads the row above)");
+    int local_blocks = gr_strip_local_blocks(height, block_rows, strip_rank, strip_count);
+    long long waves_per_block = (long long)((width + T - 1) / T) * (block_rows / T) + (strip_count > 1 ? (width + 63) / 64 : 0);
+    long long waves = waves_per_block * local_blocks;
+    if (waves <= 0) return GR_OK;
+    if (waves * 64 > 0x7fffffffLL) return fail(GR_ERROR_INVALID_ARGUMENT, "too many ray slots");
+    const int wg = 256;
+    unsigned int total_slots = (unsigned int)(waves * 64);
+    long long groups = std::min<long long>((waves * 64 + wg - 1) / wg, (long long)p->compute_units * 32 * 64 / wg);
+    unsigned int* tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
+    void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
+                    &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_slots, &keep_lanes};
+    return launch(p, K_TRACE_COMPACT, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
 // ---- camera on a timelike geodesic (cl.cl:2441-2481, 3117-3141, 4735-4940, 2569-2620, 2738-2872) --------------------

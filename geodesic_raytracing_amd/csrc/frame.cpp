@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -158,6 +159,7 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->geodesic_time = 0;
     o->next_geodesic_time = 0;
     o->parallel_transport_observer = 1;   // main.cpp:1259
+    o->ray_compaction = -1;
     o->next_camera2 = nullptr;
     o->next_geodesic_time2 = 0;
 }
@@ -611,10 +613,20 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         if (!todo.empty()) HIP_CHECK(hipEventRecord(s->main_mark, stream));   // everything up to here is older than the prefetches
         // every device runs the (tiny) prepass itself; its own row blocks (+ one halo row each) are traced here
         GR_CHECK(begin(GR_STAGE_TRACE));
-        GR_CHECK(gr_trace_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
-                                strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
-                                use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
-                                s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
+        // library default: no compaction (the benchmark workloads keep > 95 % of their lanes busy without it); experiments can
+        // switch it on for every frame with GR_TRACE_COMPACT=<keep_lanes>
+        static const int default_compaction = [] { const char* e = getenv("GR_TRACE_COMPACT"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
+        const int keep_lanes = opt.ray_compaction < 0 ? default_compaction : opt.ray_compaction;
+        if (keep_lanes > 0)
+            GR_CHECK(gr_trace_compact(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
+                                      strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
+                                      use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
+                                      s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, keep_lanes));
+        else
+            GR_CHECK(gr_trace_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
+                                    strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
+                                    use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
+                                    s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
         GR_CHECK(end(GR_STAGE_TRACE));
         for (const auto& r : todo) {
             // a free slot, else the stalest one no current request claims (a camera that was announced but never came)

@@ -740,6 +740,9 @@ struct ray_state {
     float next_ds;
     float running_dlambda_dnew;
     float f_in_x;
+    // progress of a ray that is integrated in several visits (ray compaction): accepted steps, attempts
+    int steps;
+    unsigned int tries;
 };
 
 // outcome of integrating one ray
@@ -748,9 +751,25 @@ enum { RAY_LOST = 0, RAY_TERMINATED = 1 };
 // Integrates until termination.  Returns RAY_TERMINATED when the ray reached the outer boundary (or the
 // SINGULAR terminator) - position/velocity/running_dlambda_dnew are then final - and RAY_LOST on any
 // early return of the reference (singularity guards, NaN, step cap), where nothing is written back.
-__device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg, unsigned int* attempts) {
+//
+// RESUMABLE (ray compaction): the loop also stops - `paused` - as soon as fewer than keep_lanes lanes of the wave are still
+// iterating, with everything it carries between iterations saved in `s`, so that the caller can hand the idle lanes new rays
+// and call again; integrate_begin prepares `s` for the first visit.  The arithmetic of a ray does not depend on the visits.
+__device__ __forceinline__ void integrate_begin(ray_state& s, dfg_t dfg) {
+    s.f_in_x = __builtin_fabsf(s.velocity.x);
+    s.next_ds = 0.00001f;
+#ifdef ADAPTIVE_PRECISION
+    (void)acceleration_to_precision(s.acceleration, GET_FEATURE(max_acceleration_change, dfg), s.next_ds);
+#endif
+    s.running_dlambda_dnew = 1;
+    s.steps = 0;
+    s.tries = 0;
+}
+
+template <bool RESUMABLE>
+__device__ __forceinline__ int integrate_core(ray_state& s, cfg_t cfg, dfg_t dfg, unsigned int* attempts, int keep_lanes, bool& paused) {
     float4 position = s.position, velocity = s.velocity, acceleration = s.acceleration;
-    const float f_in_x = __builtin_fabsf(velocity.x);
+    const float f_in_x = RESUMABLE ? s.f_in_x : __builtin_fabsf(velocity.x);
 #ifdef IS_CONSTANT_THETA
     position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
 #endif
@@ -758,7 +777,8 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
 #ifdef ADAPTIVE_PRECISION
     const float max_accel = GET_FEATURE(max_acceleration_change, dfg);
     const float min_step = GET_FEATURE(min_step, dfg);
-    (void)acceleration_to_precision(acceleration, max_accel, next_ds);
+    if (RESUMABLE) next_ds = s.next_ds;
+    else (void)acceleration_to_precision(acceleration, max_accel, next_ds);
 #endif
     const float subambient_precision = 0.5f;
     const float ambient_precision = 0.2f;
@@ -766,12 +786,14 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
     const float new_min = 3;
     const float universe = GET_FEATURE(universe_size, dfg);
     const bool reparam = GET_FEATURE(reparameterisation, dfg) != 0;
-    float running = 1;
+    float running = RESUMABLE ? s.running_dlambda_dnew : 1.f;
     const int loop_limit = 4096 * 4;
-    unsigned int tries = 0;
+    unsigned int tries = RESUMABLE ? s.tries : 0u;
     int result = RAY_LOST;
+    paused = false;
 
-    for (int i = 0; i < loop_limit;) {
+    int i = RESUMABLE ? s.steps : 0;
+    for (; i < loop_limit;) {
 #ifdef IS_CONSTANT_THETA
         position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
 #endif
@@ -844,13 +866,23 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
             if (reparam) poison = degenerate_accumulate(acceleration, poison);
             if (!(poison == 0.f)) break;
         }
+        if (RESUMABLE) {
+            // lanes still in the loop = the exec mask; fewer than keep_lanes of them: leave and let the caller refill the wave
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < keep_lanes) { paused = true; break; }
+        }
     }
+    if (RESUMABLE) { s.next_ds = next_ds; s.steps = i; s.tries = tries; }
     s.position = position;
     s.velocity = velocity;
     s.acceleration = acceleration;
     s.running_dlambda_dnew = running;
     if (attempts) *attempts = tries;
     return result;
+}
+
+__device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg, unsigned int* attempts) {
+    bool paused;
+    return integrate_core<false>(s, cfg, dfg, attempts, 0, paused);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1202,6 +1234,132 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
 #else
         if (!tile_counter) break;
 #endif
+    }
+}
+
+// ---- ray compaction ------------------------------------------------------------------------------
+// slot t of a device's work list = lane t % 64 of tile-wave t / 64 (the mapping of trace_tile); false for padding slots
+__device__ __forceinline__ bool trace_slot_to_pixel(unsigned int slot, int width, int height, int block_rows, int strip_rank, int strip_count,
+                                                    int& cx, int& cy) {
+    const int T = GR_TILE;
+    const int wave = (int)(slot / 64u), lane = (int)(slot % 64u);
+    const int tiles_x = (width + T - 1) / T;
+    const int tile_rows = block_rows / T;
+    const int halo_waves = strip_count > 1 ? (width + 63) / 64 : 0;
+    const int waves_per_block = tiles_x * tile_rows + halo_waves;
+    const int local_block = wave / waves_per_block;
+    const int within = wave % waves_per_block;
+    const int r0 = (local_block * strip_count + strip_rank) * block_rows;
+    if (within < tiles_x * tile_rows) {
+        cx = (within % tiles_x) * T + lane % T;
+        cy = r0 + (within / tiles_x) * T + lane / T;
+        if (cy >= r0 + block_rows) return false;
+    } else {
+        cx = (within - tiles_x * tile_rows) * 64 + lane;
+        cy = r0 + block_rows;
+    }
+    return cx < width && cy < height;
+}
+
+__device__ __forceinline__ bool prepass_skips_pixel(int cx, int cy, int width, int height, const int* __restrict__ termination_buffer,
+                                                    int prepass_width, int prepass_height) {
+    if (!termination_buffer || prepass_width == width || prepass_height == height) return false;
+    float fx = exact_ratio(cx, width);
+    float fy = exact_ratio(cy, height);
+    int lx = (int)roundf(fx * prepass_width);
+    int ly = (int)roundf(fy * prepass_height);
+    return early_terminate(lx - 1, ly, prepass_width, prepass_height, termination_buffer) &&
+           early_terminate(lx, ly, prepass_width, prepass_height, termination_buffer) &&
+           early_terminate(lx + 1, ly, prepass_width, prepass_height, termination_buffer) &&
+           early_terminate(lx, ly - 1, prepass_width, prepass_height, termination_buffer) &&
+           early_terminate(lx, ly + 1, prepass_width, prepass_height, termination_buffer);
+}
+
+// gr_trace_fused with ray compaction: a persistent wave keeps one ray per lane and, as soon as fewer than keep_lanes of them
+// are still integrating (wave-level ballot inside the Verlet loop), finishes the rays that ended, draws as many new pixels
+// from the device-side slot counter as it has idle lanes and sets those rays up, then resumes the loop.  The arithmetic of
+// a ray does not depend on which lane or in how many visits it is integrated, so the frame equals gr_trace_fused's up to
+// what the compiler contracts differently in two kernels; what changes is how many lanes of the 64 do useful work when
+// neighbouring rays need very different numbers of steps.  Measured on MI355X (4K Kerr): it does not pay for the workloads
+// of BASELINE.json - 8x8 tiles already keep 97 % (a = 0.45) and 94 % (the a = 0.9 naked singularity) of the lanes busy,
+// and the visits cost more than the idle lanes (7.1 -> 9.6 ms at keep_lanes 16..48) - so the frame driver leaves it off
+// unless asked (gr_frame_options.ray_compaction).
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
+gr_trace_compact(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+                 render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
+                 const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+                 const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+                 cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ slot_counter,
+                 unsigned int total_slots, int keep_lanes) {
+    GR_PARAMETERS_IN_REGISTERS
+    const bool need_redshift = GET_FEATURE(redshift, dfg) != 0;
+    // per-lane ray: pixel, what render-data needs from the set-up, integrator progress
+    int cx = 0, cy = 0;
+    float4 start_position = f4(0, 0, 0, 0), start_velocity = f4(0, 0, 0, 0), initial_quat = f4(0, 0, 0, 1);
+    float ku_uobsu = 1;
+    ray_state s;
+    s.position = s.velocity = s.acceleration = f4(0, 0, 0, 0);
+    s.next_ds = 0; s.running_dlambda_dnew = 1; s.f_in_x = 0; s.steps = 0; s.tries = 0;
+    bool has_ray = false;     // this lane holds a ray
+    bool integrating = false; // ... that has not ended yet
+    int outcome = RAY_LOST;
+    bool exhausted = false;   // wave-uniform: the slot counter ran past the work list
+
+    for (;;) {
+        // 1. rays that ended: render-data record, lane becomes idle
+        if (has_ray && !integrating) {
+            int terminated = 0;
+            float4 p = start_position, v = start_velocity;
+            float running = 1;
+            if (outcome == RAY_TERMINATED) { terminated = 1; p = s.position; v = s.velocity; running = s.running_dlambda_dnew; }
+            rdata[cy * width + cx] = make_render_data(p, v, initial_quat, ku_uobsu, running, terminated, cx, cy, cfg, dfg, need_redshift);
+            if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)s.tries);
+            has_ray = false;
+        }
+        // 2. refill idle lanes (skipped and padding slots use up tickets without giving work, hence the loop)
+        while (!exhausted) {
+            const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has_ray);
+            const int n_idle = __builtin_popcountll(idle);
+            if (n_idle == 0 || (n_idle <= 64 - keep_lanes && n_idle != 64)) break;   // enough rays on board
+            unsigned int base = 0;
+            if (threadIdx.x % 64 == 0) base = atomicAdd(slot_counter, (unsigned int)n_idle);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= total_slots) { exhausted = true; break; }
+            if (base + (unsigned int)n_idle >= total_slots) exhausted = true;
+            const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
+            const unsigned int slot = base + (unsigned int)my_rank;
+            if (!has_ray && slot < total_slots && trace_slot_to_pixel(slot, width, height, block_rows, strip_rank, strip_count, cx, cy)) {
+                if (prepass_skips_pixel(cx, cy, width, height, termination_buffer, prepass_width, prepass_height)) {
+                    render_data dat;
+                    dat.tex_coord = make_float2(0, 0);
+                    dat.z_shift = 0;
+                    dat.sx = cx;
+                    dat.sy = cy;
+                    dat.terminated = 2;
+                    dat.side = 1;
+                    rdata[cy * width + cx] = dat;
+                } else {
+                    lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+                    start_position = ray.position;
+                    start_velocity = ray.velocity;
+                    initial_quat = ray.initial_quat;
+                    ku_uobsu = ray.ku_uobsu;
+                    s.position = ray.position;
+                    s.velocity = ray.velocity;
+                    s.acceleration = ray.acceleration;
+                    integrate_begin(s, dfg);
+                    has_ray = true;
+                    integrating = true;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(has_ray) == 0) break;   // nothing on board and nothing left to draw
+        // 3. integrate until fewer than keep_lanes rays are still going (all of them to the end once the list is exhausted)
+        if (integrating) {
+            bool paused = false;
+            outcome = integrate_core<true>(s, cfg, dfg, nullptr, exhausted ? 1 : keep_lanes, paused);
+            integrating = paused;
+        }
     }
 }
 

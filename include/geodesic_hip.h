@@ -266,6 +266,17 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
                    const void* e0, const void* e1, const void* e2, const void* e3,
                    const void* cfg, const void* dfg, void* attempt_counter);
 
+/* gr_trace_fused with ray compaction (north_star: "wave-level ballots for step-acceptance and ray compaction"): persistent
+ * waves hold one ray per lane; whenever fewer than keep_lanes (1..64) of a wave's rays are still integrating, the finished
+ * ones are written out and the idle lanes draw new pixels from a device-side counter.  Every ray is integrated exactly as
+ * in gr_trace_fused (results agree to rounding); it can only pay when neighbouring rays need very different numbers of
+ * steps - not the case for the BASELINE workloads, where 8x8 tiles keep >= 94 % of the lanes busy. */
+int gr_trace_compact(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
+                     void* render_data, int width, int height, int block_rows, int strip_rank, int strip_count,
+                     const void* termination_buffer, int prepass_width, int prepass_height,
+                     const void* e0, const void* e1, const void* e2, const void* e3,
+                     const void* cfg, const void* dfg, void* attempt_counter, int keep_lanes);
+
 /* ---- frame driver (the enqueue sequence of main.cpp:2244-2526) ------------------------------- */
 
 typedef struct gr_render_state gr_render_state;   /* render_state.hpp:97-197: all per-frame device buffers */
@@ -307,6 +318,8 @@ typedef struct gr_frame_options {
     float geodesic_time;          /* current_geodesic_time of this frame */
     float next_geodesic_time;     /* ... of the next frame, used with next_camera (look-ahead) */
     int parallel_transport_observer;   /* 1 (default, main.cpp:1259): interpolate the transported tetrads; 0: rebuild them */
+    int ray_compaction;    /* fused mode: 0 = gr_trace_fused (one tile per wave at a time), 1..64 = gr_trace_compact with this
+                            * keep_lanes; -1 = library default */
     const struct gr_camera* next_camera2;   /* optional: the camera of the call AFTER next_camera's.  Two prepasses are then in
                             * flight on two streams, which hides their latency even when a frame traces faster than one
                             * prepass runs (row-split frames on several GPUs). */

@@ -247,3 +247,27 @@ def test_headless_render_to_png(tmp_path):
     frame2 = R.render("kerr_boyer", 640, 360, cfg=dict(a=0.45), adaptive=True)
     d = frame2[..., :3] - frame[..., :3]
     assert (np.abs(d).max(axis=2) > 0.05).mean() < 0.05
+
+
+@pytest.mark.parametrize("name,cfg,size", [("kerr_boyer", dict(a=0.45), (1920, 1080)), ("kerr_boyer", dict(a=0.9), (1280, 720)),
+                                           ("alcubierre", {}, (1280, 720)), ("schwarzschild", {}, (1000, 500))])
+def test_ray_compaction_computes_the_same_frame(name, cfg, size):
+    """gr_trace_compact (idle lanes of a wave are refilled with new rays while the others keep integrating) integrates every ray
+    as gr_trace_fused does.  The two are separate kernels, so the compiler may contract or reassociate a few operations
+    differently (exactly as between the fused kernel and the reference-shaped sequence): the number of Verlet attempts must
+    agree to 1e-4, termination flags must be equal and pixels equal to rounding."""
+    w, h = size
+    px0, rd0, st0 = render(name, w, h, cfg=cfg, options=dict(mode=gra.MODE_FUSED, ray_compaction=0, count_attempts=1))
+    want_attempts = st0.attempts()
+    for keep in (48, 32, 8):
+        px, rd, st = render(name, w, h, cfg=cfg, options=dict(mode=gra.MODE_FUSED, ray_compaction=keep, count_attempts=1))
+        assert abs(st.attempts() - want_attempts) <= 1e-4 * want_attempts, keep
+        assert (rd["terminated"] != rd0["terminated"]).mean() <= 1e-4, keep
+        assert np.array_equal(rd["sx"], rd0["sx"]) and np.array_equal(rd["sy"], rd0["sy"])
+        d = np.abs(px - px0).max(axis=2)
+        assert (d > 1e-4).mean() <= 1e-3 and np.median(d) <= 1e-6, keep
+    if h % 16 != 1:
+        part, _, _ = render(name, w, h, cfg=cfg, out_rows=16, options=dict(mode=gra.MODE_FUSED, ray_compaction=32, strip_rank=3, strip_count=h // 16,
+                                                                          block_rows=16, compact_out=1))
+        d = np.abs(part - px0[48:64]).max(axis=2)
+        assert (d > 1e-4).mean() <= 1e-3
