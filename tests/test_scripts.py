@@ -181,6 +181,16 @@ def test_every_reference_script_loads_unmodified():
 
 
 @needs_reference
+@pytest.mark.parametrize("name", ["kerr_schild", "janis_newman_winicour", "krasnikov_cylindrical"])
+def test_reference_scripts_compile_for_gfx950(name, tmp_path, monkeypatch):
+    """drop-in: an unmodified reference script goes all the way to a gfx950 code object (all 31 do:
+    tools/compile_reference_scripts.py, profiles/r01_reference_scripts_compile.txt; three here to keep the suite short)"""
+    monkeypatch.setenv("GR_CACHE_DIR", str(tmp_path))
+    gra.Program.precompile(gra.Metric(name, REF).argument_string())
+    assert any(f.endswith(".hsaco") for f in os.listdir(tmp_path))
+
+
+@needs_reference
 @pytest.mark.parametrize("name", CONFIG_METRICS)
 def test_own_scripts_equal_the_reference_scripts(name):
     a, b = gra.Metric(name, OWN), gra.Metric(name, REF)
