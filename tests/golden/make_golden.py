@@ -68,6 +68,9 @@ CASES = {
     "cosmic_string": dict(metric="cosmic_string", scripts=True, size=(48, 27), cfg=dict(mu=0.05), camera_pos=[0.0, 0.3, -6.0, 0.5]),
     "cosmic_string_hit": dict(metric="cosmic_string", scripts=True, size=(48, 27), cfg=dict(mu=0.02), camera_pos=[0.0, 0.0, -3.0, 0.0],
                               features=dict(redshift=1)),
+    "kerr_newman": dict(metric="kerr_newman_boyer", scripts=True, size=(48, 27), cfg=dict(a=0.3, rq=0.25), camera_pos=[0.0, 0.5, -5.0, 1.0]),
+    "kerr_schild": dict(metric="kerr_schild", scripts=True, size=(48, 27), cfg=dict(a=0.45), camera_pos=[0.0, 0.5, -5.0, 1.0]),
+    "kerr_schild_prepass": dict(metric="kerr_schild", scripts=True, size=(96, 64), cfg=dict(a=0.45), prepass=True),
     "kerr_moving_observer": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.3, 0.0, 0.2], features=dict(redshift=1)),
 }
 
@@ -87,6 +90,7 @@ PATH_CASES = {
                                         camera_pos=[0.0, 1.0, -8.0, 0.5], basis_speed=[0.2, 0.0, 0.3], features=dict(reparameterisation=1)),
     "alcubierre_passenger": dict(metric="alcubierre", camera_pos=[0.0, 0.0, -3.0, 0.5], basis_speed=[0.0, 0.0, 0.1]),
     "cosmic_string_flyby": dict(metric="cosmic_string", scripts=True, cfg=dict(mu=0.05), camera_pos=[0.0, 1.0, -6.0, 0.5], basis_speed=[0.0, 0.4, 0.05]),
+    "kerr_schild_plunge": dict(metric="kerr_schild", scripts=True, cfg=dict(a=0.45), camera_pos=[0.0, 1.0, -6.0, 0.5], basis_speed=[0.05, 0.3, -0.05]),
     "wormhole_crossing": dict(metric="wormhole", scripts=True, camera_pos=[0.0, 0.3, -2.5, 0.3], basis_speed=[0.05, 0.5, -0.02]),
 }
 

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 import geodesic_raytracing_amd as gra  # noqa: E402
 from gpu_stages import Stages, circ_diff, golden_names, load_golden, metric_for, rel_err  # noqa: E402
 
-PLAIN = [n for n in golden_names() if n not in ("kerr_prepass", "kerr_adaptive_sampling")]
+PLAIN = [n for n in golden_names() if not n.endswith("_prepass") and n != "kerr_adaptive_sampling"]
 CHAOTIC = {"kerr_superextremal"}
 
 
@@ -138,10 +138,11 @@ def _frame(meta, mode, tiled=0, options=None, substituted=False):
     return out.to_numpy(np.float32, (h, w, 4)), state
 
 
-def test_prepass_matches_reference():
+@pytest.mark.parametrize("name", ["kerr_prepass", "kerr_schild_prepass"])
+def test_prepass_matches_reference(name):
     """termination buffer, the terminated == 2 stencil and the final image with the prepass on (cl.cl:3213-3232, 5008-5020)"""
     from geodesic_raytracing_amd.pipeline import download
-    meta, z = load_golden("kerr_prepass")
+    meta, z = load_golden(name)
     px, state = _frame(meta, gra.MODE_REFERENCE)
     pw, ph = meta["width"] // 16, meta["height"] // 16
     term = download(0, state.buffer(gra.BUF_TERMINATION), np.int32, pw * ph).reshape(ph, pw)
@@ -176,7 +177,7 @@ def test_adaptive_sampling_matches_reference():
     assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["kerr", "schwarzschild_redshift", "alcubierre", "kerr_prepass"])
+@pytest.mark.parametrize("name", ["kerr", "schwarzschild_redshift", "alcubierre", "kerr_prepass", "kerr_schild_prepass"])
 def test_fused_and_tiled_paths_equal_reference_sequence(name):
     """the 8x8-tiled ray order is bit-identical to the reference order (same kernels); the fused kernel is the same
     device functions inlined into another kernel, where the compiler contracts/reassociates differently, so it is held
@@ -193,7 +194,7 @@ def test_fused_and_tiled_paths_equal_reference_sequence(name):
         assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
 
 
-SUBSTITUTED = ["kerr", "kerr_tilted", "kerr_far", "kerr_prepass", "kerr_moving_observer", "kerr_reparameterised", "schwarzschild_redshift",
+SUBSTITUTED = ["kerr", "kerr_tilted", "kerr_far", "kerr_prepass", "kerr_newman", "kerr_schild", "kerr_schild_prepass", "kerr_moving_observer", "kerr_reparameterised", "schwarzschild_redshift",
                "alcubierre", "ingoing_ef", "double_unequal_kerr", "cosmic_string", "wormhole_through"]
 
 
@@ -210,7 +211,8 @@ def test_substituted_program_matches_reference(name, mode):
     assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["kerr", "kerr_far", "kerr_tilted", "alcubierre", "schwarzschild", "ingoing_ef", "cosmic_string"])
+@pytest.mark.parametrize("name", ["kerr", "kerr_far", "kerr_tilted", "alcubierre", "schwarzschild", "ingoing_ef", "cosmic_string", "kerr_newman",
+                                  "kerr_schild"])
 def test_step_attempts_match_oracle(name):
     """the number of Verlet attempts is a sensitive summary of the step-size controller (a wrong precision-radius test or a
     lagging step length changes it by percent while end pixels barely move): GPU kernels - dynamic and substituted, fused

@@ -63,7 +63,10 @@ def test_scripts_and_builtins_define_the_same_metric(name):
         assert np.allclose(ma.accel(pos, vel, cfg), mb.accel(pos, vel, cfg), rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("name", CONFIG_METRICS)
+OTHER_OWN_METRICS = ["schwarzschild_ingoing_ef", "wormhole", "cosmic_string", "kerr_newman_boyer", "kerr_schild"]
+
+
+@pytest.mark.parametrize("name", CONFIG_METRICS + OTHER_OWN_METRICS)
 def test_script_metric_calculus(name):
     """F*_P are the derivatives of F*_I, and GEO_ACCELn = -Gamma v v built from them (complex-valued scripts included)"""
     m = gra.Metric(name, OWN)
@@ -101,6 +104,34 @@ def test_double_kerr_is_asymptotically_flat():
     # meridional components are equal, the frame dragging term dies out
     assert g[1, 1] == pytest.approx(g[3, 3], rel=1e-12) and 0.9 < g[1, 1] < 1.1
     assert abs(g[0, 2]) / 3000.0 < 1e-4
+
+
+def test_kerr_newman_without_charge_is_kerr_and_kerr_schild_is_kerr():
+    """physics checks of the two extra Kerr-family scripts: Kerr-Newman at rq = 0 is the Kerr script's metric; the Kerr-Schild
+    form has det g = -1, a null vector l with g = eta + f l l, and - being the same spacetime - the same Kretschmann-free
+    invariant we can get from first derivatives alone: the geodesic acceleration of a static observer far away -> M / r^2"""
+    kn, kerr = gra.Metric("kerr_newman_boyer", OWN), gra.Metric("kerr_boyer", OWN)
+    mkn, mk = MacroSet(kn.argument_string()), MacroSet(kerr.argument_string())
+    pos = [0.3, 3.7, 1.1, 0.4]
+    g1 = np.array(mkn.metric(pos, dict(rs=1.0, a=0.3, rq=0.0)))
+    g2 = np.array(mk.metric(pos, dict(rs=1.0, a=0.3)))
+    assert np.allclose(g1, g2, rtol=1e-12, atol=1e-12)
+    assert abs(np.array(mkn.metric(pos, dict(rs=1.0, a=0.3, rq=0.25)))[1, 1] - g2[1, 1]) > 1e-3       # the charge does something
+
+    ks = gra.Metric("kerr_schild", OWN)
+    mks = MacroSet(ks.argument_string())
+    cfg = dict(rs=1.0, a=0.45)
+    for p in ([0.0, 3.0, -2.0, 1.5], [1.0, 0.4, 5.0, -0.7]):
+        g = np.array(mks.metric(p, cfg))
+        assert np.linalg.det(g) == pytest.approx(-1.0, rel=1e-9)
+        h = g - np.diag([-1.0, 1, 1, 1])
+        assert np.linalg.matrix_rank(h, tol=1e-9) == 1                    # f l l
+        l = h[0] / np.sqrt(h[0, 0])                                       # l_0 = 1
+        assert -l[0] ** 2 + l[1] ** 2 + l[2] ** 2 + l[3] ** 2 == pytest.approx(0.0, abs=1e-9)
+    # a particle at rest far out on the x axis falls inwards with M / r^2 = rs / (2 r^2)
+    R = 400.0
+    acc = mks.accel([0.0, R, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], cfg)
+    assert acc[1] == pytest.approx(-0.5 / R ** 2, rel=2e-2)
 
 
 def test_config_metrics_compile_for_gfx950():
