@@ -135,3 +135,38 @@ def test_single_rank_gather_is_identity():
     frame = torch.rand((40, 5, 4))
     g.local_buffer().copy_(frame.view(5, 8, 5, 4))
     assert torch.equal(g.run(), frame)
+
+
+def test_strip_prepass_cell_rule_covers_every_cell_a_rank_reads():
+    """gr_prepass_fused skips the prepass cell rows a device's pixel rows cannot look at (integer rule restated here from
+    geodesic_kernels.hip).  Brute force over image heights, block sizes and device counts: every cell row the 5-point stencil
+    of an own pixel row (or halo row) reads must be kept; and the rule should actually save work."""
+    import math
+
+    def kept(cy, H, ph, B, rank, count):
+        lo = int(((2 * cy - 3) * H) / (2 * ph)) - 2          # C truncation towards zero
+        hi = ((2 * cy + 3) * H + 2 * ph - 1) // (2 * ph) + 2
+        lo, hi = max(lo, 0), min(hi, H - 1)
+        b_lo, b_hi = max(lo // B - 1, 0), hi // B
+        first = b_lo + ((rank - b_lo) % count + count) % count
+        return first <= b_hi
+
+    saved = {}
+    for H in (135 * 16, 1080, 720, 1000, 2161 - 1, 333):
+        ph = H // 16
+        for B in (8, 16, 24, 32):
+            for count in (2, 3, 4, 8):
+                if (H - 1) % B == 0:
+                    continue
+                total_blocks = (H + B - 1) // B
+                for rank in range(count):
+                    need = set()
+                    for b in range(rank, total_blocks, count):
+                        for cy in range(b * B, min((b + 1) * B, H - 1) + 1):       # own rows + the halo row under the block
+                            ly = int(math.floor(np.float32(np.float32(cy / H) * np.float32(ph)) + 0.5))   # roundf(fy * ph)
+                            need.update(c for c in (ly - 1, ly, ly + 1) if 0 <= c < ph)
+                    keep = {c for c in range(ph) if kept(c, H, ph, B, rank, count)}
+                    assert need <= keep, (H, B, count, rank, sorted(need - keep)[:5])
+                    saved[(H, B, count, rank)] = 1 - len(keep) / ph
+    # 4K, 16-row blocks over 8 devices (the bench layout): most of the prepass is somebody else's
+    assert all(saved[(2160, 16, 8, r)] > 0.5 for r in range(8))
