@@ -55,13 +55,18 @@ def parse():
 
 
 def cpu_baseline(metric_name, cfg_values, features_kw, target_seconds):
-    """Times the CPU oracle (oracle/restate.cpp, all host cores) on a bounded sample of the same workload:
-    a low-resolution frame with the same camera and field of view (same ray distribution)."""
-    from oracle import build_restate
+    """Times the CPU side on a bounded sample of the same workload: a low-resolution frame with the same camera and field of
+    view (same ray distribution), all host cores.  The reference's own cl.cl compiled for x86-64 (oracle/_ref, built in the
+    build container for exactly this macro string and shipped as a .so) when it is there - kind "reference" - otherwise this
+    repository's C++ restatement of it (oracle/restate.cpp) - kind "port"."""
+    from oracle import build_restate, build_ref
     from oracle.refpipe import OraclePipeline, pack_features
     import geodesic_raytracing_amd as gra
     m = gra.Metric(metric_name, os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"))
-    so = build_restate.build(m.argument_string())
+    so = build_ref.prebuilt(metric_name + "_script", m.argument_string()) or build_ref.prebuilt(metric_name, m.argument_string())
+    kind = "reference" if so else "port"
+    if not so:
+        so = build_restate.build(m.argument_string())
     pipe = OraclePipeline(so)
     cores = os.cpu_count() or 1
     feats = pack_features(**features_kw)
@@ -79,8 +84,9 @@ def cpu_baseline(metric_name, cfg_values, features_kw, target_seconds):
     w2 = int(max(96, min(1920, round(96 * scale / 16) * 16)))
     h2 = w2 * 9 // 16
     t2 = run(w2, h2)
-    return {"value": round(w2 * h2 / t2 / 1e6, 6), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{w2}x{h2} frame of the same camera/metric (init + Verlet trace of every pixel, no prepass skip), "
+    what = "the reference's cl.cl compiled for x86-64 (oracle/_ref)" if kind == "reference" else "oracle/restate.cpp"
+    return {"value": round(w2 * h2 / t2 / 1e6, 6), "unit": "Mrays/s", "cores": cores, "kind": kind,
+            "sample": f"{w2}x{h2} frame of the same camera/metric (init + Verlet trace of every pixel, no prepass skip) through {what}, "
                       f"{t2:.1f} s on {cores} threads"}
 
 

@@ -28,13 +28,26 @@ def lib_path(tag):
     return os.path.join(OUT, f"libref_{tag}.so")
 
 
+def _response_text(argument_string):
+    return "".join('"' + tok.replace("\\", "\\\\").replace('"', '\\"') + '"\n' for tok in argument_string.split())
+
+
+def prebuilt(tag, argument_string):
+    """path of an oracle/_ref library built earlier (in the build container) for exactly this macro string, else None;
+    needs neither the reference sources nor clang, so it works on the GPU box"""
+    so, rsp = lib_path(tag), os.path.join(OUT, f"{tag}.rsp")
+    if os.path.exists(so) and os.path.exists(rsp) and open(rsp).read() == _response_text(argument_string):
+        return so
+    return None
+
+
 def build(tag, argument_string, force=False):
     """Compile cl.cl with `argument_string` and link the shim; returns the .so path."""
     if not reference_available():
         raise RuntimeError("reference sources or clang not available")
     os.makedirs(OUT, exist_ok=True)
     rsp = os.path.join(OUT, f"{tag}.rsp")
-    text = "".join('"' + tok.replace("\\", "\\\\").replace('"', '\\"') + '"\n' for tok in argument_string.split())
+    text = _response_text(argument_string)
     so = lib_path(tag)
     shim = os.path.join(HERE, "ref_shim.cpp")
     if (not force and os.path.exists(so) and os.path.exists(rsp) and open(rsp).read() == text
