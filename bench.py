@@ -318,11 +318,11 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "Mrays/sec at 3840x2160 Kerr (whole frame: prepass + init + adaptive Verlet + render-data + anisotropic render)",
+            "metric": f"Mrays/sec at {W}x{H} {'Kerr' if args.metric == 'kerr_boyer' else args.metric} (whole frame: prepass + init + adaptive Verlet + render-data + anisotropic render)",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.metric} (Boyer-Lindquist rs=1 a={args.spin}) {W}x{H}, camera (0,0,-4,0) fov 90, adaptive_sampling off, "
+            "config": {"workload": f"{args.metric}{f' (Boyer-Lindquist rs=1 a={args.spin})' if args.metric == 'kerr_boyer' else ''} {W}x{H}, camera (0,0,-4,0) fov 90, adaptive_sampling off, "
                                    f"prepass {'on' if metric.info.use_prepass else 'off'}, tol {metric.info.max_acceleration_change:g}, "
                                    f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
                        "mode": args.mode, "prepass_lookahead": bool(fused and not args.no_lookahead), "prepass_lookahead_depth": depth,
