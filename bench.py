@@ -284,7 +284,7 @@ def main():
             secondary["adaptive_sampling_on_threshold32_fps"] = round(1 / t, 1)
             t = timed(camera, features, cfg_values, manager.dynamic, gra.MODE_REFERENCE)
             secondary["reference_kernel_sequence_dynamic_program_fps"] = round(1 / t, 1)
-            # the other BASELINE.json configurations, one frame at a time on this one GPU (dynamic programs, fused kernel)
+            # the other BASELINE.json configurations, one frame at a time on this one GPU (substituted programs, fused kernel)
             scripts_dir = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
             for label, name, (cw, ch), cam_pos, feats_kw in (
                     ("config1_schwarzschild_1920x1080", "schwarzschild", (1920, 1080), None, {}),
@@ -292,7 +292,7 @@ def main():
                     ("config4_alcubierre_7680x4320_redshift", "alcubierre", (7680, 4320), [0, 0, -6, 0.5], {"redshift": 1})):
                 m2 = gra.Metric(name, scripts_dir)
                 f2 = m2.features(adaptive_sampling=0, **feats_kw)
-                p2 = gra.Program(m2.argument_string(), local_rank)
+                p2 = gra.Program(m2.argument_string(features=f2, static=True, cfg_values=m2.cfg_values()), local_rank)
                 st2 = gra.RenderState(cw, ch, local_rank)
                 out2 = torch.zeros((ch, cw, 4), dtype=torch.float32, device=device)
                 c2 = gra.default_camera(cam_pos)
