@@ -161,9 +161,14 @@ def main():
                 opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=2)
                 target = slot.out.data_ptr()
             else:
-                # this rank's row blocks (block-cyclic) -> compact strip buffer -> ONE gather to rank 0 + local un-permute
-                opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=rank, strip_count=world, block_rows=plan.block_rows, compact_out=1,
-                                         time_kernels=2)
+                # this rank's row blocks (block-cyclic) -> compact strip buffer -> ONE gather to rank 0 + local un-permute.  The
+                # strip a rank renders rotates with the frame number: strips differ in cost (1.09 max/mean at 8 ranks) and with
+                # frames in flight and an asynchronous gather the ranks then run at the mean, not at the slowest strip.
+                k = frame_index[0] - 1
+                opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=slot.gather.strip_of(k), strip_count=world,
+                                         block_rows=plan.block_rows, compact_out=1, time_kernels=2)
+                opts.next_strip_rank = slot.gather.strip_of(k + in_flight)        # the frames this render state sees next
+                opts.next_strip_rank2 = slot.gather.strip_of(k + 2 * in_flight)
                 target = slot.gather.local_buffer().data_ptr()
             if lookahead is not None:
                 opts.next_camera = lookahead
@@ -172,7 +177,7 @@ def main():
             slot.state.render(program, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfg_values, opts,
                               slot.stream.cuda_stream)
             if multi:
-                slot.gather.submit(slot.out)   # asynchronous: overlaps the following frames (double-buffered strips)
+                slot.gather.submit(slot.out, rotation=frame_index[0] - 1)   # asynchronous: overlaps the following frames
 
     def barrier():
         if multi:
@@ -332,7 +337,7 @@ def main():
                                    f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
                        "mode": args.mode, "prepass_lookahead": bool(fused and not args.no_lookahead), "prepass_lookahead_depth": depth,
                        "frames_in_flight": in_flight, "priming_frames": priming, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
-                       "parallelism": f"16-row blocks, block-cyclic over {world} GPUs + one RCCL gather" if world > 1 else "single GPU"},
+                       "parallelism": f"16-row blocks, block-cyclic over {world} GPUs (assignment rotating per frame) + one RCCL gather" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)

@@ -160,6 +160,8 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->next_geodesic_time = 0;
     o->parallel_transport_observer = 1;   // main.cpp:1259
     o->ray_compaction = -1;
+    o->next_strip_rank = -1;
+    o->next_strip_rank2 = -1;
     o->next_camera2 = nullptr;
     o->next_geodesic_time2 = 0;
 }
@@ -505,7 +507,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     if (prepass_width < 1 || prepass_height < 1) use_prepass = false;
 
     // was this frame's camera set-up + prepass already done on a side stream during an earlier frame?
-    auto make_key = [&](const gr_camera* c, float time) {
+    auto make_key = [&](const gr_camera* c, float time, int frame_strip_rank) {
         gr_render_state::prefetch_key k;
         k.camera = *c;
         k.cfg = cfg;
@@ -515,14 +517,14 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         k.geodesic_time = time;
         k.transport = opt.parallel_transport_observer;
         k.strip[2] = opt.strip_count > 1 ? opt.strip_count : 1;
-        k.strip[1] = k.strip[2] > 1 ? opt.strip_rank : 0;
+        k.strip[1] = k.strip[2] > 1 ? frame_strip_rank : 0;
         k.strip[0] = k.strip[2] > 1 ? opt.block_rows : 0;
         return k;
     };
     s->frame_counter++;
     bool prefetched = false;
     if (opt.mode == GR_MODE_FUSED && use_prepass) {
-        const auto want = make_key(camera, opt.geodesic_time);
+        const auto want = make_key(camera, opt.geodesic_time, opt.strip_rank);
         gr_render_state::prefetch_slot* hit = nullptr;   // the oldest matching prefetch: it has had the most time to finish
         for (auto& slot : s->pre)
             if (slot.valid && slot.key == want && (!hit || slot.age < hit->age)) hit = &slot;
@@ -596,14 +598,16 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             GR_CHECK(end(GR_STAGE_PREPASS));
         }
         // look-ahead requests that are not already sitting in a slot
-        struct request { const gr_camera* camera; float time; };
+        struct request { const gr_camera* camera; float time; int strip_rank; };   // strip_rank < 0: this frame's
         std::vector<request> todo;
         bool claimed[gr_render_state::LOOKAHEAD] = {};   // a slot serves one request (two frames may share one camera)
         if (use_prepass) {
-            const request asked[2] = {{opt.next_camera, opt.next_geodesic_time}, {opt.next_camera2, opt.next_geodesic_time2}};
-            for (const auto& r : asked) {
+            request asked[2] = {{opt.next_camera, opt.next_geodesic_time, opt.next_strip_rank},
+                                {opt.next_camera2, opt.next_geodesic_time2, opt.next_strip_rank2}};
+            for (auto& r : asked) {
                 if (!r.camera) continue;
-                const auto k = make_key(r.camera, r.time);
+                if (r.strip_rank < 0 || r.strip_rank >= strip_count) r.strip_rank = strip_rank;
+                const auto k = make_key(r.camera, r.time, r.strip_rank);
                 bool have = false;
                 for (int i = 0; i < gr_render_state::LOOKAHEAD && !have; i++)
                     if (!claimed[i] && s->pre[i].valid && s->pre[i].key == k) claimed[i] = have = true;
@@ -649,11 +653,11 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             GR_CHECK(gr_prepass_fused_strips(p, slot->stream, slot->set.camera_pos_generic, slot->set.camera_quat,
                                              slot->set.termination_buffer, prepass_width, prepass_height, slot->set.tetrad[0],
                                              slot->set.tetrad[1], slot->set.tetrad[2], slot->set.tetrad[3], s->cfg, s->dfg, height,
-                                             block_rows, strip_rank, strip_count));
+                                             block_rows, r.strip_rank, strip_count));
             HIP_CHECK(hipEventRecord(slot->ready, slot->stream));
             slot->valid = true;
             slot->age = s->frame_counter;
-            slot->key = make_key(r.camera, r.time);
+            slot->key = make_key(r.camera, r.time, r.strip_rank);
         }
         if (out) {
             GR_CHECK(begin(GR_STAGE_RENDER));

@@ -55,6 +55,7 @@ class FrameGather:
         self.parts = [[torch.zeros(shape, dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
                       for _ in range(depth)]
         self.pending = [None] * depth
+        self.rotation = [0] * depth   # which strip each rank rendered into this buffer: strip = (rank + rotation) % world
         self.slot = 0
         self.frames_done = 0
 
@@ -72,8 +73,11 @@ class FrameGather:
         return torch.zeros((p.blocks_per_rank * self.world * p.block_rows, self.width, 4), dtype=torch.float32,
                            device=device if device is not None else self.locals[0].device)
 
-    def _assemble(self, parts, frame_out):
+    def _assemble(self, parts, frame_out, rotation=0):
         p = self.plan
+        if rotation % self.world:
+            # rank r rendered strip (r + rotation) % world, so strip s came from rank (s - rotation) % world
+            parts = [parts[(s - rotation) % self.world] for s in range(self.world)]
         padded_rows = p.blocks_per_rank * self.world * p.block_rows
         # parts[r][i] is global block i*world + r  ->  [blocks_per_rank, world, block_rows, W, 4] -> rows
         if frame_out is not None and frame_out.shape[0] == padded_rows and frame_out.is_contiguous():
@@ -86,8 +90,9 @@ class FrameGather:
             return frame_out
         return frame
 
-    def run(self, frame_out=None):
-        """one collective: gather to rank 0; returns the assembled [H, W, 4] frame on rank 0, None elsewhere"""
+    def run(self, frame_out=None, rotation=0):
+        """one collective: gather to rank 0; returns the assembled [H, W, 4] frame on rank 0, None elsewhere.
+        rotation: this frame's strip assignment was rotated, rank r rendered strip (r + rotation) % world (strip_of)"""
         i = self.slot
         if self._collective():
             dist.gather(self.locals[i], self.parts[i], dst=0, group=self.group)
@@ -96,7 +101,12 @@ class FrameGather:
             parts = [self.locals[i]]
         if self.rank != 0:
             return None
-        return self._assemble(parts, frame_out)
+        return self._assemble(parts, frame_out, rotation)
+
+    def strip_of(self, rotation):
+        """the strip_rank this rank renders in a frame whose assignment is rotated by `rotation` (e.g. the frame number):
+        over `world` consecutive frames every rank renders every strip once, which evens out strips of different cost"""
+        return (self.rank + rotation) % self.world
 
     def _finish(self, j, frame_out):
         work = self.pending[j]
@@ -108,12 +118,13 @@ class FrameGather:
         self.frames_done += 1
         if self.rank != 0:
             return None
-        return self._assemble(self.parts[j] if self._collective() else [self.locals[j]], frame_out)
+        return self._assemble(self.parts[j] if self._collective() else [self.locals[j]], frame_out, self.rotation[j])
 
-    def submit(self, frame_out=None):
+    def submit(self, frame_out=None, rotation=0):
         """call after rendering into local_buffer(): starts its gather and moves on to the other buffer.  Returns the
         frame (rank 0) whose buffer is about to be reused, if one was in flight, else None."""
         i = self.slot
+        self.rotation[i] = rotation
         if self._collective():
             self.pending[i] = dist.gather(self.locals[i], self.parts[i], dst=0, group=self.group, async_op=True)
         else:

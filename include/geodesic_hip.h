@@ -324,6 +324,8 @@ typedef struct gr_frame_options {
                             * flight on two streams, which hides their latency even when a frame traces faster than one
                             * prepass runs (row-split frames on several GPUs). */
     float next_geodesic_time2;
+    int next_strip_rank;   /* strip_rank of the next_camera / next_camera2 frames when a device's share of the image rotates from */
+    int next_strip_rank2;  /*   frame to frame (load balance over ranks); -1 = the same as this frame's */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 

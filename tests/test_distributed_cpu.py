@@ -88,12 +88,14 @@ def _pipelined_worker(rank, world, port, out_dir):
     out = g.frame_buffer() if rank == 0 else None
     if rank == 0:
         assert out.shape[0] >= height and out.shape[0] % (block * world) == 0
-    for f in frames:                       # bench.py's loop: render into local_buffer(), submit, next frame
+    for k, f in enumerate(frames):         # bench.py's loop: render into local_buffer(), submit, next frame
         local = g.local_buffer()
         local.zero_()
-        for i, (a, b) in enumerate(plan.blocks_of(rank)):
+        strip = g.strip_of(k)              # the strip assignment rotates with the frame number, as in bench.py
+        assert strip == (rank + k) % world
+        for i, (a, b) in enumerate(plan.blocks_of(strip)):
             local[i, :b - a] = f[a:b]
-        r = g.submit(out)
+        r = g.submit(out, rotation=k)
         if r is not None:
             got.append(r.clone())
     r = g.drain(out)
@@ -101,7 +103,7 @@ def _pipelined_worker(rank, world, port, out_dir):
         got.append(r.clone())
     assert g.frames_done == len(frames)
     if rank == 0:
-        # every frame comes out exactly once, in order (the drain returns the last one)
+        # every frame comes out exactly once, in order (the drain returns the last one), correctly un-rotated
         assert len(got) >= 1 and torch.equal(got[-1], frames[-1])
         for k, fr in enumerate(got[:-1]):
             assert any(torch.equal(fr, f) for f in frames)

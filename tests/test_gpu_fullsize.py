@@ -271,3 +271,40 @@ def test_ray_compaction_computes_the_same_frame(name, cfg, size):
                                                                           block_rows=16, compact_out=1))
         d = np.abs(part - px0[48:64]).max(axis=2)
         assert (d > 1e-4).mean() <= 1e-3
+
+
+def test_rotating_strips_with_lookahead_are_bit_identical():
+    """bench.py's multi-GPU loop: the strip a rank renders rotates with the frame number and the next frames' prepasses (which only
+    cover the cells of THEIR strip) are prefetched - every frame must equal the same strip rendered on its own"""
+    import ctypes
+    w, h, world, block = 1280, 720, 4, 16
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    dbg, levels = background()
+    feats = metric.features(adaptive_sampling=0)
+    cfg = metric.cfg_values(a=0.45)
+    cam = gra.default_camera()
+    rows = ((h + block - 1) // block + world - 1) // world * block
+
+    def strip_frame(state, out, strip, nxt=None, nxt2=None):
+        o = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=strip, strip_count=world, block_rows=block, compact_out=1)
+        if nxt is not None:
+            o.next_camera, o.next_strip_rank = ctypes.pointer(cam), nxt
+        if nxt2 is not None:
+            o.next_camera2, o.next_strip_rank2 = ctypes.pointer(cam), nxt2
+        state.render(prog, metric, cam, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfg, o)
+
+    alone = {}
+    for strip in range(world):
+        st, out = gra.RenderState(w, h, 0), DeviceBuffer(0, rows * w * 16)
+        strip_frame(st, out, strip)
+        st.synchronize()
+        alone[strip] = out.to_numpy(np.float32, (rows, w, 4))
+    assert not np.array_equal(alone[0], alone[1])
+    state = gra.RenderState(w, h, 0)
+    outs = [DeviceBuffer(0, rows * w * 16) for _ in range(7)]
+    for k in range(7):
+        strip_frame(state, outs[k], k % world, (k + 1) % world, (k + 2) % world)
+    state.synchronize()
+    for k in range(7):
+        assert np.array_equal(outs[k].to_numpy(np.float32, (rows, w, 4)), alone[k % world]), k

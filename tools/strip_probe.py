@@ -19,7 +19,8 @@ outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in rang
 camera = gra.default_camera()
 look = ctypes.pointer(camera)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
-  for inflight in (1, 2, 3, 4, 6):
+  for rotate in (False, True):
+   for inflight in (1, 3):
     for depth in (2,):
         counter = [0]
 
@@ -27,7 +28,11 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             k = counter[0] % inflight
             counter[0] += 1
             state, out, stream = states[k], outs[k], streams[k].cuda_stream
-            o = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=0, strip_count=world, block_rows=16, compact_out=1)
+            kf = counter[0] - 1
+            o = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=(kf % world) if rotate else 0, strip_count=world, block_rows=16, compact_out=1)
+            if rotate:
+                o.next_strip_rank = (kf + inflight) % world
+                o.next_strip_rank2 = (kf + 2 * inflight) % world
             if depth >= 1:
                 o.next_camera = look
             if depth >= 2:
@@ -42,4 +47,4 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             frame()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t) / n * 1e3
-        print(f"1 of {world} ranks, {inflight} frames in flight, look-ahead depth {depth}: {ms:6.3f} ms/frame  -> {W * H / ms / 1e3:8.1f} Mrays/s if every rank keeps up", flush=True)
+        print(f"1 of {world} ranks, rotate={rotate}, {inflight} frames in flight, look-ahead depth {depth}: {ms:6.3f} ms/frame  -> {W * H / ms / 1e3:8.1f} Mrays/s if every rank keeps up", flush=True)
