@@ -793,7 +793,30 @@ __device__ __forceinline__ int integrate_core(ray_state& s, cfg_t cfg, dfg_t dfg
     paused = false;
 
     int i = RESUMABLE ? s.steps : 0;
-    for (; i < loop_limit;) {
+    // The reference leaves the loop at its top in four ways (step cap, cylindrical singularity, runaway guard: lost; boundary
+    // reached: terminated; cl.cl:3990-4060).  Here they are one combined exit - one exec-mask update per attempt instead of
+    // four (scalar instructions are ~10 % of the loop's time on this GPU) - and the outcome is read off the final state after the
+    // loop.  The other exits (singularity detection, degenerate values) leave a state on which these tests say "lost" as well:
+    // a pre-step state that has just passed them, or NaN/Inf, which no comparison accepts.
+    auto stop_lost = [&](float4 pos, float4 vel, float4 acc, float run, int steps) {
+        bool lost = steps >= loop_limit;
+#ifdef HAS_CYLINDRICAL_SINGULARITY
+        lost |= pos.y < CYLINDRICAL_TERMINATOR;
+#endif
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        lost |= __builtin_fabsf(vel.x / run) > 1000 + f_in_x && __builtin_fabsf(acc.x / run) > 100;
+#endif
+        (void)pos; (void)vel; (void)acc; (void)run;
+        return lost;
+    };
+    auto stop_terminated = [&](float4 polar) {
+        bool t = __builtin_fabsf(polar.y) >= universe;
+#ifdef SINGULAR
+        t |= __builtin_fabsf(polar.y) < SINGULAR_TERMINATOR;
+#endif
+        return t;
+    };
+    for (;;) {
 #ifdef IS_CONSTANT_THETA
         position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
 #endif
@@ -810,20 +833,27 @@ __device__ __forceinline__ int integrate_core(ray_state& s, cfg_t cfg, dfg_t dfg
         if (ar < new_max) ds = __builtin_fminf(ds, ambient_precision);
         else ds = 0.1f * (ar - new_max) + ambient_precision;
 
-        bool should_terminate = __builtin_fabsf(polar.y) >= universe;
-#ifdef SINGULAR
-        should_terminate |= __builtin_fabsf(polar.y) < SINGULAR_TERMINATOR;
-#endif
-#ifdef HAS_CYLINDRICAL_SINGULARITY
-        if (position.y < CYLINDRICAL_TERMINATOR) break;
-#endif
-#ifndef UNCONDITIONALLY_NONSINGULAR
-        if (__builtin_fabsf(velocity.x / running) > 1000 + f_in_x && __builtin_fabsf(acceleration.x / running) > 100) break;
-#endif
-        if (should_terminate) { result = RAY_TERMINATED; break; }
+        if (stop_lost(position, velocity, acceleration, running, i) | stop_terminated(polar)) break;
 
         // velocity Verlet (step_verlet)
         tries++;
+#if defined(GR_PROBE_VALU) || defined(GR_PROBE_SALU)
+        // bottleneck probes (tools/README.md): extra independent instructions per attempt; does the frame time follow?
+        {
+#ifdef GR_PROBE_VALU
+            float probe = ds;
+#pragma unroll
+            for (int q = 0; q < GR_PROBE_VALU; q++) asm volatile("v_mul_f32 %0, 0x3f8ccccd, %0" : "+v"(probe));
+            asm volatile("" ::"v"(probe));
+#endif
+#ifdef GR_PROBE_SALU
+            int sprobe = 1;
+#pragma unroll
+            for (int q = 0; q < GR_PROBE_SALU; q++) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sprobe) : : "scc");
+            asm volatile("" ::"s"(sprobe));
+#endif
+        }
+#endif
         const float half_ds = 0.5f * ds, half_ds2 = half_ds * ds;
         float4 next_position = position + velocity * ds + acceleration * half_ds2;
         float4 half_velocity = velocity + acceleration * ds;
@@ -870,6 +900,14 @@ __device__ __forceinline__ int integrate_core(ray_state& s, cfg_t cfg, dfg_t dfg
             // lanes still in the loop = the exec mask; fewer than keep_lanes of them: leave and let the caller refill the wave
             if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < keep_lanes) { paused = true; break; }
         }
+    }
+    if (!paused) {
+        // why the loop was left (see above): the tests of the loop top on the final state, in the reference's order
+        float4 polar = gm::generic_to_spherical(position, cfg);
+#ifdef IS_CONSTANT_THETA
+        polar.z = GR_PIf / 2;
+#endif
+        if (!stop_lost(position, velocity, acceleration, running, i) && stop_terminated(polar)) result = RAY_TERMINATED;
     }
     if (RESUMABLE) { s.next_ds = next_ds; s.steps = i; s.tries = tries; }
     s.position = position;
