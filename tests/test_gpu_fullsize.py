@@ -308,3 +308,43 @@ def test_rotating_strips_with_lookahead_are_bit_identical():
     state.synchronize()
     for k in range(7):
         assert np.array_equal(outs[k].to_numpy(np.float32, (rows, w, 4)), alone[k % world]), k
+
+
+def test_frames_in_flight_on_separate_streams_are_bit_identical():
+    """bench.py's ring: three render states, each on its own stream, frames launched back to back without host synchronisation
+    (look-ahead included) - every frame must equal the one rendered alone"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")      # plain HIP streams (the library's own runtime; no torch in this process)
+    w, h, n = 1280, 720, 9
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    dbg, levels = background()
+    feats = metric.features(adaptive_sampling=0)
+    cfg = metric.cfg_values(a=0.45)
+    cams = [gra.default_camera([0, 0.15 * k, -4 - 0.2 * k, 0.1 * k]) for k in range(n)]
+    alone = []
+    st = gra.RenderState(w, h, 0)
+    single = DeviceBuffer(0, w * h * 16)
+    for k in range(n):
+        st.render(prog, metric, cams[k], single.ptr, (dbg.ptr, 1024, 512, levels), feats, cfg, gra.frame_options(mode=gra.MODE_FUSED))
+        st.synchronize()
+        alone.append(single.to_numpy(np.float32, (h, w, 4)))
+    ring = 3
+    states = [gra.RenderState(w, h, 0) for _ in range(ring)]
+    streams = []
+    for _ in range(ring):
+        handle = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(handle), 1) == 0       # hipStreamNonBlocking
+        streams.append(handle)
+    outs = [DeviceBuffer(0, w * h * 16) for _ in range(n)]
+    for k in range(n):
+        o = gra.frame_options(mode=gra.MODE_FUSED)
+        if k + ring < n:
+            o.next_camera = ctypes.pointer(cams[k + ring])          # the frame this state renders next
+        if k + 2 * ring < n:
+            o.next_camera2 = ctypes.pointer(cams[k + 2 * ring])
+        states[k % ring].render(prog, metric, cams[k], outs[k].ptr, (dbg.ptr, 1024, 512, levels), feats, cfg, o, streams[k % ring])
+    for st_ in states:
+        st_.synchronize()
+    for k in range(n):
+        assert np.array_equal(outs[k].to_numpy(np.float32, (h, w, 4)), alone[k]), k
