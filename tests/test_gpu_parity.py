@@ -235,3 +235,21 @@ def test_step_attempts_match_oracle(name):
         got["substituted fused" if substituted else "dynamic fused"] = state.attempts()
     for label, att in got.items():
         assert abs(att - want) <= 0.003 * want, (label, att, want)
+
+
+def test_randomised_poses_and_features_match_the_oracle():
+    """one random case per shipped metric (parameters, camera pose and orientation, observer speed, redshift / reparameterisation /
+    field of view / universe size), dynamic and substituted program, against the CPU oracle: tools/fuzz_parity.py with a fixed seed"""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    argv = sys.argv
+    try:
+        sys.argv = ["fuzz_parity.py", "9", "7"]
+        assert fuzz.main() == 0
+    finally:
+        sys.argv = argv

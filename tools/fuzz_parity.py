@@ -1,0 +1,94 @@
+"""Randomised parity soak (GPU box): random metric / parameters / camera pose / observer speed / features, small frames, the HIP
+fused kernel (dynamic and substituted program) against the CPU oracle (oracle/restate.cpp, pinned to the reference's kernels).
+Prints one line per case and a summary; exit status 1 if a case is outside the end-to-end tolerance of the parity tests.
+usage: PYTHONPATH=. python tools/fuzz_parity.py [cases] [seed]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import geodesic_raytracing_amd as gra  # noqa: E402
+from geodesic_raytracing_amd.pipeline import DeviceBuffer  # noqa: E402
+from oracle import build_restate  # noqa: E402
+from oracle.refpipe import OraclePipeline, pack_features  # noqa: E402
+
+SCRIPTS = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
+METRICS = {  # name -> parameter ranges
+    "minkowski": {}, "schwarzschild": {}, "kerr_boyer": {"a": (-0.49, 0.49)}, "alcubierre": {}, "schwarzschild_ingoing_ef": {},
+    "wormhole": {}, "cosmic_string": {"mu": (0.0, 0.1)}, "kerr_newman_boyer": {"a": (-0.3, 0.3), "rq": (0.0, 0.3)},
+    "kerr_schild": {"a": (-0.45, 0.45)},
+}
+
+
+def quat_from_axis_angle(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    axis /= np.linalg.norm(axis)
+    s = np.sin(angle / 2)
+    return [float(axis[0] * s), float(axis[1] * s), float(axis[2] * s), float(np.cos(angle / 2))]
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return [aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw,
+            aw * bw - ax * bx - ay * by - az * bz]
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+    w, h = 64, 36
+    bg_np, levels = gra.pack_background(gra.synthetic_background(256, 128))
+    bg = DeviceBuffer.from_numpy(0, bg_np)
+    out = DeviceBuffer(0, w * h * 16)
+    state = gra.RenderState(w, h, 0)
+    oracles, worst, failed = {}, 0.0, 0
+    names = sorted(METRICS)
+    for case in range(cases):
+        name = names[case % len(names)]
+        metric = gra.Metric(name, SCRIPTS)
+        params = {k: float(rng.uniform(*r)) for k, r in METRICS[name].items()}
+        cfg = metric.cfg_values(**params)
+        r = float(rng.uniform(3.0, 12.0))
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        pos = [float(rng.uniform(-1, 1))] + [float(x) for x in r * direction]
+        base = quat_from_axis_angle([1, 0, 0], -np.pi / 2)
+        quat = quat_mul(quat_from_axis_angle(rng.normal(size=3), float(rng.uniform(0, 1.0))), base)
+        speed = [float(x) for x in rng.uniform(-0.3, 0.3, 3)] if rng.random() < 0.5 else [0.0, 0.0, 0.0]
+        fkw = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change, redshift=int(rng.random() < 0.4),
+                   reparameterisation=int(rng.random() < 0.25), field_of_view=float(rng.choice([60.0, 90.0, 110.0])),
+                   universe_size=float(rng.choice([20.0, 30.0])), max_precision_radius=float(rng.choice([10.0, 14.0])))
+        feats = gra.default_features(**fkw)
+        key = metric.argument_string()
+        if key not in oracles:
+            oracles[key] = OraclePipeline(build_restate.build(key))
+        ref = oracles[key].frame(w, h, cfg, pack_features(**fkw), camera_pos=pos, camera_quat=quat, basis_speed=speed,
+                                 background=(bg_np, levels), nthreads=os.cpu_count() or 4)
+        oracles[key].lib.ref_last_attempts.restype = ctypes.c_uint64
+        cam = gra.default_camera(pos, quat)
+        cam.basis_speed = (gra.c_float * 3)(*speed)
+        line = f"{case:3d} {name:26s} r={r:5.2f} speed={int(any(speed))} redshift={fkw['redshift']} reparam={fkw['reparameterisation']}"
+        for label, prog in (("dyn", gra.Program(key, 0)),
+                            ("sub", gra.Program(metric.argument_string(features=feats, static=True, cfg_values=cfg), 0))):
+            o = gra.frame_options(mode=gra.MODE_FUSED, use_prepass=0, count_attempts=1)
+            state.render(prog, metric, cam, out.ptr, (bg.ptr, bg_np.shape[2], bg_np.shape[1], levels), feats, cfg, o)
+            state.synchronize()
+            px = out.to_numpy(np.float32, (h, w, 4))
+            d = px[..., :3] - ref["pixels"][..., :3]
+            bad = np.abs(d).max(axis=2) > 1e-3
+            rmse = float(np.sqrt((d[~bad] ** 2).mean())) if (~bad).any() else 0.0
+            ok = bad.mean() <= 0.01 and rmse <= 1e-4 and np.isfinite(px).all()
+            failed += not ok
+            worst = max(worst, rmse)
+            line += f" | {label}: rmse {rmse:.1e} off {bad.mean() * 100:4.1f}%{'' if ok else '  <-- FAIL'}"
+        print(line, flush=True)
+    print(f"{cases} cases x 2 programs: {failed} outside tolerance, worst masked RMSE {worst:.2e}")
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
