@@ -135,6 +135,9 @@ _SIGNATURES = {
     "gr_device_alloc": (c_int, [c_int, c_size_t, ctypes.POINTER(c_void_p)]),
     "gr_device_free": (c_int, [c_int, c_void_p]),
     "gr_device_synchronize": (c_int, [c_int]),
+    "gr_stream_create": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_stream_synchronize": (c_int, [c_void_p]),
+    "gr_stream_destroy": (c_int, [c_void_p]),
     "gr_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "gr_pack_mipped_background": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "gr_frame_to_rgba8": (c_int, [c_void_p, c_int, c_int, c_void_p]),

@@ -191,6 +191,28 @@ int gr_device_upload(int device, void* dst, const void* src, size_t bytes) {
     HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return GR_OK;
 }
+int gr_stream_create(int device, int high_priority, void** out) {
+    if (!out) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    HIP_CHECK(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    if (high_priority) {
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
+    } else {
+        HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+    *out = (void*)s;
+    return GR_OK;
+}
+int gr_stream_synchronize(void* stream) {
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return GR_OK;
+}
+int gr_stream_destroy(void* stream) {
+    if (stream) HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return GR_OK;
+}
 int gr_device_synchronize(int device) {
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipDeviceSynchronize());

@@ -380,6 +380,11 @@ int gr_device_upload(int device, void* device_dst, const void* host_src, size_t 
 int gr_device_alloc(int device, size_t bytes, void** out);
 int gr_device_free(int device, void* ptr);
 int gr_device_synchronize(int device);
+/* HIP streams of the library's own runtime (the role of the reference's cl::command_queue objects, main.cpp:1458-1461): one per
+ * frame in flight.  A caller that already has hipStream_t handles from the same runtime can pass those instead. */
+int gr_stream_create(int device, int high_priority, void** stream_out);
+int gr_stream_synchronize(void* stream);
+int gr_stream_destroy(void* stream);
 int gr_device_count(int* count);
 
 /* ---- host helper: background image ----------------------------------------------------------- */

@@ -314,7 +314,6 @@ def test_frames_in_flight_on_separate_streams_are_bit_identical():
     """bench.py's ring: three render states, each on its own stream, frames launched back to back without host synchronisation
     (look-ahead included) - every frame must equal the one rendered alone"""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")      # plain HIP streams (the library's own runtime; no torch in this process)
     w, h, n = 1280, 720, 9
     metric = gra.Metric("kerr_boyer")
     prog = gra.Program(metric.argument_string(), 0)
@@ -334,7 +333,7 @@ def test_frames_in_flight_on_separate_streams_are_bit_identical():
     streams = []
     for _ in range(ring):
         handle = ctypes.c_void_p()
-        assert hip.hipStreamCreateWithFlags(ctypes.byref(handle), 1) == 0       # hipStreamNonBlocking
+        gra.check(gra.lib.gr_stream_create(0, 0, ctypes.byref(handle)))     # streams of the library's own HIP runtime
         streams.append(handle)
     outs = [DeviceBuffer(0, w * h * 16) for _ in range(n)]
     for k in range(n):
@@ -348,3 +347,5 @@ def test_frames_in_flight_on_separate_streams_are_bit_identical():
         st_.synchronize()
     for k in range(n):
         assert np.array_equal(outs[k].to_numpy(np.float32, (h, w, 4)), alone[k]), k
+    for handle in streams:
+        gra.check(gra.lib.gr_stream_destroy(handle))
