@@ -1,7 +1,7 @@
 """Randomised parity soak (GPU box): random metric / parameters / camera pose / observer speed / features, small frames, the HIP
 fused kernel (dynamic and substituted program) against the CPU oracle (oracle/restate.cpp, pinned to the reference's kernels).
 Prints one line per case and a summary; exit status 1 if a case is outside the end-to-end tolerance of the parity tests.
-usage: PYTHONPATH=. python tools/fuzz_parity.py [cases] [seed]"""
+Test infrastructure (it runs the oracle).  usage: PYTHONPATH=. python tests/fuzz_parity.py [cases] [seed]"""
 import ctypes
 import os
 import sys

@@ -239,11 +239,11 @@ def test_step_attempts_match_oracle(name):
 
 def test_randomised_poses_and_features_match_the_oracle():
     """one random case per shipped metric (parameters, camera pose and orientation, observer speed, redshift / reparameterisation /
-    field of view / universe size), dynamic and substituted program, against the CPU oracle: tools/fuzz_parity.py with a fixed seed"""
+    field of view / universe size), dynamic and substituted program, against the CPU oracle: tests/fuzz_parity.py with a fixed seed"""
     import importlib.util
     import os
     import sys
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_parity.py")
     spec = importlib.util.spec_from_file_location("fuzz_parity", path)
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
