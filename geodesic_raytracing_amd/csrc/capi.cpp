@@ -303,6 +303,7 @@ int gr_metric_argument_string(const gr_metric* m, const gr_features* features, i
         s = gr::build_argument_string(m->desc, m->desc.raw, m->cfg, m->vars, false, fc);
     }
     if (needed) *needed = s.size() + 1;
+    if (!buffer && capacity == 0 && needed) return GR_OK;   // size query
     if (!buffer || capacity < s.size() + 1) return fail(GR_ERROR_BUFFER_TOO_SMALL, "buffer too small");
     memcpy(buffer, s.c_str(), s.size() + 1);
     return GR_OK;

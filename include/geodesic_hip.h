@@ -116,7 +116,8 @@ float gr_metric_dynamic_var_default(const gr_metric* m, int index);
  *                  feature struct (KERNEL_IS_DYNAMIC);
  *   is_static = 1: "substituted" program - cfg_values (NULL = defaults) and `features` are baked in
  *                  as literals (KERNEL_IS_STATIC), metric_manager.hpp:153-166.
- * Writes a NUL-terminated string; *needed receives the required capacity including the NUL. */
+ * Writes a NUL-terminated string; *needed receives the required capacity including the NUL.
+ * buffer = NULL with capacity = 0 is a size query and returns GR_OK. */
 int gr_metric_argument_string(const gr_metric* m, const gr_features* features, int is_static,
                               const float* cfg_values, int num_cfg_values,
                               char* buffer, size_t capacity, size_t* needed);

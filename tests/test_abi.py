@@ -132,3 +132,18 @@ def test_png_round_trip_and_screenshot_conversion(tmp_path):
     assert np.array_equal(back[..., :3], img) and (back[..., 3] == 255).all()
     with pytest.raises(gra.GeodesicError):
         read_png(str(tmp_path / "missing.png"))
+
+
+def test_cpp_example_builds_against_the_header_alone():
+    """examples/render_kerr.cpp uses nothing but include/geodesic_hip.h and the shared library (no HIP headers, no Python):
+    it must compile and link; without a GPU it must stop at the first device call with the library's error message"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
+    exe = os.path.join(root, "examples", "render_kerr")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, os.path.join(root, "geodesic_raytracing_amd", "scripts"), "kerr_boyer", "64", "36", "/tmp/never.png"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:              # no GPU here: the first device call must say so
+        assert "gr_program_create" in r.stderr and "device" in r.stderr.lower()
