@@ -49,7 +49,7 @@ class FrameOptions(ctypes.Structure):
                 ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera)), ("geodesic", c_void_p),
                 ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("parallel_transport_observer", c_int),
                 ("ray_compaction", c_int), ("next_camera2", ctypes.POINTER(Camera)), ("next_geodesic_time2", c_float),
-                ("next_strip_rank", c_int), ("next_strip_rank2", c_int)]
+                ("next_strip_rank", c_int), ("next_strip_rank2", c_int), ("rays_per_lane", c_int)]
 
 
 MODE_REFERENCE, MODE_FUSED = 0, 1
@@ -101,6 +101,9 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "gr_trace_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gr_trace_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gr_program_has_trace_pair": (c_int, [c_void_p]),
     "gr_trace_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "gr_boost_tetrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

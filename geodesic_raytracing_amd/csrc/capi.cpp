@@ -83,11 +83,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_compact", "gr_prepass_fused", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_COMPACT, K_PREPASS_FUSED, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -97,6 +97,33 @@ std::vector<std::string> split_arguments(const std::string& s) {
     std::string tok;
     while (iss >> tok) out.push_back(tok);
     return out;
+}
+
+// gr_trace_pair (two rays per lane, packed fp32) is built when
+//  * the expressions evaluated inside the Verlet loop can be instantiated on pairs of floats - no `?:` (the comparison /
+//    select forms of CMath.lt, CMath.select, csqrt) - and are small enough that two rays' temporaries fit the register
+//    file (the complex-valued double-Kerr family already needs 170-260 VGPRs for one ray), and
+//  * the program steps with the fixed heuristic step (no ADAPTIVE_PRECISION).  Measured on MI355X, 4K frames, substituted
+//    programs: Schwarzschild 1.96 -> 1.38 ms, Minkowski 1.80 -> 1.16, wormhole 1.83 -> 1.42; with the adaptive controller
+//    Kerr 7.9 -> 9.3 ms, Alcubierre 3.0 -> 3.3: the controller (sqrt, rsq, clamps, compares, the per-ray commit) has no
+//    packed form, costs twice per lane what it costs the one-ray kernel per lane, and at 133 instead of 92 VGPRs only three
+//    waves per SIMD are left to hide its serial tail - that outweighs what the packed multiplies save.
+// GR_TRACE_PAIR_BUILD=0 never builds it, =1 builds it for adaptive programs too (it is correct there, only slower).
+bool pair_kernel_applies(const std::vector<std::string>& opts) {
+    int mode = -1;
+    if (const char* e = getenv("GR_TRACE_PAIR_BUILD")) mode = e[0] == '0' ? 0 : e[0] == '1' ? 1 : -1;
+    if (mode == 0) return false;
+    static const char* const LOOP_MACROS[] = {"-DGEO_ACCEL", "-DTEMPORARIES0=", "-DTO_COORD", "-DDISTANCE_FUNC="};
+    size_t total = 0;
+    for (auto& o : opts) {
+        if (mode != 1 && o == "-DADAPTIVE_PRECISION") return false;
+        for (const char* m : LOOP_MACROS)
+            if (o.rfind(m, 0) == 0) {
+                if (o.find('?') != std::string::npos) return false;
+                total += o.size();
+            }
+    }
+    return total > 0 && total < 16384;
 }
 
 // Compiles (or fetches from the on-disk cache) the code object for one macro string.
@@ -128,6 +155,7 @@ int compile_code_object(const std::string& argument_string, std::string& code) {
         else if (tok.rfind("-cl-", 0) == 0 || tok == "-I" || tok == "./") continue;   // OpenCL-only prefix flags
         else return fail(GR_ERROR_INVALID_ARGUMENT, "unsupported token in argument string: " + tok);
     }
+    if (pair_kernel_applies(opts)) opts.push_back("-DGR_TWO_RAYS_PER_LANE");
     if (const char* extra = getenv("GR_EXTRA_FLAGS"))
         for (auto& tok : split_arguments(extra)) opts.push_back(tok);
 
@@ -326,7 +354,13 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
     p->device = device;
     p->arguments = argument_string;
     HIP_CHECK(hipModuleLoadData(&p->module, code.data()));
-    for (int k = 0; k < K_COUNT; k++) HIP_CHECK(hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]));
+    for (int k = 0; k < K_COUNT; k++) {
+        if (k == K_TRACE_PAIR) {   // built for some metrics only (pair_kernel_applies)
+            if (hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]) != hipSuccess) { p->fn[k] = nullptr; (void)hipGetLastError(); }
+            continue;
+        }
+        HIP_CHECK(hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]));
+    }
     const int huge = 0x7fffffff;
     HIP_CHECK(hipMalloc((void**)&p->tickets, gr_program::TICKET_RING * sizeof(unsigned int)));
     HIP_CHECK(hipDeviceGetAttribute(&p->compute_units, hipDeviceAttributeMultiprocessorCount, p->device));
@@ -530,11 +564,15 @@ int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, co
                                    prepass_height * 16, 8, 0, 1);
 }
 
-int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
-                   int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
-                   int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
-                   const void* dfg, void* attempt_counter) {
+// gr_trace_fused (rays_per_lane 1) and gr_trace_pair (2): same tiles, same arguments; a pair wave takes two tile-waves
+static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const void* camera_generic, const void* camera_quat, void* rdata,
+                        int width, int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
+                        int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
+                        const void* dfg, void* attempt_counter) {
     const int T = 8;
+    if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
+    if (rays_per_lane == 2 && !p->fn[K_TRACE_PAIR])
+        return fail(GR_ERROR_INVALID_ARGUMENT, "this program has no gr_trace_pair kernel (its expressions do not instantiate on pairs)");
     if (strip_count <= 1) {   // one block covering the image
         strip_count = 1;
         strip_rank = 0;
@@ -555,7 +593,7 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
     if (waves <= 0) return GR_OK;
     if (waves > 0x7fffffff) return fail(GR_ERROR_INVALID_ARGUMENT, "too many tiles");
     int total_waves = (int)waves;
-    long long groups = (waves * 64 + wg - 1) / wg;
+    long long groups = ((waves + rays_per_lane - 1) / rays_per_lane * 64 + wg - 1) / wg;
     unsigned int* tickets = nullptr;
     // persistent mode only pays when there are more tiles than wave slots (8 per SIMD, 4 SIMDs per CU)
     // experiment hook: GR_TRACE_WAVES_PER_SIMD=k launches only k persistent waves per SIMD (occupancy scaling studies)
@@ -569,8 +607,26 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
     }
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves};
-    return launch(p, K_TRACE_FUSED, stream, (unsigned)groups, 1, wg, 1, args);
+    return launch(p, rays_per_lane == 2 ? K_TRACE_PAIR : K_TRACE_FUSED, stream, (unsigned)groups, 1, wg, 1, args);
 }
+
+int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
+                   int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
+                   int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
+                   const void* dfg, void* attempt_counter) {
+    return trace_launch(p, 1, stream, camera_generic, camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, term,
+                        prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter);
+}
+
+int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
+                  int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
+                  int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
+                  const void* dfg, void* attempt_counter) {
+    return trace_launch(p, 2, stream, camera_generic, camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, term,
+                        prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter);
+}
+
+int gr_program_has_trace_pair(const gr_program* p) { return p && p->fn[K_TRACE_PAIR] ? 1 : 0; }
 
 int gr_trace_compact(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
                      int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,

@@ -3,6 +3,10 @@
 // Reference counterparts: render_state.hpp:97-197 (buffers), main.cpp:2244-2526 (the sequence of
 // launches on one in-order queue), execute_kernel main.cpp:139-205.  Everything is asynchronous on
 // the caller's stream; the only host->device traffic per frame is camera (48 B), cfg and features.
+// library default of gr_frame_options.rays_per_lane = 0 (see include/geodesic_hip.h)
+#ifndef GR_DEFAULT_RAYS_PER_LANE
+#define GR_DEFAULT_RAYS_PER_LANE 2   /* where the program has gr_trace_pair (capi.cpp: pair_kernel_applies) */
+#endif
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
@@ -164,6 +168,7 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->next_strip_rank2 = -1;
     o->next_camera2 = nullptr;
     o->next_geodesic_time2 = 0;
+    o->rays_per_lane = 0;
 }
 
 int gr_device_count(int* count) {
@@ -648,11 +653,19 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                       strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
                                       use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
                                       s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, keep_lanes));
-        else
-            GR_CHECK(gr_trace_fused(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
-                                    strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
-                                    use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
-                                    s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
+        else {
+            // two rays per lane (gr_trace_pair) where the program has that kernel, unless told otherwise
+            static const int default_rays_per_lane = [] { const char* e = getenv("GR_TRACE_RAYS_PER_LANE"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : GR_DEFAULT_RAYS_PER_LANE; }();
+            int rays_per_lane = opt.rays_per_lane == 1 || opt.rays_per_lane == 2 ? opt.rays_per_lane : default_rays_per_lane;
+            if (rays_per_lane == 2 && !gr_program_has_trace_pair(p)) {
+                if (opt.rays_per_lane == 2) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2: this program has no gr_trace_pair kernel");
+                rays_per_lane = 1;
+            }
+            GR_CHECK((rays_per_lane == 2 ? gr_trace_pair : gr_trace_fused)(
+                p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows, strip_rank, strip_count,
+                use_prepass ? s->termination_buffer : nullptr, use_prepass ? prepass_width : width, use_prepass ? prepass_height : height,
+                s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
+        }
         GR_CHECK(end(GR_STAGE_TRACE));
         for (const auto& r : todo) {
             // a free slot, else the stalest one no current request claims (a camera that was announced but never came)

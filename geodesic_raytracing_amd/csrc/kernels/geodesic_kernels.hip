@@ -311,6 +311,110 @@ __device__ __forceinline__ float distance_to_object(float4 polar, cfg_t cfg) {
     return DISTANCE_FUNC;
 }
 
+#ifdef GR_TWO_RAYS_PER_LANE
+// --- the same hosts for two rays per lane (gr_trace_pair): every variable of the generated expressions is a pair of
+// floats, one per ray, so their multiplies, adds and fmas become v_pk_mul/add/fma_f32 with nothing to shuffle ------------
+typedef float pairf __attribute__((ext_vector_type(2)));
+typedef unsigned int pairu __attribute__((ext_vector_type(2)));
+struct pair4 { pairf x, y, z, w; };
+
+__device__ __forceinline__ pairf pfma(pairf a, pairf b, pairf c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ pairf splat(float x) { pairf r; r.x = x; r.y = x; return r; }
+struct sincos_pairf { pairf s, c; };
+// sincos_reduced (above), both rays at once; the quadrant select stays per ray (v_cndmask has no packed form)
+__device__ __forceinline__ sincos_pairf sincos_reduced(pairf x) {
+#pragma clang fp reassociate(off)
+    pairf t = pfma(x, splat(0.636619772367581343f), splat(12582912.f));
+    pairf j = t - splat(12582912.f);
+    pairu q = __builtin_bit_cast(pairu, t);
+    pairf r = pfma(-j, splat(1.57079637050628662109375f), x);
+    r = pfma(-j, splat(-4.37113900018624283e-8f), r);
+    pairf r2 = r * r;
+    pairf sp = pfma(pfma(pfma(splat(-1.9515295891e-4f), r2, splat(8.3321608736e-3f)), r2, splat(-1.6666654611e-1f)), r2 * r, r);
+    pairf cp = pfma(pfma(pfma(splat(2.443315711809948e-5f), r2, splat(-1.388731625493765e-3f)), r2, splat(4.166664568298827e-2f)),
+                    r2 * r2, pfma(splat(-0.5f), r2, splat(1.0f)));
+    pairf s, c;
+    s.x = (q.x & 1) ? cp.x : sp.x; s.y = (q.y & 1) ? cp.y : sp.y;
+    c.x = (q.x & 1) ? sp.x : cp.x; c.y = (q.y & 1) ? sp.y : cp.y;
+    pairu two; two.x = 2u; two.y = 2u;
+    pairu one; one.x = 1u; one.y = 1u;
+    pairu sh; sh.x = 30u; sh.y = 30u;
+    s = __builtin_bit_cast(pairf, __builtin_bit_cast(pairu, s) ^ ((q & two) << sh));
+    c = __builtin_bit_cast(pairf, __builtin_bit_cast(pairu, c) ^ (((q + one) & two) << sh));
+    return {s, c};
+}
+// the never-in-practice large-argument case goes through one out-of-line libm call per value: inlined (as in the one-ray
+// kernel) its four copies cost the pair kernel scalar-register spills
+__device__ __attribute__((noinline)) float sin_large(float x) { return ::sinf(x); }
+__device__ __attribute__((noinline)) float cos_large(float x) { return ::cosf(x); }
+__device__ __forceinline__ pairf sin(pairf x) {
+#if defined(GR_FAST_TRIG) || defined(GR_LIBM_TRIG)
+    pairf s; s.x = gm::sin(x.x); s.y = gm::sin(x.y);
+#else
+    pairf s = sincos_reduced(x).s;
+    if (__builtin_expect(!(__builtin_fabsf(x.x) < 8192.f) || !(__builtin_fabsf(x.y) < 8192.f), 0)) { s.x = sin_large(x.x); s.y = sin_large(x.y); }
+#endif
+    return s;
+}
+__device__ __forceinline__ pairf cos(pairf x) {
+#if defined(GR_FAST_TRIG) || defined(GR_LIBM_TRIG)
+    pairf c; c.x = gm::cos(x.x); c.y = gm::cos(x.y);
+#else
+    pairf c = sincos_reduced(x).c;
+    if (__builtin_expect(!(__builtin_fabsf(x.x) < 8192.f) || !(__builtin_fabsf(x.y) < 8192.f), 0)) { c.x = cos_large(x.x); c.y = cos_large(x.y); }
+#endif
+    return c;
+}
+// everything else the expressions may call: once per ray
+#define GR_PAIR_FN1(name) \
+    __device__ __forceinline__ pairf name(pairf x) { pairf r; r.x = gm::name(x.x); r.y = gm::name(x.y); return r; }
+#define GR_PAIR_FN2(name) \
+    __device__ __forceinline__ pairf name(pairf x, pairf y) { pairf r; r.x = gm::name(x.x, y.x); r.y = gm::name(x.y, y.y); return r; } \
+    __device__ __forceinline__ pairf name(pairf x, float y) { pairf r; r.x = gm::name(x.x, y); r.y = gm::name(x.y, y); return r; }     \
+    __device__ __forceinline__ pairf name(float x, pairf y) { pairf r; r.x = gm::name(x, y.x); r.y = gm::name(x, y.y); return r; }
+GR_PAIR_FN1(tan) GR_PAIR_FN1(asin) GR_PAIR_FN1(acos) GR_PAIR_FN1(atan) GR_PAIR_FN1(exp) GR_PAIR_FN1(log) GR_PAIR_FN1(sqrt)
+GR_PAIR_FN1(fabs) GR_PAIR_FN1(sinh) GR_PAIR_FN1(cosh) GR_PAIR_FN1(tanh) GR_PAIR_FN1(sign)
+GR_PAIR_FN2(atan2) GR_PAIR_FN2(pow) GR_PAIR_FN2(fmod) GR_PAIR_FN2(fmin) GR_PAIR_FN2(fmax)
+#undef GR_PAIR_FN1
+#undef GR_PAIR_FN2
+
+#define GR_POSITION_VARS_PAIR(p) \
+    const pairf v1 = (p).x; const pairf v2 = (p).y; const pairf v3 = (p).z; const pairf v4 = (p).w; \
+    const float rs = RS_IMPL; const float c = C_IMPL; (void)v1; (void)v2; (void)v3; (void)v4; (void)rs; (void)c;
+
+__device__ __forceinline__ pair4 geodesic_acceleration(pair4 pos, pair4 vel, cfg_t cfg) {
+#ifdef GENERIC_CONSTANT_THETA
+    pos.z = splat(GR_PIf / 2);
+    vel.z = splat(0.f);
+#endif
+    GR_POSITION_VARS_PAIR(pos)
+    const pairf iv1 = vel.x; const pairf iv2 = vel.y; const pairf iv3 = vel.z; const pairf iv4 = vel.w;
+    (void)iv1; (void)iv2; (void)iv3; (void)iv4;
+    pairf TEMPORARIES0;
+    pair4 a;
+    a.x = GEO_ACCEL0;
+    a.y = GEO_ACCEL1;
+#ifndef GENERIC_CONSTANT_THETA
+    a.z = GEO_ACCEL2;
+#else
+    a.z = splat(0.f);
+#endif
+    a.w = GEO_ACCEL3;
+    return a;
+}
+__device__ __forceinline__ pair4 generic_to_spherical(pair4 in, cfg_t cfg) {
+    GR_POSITION_VARS_PAIR(in)
+    pair4 r;
+    r.x = TO_COORD1; r.y = TO_COORD2; r.z = TO_COORD3; r.w = TO_COORD4;
+    return r;
+}
+__device__ __forceinline__ pairf distance_to_object(pair4 polar, cfg_t cfg) {
+    GR_POSITION_VARS_PAIR(polar)
+    pairf d = DISTANCE_FUNC;
+    return d;
+}
+#endif  // GR_TWO_RAYS_PER_LANE
+
 }  // namespace gm
 
 // ------------------------------------------------------------------------------------------------
@@ -857,7 +961,11 @@ __device__ __forceinline__ int integrate_core(ray_state& s, cfg_t cfg, dfg_t dfg
         const float half_ds = 0.5f * ds, half_ds2 = half_ds * ds;
         float4 next_position = position + velocity * ds + acceleration * half_ds2;
         float4 half_velocity = velocity + acceleration * ds;
+#ifdef GR_PROBE_NO_ACCEL
+        float4 next_acceleration = f4(acceleration.x * 0.999f, acceleration.y * 0.999f + half_velocity.x * 1e-3f, acceleration.z * 0.999f, acceleration.w * 0.999f + next_position.y * 1e-5f);
+#else
         float4 next_acceleration = gm::geodesic_acceleration(next_position, half_velocity, cfg);
+#endif
         float4 next_velocity = velocity + (acceleration + next_acceleration) * half_ds;
         float K = 1;
         if (reparam) {
@@ -922,6 +1030,218 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
     bool paused;
     return integrate_core<false>(s, cfg, dfg, attempts, 0, paused);
 }
+
+
+#ifdef GR_TWO_RAYS_PER_LANE
+// ---- two rays per lane ---------------------------------------------------------------------------
+// integrate_core with every per-ray float held as a pair (ray 0 in the low, ray 1 in the high half of a 64-bit register
+// pair).  Measured on MI355X (tools/ubench/valu_rate.hip, tools/ubench/accel_rate.hip): an fp32 fma with three VGPR sources
+// issues in 3.8-4.1 cycles per wave64, v_pk_fma_f32 - two of them - in 4.8; v_mul 2.7 against v_pk_mul 4.5.  Three quarters of
+// the instructions of a Verlet attempt are such multiplies and fmas, so one lane stepping two rays gets through ~20 % more
+// attempts per cycle.  What has no packed form (compares, selects, rcp/rsq/sqrt, the commit of an accepted step) is done per
+// half.  The arithmetic of a ray is instruction for instruction that of integrate_core; a ray that has left the loop keeps
+// its state (the commit is per ray) while its partner goes on.
+using gm::pairf;
+using gm::pair4;
+using gm::splat;
+__device__ __forceinline__ pair4 operator+(pair4 a, pair4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ pair4 operator*(pair4 a, pairf s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+template <int H> __device__ __forceinline__ float4 half_of(pair4 v) {
+    return H == 0 ? f4(v.x.x, v.y.x, v.z.x, v.w.x) : f4(v.x.y, v.y.y, v.z.y, v.w.y);
+}
+__device__ __forceinline__ pair4 pair_of(float4 a, float4 b) {
+    pair4 r;
+    r.x.x = a.x; r.x.y = b.x; r.y.x = a.y; r.y.y = b.y; r.z.x = a.z; r.z.y = b.z; r.w.x = a.w; r.w.y = b.w;
+    return r;
+}
+
+#ifdef ADAPTIVE_PRECISION
+__device__ __forceinline__ pairf acceleration_to_precision(pair4 acc, float max_acceleration, pairf& next_ds) {
+    pair4 wa = {acc.x * (float)(W_V1), acc.y * (float)(W_V2), acc.z * (float)(W_V3), acc.w * (float)(W_V4)};
+    pairf d2 = wa.x * wa.x + wa.y * wa.y + wa.z * wa.z + wa.w * wa.w;
+    pairf current;
+    current.x = __builtin_sqrtf(d2.x); current.y = __builtin_sqrtf(d2.y);
+    current = current * 0.01f;
+    current = current / GR_W_MAX;
+    const float scale = 65536.f;
+    float err = max_acceleration;
+    pairf diff = current * scale;
+    float floor_diff = err * scale / 1e10f;
+    if (diff.x < floor_diff) diff.x = floor_diff;
+    if (diff.y < floor_diff) diff.y = floor_diff;
+    const float root = __builtin_sqrtf(err * scale);
+    next_ds.x = root * __builtin_amdgcn_rsqf(diff.x);
+    next_ds.y = root * __builtin_amdgcn_rsqf(diff.y);
+    return diff;
+}
+#endif
+
+// in: the initial states of the two rays (an inactive ray carries a copy of its partner's so that its half computes on
+// benign numbers); out: final position, velocity, running_dlambda_dnew, outcome and attempts per ray
+__device__ __forceinline__ void integrate_pair(pair4& position_io, pair4& velocity_io, pair4 acceleration, pairf& running_out,
+                                               bool active0, bool active1, cfg_t cfg, dfg_t dfg, int& result0, int& result1,
+                                               unsigned int& tries0, unsigned int& tries1) {
+    pair4 position = position_io, velocity = velocity_io;
+    pairf f_in_x;
+    f_in_x.x = __builtin_fabsf(velocity.x.x); f_in_x.y = __builtin_fabsf(velocity.x.y);
+#ifdef IS_CONSTANT_THETA
+    position.z = splat(GR_PIf / 2); velocity.z = splat(0.f); acceleration.z = splat(0.f);
+#endif
+    pairf next_ds = splat(0.00001f);
+#ifdef ADAPTIVE_PRECISION
+    const float max_accel = GET_FEATURE(max_acceleration_change, dfg);
+    const float min_step = GET_FEATURE(min_step, dfg);
+    (void)acceleration_to_precision(acceleration, max_accel, next_ds);
+#endif
+    const float subambient_precision = 0.5f;
+    const float ambient_precision = 0.2f;
+    const float new_max = GET_FEATURE(max_precision_radius, dfg);
+    const float new_min = 3;
+    const float universe = GET_FEATURE(universe_size, dfg);
+    const bool reparam = GET_FEATURE(reparameterisation, dfg) != 0;
+    pairf running = splat(1.f);
+    const int loop_limit = 4096 * 4;
+    unsigned int t0 = 0, t1 = 0;
+    int i0 = 0, i1 = 0;
+    bool alive0 = active0, alive1 = active1;
+
+    // the loop-top tests of integrate_core on one ray's numbers
+    auto stop_lost = [&](float pos_y, float vel_x_over_run, float acc_x_over_run, float fin, int steps) {
+        bool lost = steps >= loop_limit;
+#ifdef HAS_CYLINDRICAL_SINGULARITY
+        lost |= pos_y < CYLINDRICAL_TERMINATOR;
+#endif
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        lost |= __builtin_fabsf(vel_x_over_run) > 1000 + fin && __builtin_fabsf(acc_x_over_run) > 100;
+#endif
+        (void)pos_y; (void)vel_x_over_run; (void)acc_x_over_run; (void)fin;
+        return lost;
+    };
+    auto stop_terminated = [&](float polar_y) {
+        bool t = __builtin_fabsf(polar_y) >= universe;
+#ifdef SINGULAR
+        t |= __builtin_fabsf(polar_y) < SINGULAR_TERMINATOR;
+#endif
+        return t;
+    };
+    for (;;) {
+#ifdef IS_CONSTANT_THETA
+        position.z = splat(GR_PIf / 2); velocity.z = splat(0.f); acceleration.z = splat(0.f);
+#endif
+        pair4 polar = gm::generic_to_spherical(position, cfg);
+#ifdef IS_CONSTANT_THETA
+        polar.z = splat(GR_PIf / 2);
+#endif
+        pairf r_value = gm::distance_to_object(polar, cfg);
+        pairf ar;
+        ar.x = __builtin_fabsf(r_value.x); ar.y = __builtin_fabsf(r_value.y);
+        pairf ds;
+#ifdef ADAPTIVE_PRECISION
+        ds = next_ds;
+#else
+        ds.x = mixf(ambient_precision, subambient_precision, (clampf(ar.x, new_min, new_max) - new_min) / (new_max - new_min));
+        ds.y = mixf(ambient_precision, subambient_precision, (clampf(ar.y, new_min, new_max) - new_min) / (new_max - new_min));
+#endif
+        if (ar.x < new_max) ds.x = __builtin_fminf(ds.x, ambient_precision);
+        else ds.x = 0.1f * (ar.x - new_max) + ambient_precision;
+        if (ar.y < new_max) ds.y = __builtin_fminf(ds.y, ambient_precision);
+        else ds.y = 0.1f * (ar.y - new_max) + ambient_precision;
+
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        const pairf vq = velocity.x / running, aq = acceleration.x / running;
+#else
+        const pairf vq = splat(0.f), aq = splat(0.f);
+#endif
+        alive0 = alive0 && !(stop_lost(position.y.x, vq.x, aq.x, f_in_x.x, i0) | stop_terminated(polar.y.x));
+        alive1 = alive1 && !(stop_lost(position.y.y, vq.y, aq.y, f_in_x.y, i1) | stop_terminated(polar.y.y));
+        if (!(alive0 | alive1)) break;
+        t0 += alive0 ? 1u : 0u;
+        t1 += alive1 ? 1u : 0u;
+
+        // velocity Verlet (step_verlet), both rays
+        const pairf half_ds = ds * 0.5f, half_ds2 = half_ds * ds;
+        pair4 next_position = position + velocity * ds + acceleration * half_ds2;
+        pair4 half_velocity = velocity + acceleration * ds;
+#ifdef GR_PROBE_NO_ACCEL   // experiment: the loop without the metric's acceleration (results meaningless, cycles per attempt only)
+        pair4 next_acceleration = {acceleration.x * 0.999f, acceleration.y * 0.999f + half_velocity.x * 1e-3f, acceleration.z * 0.999f, acceleration.w * 0.999f + next_position.y * 1e-5f};
+#else
+        pair4 next_acceleration = gm::geodesic_acceleration(next_position, half_velocity, cfg);
+#endif
+        pair4 next_velocity = velocity + (acceleration + next_acceleration) * half_ds;
+        if (reparam) {
+            pairf K;
+            K.x = 1 / __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(next_velocity.x.x), __builtin_fabsf(next_velocity.y.x)),
+                                      __builtin_fmaxf(__builtin_fabsf(next_velocity.z.x), __builtin_fabsf(next_velocity.w.x)));
+            K.y = 1 / __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(next_velocity.x.y), __builtin_fabsf(next_velocity.y.y)),
+                                      __builtin_fmaxf(__builtin_fabsf(next_velocity.z.y), __builtin_fabsf(next_velocity.w.y)));
+            next_velocity = next_velocity * K;
+            next_acceleration = next_acceleration * K * K;
+            if (alive0) running.x *= K.x;
+            if (alive1) running.y *= K.y;
+        }
+
+        bool accept0 = true, accept1 = true;
+#ifdef ADAPTIVE_PRECISION
+        {
+            // calculate_ds_error for both rays in one straight line: every step below is two independent instructions (or
+            // one packed one), so the serial chain sqrt -> rsq -> clamp -> compare at the end of an attempt is walked once for
+            // the two rays, not once per ray, and nothing in it changes the exec mask
+            pairf suggested;
+            pairf diff = acceleration_to_precision(next_acceleration, max_accel, suggested);
+            const pairf want = suggested * 0.99f, lo = ds * (0.99f * 0.3f), hi = ds * (0.99f * 2.f), back = ds / 1.95f;
+            pairf nds;
+            nds.x = __builtin_fmaxf(clampf(want.x, lo.x, hi.x), min_step);
+            nds.y = __builtin_fmaxf(clampf(want.y, lo.y, hi.y), min_step);
+            const bool inside0 = ar.x < new_max, inside1 = ar.y < new_max;
+            next_ds.x = inside0 ? nds.x : next_ds.x;
+            next_ds.y = inside1 ? nds.y : next_ds.y;
+#ifdef SINGULARITY_DETECTION
+            const pairf dq = diff / 65536.f;
+            alive0 = alive0 & !(inside0 & (nds.x == min_step) & (dq.x > max_accel * 10000));
+            alive1 = alive1 & !(inside1 & (nds.y == min_step) & (dq.y > max_accel * 10000));
+#endif
+            accept0 = !inside0 | !(nds.x < back.x);   // back-step: retry from the same state with the smaller step
+            accept1 = !inside1 | !(nds.y < back.y);
+            (void)diff;
+        }
+#endif
+        if (alive0 && accept0) {
+            position.x.x = next_position.x.x; position.y.x = next_position.y.x; position.z.x = next_position.z.x; position.w.x = next_position.w.x;
+            velocity.x.x = next_velocity.x.x; velocity.y.x = next_velocity.y.x; velocity.z.x = next_velocity.z.x; velocity.w.x = next_velocity.w.x;
+            acceleration.x.x = next_acceleration.x.x; acceleration.y.x = next_acceleration.y.x; acceleration.z.x = next_acceleration.z.x; acceleration.w.x = next_acceleration.w.x;
+            i0++;
+            float poison = degenerate_accumulate(half_of<0>(position), degenerate_accumulate(half_of<0>(velocity), 0.f));
+            if (reparam) poison = degenerate_accumulate(half_of<0>(acceleration), poison);
+            if (!(poison == 0.f)) alive0 = false;
+        }
+        if (alive1 && accept1) {
+            position.x.y = next_position.x.y; position.y.y = next_position.y.y; position.z.y = next_position.z.y; position.w.y = next_position.w.y;
+            velocity.x.y = next_velocity.x.y; velocity.y.y = next_velocity.y.y; velocity.z.y = next_velocity.z.y; velocity.w.y = next_velocity.w.y;
+            acceleration.x.y = next_acceleration.x.y; acceleration.y.y = next_acceleration.y.y; acceleration.z.y = next_acceleration.z.y; acceleration.w.y = next_acceleration.w.y;
+            i1++;
+            float poison = degenerate_accumulate(half_of<1>(position), degenerate_accumulate(half_of<1>(velocity), 0.f));
+            if (reparam) poison = degenerate_accumulate(half_of<1>(acceleration), poison);
+            if (!(poison == 0.f)) alive1 = false;
+        }
+    }
+    // why each ray left the loop: the loop-top tests on its final state (see integrate_core)
+    {
+        pair4 polar = gm::generic_to_spherical(position, cfg);
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        const pairf vq = velocity.x / running, aq = acceleration.x / running;
+#else
+        const pairf vq = splat(0.f), aq = splat(0.f);
+#endif
+        result0 = (!stop_lost(position.y.x, vq.x, aq.x, f_in_x.x, i0) && stop_terminated(polar.y.x)) ? RAY_TERMINATED : RAY_LOST;
+        result1 = (!stop_lost(position.y.y, vq.y, aq.y, f_in_x.y, i1) && stop_terminated(polar.y.y)) ? RAY_TERMINATED : RAY_LOST;
+    }
+    position_io = position;
+    velocity_io = velocity;
+    running_out = running;
+    tries0 = t0;
+    tries1 = t1;
+}
+#endif  // GR_TWO_RAYS_PER_LANE
 
 // ------------------------------------------------------------------------------------------------
 // final position -> sky coordinates (cl.cl:211-263, 5024-5100)
@@ -1161,6 +1481,20 @@ extern "C" __global__ void gr_calculate_render_data(const lightray* __restrict__
     rdata[sy * width + sx] = dat;
 }
 
+#ifdef GR_COUNT_WAVE_SLOTS
+// the wave's longest trip count x slots_per_iteration, returned in one lane (0 in the others)
+__device__ __forceinline__ unsigned int wave_slots(unsigned int trips, unsigned int slots_per_iteration) {
+    unsigned int longest = trips;
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned int other = (unsigned int)__shfl_xor((int)longest, o, 64);
+        longest = other > longest ? other : longest;
+    }
+    const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+    const int first = __builtin_ctzll(active);
+    return (int)(threadIdx.x % 64) == first ? longest * slots_per_iteration : 0u;
+}
+#endif
+
 // init -> integrate -> render-data for one pixel per lane, 8x8 tiles, nothing but the 32-byte result is stored.
 // `wave` numbers the tile-waves of this device: image rows are dealt to devices in blocks of `block_rows` rows (block-cyclic:
 // global block gb belongs to device gb % strip_count); a block is tiles_x * block_rows/8 tile-waves, and, when the image is
@@ -1231,6 +1565,11 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                dfg, GET_FEATURE(redshift, dfg) != 0);
     }
     rdata[cy * width + cx] = dat;
+#ifdef GR_COUNT_WAVE_SLOTS
+    // experiment (tools/README.md): count the lane slots the wave spent in the Verlet loop - 64 x the trip count of its longest
+    // ray - instead of the attempts; attempts / slots = the fraction of the lanes doing useful work
+    tries = wave_slots(tries, 64u);
+#endif
     if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);
 }
 
@@ -1312,6 +1651,76 @@ __device__ __forceinline__ bool prepass_skips_pixel(int cx, int cy, int width, i
            early_terminate(lx, ly - 1, prepass_width, prepass_height, termination_buffer) &&
            early_terminate(lx, ly + 1, prepass_width, prepass_height, termination_buffer);
 }
+
+#ifdef GR_TWO_RAYS_PER_LANE
+// gr_trace_fused with two rays per lane (integrate_pair): a wave takes the tile-waves 2k and 2k+1 of trace_tile's numbering -
+// two horizontally adjacent 8x8 tiles - and lane l owns pixel l of each.  Same arguments, same records written.
+__device__ __forceinline__ void trace_tile_pair(int pair_wave, int lane, const float4* __restrict__ camera, const float4* __restrict__ camera_quat,
+                                                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank,
+                                                int strip_count, const int* __restrict__ termination_buffer, int prepass_width,
+                                                int prepass_height, const float4* __restrict__ e0, const float4* __restrict__ e1,
+                                                const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
+                                                unsigned long long* __restrict__ attempt_counter, int total_waves) {
+    int cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;
+    const bool has0 = trace_slot_to_pixel((unsigned)(2 * pair_wave) * 64u + (unsigned)lane, width, height, block_rows, strip_rank, strip_count, cx0, cy0);
+    const bool has1 = 2 * pair_wave + 1 < total_waves &&
+                      trace_slot_to_pixel((unsigned)(2 * pair_wave + 1) * 64u + (unsigned)lane, width, height, block_rows, strip_rank, strip_count, cx1, cy1);
+    const bool live0 = has0 && !prepass_skips_pixel(cx0, cy0, width, height, termination_buffer, prepass_width, prepass_height);
+    const bool live1 = has1 && !prepass_skips_pixel(cx1, cy1, width, height, termination_buffer, prepass_width, prepass_height);
+    render_data dat0, dat1;
+    dat0.tex_coord = make_float2(0, 0); dat0.z_shift = 0; dat0.sx = cx0; dat0.sy = cy0; dat0.terminated = 2; dat0.side = 1;
+    dat1.tex_coord = make_float2(0, 0); dat1.z_shift = 0; dat1.sx = cx1; dat1.sy = cy1; dat1.terminated = 2; dat1.side = 1;
+    unsigned int tries0 = 0, tries1 = 0;
+    if (live0 | live1) {
+        // a lane with one ray only steps that ray in both halves
+        const int ax = live0 ? cx0 : cx1, ay = live0 ? cy0 : cy1, bx = live1 ? cx1 : cx0, by = live1 ? cy1 : cy0;
+        lightray ray0 = make_pixel_ray(ax, ay, width, height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        lightray ray1 = make_pixel_ray(bx, by, width, height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        pair4 position = pair_of(ray0.position, ray1.position), velocity = pair_of(ray0.velocity, ray1.velocity);
+        pairf running;
+        int res0, res1;
+        integrate_pair(position, velocity, pair_of(ray0.acceleration, ray1.acceleration), running, live0, live1, cfg, dfg, res0, res1,
+                       tries0, tries1);
+        const bool need_redshift = GET_FEATURE(redshift, dfg) != 0;
+        if (live0) dat0 = make_render_data(half_of<0>(position), half_of<0>(velocity), ray0.initial_quat, ray0.ku_uobsu, running.x,
+                                           res0 == RAY_TERMINATED ? 1 : 0, cx0, cy0, cfg, dfg, need_redshift);
+        if (live1) dat1 = make_render_data(half_of<1>(position), half_of<1>(velocity), ray1.initial_quat, ray1.ku_uobsu, running.y,
+                                           res1 == RAY_TERMINATED ? 1 : 0, cx1, cy1, cfg, dfg, need_redshift);
+    }
+    if (has0) rdata[cy0 * width + cx0] = dat0;
+    if (has1) rdata[cy1 * width + cx1] = dat1;
+#ifdef GR_COUNT_WAVE_SLOTS
+    tries0 = wave_slots(tries0 > tries1 ? tries0 : tries1, 128u);
+    tries1 = 0;
+#endif
+    if (attempt_counter && (has0 | has1)) atomicAdd(attempt_counter, (unsigned long long)tries0 + (unsigned long long)tries1);
+}
+
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
+gr_trace_pair(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+              render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
+              const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+              const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+              cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
+              int total_waves) {
+    GR_PARAMETERS_IN_REGISTERS
+    const int lane = threadIdx.x % 64;
+    const int pair_waves = (total_waves + 1) / 2;
+    int wave = blockIdx.x * (GR_TRACE_BLOCK / 64) + threadIdx.x / 64;
+    for (;;) {
+        if (tile_counter) {
+            unsigned int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(tile_counter, 1u);
+            wave = (int)__builtin_amdgcn_readfirstlane(ticket);
+        }
+        if (wave >= pair_waves) break;
+        asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
+        trace_tile_pair(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
+                        termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, total_waves);
+        if (!tile_counter) break;
+    }
+}
+#endif  // GR_TWO_RAYS_PER_LANE
 
 // gr_trace_fused with ray compaction: a persistent wave keeps one ray per lane and, as soon as fewer than keep_lanes of them
 // are still integrating (wave-level ballot inside the Verlet loop), finishes the rays that ended, draws as many new pixels

@@ -103,6 +103,11 @@ class Program:
         check(lib.gr_program_kernel_info(self.handle, name.encode(), ctypes.byref(v), ctypes.byref(s), ctypes.byref(l)))
         return {"vgprs": v.value, "scratch_bytes": l.value}
 
+    @property
+    def has_trace_pair(self):
+        """True when the program has the two-rays-per-lane kernel (gr_trace_pair)"""
+        return bool(lib.gr_program_has_trace_pair(self.handle))
+
     def __del__(self):
         if getattr(self, "handle", None):
             lib.gr_program_destroy(self.handle)

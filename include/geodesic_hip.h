@@ -267,6 +267,19 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
                    const void* e0, const void* e1, const void* e2, const void* e3,
                    const void* cfg, const void* dfg, void* attempt_counter);
 
+/* gr_trace_fused with two rays per lane: a wave takes two neighbouring 8x8 tiles and every lane integrates one pixel of each,
+ * all per-ray arithmetic in packed fp32 (v_pk_fma/mul/add_f32: one instruction, two rays).  Same arguments, same records;
+ * each ray's arithmetic is that of gr_trace_fused (results agree to what the compiler contracts differently).  A program has
+ * the kernel when its Verlet-loop expressions instantiate on float pairs (no comparison/select forms, moderate size) and it
+ * steps without the adaptive controller - there it is 1.3-1.5x faster; with the controller it is slower and only built on
+ * request (GR_TRACE_PAIR_BUILD=1).  gr_program_has_trace_pair tells; GR_ERROR_INVALID_ARGUMENT when it is missing. */
+int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
+                  void* render_data, int width, int height, int block_rows, int strip_rank, int strip_count,
+                  const void* termination_buffer, int prepass_width, int prepass_height,
+                  const void* e0, const void* e1, const void* e2, const void* e3,
+                  const void* cfg, const void* dfg, void* attempt_counter);
+int gr_program_has_trace_pair(const gr_program* p);   /* 1 / 0 */
+
 /* gr_trace_fused with ray compaction (north_star: "wave-level ballots for step-acceptance and ray compaction"): persistent
  * waves hold one ray per lane; whenever fewer than keep_lanes (1..64) of a wave's rays are still integrating, the finished
  * ones are written out and the idle lanes draw new pixels from a device-side counter.  Every ray is integrated exactly as
@@ -327,6 +340,8 @@ typedef struct gr_frame_options {
     float next_geodesic_time2;
     int next_strip_rank;   /* strip_rank of the next_camera / next_camera2 frames when a device's share of the image rotates from */
     int next_strip_rank2;  /*   frame to frame (load balance over ranks); -1 = the same as this frame's */
+    int rays_per_lane;     /* fused mode without compaction: 1 = gr_trace_fused, 2 = gr_trace_pair (error if the program lacks it),
+                            * 0 = library default: 2 where the program has the pair kernel, else 1 (GR_TRACE_RAYS_PER_LANE=1|2 overrides) */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 

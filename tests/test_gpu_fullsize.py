@@ -257,7 +257,7 @@ def test_ray_compaction_computes_the_same_frame(name, cfg, size):
     differently (exactly as between the fused kernel and the reference-shaped sequence): the number of Verlet attempts must
     agree to 1e-4, termination flags must be equal and pixels equal to rounding."""
     w, h = size
-    px0, rd0, st0 = render(name, w, h, cfg=cfg, options=dict(mode=gra.MODE_FUSED, ray_compaction=0, count_attempts=1))
+    px0, rd0, st0 = render(name, w, h, cfg=cfg, options=dict(mode=gra.MODE_FUSED, ray_compaction=0, rays_per_lane=1, count_attempts=1))
     want_attempts = st0.attempts()
     for keep in (48, 32, 8):
         px, rd, st = render(name, w, h, cfg=cfg, options=dict(mode=gra.MODE_FUSED, ray_compaction=keep, count_attempts=1))
@@ -369,3 +369,71 @@ def test_cpp_example_renders_a_png(tmp_path):
     want, _, _ = render("kerr_boyer", 640, 360, cfg=dict(a=0.45), options=dict(mode=gra.MODE_FUSED), scripts=SCRIPTS)
     # same camera and metric through the Python binding; different sky, so compare where both are black
     assert ((want[..., :3].max(axis=2) == 0) == (img[..., :3].max(axis=2) == 0)).mean() > 0.999
+
+
+@pytest.mark.parametrize("name,size", [("schwarzschild", (1920, 1080)), ("minkowski", (1000, 500)), ("wormhole", (1280, 720))])
+def test_two_rays_per_lane_computes_the_same_frame(name, size):
+    """gr_trace_pair (two rays per lane, packed fp32; the library default where a program has it) integrates every ray as
+    gr_trace_fused does.  Separate kernels: the compiler may contract a few operations differently, so attempts agree to 1e-5,
+    termination flags are equal but for a few borderline rays and pixels are equal to rounding except for the strongly lensed
+    rays that amplify it (next to the photon sphere: 0.2 % of a Schwarzschild frame).  Strips rendered with the pair kernel
+    (other tile pairs, halo waves) are bit-identical to the whole frame rendered with it."""
+    w, h = size
+    metric = gra.Metric(name, SCRIPTS)
+    assert gra.Program(metric.argument_string(), 0).has_trace_pair
+    px1, rd1, st1 = render(name, w, h, scripts=SCRIPTS, options=dict(mode=gra.MODE_FUSED, rays_per_lane=1, count_attempts=1))
+    px2, rd2, st2 = render(name, w, h, scripts=SCRIPTS, options=dict(mode=gra.MODE_FUSED, rays_per_lane=2, count_attempts=1))
+    px0, rd0, st0 = render(name, w, h, scripts=SCRIPTS, options=dict(mode=gra.MODE_FUSED, count_attempts=1))       # library default
+    assert np.array_equal(px0, px2) and st0.attempts() == st2.attempts()
+    assert abs(st2.attempts() - st1.attempts()) <= 1e-5 * st1.attempts()
+    assert (rd1["terminated"] != rd2["terminated"]).mean() <= 1e-4
+    assert np.array_equal(rd1["sx"], rd2["sx"]) and np.array_equal(rd1["sy"], rd2["sy"])
+    d = np.abs(px1 - px2).max(axis=2)
+    assert (d > 1e-4).mean() <= 4e-3 and np.median(d) <= 1e-6
+    if h % 16 != 1:
+        for strip in (0, 3):
+            part, _, _ = render(name, w, h, scripts=SCRIPTS, out_rows=16,
+                                options=dict(mode=gra.MODE_FUSED, rays_per_lane=2, strip_rank=strip, strip_count=h // 16, block_rows=16,
+                                             compact_out=1))
+            assert np.array_equal(part, px2[strip * 16:strip * 16 + 16]), strip
+
+
+def test_two_rays_per_lane_needs_the_pair_kernel():
+    """adaptive programs are built without gr_trace_pair (slower there): asking for it is an error, the default falls back"""
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    assert not prog.has_trace_pair
+    state = gra.RenderState(64, 64, 0)
+    dbg, levels = background()
+    out = DeviceBuffer(0, 64 * 64 * 16)
+    with pytest.raises(gra.GeodesicError, match="gr_trace_pair"):
+        state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), metric.features(adaptive_sampling=0),
+                     metric.cfg_values(a=0.45), gra.frame_options(mode=gra.MODE_FUSED, rays_per_lane=2))
+    state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), metric.features(adaptive_sampling=0),
+                 metric.cfg_values(a=0.45), gra.frame_options(mode=gra.MODE_FUSED))
+    state.synchronize()
+
+
+def test_two_rays_per_lane_with_the_adaptive_controller(monkeypatch):
+    """GR_TRACE_PAIR_BUILD=1 builds the pair kernel for adaptive programs too: same rays (attempts to 1e-5), same pixels to
+    rounding as the one-ray kernel - correct, just not faster, which is why it is not built by default"""
+    monkeypatch.setenv("GR_TRACE_PAIR_BUILD", "1")
+    w, h = 1280, 720
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    assert prog.has_trace_pair
+    dbg, levels = background()
+    feats, cfg = metric.features(adaptive_sampling=0), metric.cfg_values(a=0.45)
+    got = {}
+    for rpl in (1, 2):
+        state = gra.RenderState(w, h, 0)
+        out = DeviceBuffer(0, w * h * 16)
+        state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfg,
+                     gra.frame_options(mode=gra.MODE_FUSED, rays_per_lane=rpl, count_attempts=1))
+        state.synchronize()
+        got[rpl] = (out.to_numpy(np.float32, (h, w, 4)), state.attempts(),
+                    download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h)["terminated"])
+    assert abs(got[2][1] - got[1][1]) <= 1e-5 * got[1][1]
+    assert (got[1][2] != got[2][2]).mean() <= 1e-4
+    d = np.abs(got[1][0] - got[2][0]).max(axis=2)
+    assert (d > 1e-3).mean() <= 5e-3 and np.median(d) <= 1e-6      # rays next to the shadow edge amplify rounding differences
