@@ -317,7 +317,8 @@ def main():
             # the other BASELINE.json configurations, one frame at a time on this one GPU (substituted programs, fused kernel)
             scripts_dir = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
             for label, name, (cw, ch), cam_pos, feats_kw in (
-                    ("config1_schwarzschild_1920x1080", "schwarzschild", (1920, 1080), None, {}),
+                    ("config1_schwarzschild_1920x1080", "schwarzschild", (1920, 1080), None, {}),                  # as shipped: fixed step
+                    ("config1_schwarzschild_adaptive_1920x1080", "schwarzschild_adaptive", (1920, 1080), None, {}),  # as worded: adaptive
                     ("config3_double_unequal_kerr_3840x2160", "double_unequal_kerr", (3840, 2160), [0, 0, -6, 0.5], {}),
                     ("config4_alcubierre_7680x4320_redshift", "alcubierre", (7680, 4320), [0, 0, -6, 0.5], {"redshift": 1})):
                 m2 = gra.Metric(name, scripts_dir)

@@ -71,6 +71,9 @@ CASES = {
     "kerr_newman": dict(metric="kerr_newman_boyer", scripts=True, size=(48, 27), cfg=dict(a=0.3, rq=0.25), camera_pos=[0.0, 0.5, -5.0, 1.0]),
     "kerr_schild": dict(metric="kerr_schild", scripts=True, size=(48, 27), cfg=dict(a=0.45), camera_pos=[0.0, 0.5, -5.0, 1.0]),
     "kerr_schild_prepass": dict(metric="kerr_schild", scripts=True, size=(96, 64), cfg=dict(a=0.45), prepass=True),
+    "schwarzschild_adaptive": dict(metric="schwarzschild_adaptive", scripts=True, size=(48, 27)),
+    "schwarzschild_adaptive_rs": dict(metric="schwarzschild_adaptive", scripts=True, size=(48, 27), cfg=dict(rs=1.6),
+                                      camera_pos=[0.0, 3.0, -6.0, 2.0], camera_quat=TILTED_QUAT),
     "kerr_moving_observer": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.3, 0.0, 0.2], features=dict(redshift=1)),
 }
 

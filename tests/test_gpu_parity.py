@@ -194,7 +194,7 @@ def test_fused_and_tiled_paths_equal_reference_sequence(name):
         assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
 
 
-SUBSTITUTED = ["kerr", "kerr_tilted", "kerr_far", "kerr_prepass", "kerr_newman", "kerr_schild", "kerr_schild_prepass", "kerr_moving_observer", "kerr_reparameterised", "schwarzschild_redshift",
+SUBSTITUTED = ["schwarzschild_adaptive", "schwarzschild_adaptive_rs", "kerr", "kerr_tilted", "kerr_far", "kerr_prepass", "kerr_newman", "kerr_schild", "kerr_schild_prepass", "kerr_moving_observer", "kerr_reparameterised", "schwarzschild_redshift",
                "alcubierre", "ingoing_ef", "double_unequal_kerr", "cosmic_string", "wormhole_through"]
 
 

@@ -63,7 +63,7 @@ def test_scripts_and_builtins_define_the_same_metric(name):
         assert np.allclose(ma.accel(pos, vel, cfg), mb.accel(pos, vel, cfg), rtol=1e-5, atol=1e-8)
 
 
-OTHER_OWN_METRICS = ["schwarzschild_ingoing_ef", "wormhole", "cosmic_string", "kerr_newman_boyer", "kerr_schild"]
+OTHER_OWN_METRICS = ["schwarzschild_adaptive", "schwarzschild_ingoing_ef", "wormhole", "cosmic_string", "kerr_newman_boyer", "kerr_schild"]
 
 
 @pytest.mark.parametrize("name", CONFIG_METRICS + OTHER_OWN_METRICS)
