@@ -1,5 +1,5 @@
 """Per-frame time of ONE rank's share of a frame split N ways (no communication), by look-ahead depth: what an N-GPU run
-can reach per frame.   usage: python tools/strip_probe.py [N ...]"""
+can reach per frame.   usage: [STRIP_PROBE_INFLIGHT=1,3,5] python tools/strip_probe.py [N ...]"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,16 +11,16 @@ metric = gra.Metric("kerr_boyer", os.path.join(ROOT, "geodesic_raytracing_amd", 
 cfg = metric.cfg_values(a=0.45)
 feats = metric.features(adaptive_sampling=0)
 program = gra.pipeline.ProgramManager(metric, 0, feats, cfg).current(wait=True)
-states = [gra.RenderState(W, H, 0) for _ in range(6)]
-streams = [torch.cuda.Stream() for _ in range(6)]
+states = [gra.RenderState(W, H, 0) for _ in range(8)]
+streams = [torch.cuda.Stream() for _ in range(8)]
 bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
 bg = torch.from_numpy(bg_np).cuda()
-outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(6)]
+outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(8)]
 camera = gra.default_camera()
 look = ctypes.pointer(camera)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
-  for rotate in (False, True):
-   for inflight in (1, 3):
+  for rotate in ((True,) if os.environ.get("STRIP_PROBE_INFLIGHT") else (False, True)):
+   for inflight in [int(x) for x in os.environ.get("STRIP_PROBE_INFLIGHT", "1,3").split(",")]:
     for depth in (2,):
         counter = [0]
 
