@@ -18,6 +18,10 @@
 //   gr_render                   render                    cl.cl:5453-5846 (read_mipmap 5421-5449)
 //   gr_trace_fused              (no counterpart) init -> integrate -> render-data in one launch,
 //                               ray state never leaves registers; persistent tile-waves
+//   gr_trace_pair               (no counterpart) gr_trace_fused with two rays per lane in packed fp32 (integrate_pair);
+//                               only built for programs whose loop expressions instantiate on float pairs
+//                               (GR_TWO_RAYS_PER_LANE, decided by the host: capi.cpp pair_kernel_applies)
+//   gr_trace_compact            (no counterpart) gr_trace_fused with ray compaction (resumable integrator)
 //   gr_prepass_fused            (no counterpart) the W/16 x H/16 prepass as one launch -> termination flags
 //   gr_boost_tetrad             boost_tetrad              cl.cl:2441-2481
 //   gr_init_inertial_ray        init_inertial_ray         cl.cl:3117-3141
