@@ -13,7 +13,6 @@ and libm, and rays near photon orbits amplify 1-ulp differences - SURVEY.md sect
   end to end (pixels)      RMSE <= 1e-4 after masking pixels off by > 1e-3; mask <= 0.5 %
                            (super-extremal Kerr, a naked singularity with chaotic orbits: mask <= 10 %, RMSE <= 3e-4)
 """
-import json
 
 import numpy as np
 import pytest
