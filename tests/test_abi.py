@@ -147,3 +147,28 @@ def test_cpp_example_builds_against_the_header_alone():
                        capture_output=True, text=True)
     if r.returncode != 0:              # no GPU here: the first device call must say so
         assert "gr_program_create" in r.stderr and "device" in r.stderr.lower()
+
+
+def test_pair_kernel_is_built_for_fixed_step_programs_only(tmp_path, monkeypatch):
+    """host rule (capi.cpp pair_kernel_applies): gr_trace_pair is compiled into programs that step without the adaptive
+    controller and whose loop expressions instantiate on float pairs; adaptive programs get it on request only"""
+    import glob
+    import os
+    import geodesic_raytracing_amd as gra
+
+    def symbols(argument_string, tag):
+        d = tmp_path / tag
+        d.mkdir()
+        monkeypatch.setenv("GR_CACHE_DIR", str(d))
+        gra.Program.precompile(argument_string)
+        (path,) = glob.glob(os.path.join(str(d), "*.hsaco"))
+        blob = open(path, "rb").read()
+        return b"gr_trace_pair" in blob, b"gr_trace_fused" in blob
+
+    fixed = gra.Metric("schwarzschild")
+    adaptive = gra.Metric("kerr_boyer")
+    assert not fixed.info.adaptive_precision and adaptive.info.adaptive_precision
+    assert symbols(fixed.argument_string(), "fixed") == (True, True)
+    assert symbols(adaptive.argument_string(), "adaptive") == (False, True)
+    monkeypatch.setenv("GR_TRACE_PAIR_BUILD", "0")
+    assert symbols(fixed.argument_string(), "never") == (False, True)

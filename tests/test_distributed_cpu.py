@@ -117,6 +117,49 @@ def test_pipelined_gather_world_size_2(tmp_path):
     assert os.path.exists(tmp_path / "ok.npy")
 
 
+def _ring_worker(rank, world, port, out_dir):
+    """bench.py --gpus N: a ring of three slots, each with its own double-buffered FrameGather and output buffer; frame k goes
+    to slot k % 3, so up to six asynchronous gathers of three different gather objects are in flight, interleaved"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    height, width, block, in_flight, n_frames = 70, 5, 8, 3, 17
+    plan = StripPlan(height, world, block)
+    gathers = [FrameGather(plan, width, torch.device("cpu"), rank, world) for _ in range(in_flight)]
+    outs = [g.frame_buffer() if rank == 0 else None for g in gathers]
+    torch.manual_seed(7)
+    frames = [torch.rand((height, width, 4)) for _ in range(n_frames)]
+    seen = {}
+    for k, f in enumerate(frames):
+        g, out = gathers[k % in_flight], outs[k % in_flight]
+        local = g.local_buffer()
+        local.zero_()
+        for i, (a, b) in enumerate(plan.blocks_of(g.strip_of(k))):
+            local[i, :b - a] = f[a:b]
+        r = g.submit(out, rotation=k)           # returns the frame whose buffer is about to be reused (two submits ago on this slot)
+        if r is not None:
+            seen[k - 2 * in_flight + in_flight] = r.clone()
+    for j, (g, out) in enumerate(zip(gathers, outs)):
+        r = g.drain(out)
+        if r is not None:
+            last = max(k for k in range(n_frames) if k % in_flight == j)
+            seen[last] = r.clone()
+    assert sum(g.frames_done for g in gathers) == n_frames
+    if rank == 0:
+        for k, fr in seen.items():
+            assert torch.equal(fr, frames[k]), k
+        assert len(seen) >= in_flight
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([len(seen)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ring_of_gathers(tmp_path, world):
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_ring_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert os.path.exists(tmp_path / "ok.npy")
+
+
 def test_pipelined_gather_without_process_group():
     plan = StripPlan(40, 1, 8)
     g = FrameGather(plan, 5, torch.device("cpu"), 0, 1)
