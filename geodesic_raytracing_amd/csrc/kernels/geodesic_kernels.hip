@@ -1830,13 +1830,14 @@ gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* _
     if (id >= prepass_width * prepass_height) return;
     int cx = id % prepass_width, cy = id / prepass_width;
     if (strip_count > 1) {
-        // pixel rows whose stencil can touch cell row cy, bounded generously (an extra cell costs nothing but time)
-        long long lo = ((long long)(2 * cy - 3) * image_height) / (2 * prepass_height) - 2;
-        long long hi = ((long long)(2 * cy + 3) * image_height + 2 * prepass_height - 1) / (2 * prepass_height) + 2;
+        // pixel rows whose stencil can touch cell row cy: round(y * ph / H) in [cy - 1, cy + 1], one row of slack either side for
+        // the float rounding of that quotient (tests/test_distributed_cpu.py checks the rule by brute force)
+        long long lo = ((long long)(2 * cy - 3) * image_height) / (2 * prepass_height) - 1;
+        long long hi = ((long long)(2 * cy + 3) * image_height + 2 * prepass_height - 1) / (2 * prepass_height) + 1;
         if (lo < 0) lo = 0;
         if (hi > image_height - 1) hi = image_height - 1;
-        // blocks b (rows b*B .. (b+1)*B inclusive of the halo row) that meet [lo, hi]
-        long long b_lo = lo / block_rows - 1, b_hi = hi / block_rows;
+        // blocks b (rows b*B .. (b+1)*B inclusive of the halo row) that meet [lo, hi]: (b+1)*B >= lo and b*B <= hi
+        long long b_lo = (lo - 1) / block_rows, b_hi = hi / block_rows;
         if (b_lo < 0) b_lo = 0;
         long long first = b_lo + (((long long)strip_rank - b_lo) % strip_count + strip_count) % strip_count;   // first own block >= b_lo
         if (first > b_hi) return;

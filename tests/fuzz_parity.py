@@ -1,7 +1,9 @@
 """Randomised parity soak (GPU box): random metric / parameters / camera pose / observer speed / features, small frames, the HIP
 fused kernel (dynamic and substituted program) against the CPU oracle (oracle/restate.cpp, pinned to the reference's kernels).
 Prints one line per case and a summary; exit status 1 if a case is outside the end-to-end tolerance of the parity tests.
-Test infrastructure (it runs the oracle).  usage: PYTHONPATH=. python tests/fuzz_parity.py [cases] [seed]"""
+Test infrastructure (it runs the oracle).  usage: PYTHONPATH=. python tests/fuzz_parity.py [cases] [seed] [only_case]
+With only_case the one case is replayed (the random stream is advanced through the earlier ones) and its inputs, the oracle's
+and the GPU's pixels and render-data go to gpurun_out/fuzz_case_<seed>_<case>.npz for a closer look."""
 import ctypes
 import os
 import sys
@@ -59,9 +61,12 @@ def main():
         base = quat_from_axis_angle([1, 0, 0], -np.pi / 2)
         quat = quat_mul(quat_from_axis_angle(rng.normal(size=3), float(rng.uniform(0, 1.0))), base)
         speed = [float(x) for x in rng.uniform(-0.3, 0.3, 3)] if rng.random() < 0.5 else [0.0, 0.0, 0.0]
+        only = int(sys.argv[3]) if len(sys.argv) > 3 else None
         fkw = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change, redshift=int(rng.random() < 0.4),
                    reparameterisation=int(rng.random() < 0.25), field_of_view=float(rng.choice([60.0, 90.0, 110.0])),
                    universe_size=float(rng.choice([20.0, 30.0])), max_precision_radius=float(rng.choice([10.0, 14.0])))
+        if only is not None and case != only:
+            continue
         feats = gra.default_features(**fkw)
         key = metric.argument_string()
         if key not in oracles:
@@ -85,6 +90,13 @@ def main():
             failed += not ok
             worst = max(worst, rmse)
             line += f" | {label}: rmse {rmse:.1e} off {bad.mean() * 100:4.1f}%{'' if ok else '  <-- FAIL'}"
+            if only is not None:
+                from geodesic_raytracing_amd.pipeline import RENDER_DATA_DTYPE, download
+                rd = download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_case_{sys.argv[2]}_{case}_{label}.npz"), pixels=px, ref_pixels=ref["pixels"],
+                         rd=rd, ref_rd=ref["render_data"], pos=np.array(pos), quat=np.array(quat), speed=np.array(speed), cfg=np.array(cfg),
+                         features=np.frombuffer(bytes(pack_features(**fkw)), dtype=np.uint8))
         print(line, flush=True)
     print(f"{cases} cases x 2 programs: {failed} outside tolerance, worst masked RMSE {worst:.2e}")
     return 1 if failed else 0

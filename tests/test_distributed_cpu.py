@@ -189,10 +189,10 @@ def test_strip_prepass_cell_rule_covers_every_cell_a_rank_reads():
     import math
 
     def kept(cy, H, ph, B, rank, count):
-        lo = int(((2 * cy - 3) * H) / (2 * ph)) - 2          # C truncation towards zero
-        hi = ((2 * cy + 3) * H + 2 * ph - 1) // (2 * ph) + 2
+        lo = int(((2 * cy - 3) * H) / (2 * ph)) - 1          # C truncation towards zero
+        hi = ((2 * cy + 3) * H + 2 * ph - 1) // (2 * ph) + 1
         lo, hi = max(lo, 0), min(hi, H - 1)
-        b_lo, b_hi = max(lo // B - 1, 0), hi // B
+        b_lo, b_hi = max(int((lo - 1) / B), 0), hi // B      # block b holds rows b*B .. (b+1)*B (halo row included)
         first = b_lo + ((rank - b_lo) % count + count) % count
         return first <= b_hi
 
@@ -213,5 +213,5 @@ def test_strip_prepass_cell_rule_covers_every_cell_a_rank_reads():
                     keep = {c for c in range(ph) if kept(c, H, ph, B, rank, count)}
                     assert need <= keep, (H, B, count, rank, sorted(need - keep)[:5])
                     saved[(H, B, count, rank)] = 1 - len(keep) / ph
-    # 4K, 16-row blocks over 8 devices (the bench layout): a third or more of the prepass is somebody else's
-    assert all(saved[(2160, 16, 8, r)] > 0.3 for r in range(8))
+    # 4K, 16-row blocks over 8 devices (the bench layout): a device needs 4 of every 8 cell rows
+    assert all(saved[(2160, 16, 8, r)] > 0.45 for r in range(8))

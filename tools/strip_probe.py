@@ -17,6 +17,7 @@ bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
 bg = torch.from_numpy(bg_np).cuda()
 outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(8)]
 camera = gra.default_camera()
+BLOCK = int(os.environ.get("STRIP_PROBE_BLOCK", "16"))
 look = ctypes.pointer(camera)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
   for rotate in ((True,) if os.environ.get("STRIP_PROBE_INFLIGHT") else (False, True)):
@@ -29,7 +30,7 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             counter[0] += 1
             state, out, stream = states[k], outs[k], streams[k].cuda_stream
             kf = counter[0] - 1
-            o = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=(kf % world) if rotate else 0, strip_count=world, block_rows=16, compact_out=1)
+            o = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=(kf % world) if rotate else 0, strip_count=world, block_rows=BLOCK, compact_out=1)
             if rotate:
                 o.next_strip_rank = (kf + inflight) % world
                 o.next_strip_rank2 = (kf + 2 * inflight) % world
@@ -47,4 +48,4 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             frame()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t) / n * 1e3
-        print(f"1 of {world} ranks, rotate={rotate}, {inflight} frames in flight, look-ahead depth {depth}: {ms:6.3f} ms/frame  -> {W * H / ms / 1e3:8.1f} Mrays/s if every rank keeps up", flush=True)
+        print(f"1 of {world} ranks, rotate={rotate}, {inflight} frames in flight, look-ahead depth {depth}, {BLOCK}-row blocks: {ms:6.3f} ms/frame  -> {W * H / ms / 1e3:8.1f} Mrays/s if every rank keeps up", flush=True)
