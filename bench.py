@@ -8,7 +8,7 @@ One "step" = one complete frame of BASELINE.json configs[2]: Kerr (Boyer-Lindqui
 a/M=0.9 - SURVEY.md section 8d), 3840x2160, adaptive sampling off (one primary ray per pixel), prepass
 as in the metric's config, all hot-path stages (camera tetrad, prepass, fused init+Verlet+render-data,
 anisotropic texture render) into a float4 HBM buffer.  Inputs (background, camera, cfg) are resident
-in HBM before the timed region.  With N > 1 the frame's rows are dealt to the ranks in 16-row blocks
+in HBM before the timed region.  With N > 1 the frame's rows are dealt to the ranks in 48-row blocks
 (block-cyclic), each rank renders its rows, and the final float4 rows are gathered on rank 0 over RCCL.
 Frames are rendered the way the reference's main loop does it (a ring of render_state objects, each frame on the next one: main.cpp:1463-1469, 1505-1510):
 --frames-in-flight F states, each with its own HIP stream and output buffer, so that the low-occupancy tail of one
@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-lookahead", action="store_true", help="do not overlap the next frame's prepass with this frame's trace")
     ap.add_argument("--lookahead-depth", type=int, default=0, help="frames of prepass look-ahead (1 or 2); default 1 on one GPU, "
                     "2 when the frame is split over several (a strip traces faster than one prepass runs)")
+    ap.add_argument("--block-rows", type=int, default=48, help="rows per block of the block-cyclic row split (N > 1); multiple of 8")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="render states / streams cycled through (1 = strictly one frame at a time)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -130,7 +131,10 @@ def main():
     camera = gra.default_camera()
 
     fused = args.mode == "fused"
-    plan = grd.StripPlan(H, world, block_rows=16)
+    # 48-row blocks: measured per-rank frame time at 4K (tools/strip_probe.py, rotating strips, 3 in flight) 16 -> 48 rows:
+    # 0.93 -> 0.87 ms at 8 ranks, 1.56 -> 1.47 at 4, 2.91 -> 2.79 at 2 (half the halo rows, a third of the redundant prepass
+    # cells); the coarser deal is evened out by the rotation of the strips over the frames
+    plan = grd.StripPlan(H, world, block_rows=args.block_rows)
     in_flight = max(1, min(args.frames_in_flight, 8)) if fused else 1
 
     class Slot:   # one frame in flight: render state (per-frame device buffers), stream, output, gather buffers
@@ -358,7 +362,7 @@ def main():
                                    f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
                        "mode": args.mode, "prepass_lookahead": bool(fused and not args.no_lookahead), "prepass_lookahead_depth": depth,
                        "frames_in_flight": in_flight, "priming_frames": priming, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
-                       "parallelism": f"16-row blocks, block-cyclic over {world} GPUs (assignment rotating per frame) + one RCCL gather" if world > 1 else "single GPU"},
+                       "parallelism": f"{plan.block_rows}-row blocks, block-cyclic over {world} GPUs (assignment rotating per frame) + one RCCL gather" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)

@@ -199,7 +199,7 @@ def test_strip_prepass_cell_rule_covers_every_cell_a_rank_reads():
     saved = {}
     for H in (135 * 16, 1080, 720, 1000, 2161 - 1, 333):
         ph = H // 16
-        for B in (8, 16, 24, 32):
+        for B in (8, 16, 24, 32, 48, 64):
             for count in (2, 3, 4, 8):
                 if (H - 1) % B == 0:
                     continue

@@ -127,7 +127,7 @@ def test_kerr_4k_bench_frame_against_the_oracle():
     assert np.percentile(err, 99) <= 1e-4 and np.percentile(err, 50) <= 2e-6
 
 
-@pytest.mark.parametrize("world,block", [(2, 16), (8, 16), (3, 24)])
+@pytest.mark.parametrize("world,block", [(2, 16), (8, 16), (3, 24), (8, 48), (4, 48), (2, 64)])   # bench.py deals 48-row blocks
 def test_row_block_decomposition_equals_full_frame(world, block):
     """what rank r of N computes in strip mode is bit-identical to the same rows of the single-GPU frame"""
     from geodesic_raytracing_amd.distributed import StripPlan
