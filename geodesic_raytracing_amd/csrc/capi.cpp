@@ -146,7 +146,7 @@ int compile_code_object(const std::string& argument_string, std::string& code) {
         // ... and its "unsafe math": approximate-function semantics for divide/sqrt/libm (a/b = a * v_rcp_f32(b) with no
         // denormal rescaling) and flushed fp32 denormals.  Measured -18 % on the Kerr Verlet kernel, parity unchanged.
         "-fapprox-func", "-fgpu-flush-denormals-to-zero",
-        // no SLP vectorisation: packed fp32 (v_pk_mul/fma_f32) issues at the scalar rate on gfx950 and needs operand
+        // no SLP vectorisation: packed fp32 (v_pk_mul/fma_f32) is at best ~1.2x the plain rate on gfx950 and needs operand
         // pairs in adjacent registers - the straight-line metric code paid ~55 v_mov per Verlet step for it.
         // Measured on the Kerr kernel: 102 -> 80 VGPRs, 12.7 -> 10.1 ms.
         "-fno-slp-vectorize"};

@@ -1039,9 +1039,9 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
 #ifdef GR_TWO_RAYS_PER_LANE
 // ---- two rays per lane ---------------------------------------------------------------------------
 // integrate_core with every per-ray float held as a pair (ray 0 in the low, ray 1 in the high half of a 64-bit register
-// pair).  Measured on MI355X (tools/ubench/valu_rate.hip, tools/ubench/accel_rate.hip): an fp32 fma with three VGPR sources
-// issues in 3.8-4.1 cycles per wave64, v_pk_fma_f32 - two of them - in 4.8; v_mul 2.7 against v_pk_mul 4.5.  Three quarters of
-// the instructions of a Verlet attempt are such multiplies and fmas, so one lane stepping two rays gets through ~20 % more
+// pair).  Measured on MI355X (tools/ubench/accel_rate.hip: the substituted Kerr acceleration + Verlet update alone): packed
+// instructions get through two rays' arithmetic in less issue time than two plain ones, 374 -> 462 G ray-steps/s.  Three
+// quarters of the instructions of a Verlet attempt are such multiplies and fmas, so one lane stepping two rays gets through more
 // attempts per cycle.  What has no packed form (compares, selects, rcp/rsq/sqrt, the commit of an accepted step) is done per
 // half.  The arithmetic of a ray is instruction for instruction that of integrate_core; a ray that has left the loop keeps
 // its state (the commit is per ray) while its partner goes on.

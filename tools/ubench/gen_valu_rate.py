@@ -27,6 +27,14 @@ SEQUENCES = {
     "cnd_fma_mix": sum(([f"v_cndmask_b32_e64 %{i}, %{i}, %8, %10", f"v_fma_f32 %{i + 1}, %{i + 1}, %8, %9"] for i in range(0, 8, 2)), []),
     "cmp_cnd": sum(([f"v_cmp_lt_f32 vcc, %{i}, %9", f"v_cndmask_b32 %{i + 1}, %{i + 1}, %8, vcc"] for i in range(0, 8, 2)), []),
     "fma_chain4": [f"v_fma_f32 %{i % 4}, %{i % 4}, %8, %9" for i in range(8)],
+    # does a source that is the previous instruction's result cost a register read?  ping-pong: each fma reads the one before
+    "fma_fwd": [f"v_fma_f32 %{(i + 1) % 2}, %{i % 2}, %8, %9" for i in range(8)],
+    "fma_fwd3": [f"v_fma_f32 %{(i + 1) % 2}, %{i % 2}, %{2 + i % 6}, %9" for i in range(8)],      # ... with a third rotating VGPR source
+    "mul_fwd": [f"v_mul_f32 %{(i + 1) % 2}, %{i % 2}, %8" for i in range(8)],
+    # same three distinct sources, register numbers chosen by the allocator (bank luck): 8 different destination/source sets
+    "fma_3distinct": [f"v_fma_f32 %{i}, %{(i + 1) % 8}, %{(i + 2) % 8}, %{(i + 3) % 8}" for i in range(8)],
+    "fma_2distinct_same": [f"v_fma_f32 %{i}, %{(i + 1) % 8}, %{(i + 1) % 8}, %{(i + 3) % 8}" for i in range(8)],
+    "fmac_2src": [f"v_fmac_f32 %{i}, %{(i + 1) % 8}, %{(i + 1) % 8}" for i in range(8)],
 }
 
 
