@@ -23,10 +23,27 @@ CASES = {
     "rot_parity_a_nb_nb": lambda i: ("v_fma_f32", 32 + i, 32 + i, 40 + (i + 1) % 4, 44 + (i + 1) % 4),
     "rot_dst_differs": lambda i: ("v_fma_f32", 48 + i, 32 + i, 40 + (i + 1) % 4, 44 + (i + 2) % 4),
 }
+
+def _rot(i): return f"v_fma_f32 v{48+i}, v{32+i}, v{40+(i+1)%4}, v{44+(i+2)%4}"
+CASES.update({
+    # what does one transcendental instruction cost inside a stream of plain fmas?  (8 instructions per block)
+    "mix_8fma": [_rot(i) for i in range(8)],
+    "mix_7fma_1rcp": [_rot(i) for i in range(7)] + ["v_rcp_f32 v55, v39"],
+    "mix_6fma_2rcp": [_rot(i) for i in range(6)] + ["v_rcp_f32 v54, v38", "v_rcp_f32 v55, v39"],
+    "mix_7fma_1sin": [_rot(i) for i in range(7)] + ["v_sin_f32 v55, v39"],
+    "mix_7fma_1sqrt": [_rot(i) for i in range(7)] + ["v_sqrt_f32 v55, v39"],
+    "mix_7fma_1rcp_used": [_rot(i) for i in range(6)] + ["v_rcp_f32 v55, v39", "v_fma_f32 v54, v55, v40, v45"],
+    "mix_4fma_4rcp": [_rot(i) for i in range(4)] + [f"v_rcp_f32 v{52+i}, v{36+i}" for i in range(4)],
+    "mix_7fma_1cmp": [_rot(i) for i in range(7)] + ["v_cmp_lt_f32 vcc, v39, v40"],
+    "mix_7fma_1cndmask": [_rot(i) for i in range(7)] + ["v_cndmask_b32 v55, v39, v40, vcc"],
+    "mix_7fma_1max": [_rot(i) for i in range(7)] + ["v_max_f32 v55, v39, v40"],
+})
 print("#include <hip/hip_runtime.h>\n#include <cstdio>")
 for name, f in CASES.items():
     lines = []
     for i in range(8):
+        if isinstance(f, list):
+            lines.append(f[i]); continue
         ins, d, a, b, c = f(i)
         if ins == "v_fmac_f32":
             lines.append(f"{ins} v{d}, v{a}, v{b}")
@@ -35,7 +52,7 @@ for name, f in CASES.items():
         else:
             lines.append(f"{ins} v{d}, v{a}, v{b}, v{c}")
     block = "\\n".join(lines)
-    clob = ", ".join(f'"v{r}"' for r in range(1, 56))
+    clob = ", ".join([f'"v{r}"' for r in range(1, 56)] + ['"vcc"'])
     init = "\\n".join([f"v_mov_b32 v{r}, 0x3f800347" for r in range(1, 56)])
     fin = "\\n".join(["v_mov_b32 %0, v1"] + [f"v_add_f32 %0, %0, v{r}" for r in range(2, 56)])
     body = "\n".join(f'        asm volatile("{block}" ::: {clob});' for _ in range(16))
