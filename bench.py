@@ -255,10 +255,11 @@ def main():
         model_flops_per_attempt = metric.info.accel_ops + metric.info.coord_ops + STEP_OVERHEAD_FLOPS
         default_workload = (args.metric == "kerr_boyer" and abs(args.spin - 0.45) < 1e-9 and (W, H) == (3840, 2160) and fused
                             and args.program == "static")
-        counted = None
+        counted, lane_utilisation = None, None
         if default_workload and os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                counted = json.load(f).get("fp32_flop_per_launch")
+                pmc = json.load(f)
+            counted, lane_utilisation = pmc.get("fp32_flop_per_launch"), pmc.get("valu_lane_utilisation")
         flop_per_frame = counted if counted else model_flops_per_attempt * attempts
         tflops = flop_per_frame * args.steps / elapsed / 1e12     # whole timed region, all stages included
         extra["valu_roofline"] = {"achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -267,6 +268,8 @@ def main():
                                   "flops_per_attempt": round(flop_per_frame / max(attempts, 1), 1),
                                   "flops_per_attempt_codegen_model": model_flops_per_attempt,
                                   "step_attempts_per_frame": int(attempts),
+                                  # SURVEY 8d "wave efficiency": active lanes per issued VALU instruction (hardware counters, profiles/)
+                                  "lane_utilisation": lane_utilisation,
                                   "basis": "fp32 FLOP of the trace launches / wall clock of the timed region (all stages)"}
         # the HBM view is what the contract's roofline object asks for; the roofline that actually binds this kernel rides along
         roofline["binding"] = {"bound": "fp32 VALU (no MFMA, no HBM traffic to speak of)", "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS,
