@@ -194,12 +194,16 @@ int compile_code_object(const std::string& argument_string, std::string& code) {
     hiprtcDestroyProgram(&prog);
 
     mkdir(cache_dir.c_str(), 0755);
-    std::string tmp = cache_path + ".tmp" + std::to_string((long)getpid());
+    // unique per writer: a background build (gr_program_create_async) and a foreground build of the same key may run in one
+    // process, and several processes share the cache directory; rename() publishes a complete file atomically
+    static std::atomic<unsigned long> writer{0};
+    std::string tmp = cache_path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(writer.fetch_add(1));
     {
         std::ofstream f(tmp, std::ios::binary);
         f.write(code.data(), (std::streamsize)code.size());
+        if (!f) { f.close(); remove(tmp.c_str()); return GR_OK; }   // cache write failed (disk full, read-only): the build still succeeded
     }
-    rename(tmp.c_str(), cache_path.c_str());
+    if (rename(tmp.c_str(), cache_path.c_str()) != 0) remove(tmp.c_str());
     return GR_OK;
 }
 
@@ -225,6 +229,14 @@ struct gr_program {
     std::atomic<unsigned> next_ticket{0};
     int compute_units = 256;
     std::string arguments;
+    // identity for caches keyed by program (frame.cpp prefetch slots): an address can be reused by a later program, this cannot
+    unsigned long long serial = 0;
+    ~gr_program() {
+        if (module || tickets || huge_count) (void)hipSetDevice(device);
+        if (tickets) (void)hipFree(tickets);
+        if (huge_count) (void)hipFree(huge_count);
+        if (module) (void)hipModuleUnload(module);
+    }
 };
 
 extern "C" {
@@ -353,6 +365,8 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
     auto p = std::make_unique<gr_program>();
     p->device = device;
     p->arguments = argument_string;
+    static std::atomic<unsigned long long> next_serial{1};
+    p->serial = next_serial.fetch_add(1);
     HIP_CHECK(hipModuleLoadData(&p->module, code.data()));
     for (int k = 0; k < K_COUNT; k++) {
         if (k == K_TRACE_PAIR) {   // built for some metrics only (pair_kernel_applies)
@@ -420,12 +434,10 @@ void gr_program_future_destroy(gr_program_future* f) {
 }
 
 void gr_program_destroy(gr_program* p) {
-    if (!p) return;
-    if (p->huge_count) (void)hipFree(p->huge_count);
-    if (p->tickets) (void)hipFree(p->tickets);
-    if (p->module) (void)hipModuleUnload(p->module);
-    delete p;
+    delete p;   // ~gr_program releases the module and its device buffers (also on gr_program_create's error paths)
 }
+
+unsigned long long gr_program_serial(const gr_program* p) { return p ? p->serial : 0; }
 
 int gr_program_kernel_info(const gr_program* p, const char* kernel_name, int* vgprs, int* sgprs, int* scratch_bytes) {
     if (!p || !kernel_name) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");

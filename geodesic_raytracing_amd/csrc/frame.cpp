@@ -72,7 +72,7 @@ struct gr_render_state {
         gr_camera camera{};
         std::vector<float> cfg;
         gr_features features{};
-        const void* program = nullptr;
+        unsigned long long program = 0;   // gr_program_serial: an address could be reused by a later program
         const void* geodesic = nullptr;
         float geodesic_time = 0;
         int transport = 0;
@@ -513,6 +513,14 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     else features.max_acceleration_change = info.max_acceleration_change;   // metric_manager.hpp:50
 
     const int width = s->width, height = s->height;
+    // The defaults of gr_features (adaptive_sampling on, as the reference's GUI) and of gr_frame_options (fused mode) must work
+    // together: the fused kernels trace every pixel, so a whole-frame request with adaptive sampling takes the reference-shaped
+    // sequence, which implements it (cl.cl:5223-5345).  Strips are traced in full: adaptive sampling is an approximation of
+    // exactly that frame.
+    if (opt.mode == GR_MODE_FUSED && features.adaptive_sampling != 0 && !features.use_triangle_rendering) {
+        if (opt.strip_count > 1) features.adaptive_sampling = 0;
+        else opt.mode = GR_MODE_REFERENCE;
+    }
     bool use_prepass = opt.use_prepass < 0 ? info.use_prepass != 0 : opt.use_prepass != 0;
     bool adaptive = features.adaptive_sampling != 0 && !features.use_triangle_rendering;
 
@@ -521,11 +529,22 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     for (int i = 0; i < info.num_dynamic_vars; i++)
         cfg[i] = (cfg_values && i < num_cfg_values) ? cfg_values[i] : gr_metric_dynamic_var_default(m, i);
     if ((int)cfg.size() > CFG_MAX) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "too many dynamic variables");
-    if (cfg != s->host_cfg) {
+    const bool cfg_changed = cfg != s->host_cfg;
+    const bool features_changed = !s->features_valid || memcmp(&features, &s->host_features, sizeof(features)) != 0;
+    if (cfg_changed || features_changed) {
+        // Look-ahead prepasses read s->cfg / s->dfg on their side streams: the upload below must not overtake one that is still
+        // running (it would read a mix of old and new parameters), and what the slots hold was computed for the old parameters.
+        for (auto& slot : s->pre) {
+            if (!slot.valid) continue;
+            HIP_CHECK(hipStreamWaitEvent(stream, slot.ready, 0));
+            slot.valid = false;
+        }
+    }
+    if (cfg_changed) {
         HIP_CHECK(hipMemcpyAsync(s->cfg, cfg.data(), cfg.size() * sizeof(float), hipMemcpyHostToDevice, stream));
         s->host_cfg = cfg;
     }
-    if (!s->features_valid || memcmp(&features, &s->host_features, sizeof(features)) != 0) {
+    if (features_changed) {
         HIP_CHECK(hipMemcpyAsync(s->dfg, &features, sizeof(features), hipMemcpyHostToDevice, stream));
         s->host_features = features;
         s->features_valid = true;
@@ -539,7 +558,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         k.camera = *c;
         k.cfg = cfg;
         k.features = features;
-        k.program = (const void*)p;
+        k.program = gr_program_serial(p);
         k.geodesic = (const void*)opt.geodesic;
         k.geodesic_time = time;
         k.transport = opt.parallel_transport_observer;
@@ -613,7 +632,6 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     }
 
     if (opt.mode == GR_MODE_FUSED) {
-        if (adaptive) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused mode traces every pixel: turn adaptive_sampling off");
         int strip_count = opt.strip_count > 1 ? opt.strip_count : 1;
         int strip_rank = strip_count > 1 ? opt.strip_rank : 0;
         int block_rows = strip_count > 1 ? opt.block_rows : ((height + 7) / 8) * 8;

@@ -351,12 +351,16 @@ __device__ __forceinline__ sincos_pairf sincos_reduced(pairf x) {
 // kernel) its four copies cost the pair kernel scalar-register spills
 __device__ __attribute__((noinline)) float sin_large(float x) { return ::sinf(x); }
 __device__ __attribute__((noinline)) float cos_large(float x) { return ::cosf(x); }
+__device__ __forceinline__ bool large_finite(float x) { return __builtin_fabsf(x) >= 8192.f && __builtin_fabsf(x) <= 3.402823466e+38f; }
 __device__ __forceinline__ pairf sin(pairf x) {
 #if defined(GR_FAST_TRIG) || defined(GR_LIBM_TRIG)
     pairf s; s.x = gm::sin(x.x); s.y = gm::sin(x.y);
 #else
     pairf s = sincos_reduced(x).s;
-    if (__builtin_expect(!(__builtin_fabsf(x.x) < 8192.f) || !(__builtin_fabsf(x.y) < 8192.f), 0)) { s.x = sin_large(x.x); s.y = sin_large(x.y); }
+    // per half: a ray's value must not depend on what its lane partner holds (a partner frozen at a NaN/Inf final state keeps
+    // being evaluated).  NaN/Inf need no libm either: the polynomial already returns NaN for them.
+    if (__builtin_expect(large_finite(x.x), 0)) s.x = sin_large(x.x);
+    if (__builtin_expect(large_finite(x.y), 0)) s.y = sin_large(x.y);
 #endif
     return s;
 }
@@ -365,7 +369,8 @@ __device__ __forceinline__ pairf cos(pairf x) {
     pairf c; c.x = gm::cos(x.x); c.y = gm::cos(x.y);
 #else
     pairf c = sincos_reduced(x).c;
-    if (__builtin_expect(!(__builtin_fabsf(x.x) < 8192.f) || !(__builtin_fabsf(x.y) < 8192.f), 0)) { c.x = cos_large(x.x); c.y = cos_large(x.y); }
+    if (__builtin_expect(large_finite(x.x), 0)) c.x = cos_large(x.x);
+    if (__builtin_expect(large_finite(x.y), 0)) c.y = cos_large(x.y);
 #endif
     return c;
 }
@@ -1019,7 +1024,10 @@ __device__ __forceinline__ int integrate_core(ray_state& s, cfg_t cfg, dfg_t dfg
 #ifdef IS_CONSTANT_THETA
         polar.z = GR_PIf / 2;
 #endif
-        if (!stop_lost(position, velocity, acceleration, running, i) && stop_terminated(polar)) result = RAY_TERMINATED;
+        // ... and a state that is degenerate anywhere is the reference's plain `return` (cl.cl:4235-4244, terminated stays 0) even
+        // when its position happens to lie beyond the boundary: a finite position can come with a NaN/Inf velocity or acceleration
+        const bool finite = degenerate_accumulate(position, degenerate_accumulate(velocity, degenerate_accumulate(acceleration, 0.f))) == 0.f;
+        if (!stop_lost(position, velocity, acceleration, running, i) && stop_terminated(polar) && finite) result = RAY_TERMINATED;
     }
     if (RESUMABLE) { s.next_ds = next_ds; s.steps = i; s.tries = tries; }
     s.position = position;
@@ -1236,8 +1244,10 @@ __device__ __forceinline__ void integrate_pair(pair4& position_io, pair4& veloci
 #else
         const pairf vq = splat(0.f), aq = splat(0.f);
 #endif
-        result0 = (!stop_lost(position.y.x, vq.x, aq.x, f_in_x.x, i0) && stop_terminated(polar.y.x)) ? RAY_TERMINATED : RAY_LOST;
-        result1 = (!stop_lost(position.y.y, vq.y, aq.y, f_in_x.y, i1) && stop_terminated(polar.y.y)) ? RAY_TERMINATED : RAY_LOST;
+        const bool finite0 = degenerate_accumulate(half_of<0>(position), degenerate_accumulate(half_of<0>(velocity), degenerate_accumulate(half_of<0>(acceleration), 0.f))) == 0.f;
+        const bool finite1 = degenerate_accumulate(half_of<1>(position), degenerate_accumulate(half_of<1>(velocity), degenerate_accumulate(half_of<1>(acceleration), 0.f))) == 0.f;
+        result0 = (!stop_lost(position.y.x, vq.x, aq.x, f_in_x.x, i0) && stop_terminated(polar.y.x) && finite0) ? RAY_TERMINATED : RAY_LOST;
+        result1 = (!stop_lost(position.y.y, vq.y, aq.y, f_in_x.y, i1) && stop_terminated(polar.y.y) && finite1) ? RAY_TERMINATED : RAY_LOST;
     }
     position_io = position;
     velocity_io = velocity;

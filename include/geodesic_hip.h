@@ -279,6 +279,8 @@ int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const
                   const void* e0, const void* e1, const void* e2, const void* e3,
                   const void* cfg, const void* dfg, void* attempt_counter);
 int gr_program_has_trace_pair(const gr_program* p);   /* 1 / 0 */
+/* Process-unique identity of a program object (never reused, unlike its address); 0 for NULL. */
+unsigned long long gr_program_serial(const gr_program* p);
 
 /* gr_trace_fused with ray compaction (north_star: "wave-level ballots for step-acceptance and ray compaction"): persistent
  * waves hold one ray per lane; whenever fewer than keep_lanes (1..64) of a wave's rays are still integrating, the finished

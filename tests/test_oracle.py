@@ -59,6 +59,52 @@ def test_fixtures_are_what_the_reference_computes(name):
     assert np.array_equal(r["pixels"], z["pixels"])
 
 
+SYMPY_CASES = [("schwarzschild", "schwarzschild"), ("schwarzschild", "schwarzschild_tilted"), ("schwarzschild", "schwarzschild_redshift"),
+               ("kerr_boyer", "kerr"), ("kerr_boyer", "kerr_tilted"), ("kerr_boyer", "kerr_prepass"), ("kerr_boyer", "kerr_moving_observer"),
+               ("kerr_boyer", "kerr_reparameterised"), ("alcubierre", "alcubierre")]
+
+
+@pytest.mark.skipif(not build_ref.reference_available(), reason="reference sources only exist in the build container")
+@pytest.mark.parametrize("metric,name", SYMPY_CASES)
+def test_reference_with_independent_sympy_macros_agrees_with_the_fixtures(metric, name):
+    """The fixtures come from the reference's cl.cl compiled with THIS repository's generated macro strings.  Here the same
+    cl.cl is compiled with strings derived independently by sympy from the reference's metric scripts and the conventions of
+    metric.hpp:96-274, 664-708, 725-959 (tools/sympy_macros.py shares no code with csrc/sym.cpp / metric_codegen.cpp) and must
+    land on the same rays and pixels: a generator that misread metric.hpp (index order of F*_P, the Christoffel
+    contraction, differentials, flags) would not.  Equivalent expression trees round differently, hence tolerances."""
+    pytest.importorskip("sympy")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import sympy_macros
+    meta, z = load_golden(name)
+    assert meta["metric"] == metric and not meta.get("scripts")
+    so = build_ref.build(metric + "_sympy", sympy_macros.argument_string(metric))
+    r = run_oracle(so, meta)
+    assert np.abs(r["camera_generic"] - z["camera_generic"]).max() <= 2e-6
+    assert np.abs(r["tetrad"] - z["tetrad"]).max() <= 2e-6
+    gi, ri = z["rays_init"], r["rays_init"]
+    for f in ("position", "velocity", "acceleration", "initial_quat"):
+        assert np.abs(ri[f] - gi[f]).max() <= 2e-5, f
+    assert (ri["terminated"] == gi["terminated"]).all()
+    assert (r["rays"]["terminated"] != z["rays"]["terminated"]).mean() <= 0.005
+    both = (r["rays"]["terminated"] == 1) & (z["rays"]["terminated"] == 1)
+    err = rel_err(r["rays"]["position"][both], z["rays"]["position"][both]).max(axis=1)
+    assert np.percentile(err, 90) <= 1e-3
+    if "termination" in z:
+        assert (r["termination"] != z["termination"]).mean() <= 0.01
+    rd, gd = r["render_data"], z["render_data"]
+    same = (rd["terminated"] == 1) & (gd["terminated"] == 1)
+    assert np.percentile(circ_diff(rd["tex_coord"][same], gd["tex_coord"][same]), 99) <= 1e-4
+    if meta["features"].get("redshift"):
+        # end to end (unlike the per-stage GPU tests): rays that wind around the photon sphere amplify last-place differences
+        assert np.percentile(np.abs(rd["z_shift"][same] - gd["z_shift"][same]), 90) <= 1e-4
+    d = r["pixels"][..., :3] - z["pixels"][..., :3]
+    bad = np.abs(d).max(axis=2) > 1e-3
+    assert bad.mean() <= 0.005
+    assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
+
+
 def run_path_oracle(so, meta):
     return OraclePipeline(so).geodesic_camera(meta["cfg"], pack_features(**meta["features"]), camera_pos=meta["camera_pos"],
                                               basis_speed=meta["basis_speed"], max_len=meta["max_len"],

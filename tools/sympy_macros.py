@@ -1,0 +1,291 @@
+"""TEST INFRASTRUCTURE (build container only; needs sympy).  An INDEPENDENT second generator of the reference's `-D` macro
+set: Schwarzschild, Kerr (Boyer-Lindquist) and Alcubierre are written down here from the reference's own metric scripts
+(/root/reference/scripts/{schwarzschild,kerr_boyer,alcubierre}.js + their .json settings) and differentiated with sympy,
+following the reference generator's conventions as read from its source - NOT from this repository's csrc/sym.cpp /
+metric_codegen.cpp, which it shares no code with:
+
+  * metric_info (metric.hpp:96-131): partials.idx(k, i, j) = d g_ij / d v_k;
+  * calculate_acceleration (metric.hpp:184-244): Gamma^i_kl = 1/2 g^im (d_l g_mk + d_k g_ml - d_m g_kl), a^i = -Gamma^i_kl iv_k iv_l;
+  * total_diff (metric.hpp:247-274): coordinate transforms and their total differentials in dv1..dv4;
+  * debiggen (metric.hpp:664-708): a metric without off-diagonal terms is reduced to F1..4_I and F1..16_P,
+    F(var*4+wrt+1)_P = d g_var,var / d v_wrt (build_argument_string, metric.hpp:749-762); otherwise F1..16_I, F1..64_P
+    = partials in [wrt*16 + i*4 + j] order + GENERIC_BIG_METRIC (:764-769);
+  * the flag macros of build_argument_string (metric.hpp:725-959) from the .json settings;
+  * temporaries in the reference's own TEMPORARIES0=name=expr,... form (equation_context.hpp:59-97), position-only.
+
+tests/test_oracle.py feeds these strings to the SAME /root/reference/cl.cl object the golden fixtures come from
+(oracle/build_ref.py) and requires its rays and pixels to agree with the committed fixtures - generated from this
+repository's strings - within the stage tolerances.  Different-but-equivalent expression trees round differently in fp32,
+so the comparison is by tolerance, not bit for bit.
+
+FIX_LIGHTn is emitted as the identity: cl.cl defines fix_light_velocity from it (cl.cl:3253-3266) but its only call is
+commented out (cl.cl:3315), so its value is never evaluated.
+
+    python tools/sympy_macros.py kerr_boyer        # prints the argument string
+"""
+import sys
+
+import sympy as sp
+
+v = sp.symbols("v1 v2 v3 v4", real=True)
+iv = sp.symbols("iv1 iv2 iv3 iv4", real=True)
+dv = sp.symbols("dv1 dv2 dv3 dv4", real=True)
+
+
+def cfg_symbol(name):
+    return sp.Symbol("cfg->" + name, real=True)
+
+
+# ---- printing: fp32 C expressions ---------------------------------------------------------------------------------------
+
+def _lit(x):
+    import numpy as np
+    f = float(np.float32(float(x)))
+    s = repr(f)
+    if "e" in s or "." in s:
+        return s + "f"
+    return s + ".0f"
+
+
+def c_expr(e):
+    """fully parenthesised fp32 C; integer powers become products, no double literals, no pow(double, double)"""
+    if e.is_Symbol:
+        return e.name
+    if e.is_Number:
+        if e.is_negative:
+            return "(-" + _lit(-e) + ")"
+        return _lit(e)
+    if e == sp.pi:
+        return _lit(sp.N(sp.pi, 20))
+    if e.is_Add:
+        return "(" + "+".join(c_expr(a) for a in e.args) + ")"
+    if e.is_Mul:
+        num, den = [], []
+        for a in e.args:
+            if a.is_Pow and a.exp.is_Number and a.exp.is_negative:
+                den.append(sp.Pow(a.base, -a.exp))
+            else:
+                num.append(a)
+        s = "(" + "*".join(c_expr(a) for a in num) + ")" if num else "1.0f"
+        if den:
+            s = "(" + s + "/(" + "*".join(c_expr(a) for a in den) + "))"
+        return s
+    if e.is_Pow:
+        b, x = e.base, e.exp
+        if x.is_Integer:
+            n = int(x)
+            body = "(" + "*".join([c_expr(b)] * abs(n)) + ")"
+            return body if n > 0 else "(1.0f/" + body + ")"
+        if x == sp.Rational(1, 2):
+            return "sqrt(" + c_expr(b) + ")"
+        if x == sp.Rational(-1, 2):
+            return "(1.0f/sqrt(" + c_expr(b) + "))"
+        if x.is_Rational and x.q == 2:
+            n = int(x.p)
+            root = "sqrt(" + c_expr(b) + ")"
+            body = "(" + "*".join([root] * abs(n)) + ")"
+            return body if n > 0 else "(1.0f/" + body + ")"
+        raise ValueError("unsupported power " + str(e))
+    if isinstance(e, sp.Function):
+        name = {"Abs": "fabs"}.get(type(e).__name__, type(e).__name__)
+        return name + "(" + ",".join(c_expr(a) for a in e.args) + ")"
+    raise ValueError("unsupported expression " + str(type(e)))
+
+
+# ---- the three metrics, from the reference's scripts ---------------------------------------------------------------------
+
+def cartesian_to_polar(t, x, y, z):          # metric.hpp:27-36
+    return [t, sp.sqrt(x * x + y * y + z * z), sp.atan2(sp.sqrt(x * x + y * y), z), sp.atan2(y, x)]
+
+
+def polar_to_cartesian(t, r, theta, phi):    # scripts/coordinates/polar_to_cartesian.js
+    return [t, r * sp.sin(theta) * sp.cos(phi), r * sp.sin(theta) * sp.sin(phi), r * sp.cos(theta)]
+
+
+def identity(t, a, b, c):
+    return [t, a, b, c]
+
+
+def schwarzschild(t, r, theta, phi):         # scripts/schwarzschild.js
+    rs, c = 1, 1
+    return sp.diag(-(1 - sp.Integer(rs) / r) * c * c, 1 / (1 - sp.Integer(rs) / r), r * r, r * r * sp.sin(theta) ** 2)
+
+
+def kerr_boyer(t, r, theta, phi):            # scripts/kerr_boyer.js
+    rs, a = cfg_symbol("rs"), cfg_symbol("a")
+    E = r * r + a * a * sp.cos(theta) ** 2
+    D = r * r - rs * r + a * a
+    g = sp.zeros(4, 4)
+    g[0, 0] = -(1 - rs * r / E)
+    g[1, 1] = E / D
+    g[2, 2] = E
+    g[3, 3] = (r * r + a * a + (rs * r * a * a / E) * sp.sin(theta) ** 2) * sp.sin(theta) ** 2
+    g[0, 3] = g[3, 0] = -rs * r * a * sp.sin(theta) ** 2 / E
+    return g
+
+
+def alcubierre(t, x, y, z):                  # scripts/alcubierre.js
+    vel, sigma, R = cfg_symbol("velocity"), cfg_symbol("sigma"), cfg_symbol("R")
+    rs_t = sp.sqrt((x - vel * t) ** 2 + y * y + z * z)
+    f = (sp.tanh(sigma * (rs_t + R)) - sp.tanh(sigma * (rs_t - R))) / (2 * sp.tanh(sigma * R))
+    g = sp.eye(4)
+    g[0, 0] = vel * vel * f * f - 1
+    g[0, 1] = g[1, 0] = -vel * f
+    return g
+
+
+def alcubierre_distance(t, r, theta, phi):   # scripts/origins/alcubierre_origin.js (takes polar coordinates)
+    c = polar_to_cartesian(t, r, theta, phi)
+    x = c[1] - cfg_symbol("velocity") * t
+    return sp.sqrt(x * x + c[2] * c[2] + c[3] * c[3])
+
+
+def radius(t, r, theta, phi):                # scripts/origins/at_origin.js
+    return r
+
+
+# settings resolved from scripts/<name>.json + the base it inherits (polar_base.json / cartesian_base.json)
+METRICS = {
+    "schwarzschild": dict(g=schwarzschild, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                          periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=1.05, adaptive=False, detect=False, dynvars=[]),
+    "kerr_boyer": dict(g=kerr_boyer, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                       periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=True, dynvars=["rs", "a"]),
+    "alcubierre": dict(g=alcubierre, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=alcubierre_distance,
+                       system="CARTESIAN", periodicity=None, singular=None, adaptive=True, detect=False,
+                       dynvars=["velocity", "sigma", "R"], nonsingular=True),
+}
+
+
+def block_inverse(g):
+    """inverse of a symmetric 4x4 by the connected blocks of its zero pattern (1x1 and 2x2 in closed form)"""
+    n = 4
+    seen, blocks = set(), []
+    for s in range(n):
+        if s in seen:
+            continue
+        comp, todo = [], [s]
+        while todo:
+            i = todo.pop()
+            if i in seen:
+                continue
+            seen.add(i)
+            comp.append(i)
+            todo += [j for j in range(n) if j != i and g[i, j] != 0]
+        blocks.append(sorted(comp))
+    inv = sp.zeros(n, n)
+    for b in blocks:
+        sub = g.extract(b, b)
+        if len(b) == 1:
+            si = sp.Matrix([[1 / sub[0, 0]]])
+        elif len(b) == 2:
+            det = sub[0, 0] * sub[1, 1] - sub[0, 1] * sub[1, 0]
+            si = sp.Matrix([[sub[1, 1], -sub[0, 1]], [-sub[1, 0], sub[0, 0]]]) / det
+        else:
+            si = sub.inv(method="ADJ")
+        for a, i in enumerate(b):
+            for c, j in enumerate(b):
+                inv[i, j] = si[a, c]
+    return inv
+
+
+def total_diff(f):
+    """metric.hpp:247-274: values and total differentials sum_j (d f_i / d v_j) dv_j"""
+    vals = f(*v)
+    return vals, [sum(sp.diff(vals[i], v[j]) * dv[j] for j in range(4)) for i in range(4)]
+
+
+def is_polar_spherically_symmetric(g):       # metric.hpp:556-622, for the metric forms used here
+    if any(g[i, j] != 0 for (i, j) in [(0, 2), (0, 3), (1, 2), (1, 3)]):
+        return False
+    return sp.simplify(g[3, 3] / sp.sin(v[2]) ** 2 - g[2, 2]) == 0
+
+
+def argument_string(name):
+    m = METRICS[name]
+    g = m["g"](*v)
+    partial = [[[sp.diff(g[i, j], v[k]) for j in range(4)] for i in range(4)] for k in range(4)]   # [k][i][j] = d_k g_ij
+    ginv = block_inverse(g)
+    # acceleration as position-only coefficients of the velocity monomials (so that temporaries never mention iv*)
+    coeff = {}
+    for i in range(4):
+        for k in range(4):
+            for l in range(k, 4):
+                def gamma(kk, ll):
+                    return sp.Rational(1, 2) * sum(ginv[i, mm] * (partial[ll][mm][kk] + partial[kk][mm][ll] - partial[mm][kk][ll]) for mm in range(4))
+                c = gamma(k, l) if k == l else gamma(k, l) + gamma(l, k)
+                if c != 0:
+                    coeff[(i, k, l)] = c
+    diagonal = all(g[i, j] == 0 for i in range(4) for j in range(4) if i != j)
+    named = {}
+    if diagonal:
+        for i in range(4):
+            named[f"F{i + 1}_I"] = g[i, i]
+        for var in range(4):
+            for wrt in range(4):
+                named[f"F{var * 4 + wrt + 1}_P"] = partial[wrt][var][var]
+    else:
+        for i in range(4):
+            for j in range(4):
+                named[f"F{i * 4 + j + 1}_I"] = g[i, j]
+        for k in range(4):
+            for i in range(4):
+                for j in range(4):
+                    named[f"F{k * 16 + i * 4 + j + 1}_P"] = partial[k][i][j]
+    for key, c in coeff.items():
+        named["C%d%d%d" % key] = c
+
+    keys = list(named)
+    repl, reduced = sp.cse([named[k] for k in keys], symbols=(sp.Symbol("pv%d" % n) for n in range(100000)), optimizations="basic")
+    reduced = dict(zip(keys, reduced))
+
+    out = ["-DRS_IMPL=1", "-DC_IMPL=1"]
+    out += [f"-D{k}={c_expr(reduced[k])}" for k in keys if k.endswith("_I")]
+    out += [f"-D{k}={c_expr(reduced[k])}" for k in keys if k.endswith("_P")]
+    if not diagonal:
+        out.append("-DGENERIC_BIG_METRIC")
+    to_vals, to_diff = total_diff(m["to_polar"])
+    from_vals, from_diff = total_diff(m["from_polar"])
+    for tag, exprs in (("TO_COORD", to_vals), ("TO_DCOORD", to_diff), ("FROM_COORD", from_vals), ("FROM_DCOORD", from_diff)):
+        out += [f"-D{tag}{i + 1}={c_expr(sp.sympify(e))}" for i, e in enumerate(exprs)]
+    if m["periodicity"]:
+        out += [f"-DCOORDINATE_PERIODICITY{i + 1}={c_expr(sp.sympify(p))}" for i, p in enumerate(m["periodicity"])]
+        out.append("-DHAS_COORDINATE_PERIODICITY")
+    out += ["-DGENERIC_METRIC", "-DVERLET_INTEGRATION_GENERIC"]
+    symmetric = m["system"] == "X_Y_THETA_PHI" and is_polar_spherically_symmetric(g)
+    if symmetric:
+        out.append("-DGENERIC_CONSTANT_THETA")
+    if m["singular"] is not None:
+        out += ["-DSINGULAR", "-DSINGULAR_TERMINATOR=" + _lit(m["singular"])]
+    if m["adaptive"]:
+        out.append("-DADAPTIVE_PRECISION")
+        if m["detect"]:
+            out.append("-DSINGULARITY_DETECTION")
+    if m["system"] == "X_Y_THETA_PHI":
+        out += ["-DW_V1=1", "-DW_V2=1", "-DW_V3=8", "-DW_V4=8" if symmetric else "-DW_V4=32"]
+    else:
+        out += ["-DW_V1=1", "-DW_V2=1", "-DW_V3=1", "-DW_V4=1"]
+    if m.get("nonsingular"):
+        out.append("-DUNCONDITIONALLY_NONSINGULAR")
+    out.append("-DDISTANCE_FUNC=" + c_expr(sp.sympify(m["distance"](*v))))
+    if m["dynvars"]:
+        out.append("-DDYNVARS=" + ",".join(m["dynvars"]))
+    c2p, c2p_d = total_diff(cartesian_to_polar)
+    out += [f"-DCART_TO_POL{i}={c_expr(sp.sympify(e))}" for i, e in enumerate(c2p)]
+    out += [f"-DCART_TO_POL_D{i}={c_expr(sp.sympify(e))}" for i, e in enumerate(c2p_d)]
+    for i in range(4):
+        terms = [c_expr(reduced["C%d%d%d" % (i, k, l)]) + f"*({iv[k].name}*{iv[l].name})"
+                 for k in range(4) for l in range(k, 4) if (i, k, l) in coeff]
+        out.append(f"-DGEO_ACCEL{i}=" + ("(-(" + "+".join(terms) + "))" if terms else "0.0f"))
+    out += [f"-DFIX_LIGHT{i}=iv{i + 1}" for i in range(4)]
+    out.append("-DMETRIC_TIME_G00=" + c_expr(reduced["F1_I"]))
+    out.append("-DTEMPORARIES0=" + (",".join(f"{s.name}={c_expr(e)}" for s, e in repl) if repl else "DUMMY"))
+    out += ["-DKERNEL_IS_DYNAMIC",
+            "-DDYNAMIC_FLOAT_FEATURES=adaptive_sampling_threshold,field_of_view,max_acceleration_change,max_precision_radius,min_step,ray_skip,universe_size",
+            "-DDYNAMIC_BOOL_FEATURES=adaptive_sampling,redshift,reparameterisation,use_old_redshift,use_triangle_rendering"]
+    text = " ".join(out)
+    assert " " not in "".join(tok.split("=", 1)[-1] for tok in out), "a macro value contains a space"
+    return "-DLINEAR_FRAMEBUFFER " + text
+
+
+if __name__ == "__main__":
+    print(argument_string(sys.argv[1] if len(sys.argv) > 1 else "kerr_boyer"))
