@@ -104,6 +104,7 @@ _SIGNATURES = {
     "gr_trace_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gr_program_has_trace_pair": (c_int, [c_void_p]),
+    "gr_program_serial": (ctypes.c_ulonglong, [c_void_p]),
     "gr_trace_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "gr_boost_tetrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -132,6 +133,7 @@ _SIGNATURES = {
     "gr_render_state_stage_ms": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float)]),
     "gr_render_state_trace_log": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int), c_int]),
     "gr_render_state_attempts": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
+    "gr_render_state_shader_clock": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "gr_render_state_buffer": (c_void_p, [c_void_p, c_int]),
     "gr_device_download": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     "gr_device_upload": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),

@@ -126,6 +126,35 @@ bool pair_kernel_applies(const std::vector<std::string>& opts) {
     return total > 0 && total < 16384;
 }
 
+// VGPRs and scratch bytes per lane of one kernel, read from the code object's metadata note (msgpack: the kernel's map holds
+// ".name", later ".private_segment_fixed_size" and ".vgpr_count" - keys are sorted).  false when the note is not understood.
+bool kernel_resources(const std::string& code, const char* kernel, int& vgprs, int& scratch_bytes) {
+    auto msgpack_uint = [&](size_t at, long& value) -> bool {
+        if (at >= code.size()) return false;
+        const unsigned char c = (unsigned char)code[at];
+        if (c < 0x80) { value = c; return true; }
+        if (c == 0xcc && at + 1 < code.size()) { value = (unsigned char)code[at + 1]; return true; }
+        if (c == 0xcd && at + 2 < code.size()) { value = ((unsigned char)code[at + 1] << 8) | (unsigned char)code[at + 2]; return true; }
+        if (c == 0xce && at + 4 < code.size()) {
+            value = ((long)(unsigned char)code[at + 1] << 24) | ((unsigned char)code[at + 2] << 16) | ((unsigned char)code[at + 3] << 8) | (unsigned char)code[at + 4];
+            return true;
+        }
+        return false;
+    };
+    const std::string name_key = std::string(".name") + (char)(0xa0 + strlen(kernel)) + kernel;   // fixstr key, fixstr value (< 32 chars)
+    if (strlen(kernel) >= 32) return false;
+    size_t at = code.find(name_key);
+    if (at == std::string::npos) return false;
+    const std::string scratch_key = ".private_segment_fixed_size", vgpr_key = ".vgpr_count";
+    size_t s = code.find(scratch_key, at), v = code.find(vgpr_key, at);
+    if (s == std::string::npos || v == std::string::npos) return false;
+    long sv = 0, vv = 0;
+    if (!msgpack_uint(s + scratch_key.size(), sv) || !msgpack_uint(v + vgpr_key.size(), vv)) return false;
+    vgprs = (int)vv;
+    scratch_bytes = (int)sv;
+    return vgprs > 0 && vgprs <= 512;
+}
+
 // Compiles (or fetches from the on-disk cache) the code object for one macro string.
 int compile_code_object(const std::string& argument_string, std::string& code) {
     std::string source_path;
@@ -173,25 +202,56 @@ int compile_code_object(const std::string& argument_string, std::string& code) {
     std::string cache_path = cache_dir + "/" + name;
     if (read_file(cache_path, code) && !code.empty()) return GR_OK;
 
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, source.c_str(), "geodesic_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-        return fail(GR_ERROR_COMPILE, "hiprtcCreateProgram failed");
-    std::vector<const char*> copts;
-    for (auto& o : opts) copts.push_back(o.c_str());
-    hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
-    if (r != HIPRTC_SUCCESS) {
+    // one hiprtc build of the kernel source with `options`
+    auto build = [&](const std::vector<std::string>& options, std::string& out) -> int {
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, source.c_str(), "geodesic_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+            return fail(GR_ERROR_COMPILE, "hiprtcCreateProgram failed");
+        std::vector<const char*> copts;
+        for (auto& o : options) copts.push_back(o.c_str());
+        hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+        if (r != HIPRTC_SUCCESS) {
+            size_t n = 0;
+            hiprtcGetProgramLogSize(prog, &n);
+            std::string log(n, '\0');
+            if (n) hiprtcGetProgramLog(prog, &log[0]);
+            hiprtcDestroyProgram(&prog);
+            return fail(GR_ERROR_COMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
+        }
         size_t n = 0;
-        hiprtcGetProgramLogSize(prog, &n);
-        std::string log(n, '\0');
-        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcGetCodeSize(prog, &n);
+        out.assign(n, '\0');
+        hiprtcGetCode(prog, &out[0]);
         hiprtcDestroyProgram(&prog);
-        return fail(GR_ERROR_COMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
+        return GR_OK;
+    };
+    int rc = build(opts, code);
+    if (rc != GR_OK) return rc;
+
+    // Occupancy of the fused trace kernel.  Measured on MI355X (4K Kerr, substituted program, trace launch alone): the register
+    // allocator, given the whole file, takes 99 VGPRs (4 waves per SIMD) - 6.66 ms; held to 72 (7 waves, 60 bytes of spills, none
+    // of them inside the Verlet loop) - 6.25 ms; 96 / 80 / 64 VGPRs: 6.80 / 6.47 / 6.57 ms.  The loop's dependent chains want more
+    // waves than the allocator's appetite leaves.  Rule: rebuild with the register budget of three quarters of what the free build
+    // took, rounded down to an occupancy step, and keep that build unless it spills more than 64 bytes per lane.
+    bool tuned_by_caller = false;
+    for (auto& o : opts) tuned_by_caller |= o.rfind("-DGR_FUSED_WAVES", 0) == 0 || o.rfind("-DGR_TRACE_WAVES", 0) == 0;
+    const char* tuning = getenv("GR_OCCUPANCY_TUNING");
+    if (!tuned_by_caller && !(tuning && tuning[0] == '0')) {
+        int vgprs = 0, scratch = 0;
+        if (kernel_resources(code, "gr_trace_fused", vgprs, scratch) && vgprs > 64) {
+            auto waves_of = [](int regs) { int w = 512 / (((regs + 7) / 8) * 8); return w > 8 ? 8 : w; };
+            int target_waves = waves_of(vgprs * 3 / 4);
+            while (target_waves > 1 && (512 / target_waves) / 8 * 8 > vgprs * 3 / 4) target_waves++;   // budget of w waves <= 3/4 of the free build
+            if (target_waves > 8) target_waves = 8;
+            if (target_waves > waves_of(vgprs)) {
+                std::vector<std::string> capped = opts;
+                capped.push_back("-DGR_FUSED_WAVES=" + std::to_string(target_waves));
+                std::string code2;
+                int v2 = 0, s2 = 0;
+                if (build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2) && s2 <= scratch + 64) code.swap(code2);
+            }
+        }
     }
-    size_t n = 0;
-    hiprtcGetCodeSize(prog, &n);
-    code.assign(n, '\0');
-    hiprtcGetCode(prog, &code[0]);
-    hiprtcDestroyProgram(&prog);
 
     mkdir(cache_dir.c_str(), 0755);
     // unique per writer: a background build (gr_program_create_async) and a foreground build of the same key may run in one

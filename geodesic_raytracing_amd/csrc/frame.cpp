@@ -45,7 +45,7 @@ struct gr_render_state {
     void* render_data_count = nullptr;
     void* cfg = nullptr;            // struct dynamic_config (floats in declaration order)
     void* dfg = nullptr;            // struct dynamic_feature_config
-    void* attempts = nullptr;       // uint64
+    void* attempts = nullptr;       // uint64[4]: attempts, shader cycles, 100 MHz ticks, waves (the last three: fused trace only)
     // per-pixel buffers (render_state.hpp:172-196); ray records are allocated on first use
     void* rays_in = nullptr;
     void* rays_adaptive = nullptr;
@@ -247,7 +247,7 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
     A(&s->render_data_count, 4);
     A(&s->cfg, CFG_MAX * sizeof(float));
     A(&s->dfg, sizeof(gr_features));
-    A(&s->attempts, 8);
+    A(&s->attempts, 32);
     size_t px = (size_t)width * height;
     A(&s->render_data, px * sizeof(gr_render_data));
     A(&s->termination_buffer, px * sizeof(int));
@@ -350,6 +350,15 @@ int gr_render_state_trace_log(gr_render_state* s, float* total_ms, int* launches
     if (total_ms) *total_ms = (float)sum;
     if (launches) *launches = (int)s->trace_log_used;
     if (reset) s->trace_log_used = 0;
+    return GR_OK;
+}
+
+int gr_render_state_shader_clock(gr_render_state* s, double* mhz) {
+    if (!s || !mhz) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    HIP_CHECK(hipSetDevice(s->device));
+    unsigned long long v[4] = {};
+    HIP_CHECK(hipMemcpy(v, s->attempts, 32, hipMemcpyDeviceToHost));
+    *mhz = v[2] ? 100.0 * (double)v[1] / (double)v[2] : 0.0;   // cycles per tick of the 100 MHz reference clock
     return GR_OK;
 }
 
@@ -606,7 +615,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     };
     void* attempts = nullptr;
     if (opt.count_attempts) {
-        HIP_CHECK(hipMemsetAsync(s->attempts, 0, 8, stream));
+        HIP_CHECK(hipMemsetAsync(s->attempts, 0, 32, stream));
         attempts = s->attempts;
     }
 

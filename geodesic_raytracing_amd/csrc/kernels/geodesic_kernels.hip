@@ -114,6 +114,12 @@ struct dynamic_feature_config {
 #define GR_TRACE_WAVES 1
 #endif
 
+// the same for gr_trace_fused alone: the host rebuilds a program with this set when that buys the kernel occupancy without
+// spilling in its loop (capi.cpp compile_code_object)
+#ifndef GR_FUSED_WAVES
+#define GR_FUSED_WAVES GR_TRACE_WAVES
+#endif
+
 typedef const dynamic_config* __restrict__ cfg_t;
 typedef const dynamic_feature_config* __restrict__ dfg_t;
 
@@ -144,6 +150,9 @@ __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
 // The metric expressions evaluate sin(theta) and cos(theta) together every Verlet step, where the two separate libm
 // calls (each with its own large-argument branch) were ~25 % of the step's instructions.
 struct sincos_pair { float s, c; };
+// POISON_LARGE: an argument outside the polynomial's range (|x| >= 8192) returns NaN for both - two full-rate instructions, no
+// compare, no branch, no flag to carry: x * 4.154e34 overflows exactly then, and fma(inf, 0, r) is NaN while fma(finite, 0, r) is r
+template <bool POISON_LARGE = false>
 __device__ __forceinline__ sincos_pair sincos_reduced(float x) {
 #pragma clang fp reassociate(off)
     // nearest multiple of pi/2 by the 1.5 * 2^23 trick: the rounded quotient lands in the low mantissa bits of t (so the
@@ -155,6 +164,7 @@ __device__ __forceinline__ sincos_pair sincos_reduced(float x) {
     unsigned int q = __builtin_bit_cast(unsigned int, t);
     float r = __builtin_fmaf(-j, 1.57079637050628662109375f, x);   // pi/2 = hi + lo, fma keeps the product exact
     r = __builtin_fmaf(-j, -4.37113900018624283e-8f, r);
+    if (POISON_LARGE) r = __builtin_fmaf(x * 4.1539e34f, 0.f, r);
     float r2 = r * r;
     float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
     float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
@@ -265,6 +275,43 @@ __device__ __forceinline__ float4 coordinate_period(cfg_t cfg) {
 }
 
 // closed-form geodesic acceleration (GEO_ACCELn; step_verlet cl.cl:3279-3309)
+#if defined(GR_FAST_TRIG) || defined(GR_LIBM_TRIG)
+#define GR_ACCEL_TRIG(LIBM)
+#else
+// Inside the Verlet loop the expressions' sin / cos are the bare polynomial, which answers an argument outside its range with
+// NaN.  The step controller then treats the attempt like any other that ends in a degenerate velocity - the ray leaves the fast
+// loop - and whoever left that way has the attempt redone by a loop that calls libm (integrate_pingpong): a genuinely
+// degenerate step is found degenerate again, a large argument - never seen in practice - is integrated on.  libm's argument
+// reduction, two copies of it per evaluation, stays out of the loop body every ray runs and out of its register budget, and
+// the fast loop carries no flag for it.
+#define GR_ACCEL_TRIG(LIBM)                                                                              \
+    auto sin = [&](float x) -> float { return LIBM ? ::sinf(x) : sincos_reduced<true>(x).s; };           \
+    auto cos = [&](float x) -> float { return LIBM ? ::cosf(x) : sincos_reduced<true>(x).c; };           \
+    (void)sin; (void)cos;
+#endif
+template <bool LIBM>
+__device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 vel, cfg_t cfg) {
+#ifdef GENERIC_CONSTANT_THETA
+    pos.z = GR_PIf / 2;
+    vel.z = 0.f;
+#endif
+    GR_POSITION_VARS(pos)
+    const float iv1 = vel.x; const float iv2 = vel.y; const float iv3 = vel.z; const float iv4 = vel.w;
+    (void)iv1; (void)iv2; (void)iv3; (void)iv4;
+    GR_ACCEL_TRIG(LIBM)
+    float TEMPORARIES0;
+    float4 a;
+    a.x = GEO_ACCEL0;
+    a.y = GEO_ACCEL1;
+#ifndef GENERIC_CONSTANT_THETA
+    a.z = GEO_ACCEL2;
+#else
+    a.z = 0.f;
+#endif
+    a.w = GEO_ACCEL3;
+    return a;
+}
+// everywhere outside the Verlet loop (ray set-up, geodesic paths): gm::sin / gm::cos with their own large-argument branches
 __device__ __forceinline__ float4 geodesic_acceleration(float4 pos, float4 vel, cfg_t cfg) {
 #ifdef GENERIC_CONSTANT_THETA
     pos.z = GR_PIf / 2;
@@ -1038,10 +1085,327 @@ __device__ __forceinline__ int integrate_core(ray_state& s, cfg_t cfg, dfg_t dfg
     return result;
 }
 
+
+// ---- the integrator as it runs by default ---------------------------------------------------------------------------------
+// The same algorithm written for the machine's costs.  Measured facts it is built on (MI355X, 4K Kerr): one more VALU
+// instruction per attempt costs ~0.35 % of the frame, a scalar one ~0.15 %; a step is REJECTED once in ~35 000 attempts
+// (oracle count, 192x108 Kerr: 357 of 12.7 M), so everything is arranged for the accepting path and a rejection may be slow.
+//   * two attempts per trip, the state ping-ponging between two register sets: the accepted state is written where the next
+//     attempt reads it, and only a rejection copies (the one-attempt loop paid 7 v_mov / v_xor per attempt to move the new
+//     state into the loop-carried registers);
+//   * the controller works on the squared, scaled error q = (|W a| 0.01 / Wmax 65536)^2: one multiply, one max against the
+//     squared floor, suggestion = sqrt(err 65536) q^(-1/4) (v_sqrt, v_rsq), clamp by v_med3; the singularity test
+//     (cl.cl:3446-3449) is one compare of q in the hot path, its second condition only behind it;
+//   * IS_DEGENERATE (cl.cl:4235-4244) on the new velocity alone inside the loop - a non-finite acceleration makes the velocity
+//     computed from it non-finite in the same step, a non-finite position needs a non-finite velocity first - and on all three
+//     vectors once after the loop, where the outcome is decided;
+//   * the step cap (cl.cl:3974: 16384 accepted steps) is the borrow of the subtraction that counts the steps down; the
+//     attempt count the profiling launches ask for follows from it after the loop;
+__device__ __forceinline__ float min_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// dst = src as instructions the compiler can neither turn into selects nor move out of the (rarely executed) block they are in
+__device__ __forceinline__ void overwrite(float4& dst, float4 src) {
+    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                 : "+v"(dst.x), "+v"(dst.y), "+v"(dst.z), "+v"(dst.w) : "v"(src.x), "v"(src.y), "v"(src.z), "v"(src.w));
+}
+
+#define GR_INTEGRATOR_MAX_BLOCK 256
+// Fourteen floats of a lane to its LDS slots (component c at byte c * 4 * GR_INTEGRATOR_MAX_BLOCK): opaque stores, so that they stay
+// in the rarely executed block they are written in.  The same lane reads them back; LDS serves a wave's requests in order.
+__device__ __forceinline__ void park(unsigned int lds_byte_address, float4 p, float4 v, float4 a, float e0, float e1) {
+    asm volatile("ds_write_b32 %0, %1 offset:12288\n\tds_write_b32 %0, %2 offset:13312" : : "v"(lds_byte_address), "v"(e0), "v"(e1) : "memory");
+    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:1024\n\tds_write_b32 %0, %3 offset:2048\n\tds_write_b32 %0, %4 offset:3072\n\t"
+                 "ds_write_b32 %0, %5 offset:4096\n\tds_write_b32 %0, %6 offset:5120\n\tds_write_b32 %0, %7 offset:6144\n\tds_write_b32 %0, %8 offset:7168\n\t"
+                 "ds_write_b32 %0, %9 offset:8192\n\tds_write_b32 %0, %10 offset:9216\n\tds_write_b32 %0, %11 offset:10240\n\tds_write_b32 %0, %12 offset:11264"
+                 : : "v"(lds_byte_address), "v"(p.x), "v"(p.y), "v"(p.z), "v"(p.w), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w)
+                 : "memory");
+}
+// largest workgroup of a kernel that integrates rays (the fused trace kernels; gr_do_generic_rays and the prepass use 64)
+// the same with a wave-uniform first operand (a feature value, a literal): no VGPR is spent on it
+__device__ __forceinline__ float min_f32_uniform(float uniform, float x) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(x)); return r; }
+__device__ __forceinline__ float max_f32_uniform(float uniform, float x) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(x)); return r; }
+
+#ifdef ADAPTIVE_PRECISION
+struct step_controller {
+    float floor_q, root, singular_q, min_step;
+    __device__ __forceinline__ step_controller(float max_acceleration, float min_step_in) {
+        const float scale = 65536.f;
+        const float floor_diff = max_acceleration * scale / 1e10f;
+        floor_q = floor_diff * floor_diff;
+        root = __builtin_sqrtf(max_acceleration * scale);
+        const float singular = max_acceleration * 10000 * scale;
+        singular_q = singular * singular;
+        min_step = min_step_in;
+    }
+    // diff^2 of acceleration_to_precision (cl.cl:3400-3429), floored
+    __device__ __forceinline__ float error_q(float4 acc) const {
+        const float k = 0.01f * 65536.f / GR_W_MAX;
+        const float wx = acc.x * (float)(W_V1), wy = acc.y * (float)(W_V2), wz = acc.z * (float)(W_V3), ww = acc.w * (float)(W_V4);
+        const float d2 = __builtin_fmaf(wx, wx, __builtin_fmaf(wy, wy, __builtin_fmaf(wz, wz, ww * ww)));
+        return max_f32_uniform(floor_q, d2 * (k * k));   // a NaN error takes the floor: the step is then accepted and its velocity is caught as degenerate
+    }
+    __device__ __forceinline__ float suggestion(float q) const { return root * __builtin_amdgcn_rsqf(__builtin_sqrtf(q)); }
+};
+#endif
+
+template <bool LIBM> struct trig_flavour { static constexpr bool value = LIBM; };
+
+template <bool RESUMABLE>
+__device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t dfg, unsigned int* attempts, int keep_lanes, bool& paused) {
+    float4 p0 = s.position, v0 = s.velocity, a0 = s.acceleration;
+    float4 p1 = p0, v1 = v0, a1 = a0;
+    const float f_in_x = RESUMABLE ? s.f_in_x : __builtin_fabsf(v0.x);
+    float next_ds = 0.00001f;
+#ifdef ADAPTIVE_PRECISION
+    const step_controller controller(GET_FEATURE(max_acceleration_change, dfg), GET_FEATURE(min_step, dfg));
+    if (RESUMABLE) next_ds = s.next_ds;
+    else {
+        float4 a = a0;
+#ifdef IS_CONSTANT_THETA
+        a.z = 0;
+#endif
+        next_ds = controller.suggestion(controller.error_q(a));
+    }
+#endif
+    const float subambient_precision = 0.5f;
+    const float ambient_precision = 0.2f;
+    const float new_max = GET_FEATURE(max_precision_radius, dfg);
+    const float new_min = 3;
+    const float universe = GET_FEATURE(universe_size, dfg);
+    const bool reparam = GET_FEATURE(reparameterisation, dfg) != 0;
+    float running = RESUMABLE ? s.running_dlambda_dnew : 1.f;
+    const int loop_limit = 4096 * 4;
+    // accepted steps the ray may still take (cl.cl:3974: 16384 in all).  Every attempt() entered takes one - the borrow of that very
+    // subtraction is the step-cap test - and a rejection (rare) gives it back.
+    const unsigned int budget_before = (unsigned int)(loop_limit - (RESUMABLE ? s.steps : 0));
+    unsigned int budget = budget_before;
+    unsigned int rejections = 0;
+    paused = false;
+
+    auto stop_lost = [&](float4 pos, float4 vel, float4 acc, float run) {
+        bool lost = false;
+#ifdef HAS_CYLINDRICAL_SINGULARITY
+        lost |= pos.y < CYLINDRICAL_TERMINATOR;
+#endif
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        lost |= __builtin_fabsf(vel.x / run) > 1000 + f_in_x && __builtin_fabsf(acc.x / run) > 100;
+#endif
+        (void)pos; (void)vel; (void)acc; (void)run;
+        return lost;
+    };
+    auto stop_terminated = [&](float4 polar) {
+        bool t = __builtin_fabsf(polar.y) >= universe;
+#ifdef SINGULAR
+        t |= __builtin_fabsf(polar.y) < SINGULAR_TERMINATOR;
+#endif
+        return t;
+    };
+    const float far_offset = ambient_precision - 0.1f * new_max;
+    // One Verlet attempt from (p, v, a): the state the next attempt starts from goes to (po, vo, ao) - the new state, or the old
+    // one again after a rejection.  Returns true when the loop is to be left: the ray is done and (p, v, a) is its final state
+    // (what the loop carries - step suggestion, budget - is then that of the abandoned attempt); or pause_wave was raised
+    // (RESUMABLE): the step was taken, the wave wants new rays, the state is (po, vo, ao).
+    bool pause_wave = false;
+    auto attempt = [&](auto libm, float4 position, float4 velocity, float4 acceleration, float4& po, float4& vo, float4& ao, float& ds_used,
+                       float& running_before) -> bool {
+        // the for-loop condition of the reference, then its loop-top exits (cl.cl:3974, 4086-4130)
+        if (__builtin_expect(__builtin_usub_overflow(budget, 1u, &budget), 0)) return true;
+#ifdef IS_CONSTANT_THETA
+        position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
+#endif
+        float4 polar = gm::generic_to_spherical(position, cfg);
+#ifdef IS_CONSTANT_THETA
+        polar.z = GR_PIf / 2;
+#endif
+        const float ar = __builtin_fabsf(gm::distance_to_object(polar, cfg));
+        const bool inside = ar < new_max;
+#ifdef ADAPTIVE_PRECISION
+        const float near_ds = min_f32_uniform(ambient_precision, next_ds);
+#else
+        const float near_ds = min_f32_uniform(ambient_precision, mixf(ambient_precision, subambient_precision, (clampf(ar, new_min, new_max) - new_min) / (new_max - new_min)));
+#endif
+        const float far_ds = __builtin_fmaf(0.1f, ar, far_offset);   // 0.1 (|r| - max_precision_radius) + ambient
+        const float ds = inside ? near_ds : far_ds;
+        ds_used = ds;
+        running_before = running;
+        if (stop_lost(position, velocity, acceleration, running) | stop_terminated(polar)) return true;
+#if defined(GR_PROBE_VALU) || defined(GR_PROBE_SALU)
+        // bottleneck probes (tools/README.md): extra independent instructions per attempt; does the frame time follow?
+        {
+#ifdef GR_PROBE_VALU
+            float probe = ds;
+#pragma unroll
+            for (int q = 0; q < GR_PROBE_VALU; q++) asm volatile("v_mul_f32 %0, 0x3f8ccccd, %0" : "+v"(probe));
+            asm volatile("" ::"v"(probe));
+#endif
+#ifdef GR_PROBE_SALU
+            int sprobe = 1;
+#pragma unroll
+            for (int q = 0; q < GR_PROBE_SALU; q++) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sprobe) : : "scc");
+            asm volatile("" ::"s"(sprobe));
+#endif
+        }
+#endif
+        // velocity Verlet (step_verlet, cl.cl:3273-3346) in the reference's operation order.  (Through the half-kicked velocity
+        // h = v + a ds/2 - x' = x + h ds, v~ = h + a ds/2, v' = h + a' ds/2 - it is 16 fmas instead of 20 operations and the same
+        // algebra, but its roundings are not the reference's: measured against the golden pixels the RMSE of the Kerr cases went
+        // from 7e-6 to 3.7e-5 and pixels off by > 1e-3 from 0-1 to 3-6 per fixture.  Parity first: 4 instructions.)
+        const float half_ds = 0.5f * ds, half_ds2 = half_ds * ds;
+        const float4 next_position = position + velocity * ds + acceleration * half_ds2;
+        const float4 predicted = velocity + acceleration * ds;
+#ifdef GR_PROBE_NO_ACCEL
+        float4 next_acceleration = f4(acceleration.x * 0.999f, acceleration.y * 0.999f + predicted.x * 1e-3f, acceleration.z * 0.999f, acceleration.w * 0.999f + next_position.y * 1e-5f);
+#else
+        float4 next_acceleration = gm::geodesic_acceleration_with<decltype(libm)::value>(next_position, predicted, cfg);
+#endif
+        float4 next_velocity = velocity + (acceleration + next_acceleration) * half_ds;
+        if (reparam) {
+            const float md = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(next_velocity.x), __builtin_fabsf(next_velocity.y)),
+                                             __builtin_fmaxf(__builtin_fabsf(next_velocity.z), __builtin_fabsf(next_velocity.w)));
+            const float K = 1 / md;
+            next_velocity = next_velocity * K;
+            next_acceleration = next_acceleration * K * K;
+            running *= K;   // also on an attempt that is then rejected, as the reference does (cl.cl:4152-4154)
+        }
+
+        bool accept = true, dead = false;
+#ifdef ADAPTIVE_PRECISION
+        if (inside) {
+            // calculate_ds_error (cl.cl:3431-3456)
+            const float q = controller.error_q(next_acceleration);
+            // 0.99 * ds * clamp(suggested / ds, 0.3, 2) with ds > 0, without forming the quotient
+            float nds = __builtin_amdgcn_fmed3f(0.99f * controller.suggestion(q), (0.99f * 0.3f) * ds, (0.99f * 2.f) * ds);
+            nds = max_f32_uniform(controller.min_step, nds);
+            next_ds = nds;
+#ifdef SINGULARITY_DETECTION
+            dead = (q > controller.singular_q) & (nds == controller.min_step);   // DS_RETURN: lost
+#endif
+            accept = !(nds < ds * (1 / 1.95f));   // back-step: retry from the same state with the smaller step
+        }
+#endif
+        // IS_DEGENERATE on the accepted velocity: a non-finite sum <=> a non-finite component (finite components cannot
+        // overflow the sum below ~1e38).  A rejected attempt is not tested (the reference `continue`s before its test: an
+        // overshoot into a singularity is retried with the smaller step).
+        const float poison = (next_velocity.x + next_velocity.y) + (next_velocity.z + next_velocity.w);
+        dead |= accept & !(__builtin_fabsf(poison) <= 3.402823466e+38f);
+        // The new state is written where the next attempt reads it; a rejection (once in ~35 000 attempts) puts the old state
+        // back over it.  The copies are opaque to the compiler on purpose: as plain assignments it turns the two outcomes into
+        // twelve selects per attempt.
+        po = next_position;
+        vo = next_velocity;
+        ao = next_acceleration;
+        if (__builtin_expect(!accept, 0)) {
+            overwrite(po, position);
+            overwrite(vo, velocity);
+            overwrite(ao, acceleration);
+            asm volatile("v_add_u32 %0, 1, %0\n\tv_add_u32 %1, 1, %1" : "+v"(rejections), "+v"(budget));   // the step it did not take
+        }
+        // the rare exit: the state the ray is left in, (p, v, a), has just passed the loop-top tests
+        if (__builtin_expect(dead, 0)) return true;
+        if (RESUMABLE) {
+            // lanes still in the loop = the exec mask; fewer than keep_lanes of them: leave and let the caller refill the wave
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < keep_lanes) { pause_wave = true; return true; }
+        }
+        return false;
+    };
+
+    // The state a ray leaves the fast loop in is parked in LDS - once per ray, its own slot, read back by the same lane after the
+    // loop.  Left to the compiler, "whichever set the ray was in when it left" becomes twelve running copies per attempt; kept in
+    // registers of its own it costs twelve VGPRs across the loop, i.e. a wave per SIMD.
+    __shared__ float exit_state[14][GR_INTEGRATOR_MAX_BLOCK];
+    const unsigned int slot = (unsigned int)(size_t)(__attribute__((address_space(3))) float*)&exit_state[0][threadIdx.x];
+    {
+        const trig_flavour<false> polynomial;
+        for (;;) {
+            float4 p1, v1, a1;
+            float ds_used, running_before;
+            if (attempt(polynomial, p0, v0, a0, p1, v1, a1, ds_used, running_before)) {
+                const bool out = RESUMABLE && pause_wave;
+                park(slot, out ? p1 : p0, out ? v1 : v0, out ? a1 : a0, ds_used, running_before);
+                break;
+            }
+            if (attempt(polynomial, p1, v1, a1, p0, v0, a0, ds_used, running_before)) {
+                const bool out = RESUMABLE && pause_wave;
+                park(slot, out ? p0 : p1, out ? v0 : v1, out ? a0 : a1, ds_used, running_before);
+                break;
+            }
+        }
+    }
+    const int lane_slot = threadIdx.x;
+    float4 position = f4(exit_state[0][lane_slot], exit_state[1][lane_slot], exit_state[2][lane_slot], exit_state[3][lane_slot]);
+    float4 velocity = f4(exit_state[4][lane_slot], exit_state[5][lane_slot], exit_state[6][lane_slot], exit_state[7][lane_slot]);
+    float4 acceleration = f4(exit_state[8][lane_slot], exit_state[9][lane_slot], exit_state[10][lane_slot], exit_state[11][lane_slot]);
+#ifdef IS_CONSTANT_THETA
+    position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
+#endif
+    // Why the loop was left is read off what it leaves behind (flags set inside it would have to be carried through it per lane):
+    // an exhausted step budget has wrapped around; otherwise the loop-top tests on the final state, in the reference's order
+    // (cl.cl:3990-4130) - every other exit leaves a state that has just passed them.
+    bool capped, lost_at_top, terminated_at_top;
+    auto classify = [&]() {
+        capped = budget == 0xffffffffu;
+        float4 polar = gm::generic_to_spherical(position, cfg);
+#ifdef IS_CONSTANT_THETA
+        polar.z = GR_PIf / 2;
+#endif
+        lost_at_top = stop_lost(position, velocity, acceleration, running);
+        terminated_at_top = stop_terminated(polar);
+    };
+    classify();
+#if !defined(GR_FAST_TRIG) && !defined(GR_LIBM_TRIG) && !defined(GR_PROBE_NO_SLOW_TRIG)
+    if (__builtin_expect(!capped && !pause_wave && !(lost_at_top | terminated_at_top), 0)) {
+        // Left at the bottom of an attempt: degenerate for good, or a sin / cos argument outside the polynomial's range.  The
+        // attempt is done again, and the ray integrated on if it was the latter, one attempt per trip with sin / cos from libm.
+        // What the loop carries is put back to what it was before the abandoned attempt.
+        const float ds_used = exit_state[12][lane_slot];
+        float4 polar = gm::generic_to_spherical(position, cfg);
+        if (__builtin_fabsf(gm::distance_to_object(polar, cfg)) < new_max) next_ds = ds_used;   // min(next_ds, ambient) gives ds_used again
+        running = exit_state[13][lane_slot];
+        budget++;
+        const trig_flavour<true> precise;
+        for (;;) {
+            float4 np, nv, na;
+            float unused_ds, unused_running;
+            const bool leave = attempt(precise, position, velocity, acceleration, np, nv, na, unused_ds, unused_running);
+            if (leave && !pause_wave) break;
+            position = np; velocity = nv; acceleration = na;
+            if (leave) break;
+        }
+        classify();
+    }
+#endif
+    paused = RESUMABLE && pause_wave;
+    const bool left_at_top = !capped && !paused && (lost_at_top | terminated_at_top);
+    int result = RAY_LOST;
+    if (!paused) {
+        // a state that is degenerate anywhere is the reference's plain `return` (cl.cl:4235-4244, terminated stays 0) even when its
+        // position happens to lie beyond the boundary
+        const bool finite = degenerate_accumulate(position, degenerate_accumulate(velocity, degenerate_accumulate(acceleration, 0.f))) == 0.f;
+        if (!capped && !lost_at_top && terminated_at_top && finite) result = RAY_TERMINATED;
+    }
+    // every attempt() entered took one step off the budget; the entry that found the ray finished (or the budget empty) made none
+    const unsigned int taken = capped ? budget_before : budget_before - budget - (left_at_top ? 1u : 0u);
+    if (RESUMABLE) { s.next_ds = next_ds; s.steps += (int)taken; s.tries += taken + rejections; }
+    s.position = position;
+    s.velocity = velocity;
+    s.acceleration = acceleration;
+    s.running_dlambda_dnew = running;
+    if (attempts) *attempts = RESUMABLE ? s.tries : taken + rejections;
+    return result;
+}
+
+#ifdef GR_INTEGRATOR_V1   // the one-attempt-per-trip loop of round 1, kept for A/B measurements
 __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg, unsigned int* attempts) {
     bool paused;
     return integrate_core<false>(s, cfg, dfg, attempts, 0, paused);
 }
+#else
+__device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg, unsigned int* attempts) {
+    bool paused;
+    return integrate_pingpong<false>(s, cfg, dfg, attempts, 0, paused);
+}
+#endif
 
 
 #ifdef GR_TWO_RAYS_PER_LANE
@@ -1595,7 +1959,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
 // persistent waves - the launch only fills the machine and every wave keeps drawing the next tile from the device-side
 // counter until total_waves are handed out, so a SIMD slot never idles between the end of a short tile (prepass-skipped
 // tiles finish in a few hundred cycles) and the dispatcher's next workgroup.
-extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
 gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
@@ -1604,6 +1968,10 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                int total_waves) {
     GR_PARAMETERS_IN_REGISTERS
     const int lane = threadIdx.x % 64;
+    // profiling launches (attempt_counter != NULL) also measure the shader clock they ran at: every wave adds its lifetime in
+    // shader cycles (s_memtime) and in ticks of the constant 100 MHz reference clock (s_memrealtime) to attempt_counter[1], [2]
+    unsigned long long born_cycles = 0, born_ticks = 0;
+    if (attempt_counter) { born_cycles = __builtin_amdgcn_s_memtime(); born_ticks = __builtin_amdgcn_s_memrealtime(); }
     // one call site for both modes: the two schedules must run the very same instructions per pixel (strip renders are
     // compared bit for bit with whole-frame renders)
     int wave = blockIdx.x * (GR_TRACE_BLOCK / 64) + threadIdx.x / 64;
@@ -1625,6 +1993,11 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
 #else
         if (!tile_counter) break;
 #endif
+    }
+    if (attempt_counter && lane == 0) {
+        atomicAdd(attempt_counter + 1, (unsigned long long)__builtin_amdgcn_s_memtime() - born_cycles);
+        atomicAdd(attempt_counter + 2, (unsigned long long)__builtin_amdgcn_s_memrealtime() - born_ticks);
+        atomicAdd(attempt_counter + 3, 1ull);
     }
 }
 
@@ -1818,7 +2191,11 @@ gr_trace_compact(const float4* __restrict__ g_generic_camera_in, const float4* _
         // 3. integrate until fewer than keep_lanes rays are still going (all of them to the end once the list is exhausted)
         if (integrating) {
             bool paused = false;
+#ifdef GR_INTEGRATOR_V1
             outcome = integrate_core<true>(s, cfg, dfg, nullptr, exhausted ? 1 : keep_lanes, paused);
+#else
+            outcome = integrate_pingpong<true>(s, cfg, dfg, nullptr, exhausted ? 1 : keep_lanes, paused);
+#endif
             integrating = paused;
         }
     }

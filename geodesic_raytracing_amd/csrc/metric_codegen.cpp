@@ -258,42 +258,15 @@ void MetricDescriptor::load(const MetricFunctions& f, const MetricConfig& cfg) {
     // whose coefficients are plain partial derivatives, then one raise  a^i = -g^{im} w_m.  Forming the 40 mixed
     // Christoffel symbols g^{im} Gamma_{m,kl} first costs ~25 more multiplications per Verlet step for Kerr.
     E lowered[4];
-    static const bool directional = [] { const char* e = getenv("GR_ACCEL_FORM"); return !(e && std::string(e) == "lowered"); }();
-    if (!directional) {
-        for (int m = 0; m < 4; m++) {
-            E sum = constant(0.0);
-            for (int k = 0; k < 4; k++)
-                for (int l = k; l < 4; l++) {
-                    E bracket = sub(add(dg[l][m][k], dg[k][m][l]), dg[m][k][l]);
-                    if (k == l) bracket = mul(constant(0.5), bracket);   // off-diagonal pairs appear twice
-                    sum = add(sum, mul(bracket, vv[k][l]));
-                }
-            lowered[m] = sum;
-        }
-    } else {
-        // The same w_m with the velocity contracted into the derivatives first:
-        //   w_m = (Dg)_mk v^k - 1/2 S_m,   (Dg)_mk = v^l d_l g_mk  (the metric's rate of change along the ray),
-        //   S_m = d_m g_kl v^k v^l = sum_k d_m g_kk (v^k)^2 + sum_{k<l} d_m g_kl (2 v^k v^l).
-        // A metric that depends on n of its coordinates costs ~2n ops per non-zero component for Dg, one product per (m,k)
-        // for the first term and a quadratic form only for the n coordinates it depends on; the 1/2 and the factor 2 of the
-        // mixed terms fold into one fma and one addition.  Kerr: 54 -> 40 velocity-dependent operations per evaluation.
-        E twice[4][4];
+    for (int m = 0; m < 4; m++) {
+        E sum = constant(0.0);
         for (int k = 0; k < 4; k++)
-            for (int l = k + 1; l < 4; l++) twice[k][l] = mul(add(vel[k], vel[k]), vel[l]);
-        for (int m = 0; m < 4; m++) {
-            E first = constant(0.0);
-            for (int k = 0; k < 4; k++) {
-                E rate = constant(0.0);
-                for (int l = 0; l < 4; l++) rate = add(rate, mul(dg[l][m][k], vel[l]));
-                first = add(first, mul(rate, vel[k]));
+            for (int l = k; l < 4; l++) {
+                E bracket = sub(add(dg[l][m][k], dg[k][m][l]), dg[m][k][l]);
+                if (k == l) bracket = mul(constant(0.5), bracket);   // off-diagonal pairs appear twice
+                sum = add(sum, mul(bracket, vv[k][l]));
             }
-            E quad = constant(0.0);
-            for (int k = 0; k < 4; k++) {
-                quad = add(quad, mul(dg[m][k][k], vv[k][k]));
-                for (int l = k + 1; l < 4; l++) quad = add(quad, mul(dg[m][k][l], twice[k][l]));
-            }
-            lowered[m] = sub(first, mul(constant(0.5), quad));
-        }
+        lowered[m] = sum;
     }
     raw.accel.clear();
     for (int i = 0; i < 4; i++) {

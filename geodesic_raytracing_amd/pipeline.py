@@ -239,6 +239,12 @@ class RenderState:
         check(lib.gr_render_state_trace_log(self.handle, ctypes.byref(total), ctypes.byref(n), int(reset)))
         return total.value, n.value
 
+    def shader_clock_mhz(self):
+        """average shader clock of the last fused trace launch rendered with count_attempts (0.0 if there was none)"""
+        v = ctypes.c_double(0)
+        check(lib.gr_render_state_shader_clock(self.handle, ctypes.byref(v)))
+        return v.value
+
     def attempts(self):
         v = ctypes.c_ulonglong()
         check(lib.gr_render_state_attempts(self.handle, ctypes.byref(v)))

@@ -386,6 +386,10 @@ int gr_render_state_stage_ms(gr_render_state* s, int stage, float* ms);
 int gr_render_state_trace_log(gr_render_state* s, float* total_ms, int* launches, int reset);
 /* total Verlet step attempts of the last frame rendered with count_attempts (synchronises the device) */
 int gr_render_state_attempts(gr_render_state* s, unsigned long long* attempts);
+/* average shader clock (MHz) the fused trace kernel of that frame ran at: wave lifetimes in shader cycles (s_memtime) over the
+ * same lifetimes in ticks of the constant 100 MHz reference clock (s_memrealtime); 0 when the frame was not traced by
+ * gr_trace_fused with count_attempts (synchronises the device) */
+int gr_render_state_shader_clock(gr_render_state* s, double* mhz);
 
 enum { GR_BUF_RAYS_IN = 0, GR_BUF_RAYS_COUNT = 1, GR_BUF_RENDER_DATA = 2, GR_BUF_TERMINATION = 3, GR_BUF_CAMERA_GENERIC = 4,
        GR_BUF_TETRAD0 = 5, GR_BUF_TETRAD1 = 6, GR_BUF_TETRAD2 = 7, GR_BUF_TETRAD3 = 8, GR_BUF_RAYS_ADAPTIVE = 9,

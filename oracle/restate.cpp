@@ -934,6 +934,29 @@ void ref_do_generic_rays(void* rays_v, const int* count, int n_items, const void
     for (auto a : per_thread) g_attempts += a;
 }
 
+// Step attempts of every ray of `rays_v` (traced on copies; a ray skipped by the prepass counts 0).  Not a reference kernel: the
+// parity tests use it to tell ordinary rays from the ones that linger near a photon orbit (positions are
+// held to 1e-3 for rays with fewer than twice the median number of attempts).
+void ref_attempts_per_ray(const void* rays_v, const int* count, int n_items, const void* cfg, const void* dfg, int* attempts_out,
+                          int nthreads) {
+    const lightray* rays = (const lightray*)rays_v;
+    long n = std::min<long>(n_items, *count);
+    if (nthreads < 1) nthreads = 1;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++)
+        pool.emplace_back([&, t]() {
+            for (long id = t; id < n; id += nthreads) {
+                attempts_out[id] = 0;
+                if (rays[id].terminated == 2) continue;
+                lightray copy = rays[id];
+                uint64_t a = 0;
+                trace_ray(&copy, (cfg_t)cfg, (dfg_t)dfg, &a);
+                attempts_out[id] = (int)a;
+            }
+        });
+    for (auto& th : pool) th.join();
+}
+
 // calculate_singularities, cl.cl:5008-5020
 void ref_calculate_singularities(const void* rays_v, const int* count, int n_items, int* term, int w, int h) {
     const lightray* rays = (const lightray*)rays_v;
