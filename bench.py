@@ -33,6 +33,21 @@ TRACE_BYTES_PER_RAY = 32       # gr_trace_fused: one 32-byte render_data record 
 STEP_OVERHEAD_FLOPS = 90       # integrator + step controller per Verlet attempt
 
 
+def committed_counters(workload_tag, build_key):
+    """Hardware counters of the fused trace kernel collected by tools/final_profiles.sh for one workload (profiles/pmc_<tag>.json).
+    They describe ONE build of the kernel: the file carries that build's key (gr_program_build_key) and is only used when the
+    program that runs now has the same one; otherwise the line says so instead of quoting counters of another kernel."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{workload_tag}.json")
+    if not os.path.exists(path):
+        return None, f"no profiles/pmc_{workload_tag}.json"
+    with open(path) as f:
+        pmc = json.load(f)
+    if pmc.get("build_key") != build_key:
+        return None, (f"profiles/pmc_{workload_tag}.json was collected for build {pmc.get('build_key')}, this run is build {build_key}: "
+                      f"stale, not used (re-run tools/final_profiles.sh)")
+    return pmc, f"profiles/pmc_{workload_tag}.json (build {build_key})"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,61 +235,85 @@ def main():
     launches = sum(n for _, n in logged)
     avg_launch_s = sum(ms for ms, _ in logged) / max(launches, 1) * 1e-3
 
-    # roofline of the dominant kernel from the launches of the timed region; stage breakdown and step-attempt count from a
-    # few strictly sequential frames afterwards (stages of overlapping frames cannot be told apart)
+    # roofline of the dominant kernel.  Launches of frames in flight overlap on the GPU, so their durations say nothing about one
+    # launch's cost; the per-launch duration the roofline divides by comes from launches run one at a time right after the timed
+    # region (same program, same frame; HIP events on the launch's own stream) and is reported next to the overlapped average.
     extra = {}
     local_pixels = W * H if world == 1 else sum(b - a for a, b in plan.blocks_of(rank)) * W + plan.local_blocks(rank) * W
     alg_bytes = (TRACE_BYTES_PER_RAY if fused else 140) * local_pixels
-    achieved = alg_bytes / avg_launch_s / 1e9
-    # HBM bytes per launch from the PMC passes of the same command (FETCH_SIZE and WRITE_SIZE in separate rocprofv3
-    # --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); committed summary, not live
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_trace_kernel.json")
-    if fused and world == 1 and os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    roofline = {"bound": "hbm", "kernel": "gr_trace_fused" if fused else "gr_do_generic_rays", "achieved": round(achieved, 3),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches_timed": launches, "concurrent_launches": in_flight,
-                "note": "register-resident ODE integrator: fp32 VALU bound, see valu_roofline (SURVEY.md 8d); launches of "
-                        "frames in flight overlap, so one launch's duration is longer than a frame's share of the wall clock"}
     extra["fps"] = round(1e3 / ms_per_step, 2)
-    if not multi:
-        stage_sum = {}
-        attempts = 0
-        for _ in range(3):
-            opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=1, count_attempts=1)
-            state.render(program, metric, camera, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features, cfg_values, opts, stream)
+
+    def exclusive_frames(prog, cfgv, n=5):
+        """n frames one at a time with per-stage events and the attempt / shader-clock counters: stage ms (means), attempts,
+        MHz"""
+        stage_sum, attempts, clocks = {}, 0, []
+        for _ in range(n):
+            if multi:
+                opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=rank, strip_count=world, block_rows=plan.block_rows, compact_out=1,
+                                         time_kernels=1, count_attempts=1)
+                target = ring[0].gather.local_buffer().data_ptr()
+            else:
+                opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=1, count_attempts=1)
+                target = out.data_ptr()
+            state.render(prog, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfgv, opts, stream)
             torch.cuda.synchronize()
             attempts = state.attempts()
+            clocks.append(state.shader_clock_mhz())
             for k, v in state.stage_ms().items():
                 stage_sum.setdefault(k, []).append(v)
-        # fp32 FLOP of one trace launch: counted by the hardware for the default workload (SQ_INSTS_VALU_{ADD,MUL,FMA x2,TRANS}_F32
-        # x 64 lanes, profiles/pmc_trace_kernel.json); the code generator's operation count is the fallback and is reported next
-        # to it (it counts every DAG node and a fixed 90 for integrator + controller, more than the compiled loop executes)
+        return {k: float(np.mean(v[1:])) for k, v in stage_sum.items()}, attempts, float(np.mean(clocks[1:]))
+
+    def roofline_blocks(prog, cfgv, tag, wall_s_per_frame, overlapped_launch_s=None, launches=0):
+        """the contract's HBM roofline object and the binding fp32-VALU one for one workload"""
+        stages, attempts, mhz = exclusive_frames(prog, cfgv)
+        launch_s = stages["trace"] * 1e-3
+        achieved = alg_bytes / launch_s / 1e9
+        pmc, pmc_note = committed_counters(tag, prog.build_key) if (fused and world == 1) else (None, "counters are collected on one GPU")
+        roof = {"bound": "hbm", "kernel": "gr_trace_fused" if fused else "gr_do_generic_rays", "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None, "traffic_source": pmc_note,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(launch_s * 1e3, 4),
+                "avg_launch_basis": "launches run one at a time after the timed region (4 frames, HIP events on the launch's stream)",
+                "shader_clock_mhz_during_launch": round(mhz, 1),
+                "note": "register-resident ODE integrator: fp32 VALU bound, see valu_roofline (SURVEY.md 8d)"}
+        if overlapped_launch_s is not None:
+            roof["avg_launch_ms_overlapped"] = round(overlapped_launch_s * 1e3, 4)
+            roof["launches_timed"] = launches
+            roof["concurrent_launches"] = in_flight
+        # fp32 FLOP of one trace launch: counted by the hardware (SQ_INSTS_VALU_{ADD,MUL,FMA x2,TRANS}_F32 x 64 lanes) when the
+        # committed counters belong to this build; otherwise the code generator's operation count (every DAG node + a fixed 90
+        # for integrator and controller: more than the compiled loop executes), and the line says which
         model_flops_per_attempt = metric.info.accel_ops + metric.info.coord_ops + STEP_OVERHEAD_FLOPS
-        default_workload = (args.metric == "kerr_boyer" and abs(args.spin - 0.45) < 1e-9 and (W, H) == (3840, 2160) and fused
-                            and args.program == "static")
-        counted, lane_utilisation = None, None
-        if default_workload and os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f)
-            counted, lane_utilisation = pmc.get("fp32_flop_per_launch"), pmc.get("valu_lane_utilisation")
+        counted = pmc.get("fp32_flop_per_launch") if pmc else None
         flop_per_frame = counted if counted else model_flops_per_attempt * attempts
-        tflops = flop_per_frame * args.steps / elapsed / 1e12     # whole timed region, all stages included
-        extra["valu_roofline"] = {"achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
-                                  "flop_per_frame": int(flop_per_frame), "flop_source": "hardware counters (profiles/)" if counted else "code generator model",
-                                  "flops_per_attempt": round(flop_per_frame / max(attempts, 1), 1),
-                                  "flops_per_attempt_codegen_model": model_flops_per_attempt,
-                                  "step_attempts_per_frame": int(attempts),
-                                  # SURVEY 8d "wave efficiency": active lanes per issued VALU instruction (hardware counters, profiles/)
-                                  "lane_utilisation": lane_utilisation,
-                                  "basis": "fp32 FLOP of the trace launches / wall clock of the timed region (all stages)"}
-        # the HBM view is what the contract's roofline object asks for; the roofline that actually binds this kernel rides along
-        roofline["binding"] = {"bound": "fp32 VALU (no MFMA, no HBM traffic to speak of)", "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 4)}
-        extra["stage_ms_sequential_frame"] = {k: round(float(np.mean(v)), 4) for k, v in stage_sum.items()}
+        tflops_wall = flop_per_frame / wall_s_per_frame / 1e12        # all stages, the way frames are produced
+        tflops_launch = flop_per_frame / launch_s / 1e12              # the kernel on its own
+        peak_at_clock = VALU_PEAK_TFLOPS * mhz / 2400.0 if mhz > 0 else None
+        valu = {"achieved": round(tflops_wall, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops_wall / VALU_PEAK_TFLOPS, 4),
+                "basis": "fp32 FLOP of the trace launch / wall clock per frame of the timed region (all stages)",
+                "kernel_alone": {"achieved": round(tflops_launch, 3), "frac": round(tflops_launch / VALU_PEAK_TFLOPS, 4),
+                                 "frac_of_peak_at_measured_clock": round(tflops_launch / peak_at_clock, 4) if peak_at_clock else None,
+                                 "shader_clock_mhz": round(mhz, 1), "peak_at_measured_clock": round(peak_at_clock, 1) if peak_at_clock else None},
+                "flop_per_frame": int(flop_per_frame), "flop_source": pmc_note if counted else "code generator model (" + pmc_note + ")",
+                "flops_per_attempt": round(flop_per_frame / max(attempts, 1), 1), "flops_per_attempt_codegen_model": model_flops_per_attempt,
+                "valu_instructions_per_attempt": round(pmc["valu_wave_instructions_per_launch"] * 64 / max(attempts, 1), 1) if pmc and pmc.get("valu_wave_instructions_per_launch") else None,
+                "step_attempts_per_frame": int(attempts),
+                # SURVEY 8d "wave efficiency": active lanes per issued VALU instruction (hardware counters)
+                "lane_utilisation": pmc.get("valu_lane_utilisation") if pmc else None}
+        roof["binding"] = {"bound": "fp32 VALU (no MFMA, no HBM traffic to speak of)", "achieved": round(tflops_wall, 3), "peak": VALU_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(tflops_wall / VALU_PEAK_TFLOPS, 4)}
+        return roof, valu, stages
+
+    kerr_4k = args.metric == "kerr_boyer" and (W, H) == (3840, 2160) and fused and args.program == "static"
+    tag = ("kerr_a045_4k" if abs(args.spin - 0.45) < 1e-9 else "kerr_a09_4k" if abs(args.spin - 0.9) < 1e-9 else None) if kerr_4k else None
+    tag = tag or f"{args.metric}_{W}x{H}"
+    roofline, valu, stages = roofline_blocks(program, cfg_values, tag, elapsed / args.steps, avg_launch_s, launches)
+    extra["valu_roofline"] = valu
+    extra["stage_ms_sequential_frame"] = {k: round(v, 4) for k, v in stages.items()}
+    if multi:
+        # per-rank view of the split (rank 0's): what the SCALE run needs to tell imbalance from communication
+        extra["rank0_rows"] = sum(b - a for a, b in plan.blocks_of(rank))
+    if not multi:
         rd = np.empty(W * H, dtype=gra.pipeline.RENDER_DATA_DTYPE)
         gra.check(gra.lib.gr_device_download(local_rank, rd.ctypes.data_as(ctypes.c_void_p), state.buffer(gra.BUF_RENDER_DATA), rd.nbytes))
         skipped = int((rd["terminated"] == 2).sum())
@@ -314,6 +353,10 @@ def main():
             barrier()
             t = (time.perf_counter() - t) / 8
             secondary["superextremal_a0.9_substituted_pipelined_Mrays_per_s"] = round(W * H / t / 1e6, 1)
+            # ... with its own roofline objects: every pixel is traced here (no shadow for the prepass to skip)
+            roof09, valu09, stages09 = roofline_blocks(prog09, cfg09, "kerr_a09_4k", t)
+            secondary["superextremal_a0.9_substituted"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "roofline": roof09,
+                                                          "valu_roofline": valu09, "stage_ms_sequential_frame": {k: round(v, 4) for k, v in stages09.items()}}
             for slot in ring:
                 slot.state.trace_log(reset=True)
         if timed:
@@ -364,7 +407,7 @@ def main():
                                    f"prepass {'on' if metric.info.use_prepass else 'off'}, tol {metric.info.max_acceleration_change:g}, "
                                    f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
                        "mode": args.mode, "prepass_lookahead": bool(fused and not args.no_lookahead), "prepass_lookahead_depth": depth,
-                       "frames_in_flight": in_flight, "priming_frames": priming, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
+                       "frames_in_flight": in_flight, "priming_frames": priming, "build_key": program.build_key, "counters_tag": tag, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
                        "parallelism": f"{plan.block_rows}-row blocks, block-cyclic over {world} GPUs (assignment rotating per frame) + one RCCL gather" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -156,7 +156,7 @@ bool kernel_resources(const std::string& code, const char* kernel, int& vgprs, i
 }
 
 // Compiles (or fetches from the on-disk cache) the code object for one macro string.
-int compile_code_object(const std::string& argument_string, std::string& code) {
+int compile_code_object(const std::string& argument_string, std::string& code, std::string* key_out = nullptr) {
     std::string source_path;
     if (const char* env = getenv("GR_KERNEL_SOURCE")) source_path = env;
     else source_path = library_dir() + "/csrc/kernels/geodesic_kernels.hip";
@@ -193,8 +193,13 @@ int compile_code_object(const std::string& argument_string, std::string& code) {
     uint64_t h = fnv1a(source);
     for (auto& o : opts) h = fnv1a(o + "\n", h);
     h = fnv1a("hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor), h);
+    {
+        const char* tuning = getenv("GR_OCCUPANCY_TUNING");   // changes what is built for the same options (see below)
+        if (tuning && tuning[0] == '0') h = fnv1a("no occupancy tuning", h);
+    }
     char name[64];
     snprintf(name, sizeof(name), "%016llx.hsaco", (unsigned long long)h);
+    if (key_out) key_out->assign(name, 16);
 
     std::string cache_dir;
     if (const char* env = getenv("GR_CACHE_DIR")) cache_dir = env;
@@ -289,6 +294,7 @@ struct gr_program {
     std::atomic<unsigned> next_ticket{0};
     int compute_units = 256;
     std::string arguments;
+    std::string key;   // what the code object was built from: kernel source, every compile option, hiprtc version (16 hex digits)
     // identity for caches keyed by program (frame.cpp prefetch slots): an address can be reused by a later program, this cannot
     unsigned long long serial = 0;
     ~gr_program() {
@@ -418,11 +424,12 @@ int gr_program_precompile(const char* argument_string) {
 
 int gr_program_create(const char* argument_string, int device, gr_program** out) {
     if (!argument_string || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
-    std::string code;
-    int rc = compile_code_object(argument_string, code);
+    std::string code, key;
+    int rc = compile_code_object(argument_string, code, &key);
     if (rc != GR_OK) return rc;
     HIP_CHECK(hipSetDevice(device));
     auto p = std::make_unique<gr_program>();
+    p->key = key;
     p->device = device;
     p->arguments = argument_string;
     static std::atomic<unsigned long long> next_serial{1};
@@ -498,6 +505,8 @@ void gr_program_destroy(gr_program* p) {
 }
 
 unsigned long long gr_program_serial(const gr_program* p) { return p ? p->serial : 0; }
+
+const char* gr_program_build_key(const gr_program* p) { return p ? p->key.c_str() : ""; }
 
 int gr_program_kernel_info(const gr_program* p, const char* kernel_name, int* vgprs, int* sgprs, int* scratch_bytes) {
     if (!p || !kernel_name) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");

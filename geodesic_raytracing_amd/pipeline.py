@@ -104,6 +104,11 @@ class Program:
         return {"vgprs": v.value, "scratch_bytes": l.value}
 
     @property
+    def build_key(self):
+        """identity of the code object (kernel source + compile options + hiprtc version), 16 hex digits"""
+        return lib.gr_program_build_key(self.handle).decode()
+
+    @property
     def has_trace_pair(self):
         """True when the program has the two-rays-per-lane kernel (gr_trace_pair)"""
         return bool(lib.gr_program_has_trace_pair(self.handle))

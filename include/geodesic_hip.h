@@ -281,6 +281,10 @@ int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const
 int gr_program_has_trace_pair(const gr_program* p);   /* 1 / 0 */
 /* Process-unique identity of a program object (never reused, unlike its address); 0 for NULL. */
 unsigned long long gr_program_serial(const gr_program* p);
+/* What the program's code object was built from - kernel source, every compile option, hiprtc version - as 16 hex digits (the
+ * name of its cache file).  Measurements that belong to one build (hardware counters under profiles/) carry it, so that a
+ * reader can tell whether they still describe the kernel that runs. */
+const char* gr_program_build_key(const gr_program* p);
 
 /* gr_trace_fused with ray compaction (north_star: "wave-level ballots for step-acceptance and ray compaction"): persistent
  * waves hold one ray per lane; whenever fewer than keep_lanes (1..64) of a wave's rays are still integrating, the finished

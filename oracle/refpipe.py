@@ -122,6 +122,18 @@ class OraclePipeline:
         self.lib.ref_attempts_per_ray(_p(rays), _p(count), len(rays), _p(cfg), _p(dfg), _p(out), nthreads)
         return out
 
+    def trace_f64(self, rays_init, cfg_values, features_bytes, nthreads=8):
+        """final positions [n, 4] (float64) and termination flags of the initial rays integrated in float64 (restatement back
+        end only; see ref_trace_f64)"""
+        cfg = np.array(list(cfg_values) if len(cfg_values) else [0.0], dtype="<f4")
+        dfg = np.frombuffer(features_bytes, dtype=np.uint8).copy()
+        rays = np.ascontiguousarray(rays_init)
+        count = np.array([len(rays)], dtype="<i4")
+        pos = np.zeros((len(rays), 4), dtype="<f8")
+        term = np.zeros(len(rays), dtype="<i4")
+        self.lib.ref_trace_f64(_p(rays), _p(count), len(rays), _p(cfg), _p(dfg), _p(pos), _p(term), nthreads)
+        return pos, term
+
     def geodesic_camera(self, cfg_values, features_bytes, camera_pos=(0, 0, -4, 0), basis_speed=(0, 0, 0), max_len=4096,
                         target_times=(), parallel_transport=True, flip=0.0):
         """Snapshot of the camera's timelike geodesic, main.cpp:2675-2760, then one handle_interpolating_geodesic call per

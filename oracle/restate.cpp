@@ -582,6 +582,155 @@ bool trace_ray(lightray* ray, cfg_t cfg, dfg_t dfg, uint64_t* attempts) {
     return false;
 }
 
+// ---- the same integrator in float64 -------------------------------------------------------------------
+// Not a reference kernel: the reference's discrete algorithm (same steps, same controller, same thresholds, the same float
+// parameters) evaluated in double precision, as a yardstick for rays on which two fp32 builds disagree.  Along a ray that grazes
+// the polar axis of a Boyer-Lindquist chart every last-place difference is amplified (d phi / d lambda ~ 1 / sin^2 theta): the
+// number of pixels in which one fp32 build differs from another then measures how many roundings they do not share, not an
+// error of either - what each of them is off from this evaluation does (tests/test_gpu_parity.py, tools/polar_probe.py).
+namespace gen64 {
+inline double sin(double x) { return std::sin(x); }
+inline double cos(double x) { return std::cos(x); }
+inline double tan(double x) { return std::tan(x); }
+inline double asin(double x) { return std::asin(x); }
+inline double acos(double x) { return std::acos(x); }
+inline double atan(double x) { return std::atan(x); }
+inline double atan2(double y, double x) { return std::atan2(y, x); }
+inline double exp(double x) { return std::exp(x); }
+inline double log(double x) { return std::log(x); }
+inline double sqrt(double x) { return std::sqrt(x); }
+inline double fabs(double x) { return std::fabs(x); }
+inline double sinh(double x) { return std::sinh(x); }
+inline double cosh(double x) { return std::cosh(x); }
+inline double tanh(double x) { return std::tanh(x); }
+inline double pow(double x, double y) { return std::pow(x, y); }
+inline double fmod(double x, double y) { return std::fmod(x, y); }
+inline double fmin(double x, double y) { return std::fmin(x, y); }
+inline double fmax(double x, double y) { return std::fmax(x, y); }
+inline double sign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); }
+struct d4 { double x, y, z, w; };
+inline d4 operator+(d4 a, d4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline d4 operator*(d4 a, double s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+#define POSITION_VARS64(p)                                                                        \
+    const double v1 = (p).x, v2 = (p).y, v3 = (p).z, v4 = (p).w;                                    \
+    const double rs = RS_IMPL, c = C_IMPL;                                                         \
+    (void)v1; (void)v2; (void)v3; (void)v4; (void)rs; (void)c;
+d4 geo_accel(d4 pos, d4 vel, cfg_t cfg) {
+#ifdef GENERIC_CONSTANT_THETA
+    pos.z = (double)(PIf / 2);
+    vel.z = 0;
+#endif
+    POSITION_VARS64(pos)
+    const double iv1 = vel.x, iv2 = vel.y, iv3 = vel.z, iv4 = vel.w;
+    (void)iv1; (void)iv2; (void)iv3; (void)iv4;
+    double TEMPORARIES0;
+    d4 a;
+    a.x = GEO_ACCEL0;
+    a.y = GEO_ACCEL1;
+#ifndef GENERIC_CONSTANT_THETA
+    a.z = GEO_ACCEL2;
+#else
+    a.z = 0;
+#endif
+    a.w = GEO_ACCEL3;
+    return a;
+}
+d4 to_spherical(d4 in, cfg_t cfg) { POSITION_VARS64(in) return {TO_COORD1, TO_COORD2, TO_COORD3, TO_COORD4}; }
+double distance_to_object(d4 polar, cfg_t cfg) { POSITION_VARS64(polar) return DISTANCE_FUNC; }
+}  // namespace gen64
+
+// trace_ray in float64; returns the reference's `terminated` (1 reached the boundary, 0 otherwise) and the final position
+int trace_ray_f64(const lightray& ray, double position_out[4], cfg_t cfg, dfg_t dfg) {
+    using gen64::d4;
+    auto widen = [](v4 v) { return d4{v.x, v.y, v.z, v.w}; };
+    d4 position = widen(ray.position), velocity = widen(ray.velocity), acceleration = widen(ray.acceleration);
+    const double f_in_x = std::fabs(velocity.x);
+    const double half_pi = (double)(PIf / 2);
+#ifdef ADAPTIVE_PRECISION
+    const double max_accel = GET_FEATURE(max_acceleration_change, dfg), min_step = GET_FEATURE(min_step, dfg);
+    auto precision = [&](d4 acc, double* next_ds_out) {
+        const double divisor = (double)std::max(std::max(W_V1, W_V2), std::max(W_V3, W_V4));
+        const double ax = acc.x * (double)(W_V1), ay = acc.y * (double)(W_V2), az = acc.z * (double)(W_V3), aw = acc.w * (double)(W_V4);
+        double current = std::sqrt(ax * ax + ay * ay + az * az + aw * aw) * (double)0.01f / divisor;
+        const double big = 256 * 256;
+        double diff = current * big;
+        const double lowest = max_accel * big / 1e10;
+        if (diff < lowest) diff = lowest;
+        *next_ds_out = std::sqrt((max_accel * big) / diff);
+        return diff;
+    };
+#endif
+#ifdef IS_CONSTANT_THETA
+    position.z = half_pi; velocity.z = 0; acceleration.z = 0;
+#endif
+    double next_ds = (double)0.00001f;
+#ifdef ADAPTIVE_PRECISION
+    (void)precision(acceleration, &next_ds);
+#endif
+    const double subambient = 0.5, ambient = (double)0.2f;
+    double running = 1;
+    const double new_max = GET_FEATURE(max_precision_radius, dfg), new_min = 3, universe = GET_FEATURE(universe_size, dfg);
+    for (int i = 0; i < 4096 * 4; i++) {
+#ifdef IS_CONSTANT_THETA
+        position.z = half_pi; velocity.z = 0; acceleration.z = 0;
+#endif
+        d4 polar = gen64::to_spherical(position, cfg);
+#ifdef IS_CONSTANT_THETA
+        polar.z = half_pi;
+#endif
+        const double ar = std::fabs(gen64::distance_to_object(polar, cfg));
+        double ds = ambient + (subambient - ambient) * ((std::fmin(std::fmax(ar, new_min), new_max) - new_min) / (new_max - new_min));
+#ifdef ADAPTIVE_PRECISION
+        ds = next_ds;
+#endif
+        if (ar < new_max) ds = std::fmin(ds, ambient);
+        else ds = (double)0.1f * (ar - new_max) + ambient;
+        bool should_terminate = std::fabs(polar.y) >= universe;
+#ifdef SINGULAR
+        should_terminate |= std::fabs(polar.y) < SINGULAR_TERMINATOR;
+#endif
+#ifdef HAS_CYLINDRICAL_SINGULARITY
+        if (position.y < CYLINDRICAL_TERMINATOR) return 0;
+#endif
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        if (std::fabs(velocity.x / running) > 1000 + f_in_x && std::fabs(acceleration.x / running) > 100) return 0;
+#endif
+        if (should_terminate) {
+            position_out[0] = position.x; position_out[1] = position.y; position_out[2] = position.z; position_out[3] = position.w;
+            return 1;
+        }
+        d4 next_position = position + velocity * ds + acceleration * (0.5 * ds * ds);
+        d4 half_velocity = velocity + acceleration * ds;
+        d4 next_acceleration = gen64::geo_accel(next_position, half_velocity, cfg);
+        d4 next_velocity = velocity + (acceleration + next_acceleration) * (0.5 * ds);
+        double K = 1 / std::fmax(std::fmax(std::fabs(next_velocity.x), std::fabs(next_velocity.y)),
+                                 std::fmax(std::fabs(next_velocity.z), std::fabs(next_velocity.w)));
+        if (!GET_FEATURE(reparameterisation, dfg)) K = 1;
+        next_velocity = next_velocity * K;
+        next_acceleration = next_acceleration * (K * K);
+        running *= K;
+#ifdef ADAPTIVE_PRECISION
+        if (ar < new_max) {
+            double suggested = 0;
+            const double diff = precision(next_acceleration, &suggested);
+            double nds = (double)0.99f * ds * std::fmin(std::fmax(suggested / ds, (double)0.3f), 2.0);
+            nds = std::fmax(nds, min_step);
+            next_ds = nds;
+#ifdef SINGULARITY_DETECTION
+            if (nds == min_step && (diff / (256 * 256)) > max_accel * 10000) return 0;
+#endif
+            if (nds < ds / (double)1.95f) { i--; continue; }
+        }
+#endif
+        position = next_position;
+        velocity = next_velocity;
+        acceleration = next_acceleration;
+        auto bad = [](d4 v) { return !std::isfinite(v.x) || !std::isfinite(v.y) || !std::isfinite(v.z) || !std::isfinite(v.w); };
+        if (bad(position) || bad(velocity) || bad(acceleration)) return 0;
+    }
+    return 0;
+}
+
 // ---- render data (cl.cl:211-263, 5024-5100, 5135-5213) -------------------------------------------------
 v3 fix_ray_position_cart(v3 pos, v3 vel, float radius) {
     vel = normalize(vel);
@@ -952,6 +1101,23 @@ void ref_attempts_per_ray(const void* rays_v, const int* count, int n_items, con
                 uint64_t a = 0;
                 trace_ray(&copy, (cfg_t)cfg, (dfg_t)dfg, &a);
                 attempts_out[id] = (int)a;
+            }
+        });
+    for (auto& th : pool) th.join();
+}
+
+// Final positions (float64, 4 per ray) and termination flags of every ray of `rays_v` integrated in float64 (trace_ray_f64).
+void ref_trace_f64(const void* rays_v, const int* count, int n_items, const void* cfg, const void* dfg, double* positions_out,
+                   int* terminated_out, int nthreads) {
+    const lightray* rays = (const lightray*)rays_v;
+    long n = std::min<long>(n_items, *count);
+    if (nthreads < 1) nthreads = 1;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++)
+        pool.emplace_back([&, t]() {
+            for (long id = t; id < n; id += nthreads) {
+                for (int k = 0; k < 4; k++) positions_out[4 * id + k] = 0;
+                terminated_out[id] = rays[id].terminated == 2 ? 2 : trace_ray_f64(rays[id], positions_out + 4 * id, (cfg_t)cfg, (dfg_t)dfg);
             }
         });
     for (auto& th : pool) th.join();

@@ -7,6 +7,7 @@ cases (boosted tetrad, path, velocities, step lengths, transported tetrads, inte
 
     python tests/golden/make_golden.py            # everything
     python tests/golden/make_golden.py paths      # only the geodesic-camera cases
+    python tests/golden/make_golden.py polar      # only the polar-axis cases of the round-1 soak
 """
 import json
 import os
@@ -78,6 +79,26 @@ CASES = {
 }
 
 
+# The three cases of the round-1 randomised soak (tests/fuzz_parity.py, seeds 13 and 14: cases 3, 212, 593; profiles/r01_fuzz_parity_c.txt,
+# _d.txt) in which more than 1 % of the pixels differed from the CPU oracle by > 1e-3: rays grazing the polar axis of a
+# Boyer-Lindquist chart, where the azimuth is ill-conditioned.  Inputs as the soak drew them; written to tests/golden/polar/.
+POLAR_CASES = {
+    "kerr_newman_axis_13_3": dict(metric="kerr_newman_boyer", scripts=True, size=(64, 36), cfg=dict(a=-0.07701381890452633, rq=0.08033102227764341),
+                                  camera_pos=[-0.12210349379566643, 2.336140467952985, -5.813854583897942, 4.5921835070083885],
+                                  camera_quat=[-0.6452631134533329, 0.3845326488696672, 0.25704341221794286, 0.6080286511383697],
+                                  basis_speed=[0.25712762010323004, 0.24499169545333604, 0.05988015004618735],
+                                  features=dict(redshift=1, field_of_view=110.0)),
+    "kerr_axis_14_212": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(64, 36), cfg=dict(a=-0.3781121696717211),
+                             camera_pos=[-0.38076163181618994, -1.030097049394777, -4.097520346780326, 10.297632932742129],
+                             camera_quat=[-0.48973360944394195, 0.38470397819020696, 0.05992094927213021, 0.7801110951550196],
+                             basis_speed=[0.25693443837157964, -0.005530704062480685, -0.11287332257573171],
+                             features=dict(reparameterisation=1, field_of_view=60.0)),
+    "kerr_newman_axis_14_593": dict(metric="kerr_newman_boyer", scripts=True, size=(64, 36), cfg=dict(a=-0.20899657409613298, rq=0.2607815362064193),
+                                    camera_pos=[0.9053243236344846, 0.34132324238627365, -7.772548711815563, 5.744398311974292],
+                                    camera_quat=[-0.41112675071678806, 0.2556906394720302, 0.05289661426400266, 0.873383672809863],
+                                    features=dict(redshift=1, universe_size=30.0, max_precision_radius=14.0)),
+}
+
 # camera riding a timelike geodesic (boost_tetrad .. handle_interpolating_geodesic): name -> spec
 PATH_TIMES = (0.0, 0.37, 1.5, 7.3, 19.0, 1.0e6)
 PATH_CASES = {
@@ -121,7 +142,7 @@ def make_path_case(name, spec):
     print(f"path {name}: {res['count']} steps, proper time {res['ds'].sum():.3f}, end {res['path'][-1].round(3).tolist()}")
 
 
-def make_case(name, spec, scripts_dir=None):
+def make_case(name, spec, scripts_dir=None, subdir=None):
     own_scripts = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
     metric = gra.Metric(spec["metric"], own_scripts if spec.get("scripts") else None)
     so = build_ref.build(spec.get("tag", spec["metric"]), metric.argument_string())
@@ -144,7 +165,9 @@ def make_case(name, spec, scripts_dir=None):
     if "adaptive_count" in res:
         meta["adaptive_count"] = res["adaptive_count"]
     arrays["pixels"] = arrays["pixels"].astype(np.float32)
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=json.dumps(meta), **arrays)
+    if subdir:
+        os.makedirs(os.path.join(HERE, subdir), exist_ok=True)
+    np.savez_compressed(os.path.join(HERE, subdir or "", name + ".npz"), meta=json.dumps(meta), **arrays)
     term = np.bincount(res["rays"]["terminated"], minlength=3)
     print(f"{name}: rays {len(res['rays'])} terminated {term.tolist()} pixel mean {arrays['pixels'][..., :3].mean():.4f}")
 
@@ -155,6 +178,10 @@ if __name__ == "__main__":
         if only and name not in only:
             continue
         make_case(name, spec)
+    for name, spec in POLAR_CASES.items():
+        if only and name not in only and "polar" not in only:
+            continue
+        make_case(name, spec, subdir="polar")
     for name, spec in PATH_CASES.items():
         if only and ("path_" + name) not in only and "paths" not in only:
             continue

@@ -250,3 +250,50 @@ def test_randomised_poses_and_features_match_the_oracle():
         assert fuzz.main() == 0
     finally:
         sys.argv = argv
+
+
+POLAR = ["kerr_newman_axis_13_3", "kerr_axis_14_212", "kerr_newman_axis_14_593"]
+
+
+def sky_error(position, position_f64):
+    """largest error of the two angular coordinates (Boyer-Lindquist theta, phi) of final positions against the float64 run"""
+    d = np.abs(np.asarray(position, dtype=np.float64)[:, 2:] - position_f64[:, 2:])
+    return d.max(axis=1)
+
+
+@pytest.mark.parametrize("name", POLAR)
+def test_polar_axis_cases_of_the_soak(name):
+    """The three cases of the round-1 randomised soak in which > 1 % of the pixels were off by > 1e-3 (tests/golden/polar, inputs as
+    the soak drew them, expected output from the reference's cl.cl): rays grazing the polar axis of a Boyer-Lindquist chart.  There
+    d phi / d lambda ~ 1 / sin^2 theta amplifies every last-place difference, so two fp32 builds agree only as far as they share
+    their roundings - the CPU restatement (same operation order as the reference) disagrees with it in 11-30 pixels, the GPU
+    (contraction, reassociation) in 24-52 - and the reference itself is off from a float64 evaluation of the same algorithm
+    (oracle ref_trace_f64) in as many rays as the GPU is.  Rules: flags equal; the GPU is not further from the float64 evaluation
+    than the reference is (rays whose sky angles are off by > 1e-3: at most 1.5x the reference's count + 4); and its pixels differ
+    from the reference's in at most twice as many places as the larger of (CPU restatement vs reference) and (reference vs
+    float64) + 4.  Measured (dynamic / substituted program): 13/3 27/24 pixels (CPU 22), 14/212 51/52 (CPU 11, reference vs float64
+    48 rays), 14/593 32/29 (CPU 30); GR_LIBM_TRIG, correctly rounded divide/sqrt and no contraction change none of it."""
+    from oracle import build_restate
+    from oracle.refpipe import OraclePipeline, pack_features
+    meta, z = load_golden("polar/" + name)
+    pipe = OraclePipeline(build_restate.build(metric_for(meta).argument_string()))
+    feats = pack_features(**meta["features"])
+    p64, t64 = pipe.trace_f64(z["rays_init"], meta["cfg"], feats, nthreads=8)
+    want = z["rays"]
+    got = Stages(meta).trace(z["rays_init"])
+    assert (got["terminated"] != want["terminated"]).mean() <= 0.005
+    both = (t64 == 1) & (want["terminated"] == 1) & (got["terminated"] == 1)
+    reference_off = int((sky_error(want["position"][both], p64[both]) > 1e-3).sum())
+    gpu_off = int((sky_error(got["position"][both], p64[both]) > 1e-3).sum())
+    assert gpu_off <= 1.5 * reference_off + 4, (gpu_off, reference_off)
+    # pixels, end to end, both programs
+    bg, levels = background(meta)
+    cpu = pipe.frame(meta["width"], meta["height"], meta["cfg"], feats, camera_pos=meta["camera_pos"], camera_quat=meta["camera_quat"],
+                     basis_speed=meta["basis_speed"], background=(bg, levels), nthreads=8)
+    cpu_bad = int((np.abs(cpu["pixels"][..., :3] - z["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
+    for substituted in (False, True):
+        px, _ = _frame(meta, gra.MODE_FUSED, substituted=substituted)
+        d = px[..., :3] - z["pixels"][..., :3]
+        bad = np.abs(d).max(axis=2) > 1e-3
+        assert bad.sum() <= 2 * max(cpu_bad, reference_off) + 4, (int(bad.sum()), cpu_bad, reference_off)
+        assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4

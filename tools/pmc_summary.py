@@ -15,10 +15,13 @@ def load(dirs):
     return {k: {n: sum(v) / len(v) for n, v in c.items()} for k, c in agg.items()}
 
 if __name__ == "__main__":
-    out_txt, out_json = sys.argv[1], sys.argv[2]
-    data = load(sys.argv[3:])
+    # usage: pmc_summary.py <out.txt> <out.json> <log of one of the profiled bench runs> <pmc dir> ...
+    out_txt, out_json, bench_log = sys.argv[1], sys.argv[2], sys.argv[3]
+    bench_line = json.loads([ln for ln in open(bench_log).read().splitlines() if ln.startswith("{")][-1])
+    build_key, workload = bench_line["config"]["build_key"], bench_line["config"]["workload"]
+    data = load(sys.argv[4:])
     lines = ["# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --frames-in-flight 1 --no-lookahead   (tools/final_profiles.sh; one pass per counter set)",
-             "# 3840x2160 Kerr a=0.45, fused mode, substituted program; per-dispatch means; FETCH_SIZE / WRITE_SIZE in KiB"]
+             f"# {workload}; build {build_key}; per-dispatch means; FETCH_SIZE / WRITE_SIZE in KiB"]
     for k in sorted(data):
         for n in sorted(data[k]):
             lines.append(f"{k:22s} {n:26s} {data[k][n]:16.6g}")
@@ -44,7 +47,7 @@ if __name__ == "__main__":
         flop_counters = None
         if "SQ_INSTS_VALU_FMA_F32" in t:
             flop_counters = round(64 * (t["SQ_INSTS_VALU_ADD_F32"] + t["SQ_INSTS_VALU_MUL_F32"] + 2 * t["SQ_INSTS_VALU_FMA_F32"] + t["SQ_INSTS_VALU_TRANS_F32"]))
-        json.dump({"kernel": "gr_trace_fused", "workload": "kerr_boyer a=0.45 3840x2160 substituted program",
+        json.dump({"kernel": "gr_trace_fused", "workload": workload, "build_key": build_key,
                    "fp32_flop_per_launch": flop_counters, "valu_wave_instructions_per_launch": round(t["SQ_INSTS_VALU"]), "hbm_bytes_per_launch": round(hbm), "fetch_size_bytes": round(fetch), "write_size_bytes": round(write),
                    "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)", "valu_lane_utilisation": round(lane_util, 4),
                    "source": "profiles/" + os.path.basename(out_txt)}, open(out_json, "w"), indent=1)
