@@ -152,15 +152,40 @@ def main():
     plan = grd.StripPlan(H, world, block_rows=args.block_rows)
     in_flight = max(1, min(args.frames_in_flight, 8)) if fused else 1
 
+    # N > 1: the C ABI's gr_render_frame_tiled (csrc/tiled.cpp) - this rank's share of the rows, then per block an ncclSend /
+    # ncclRecv straight to the block's rows of rank 0's frame (no staging, no un-permute).  GR_BENCH_GATHER=torch selects the
+    # round-1 path instead (compact strips -> torch.distributed.gather -> un-permute on rank 0), which is also the fallback
+    # when the RCCL communicator cannot be built.
+    tiled = None
+    gather_path = "none"
+    if multi:
+        gather_path = "torch.distributed.gather + un-permute"
+        if os.environ.get("GR_BENCH_GATHER", "rccl") != "torch":
+            try:
+                uid = [gra.TiledFrame.unique_id() if rank == 0 else None] if world > 1 else [None]
+                if world > 1:
+                    dist.broadcast_object_list(uid, src=0)
+                tiled = gra.TiledFrame(world, rank, local_rank, uid[0], W, H, args.block_rows)
+                gather_path = "gr_render_frame_tiled: ncclSend/ncclRecv per block into the frame (RCCL called directly)"
+            except Exception as e:   # noqa: BLE001
+                print(f"[bench] rank {rank}: gr_tiled_create failed ({e}); using the torch.distributed gather", file=sys.stderr)
+                tiled = None
+        if world > 1:   # every rank must take the same path
+            flag = torch.tensor([1 if tiled is not None else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                tiled, gather_path = None, "torch.distributed.gather + un-permute"
+
     class Slot:   # one frame in flight: render state (per-frame device buffers), stream, output, gather buffers
         def __init__(self, first):
             self.state = gra.RenderState(W, H, local_rank)
             self.stream = torch.cuda.current_stream() if first and in_flight == 1 else torch.cuda.Stream(device=device)
             self.gather = grd.FrameGather(plan, W, device, rank, world) if multi else None
-            # rank 0's frame; in the multi-GPU path padded to whole blocks so that the un-permute writes it directly
+            # rank 0's frame; in the torch gather path padded to whole blocks so that the un-permute writes it directly
             self.out = None
             if rank == 0:
-                self.out = self.gather.frame_buffer(device) if multi else torch.zeros((H, W, 4), dtype=torch.float32, device=device)
+                self.out = (self.gather.frame_buffer(device) if (multi and tiled is None)
+                            else torch.zeros((H, W, 4), dtype=torch.float32, device=device))
 
     ring = [Slot(i == 0) for i in range(in_flight)]
     state, out, stream = ring[0].state, ring[0].out, ring[0].stream.cuda_stream
@@ -195,13 +220,23 @@ def main():
                 opts.next_camera = lookahead
                 if depth == 2:
                     opts.next_camera2 = lookahead
+            if tiled is not None:
+                k = frame_index[0] - 1
+                opts.next_strip_rank = tiled.share(k + in_flight)
+                opts.next_strip_rank2 = tiled.share(k + 2 * in_flight)
+                tiled.render(slot.state, prog, metric, camera, slot.out.data_ptr() if rank == 0 else None, (bg.data_ptr(), 4096, 2048, levels),
+                             features, cfgv, opts, slot.stream.cuda_stream, rotation=k)
+                return
             slot.state.render(prog, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfgv, opts,
                               slot.stream.cuda_stream)
             if multi:
                 slot.gather.submit(slot.out, rotation=frame_index[0] - 1)   # asynchronous: overlaps the following frames
 
     def barrier():
-        if multi:
+        if multi and tiled is not None:
+            torch.cuda.synchronize()   # sends / receives are ordered on the frames' streams
+            dist.barrier()
+        elif multi:
             for slot in ring:
                 with torch.cuda.stream(slot.stream):
                     slot.gather.drain(slot.out)   # every frame submitted so far is gathered and assembled on rank 0
@@ -408,13 +443,22 @@ def main():
                                    f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
                        "mode": args.mode, "prepass_lookahead": bool(fused and not args.no_lookahead), "prepass_lookahead_depth": depth,
                        "frames_in_flight": in_flight, "priming_frames": priming, "build_key": program.build_key, "counters_tag": tag, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
-                       "parallelism": f"{plan.block_rows}-row blocks, block-cyclic over {world} GPUs (assignment rotating per frame) + one RCCL gather" if world > 1 else "single GPU"},
+                       "parallelism": f"{plan.block_rows}-row blocks, block-cyclic over {world} GPUs (assignment rotating per frame); {gather_path}" if multi else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)
-        print(json.dumps(line), flush=True)
     if multi:
+        if tiled is not None:
+            tiled.close()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio when a communicator comes up: get it out before the one JSON line,
+        # which is the last thing on stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

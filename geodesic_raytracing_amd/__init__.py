@@ -135,6 +135,17 @@ _SIGNATURES = {
     "gr_render_state_trace_log": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int), c_int]),
     "gr_render_state_attempts": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gr_render_state_shader_clock": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "gr_tiled_unique_id": (c_int, [c_void_p]),
+    "gr_tiled_create": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_tiled_create_local": (c_int, [c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_tiled_destroy": (None, [c_void_p]),
+    "gr_render_frame_tiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Camera), ctypes.POINTER(Features),
+                                      ctypes.POINTER(c_float), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                      ctypes.POINTER(FrameOptions), c_int]),
+    "gr_tiled_join": (c_int, [c_void_p, c_void_p]),
+    "gr_tiled_share": (c_int, [c_void_p, c_int]),
+    "gr_tiled_block_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "gr_tiled_block_rows_of": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gr_render_state_buffer": (c_void_p, [c_void_p, c_int]),
     "gr_device_download": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     "gr_device_upload": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
@@ -170,5 +181,5 @@ def check(rc):
         raise GeodesicError(f"libgeodesic_hip error {rc}: {msg.decode(errors='replace') if msg else ''}")
 
 
-from .pipeline import (GeodesicCamera, Metric, Program, RenderState, default_camera, default_features, frame_options,  # noqa: E402,F401
+from .pipeline import (GeodesicCamera, Metric, Program, RenderState, TiledFrame, default_camera, default_features, frame_options,  # noqa: E402,F401
                        synthetic_background, pack_background)

@@ -119,6 +119,69 @@ class Program:
             self.handle = None
 
 
+class TiledFrame:
+    """One participant of a frame split over several GPUs through the C ABI (gr_tiled_*, csrc/tiled.cpp): renders this
+    participant's share of the rows and ships the finished float4 blocks straight to their place in participant 0's frame.
+    TiledFrame(world, rank, device, unique_id, ...): one process per GPU, RCCL (unique_id = TiledFrame.unique_id() made on rank 0
+    and distributed by the caller, e.g. torch.distributed.broadcast).  TiledFrame.local(devices, ...): one process, peer copies."""
+
+    def __init__(self, world, rank, device, unique_id, width, height, block_rows=48, _handle=None):
+        self.world, self.rank, self.device = world, rank, device
+        if _handle is not None:
+            self.handle = _handle
+            return
+        self.handle = c_void_p()
+        buf = (ctypes.c_char * 128).from_buffer_copy(bytes(unique_id)) if unique_id is not None else None
+        check(lib.gr_tiled_create(world, rank, device, buf, width, height, block_rows, ctypes.byref(self.handle)))
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_char * 128)()
+        check(lib.gr_tiled_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def local(devices, width, height, block_rows=48):
+        n = len(devices)
+        handles = (c_void_p * n)()
+        check(lib.gr_tiled_create_local(n, (c_int * n)(*devices), width, height, block_rows, handles))
+        return [TiledFrame(n, r, devices[r], None, width, height, block_rows, _handle=c_void_p(handles[r])) for r in range(n)]
+
+    def share(self, rotation):
+        return lib.gr_tiled_share(self.handle, rotation)
+
+    def render(self, state, program, metric, camera, frame_ptr, background=None, features=None, cfg_values=None, options=None, stream=None,
+               rotation=0):
+        arr, n = None, 0
+        if cfg_values is not None:
+            n = len(cfg_values)
+            arr = (c_float * n)(*cfg_values)
+        bg1 = bg2 = None
+        bw = bh = bl = 0
+        if background is not None:
+            ptrs, bw, bh, bl = background
+            bg1, bg2 = ptrs if isinstance(ptrs, tuple) else (ptrs, ptrs)
+        if features is None:
+            features = metric.features()
+        check(lib.gr_render_frame_tiled(self.handle, state.handle, program.handle, metric.handle, stream, ctypes.byref(camera),
+                                        ctypes.byref(features), arr, n, bg1, bg2, bw, bh, bl, frame_ptr,
+                                        ctypes.byref(options) if options is not None else None, rotation))
+
+    def join(self, stream=None):
+        check(lib.gr_tiled_join(self.handle, stream))
+
+    def close(self):
+        if self.handle:
+            lib.gr_tiled_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ProgramManager:
     """metric_manager (metric_manager.hpp:19-219): the "dynamic" program (reads $cfg / features from memory) is usable at
     once; the "substituted" program with every parameter baked in is built in the background and swapped in when ready.

@@ -413,6 +413,39 @@ int gr_stream_synchronize(void* stream);
 int gr_stream_destroy(void* stream);
 int gr_device_count(int* count);
 
+/* ---- one frame over several GPUs (the reference is single-GPU) ------------------------------------------
+ * Image rows are dealt to `world` participants in blocks of block_rows rows, block-cyclically; each renders its share with
+ * gr_render_frame's strip mode (own prepass cells, one halo row per block, no exchange while tracing) and the finished float4 rows
+ * go to participant 0 - every block straight to its final place in its frame buffer, nothing is staged or un-permuted there.
+ *   GR_TRANSPORT_RCCL: one process per GPU.  Participant 0 calls gr_tiled_unique_id and hands the 128 bytes to the others by any
+ *     means; everybody then calls gr_tiled_create (collective: returns when all have).  Per frame and block: ncclSend on the
+ *     owner / ncclRecv on participant 0 at the block's row offset, one group per frame, enqueued on the caller's stream.
+ *     librccl is loaded at run time (dlopen), the library has no link dependency on it.
+ *   GR_TRANSPORT_PEER: one process driving `count` devices (gr_tiled_create_local; devices may repeat): hipMemcpyPeerAsync per
+ *     block on the owner's stream; gr_tiled_join makes participant 0's stream wait for them.
+ * gr_render_frame_tiled = gr_render_frame for this participant's share + the transfer.  `options` as for gr_render_frame (mode,
+ * strip_* and compact_out are overridden; next_camera / next_strip_rank look-ahead works as there, see gr_tiled_share).
+ * `rotation`: participant r renders share (r + rotation) % world - rotate with the frame number to even out shares of different
+ * cost.  frame_on_root: float4[height * width] on participant 0's device; NULL elsewhere with RCCL, the same pointer for every
+ * participant with peer copies. */
+typedef struct gr_tiled gr_tiled;
+enum { GR_TRANSPORT_RCCL = 0, GR_TRANSPORT_PEER = 1 };
+int gr_tiled_unique_id(void* id_out_128_bytes);
+int gr_tiled_create(int world, int rank, int device, const void* unique_id_128_bytes, int width, int height, int block_rows, gr_tiled** out);
+int gr_tiled_create_local(int count, const int* devices, int width, int height, int block_rows, gr_tiled** out_array);
+void gr_tiled_destroy(gr_tiled* t);
+int gr_render_frame_tiled(gr_tiled* t, gr_render_state* s, gr_program* p, const gr_metric* m, void* stream, const gr_camera* camera,
+                          const gr_features* features, const float* cfg_values, int num_cfg_values,
+                          const void* background1, const void* background2, int bg_width, int bg_height, int bg_levels,
+                          void* frame_on_root, const gr_frame_options* options, int rotation);
+int gr_tiled_join(gr_tiled* root, void* stream);
+/* the share participant t renders in a frame with this rotation (what to put into options->next_strip_rank for a look-ahead) */
+int gr_tiled_share(const gr_tiled* t, int rotation);
+/* rows [row_begin, row_end) of the local_block-th block of a share; returns 1, 0 for a padding block past the image, -1 on bad
+ * arguments.  Pure arithmetic: global block = local_block * world + share. */
+int gr_tiled_block_rows(int height, int block_rows, int world, int share, int local_block, int* row_begin, int* row_end);
+int gr_tiled_block_rows_of(const gr_tiled* t, int share, int local_block, int* row_begin, int* row_end);
+
 /* ---- host helper: background image ----------------------------------------------------------- */
 
 /* load_mipped_image (graphics_settings.cpp:152-212): packs an RGBA8 image and its box-filtered mip

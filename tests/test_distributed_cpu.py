@@ -25,6 +25,29 @@ def test_plan_partitions_every_row_once():
         assert all(plan.owner_of_row(y) == (y // block) % world for y in (0, height // 2, height - 1))
 
 
+def test_c_abi_block_arithmetic_matches_the_plan():
+    """gr_tiled_block_rows (csrc/tiled.cpp: where gr_render_frame_tiled's ncclSend / ncclRecv / peer copies put a block) against
+    StripPlan, which the gloo tests below prove against a known frame: every share's blocks, in order, padding blocks reported"""
+    import ctypes
+    import geodesic_raytracing_amd as gra
+    for height, world, block in [(2160, 8, 48), (2160, 8, 16), (1080, 4, 16), (54, 2, 8), (100, 3, 8), (2160, 1, 16), (4320, 8, 48), (360, 5, 24)]:
+        plan = StripPlan(height, world, block)
+        covered = []
+        for share in range(world):
+            want = plan.blocks_of(share)
+            for i in range(plan.blocks_per_rank + 1):
+                a, b = ctypes.c_int(-1), ctypes.c_int(-1)
+                rc = gra.lib.gr_tiled_block_rows(height, block, world, share, i, ctypes.byref(a), ctypes.byref(b))
+                if i < len(want):
+                    assert rc == 1 and (a.value, b.value) == want[i]
+                    covered.extend(range(a.value, b.value))
+                else:
+                    assert rc == 0
+        assert sorted(covered) == list(range(height))
+    a, b = ctypes.c_int(), ctypes.c_int()
+    assert gra.lib.gr_tiled_block_rows(100, 8, 3, 3, 0, ctypes.byref(a), ctypes.byref(b)) == -1   # share out of range
+
+
 def test_plan_balances_the_shadow():
     """a centred disc (the black-hole shadow, skipped by the prepass) is spread evenly over ranks"""
     h, w = 2160, 3840

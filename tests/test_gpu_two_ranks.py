@@ -64,3 +64,63 @@ def test_two_ranks_assemble_the_single_gpu_frames(tmp_path):
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok.npy")
+
+
+def test_c_abi_tiled_frame_with_peer_copies_equals_the_single_gpu_frame():
+    """gr_render_frame_tiled (csrc/tiled.cpp) with the peer-copy transport: 3 and 8 participants on the one GPU of the test box
+    render their rotating shares (with the look-ahead bench.py uses), their blocks are copied straight to their rows of
+    participant 0's frame, and the result is the single-GPU frame bit for bit - every block offset the RCCL transport uses is
+    exercised (it differs only in ncclSend / ncclRecv instead of hipMemcpyPeerAsync)."""
+    import geodesic_raytracing_amd as gra
+    from geodesic_raytracing_amd.pipeline import DeviceBuffer
+    w, h = 640, 360
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    feats = metric.features(adaptive_sampling=0)
+    cfg = metric.cfg_values(a=0.45)
+    packed, levels = gra.pack_background(gra.synthetic_background(512, 256))
+    bg = DeviceBuffer.from_numpy(0, packed)
+    cams = [gra.default_camera([0, 0.1 * k, -4 - 0.3 * k, 0.05 * k]) for k in range(4)]
+    full = DeviceBuffer(0, w * h * 16)
+    single = gra.RenderState(w, h, 0)
+    want = []
+    for cam in cams:
+        single.render(prog, metric, cam, full.ptr, (bg.ptr, 512, 256, levels), feats, cfg, gra.frame_options(mode=gra.MODE_FUSED))
+        single.synchronize()
+        want.append(full.to_numpy(np.float32, (h, w, 4)))
+    for world, block in ((3, 24), (8, 16)):
+        parts = gra.TiledFrame.local([0] * world, w, h, block)
+        states = [gra.RenderState(w, h, 0) for _ in range(world)]
+        frame = DeviceBuffer(0, w * h * 16)
+        for k, cam in enumerate(cams):
+            for r in range(world):
+                o = gra.frame_options(mode=gra.MODE_FUSED)
+                if k + 1 < len(cams):
+                    o.next_camera, o.next_strip_rank = ctypes.pointer(cams[k + 1]), parts[r].share(k + 1)
+                parts[r].render(states[r], prog, metric, cam, frame.ptr, (bg.ptr, 512, 256, levels), feats, cfg, o, rotation=k)
+            parts[0].join()
+            gra.check(gra.lib.gr_device_synchronize(0))
+            assert np.array_equal(frame.to_numpy(np.float32, (h, w, 4)), want[k]), (world, k)
+        for p in parts:
+            p.close()
+
+
+def test_c_abi_tiled_frame_rccl_single_participant():
+    """the RCCL entry points with world = 1 (no communicator needed, the frame is rendered in place), and - when librccl loads -
+    the unique id call"""
+    import geodesic_raytracing_amd as gra
+    from geodesic_raytracing_amd.pipeline import DeviceBuffer
+    w, h = 320, 180
+    metric = gra.Metric("schwarzschild")
+    prog = gra.Program(metric.argument_string(), 0)
+    feats = metric.features(adaptive_sampling=0)
+    packed, levels = gra.pack_background(gra.synthetic_background(256, 128))
+    bg = DeviceBuffer.from_numpy(0, packed)
+    one = gra.TiledFrame(1, 0, 0, None, w, h, 16)
+    state, frame, full = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16), DeviceBuffer(0, w * h * 16)
+    one.render(state, prog, metric, gra.default_camera(), frame.ptr, (bg.ptr, 256, 128, levels), feats, metric.cfg_values(), None, rotation=5)
+    state.render(prog, metric, gra.default_camera(), full.ptr, (bg.ptr, 256, 128, levels), feats, metric.cfg_values(), gra.frame_options(mode=gra.MODE_FUSED))
+    state.synchronize()
+    assert np.array_equal(frame.to_numpy(np.float32, (h, w, 4)), full.to_numpy(np.float32, (h, w, 4)))
+    uid = gra.TiledFrame.unique_id()
+    assert len(uid) == 128 and any(uid)
