@@ -83,11 +83,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_prepass", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_PREPASS, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -636,6 +636,21 @@ int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_gene
     void* args[] = {&camera_generic, &camera_quat, &term, &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg,
                     &image_height, &block_rows, &strip_rank, &strip_count};
     return launch(p, K_PREPASS_FUSED, stream, blocks((long long)prepass_width * prepass_height, 64), 1, 64, 1, args);
+}
+
+int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, float flip, const float basis_speed[3], void* position_generic_out,
+                      void* e0_out, void* e1_out, void* e2_out, void* e3_out, const void* camera_quat, void* term, int prepass_width,
+                      int prepass_height, const void* cfg, const void* dfg, int image_height, int block_rows, int strip_rank, int strip_count) {
+    if (!basis_speed) return fail(GR_ERROR_INVALID_ARGUMENT, "null basis speed");
+    if (prepass_width < 0 || prepass_height < 0) return fail(GR_ERROR_INVALID_ARGUMENT, "negative prepass size");
+    if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = 8; }
+    if (block_rows <= 0 || strip_rank < 0 || strip_rank >= strip_count) return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
+    if (image_height <= 0) image_height = prepass_height > 0 ? prepass_height * 16 : 16;
+    float sx = basis_speed[0], sy = basis_speed[1], sz = basis_speed[2];
+    void* args[] = {&position_cart, &flip, &sx, &sy, &sz, &position_generic_out, &e0_out, &e1_out, &e2_out, &e3_out, &camera_quat, &term,
+                    &prepass_width, &prepass_height, &cfg, &dfg, &image_height, &block_rows, &strip_rank, &strip_count};
+    long long cells = (long long)prepass_width * prepass_height;
+    return launch(p, K_CAMERA_PREPASS, stream, blocks(cells > 0 ? cells : 1, 64), 1, 64, 1, args);
 }
 
 int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* term,

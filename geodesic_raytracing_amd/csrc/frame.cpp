@@ -633,7 +633,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         GR_CHECK(gr_cart_to_generic(p, st, cart, generic, 1, cam->flip, s->cfg));
         return gr_init_basis_vectors(p, st, generic, 1, cam->basis_speed, tetrad[0], tetrad[1], tetrad[2], tetrad[3], s->cfg);
     };
-    if (!prefetched) {
+    // fused mode with a Cartesian camera: camera set-up and prepass are one launch (gr_camera_prepass), issued below
+    const bool one_launch_setup = opt.mode == GR_MODE_FUSED && !gc;
+    if (!prefetched && !one_launch_setup) {
         GR_CHECK(begin(GR_STAGE_CAMERA));
         GR_CHECK(camera_setup(stream, s->camera_pos_cart, s->camera_pos_generic, s->tetrad, camera, opt.geodesic_time,
                               gc ? gc->interpolated_velocity : nullptr));
@@ -644,7 +646,14 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         int strip_count = opt.strip_count > 1 ? opt.strip_count : 1;
         int strip_rank = strip_count > 1 ? opt.strip_rank : 0;
         int block_rows = strip_count > 1 ? opt.block_rows : ((height + 7) / 8) * 8;
-        if (use_prepass && !prefetched) {
+        if (!prefetched && one_launch_setup) {
+            GR_CHECK(begin(GR_STAGE_PREPASS));
+            GR_CHECK(gr_camera_prepass(p, stream, s->camera_pos_cart, camera->flip, camera->basis_speed, s->camera_pos_generic, s->tetrad[0],
+                                       s->tetrad[1], s->tetrad[2], s->tetrad[3], s->camera_quat, s->termination_buffer,
+                                       use_prepass ? prepass_width : 0, use_prepass ? prepass_height : 0, s->cfg, s->dfg, height, block_rows,
+                                       strip_rank, strip_count));
+            GR_CHECK(end(GR_STAGE_PREPASS));
+        } else if (use_prepass && !prefetched) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_prepass_fused_strips(p, stream, s->camera_pos_generic, s->camera_quat, s->termination_buffer, prepass_width,
                                              prepass_height, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg,
@@ -710,12 +719,19 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             HIP_CHECK(hipStreamWaitEvent(slot->stream, s->main_mark, 0));
             HIP_CHECK(hipMemcpyAsync(slot->set.camera_pos_cart, r.camera->position, 16, hipMemcpyHostToDevice, slot->stream));
             HIP_CHECK(hipMemcpyAsync(slot->set.camera_quat, r.camera->quat, 16, hipMemcpyHostToDevice, slot->stream));
-            GR_CHECK(camera_setup(slot->stream, slot->set.camera_pos_cart, slot->set.camera_pos_generic, slot->set.tetrad, r.camera, r.time,
-                                  slot->velocity));
-            GR_CHECK(gr_prepass_fused_strips(p, slot->stream, slot->set.camera_pos_generic, slot->set.camera_quat,
-                                             slot->set.termination_buffer, prepass_width, prepass_height, slot->set.tetrad[0],
-                                             slot->set.tetrad[1], slot->set.tetrad[2], slot->set.tetrad[3], s->cfg, s->dfg, height,
-                                             block_rows, r.strip_rank, strip_count));
+            if (one_launch_setup) {
+                GR_CHECK(gr_camera_prepass(p, slot->stream, slot->set.camera_pos_cart, r.camera->flip, r.camera->basis_speed,
+                                           slot->set.camera_pos_generic, slot->set.tetrad[0], slot->set.tetrad[1], slot->set.tetrad[2],
+                                           slot->set.tetrad[3], slot->set.camera_quat, slot->set.termination_buffer, prepass_width,
+                                           prepass_height, s->cfg, s->dfg, height, block_rows, r.strip_rank, strip_count));
+            } else {
+                GR_CHECK(camera_setup(slot->stream, slot->set.camera_pos_cart, slot->set.camera_pos_generic, slot->set.tetrad, r.camera, r.time,
+                                      slot->velocity));
+                GR_CHECK(gr_prepass_fused_strips(p, slot->stream, slot->set.camera_pos_generic, slot->set.camera_quat,
+                                                 slot->set.termination_buffer, prepass_width, prepass_height, slot->set.tetrad[0],
+                                                 slot->set.tetrad[1], slot->set.tetrad[2], slot->set.tetrad[3], s->cfg, s->dfg, height,
+                                                 block_rows, r.strip_rank, strip_count));
+            }
             HIP_CHECK(hipEventRecord(slot->ready, slot->stream));
             slot->valid = true;
             slot->age = s->frame_counter;

@@ -2207,13 +2207,9 @@ gr_trace_compact(const float4* __restrict__ g_generic_camera_in, const float4* _
 // row cy reads the cell rows round(cy * ph / H) - 1 .. + 1 (init_rays_generic's 5-point stencil, cl.cl:3213-3232), so
 // cell row cp matters to this device only if one of its blocks (or the halo row under it) intersects the pixel rows
 // that map to cp - 1 .. cp + 1.  The prepass is otherwise replicated work: 11 % of a device's frame at 8 devices.
-extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
-gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
-                 int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
-                 const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
-                 cfg_t cfg_in, dfg_t dfg_in, int image_height, int block_rows, int strip_rank, int strip_count) {
-    GR_PARAMETERS_IN_REGISTERS
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void prepass_cell(int id, float4 camera, float4 camera_quat, float4 e0, float4 e1, float4 e2, float4 e3,
+                                             int* __restrict__ termination_buffer, int prepass_width, int prepass_height, cfg_t cfg, dfg_t dfg,
+                                             int image_height, int block_rows, int strip_rank, int strip_count) {
     if (id >= prepass_width * prepass_height) return;
     int cx = id % prepass_width, cy = id / prepass_width;
     if (strip_count > 1) {
@@ -2229,13 +2225,55 @@ gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* _
         long long first = b_lo + (((long long)strip_rank - b_lo) % strip_count + strip_count) % strip_count;   // first own block >= b_lo
         if (first > b_hi) return;
     }
-    lightray ray = make_pixel_ray(cx, cy, prepass_width, prepass_height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+    lightray ray = make_pixel_ray(cx, cy, prepass_width, prepass_height, camera, camera_quat, e0, e1, e2, e3, 0, cfg, dfg);
     ray_state s;
     s.position = ray.position;
     s.velocity = ray.velocity;
     s.acceleration = ray.acceleration;
     int res = integrate_ray(s, cfg, dfg, nullptr);
     termination_buffer[id] = res == RAY_TERMINATED ? 0 : 1;
+}
+
+extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
+gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+                 int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+                 const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+                 cfg_t cfg_in, dfg_t dfg_in, int image_height, int block_rows, int strip_rank, int strip_count) {
+    GR_PARAMETERS_IN_REGISTERS
+    prepass_cell(blockIdx.x * blockDim.x + threadIdx.x, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, termination_buffer,
+                 prepass_width, prepass_height, cfg, dfg, image_height, block_rows, strip_rank, strip_count);
+}
+
+// cart_to_generic_kernel + init_basis_vectors + the prepass in ONE launch (the reference: three of its launches and the prepass
+// sequence, main.cpp:2311, 2329, 2380-2436).  The camera's metric coordinates and tetrad - one lane's worth of work, ~900
+// instructions - are computed by every lane of the launch for itself (same inputs, same instructions, same values), lane 0 of the
+// launch also stores them for gr_trace_fused.  What this buys is the launch chain of a frame: two single-lane kernels with their
+// queue latencies sat in front of every prepass (1.3 ms on average on the look-ahead stream under load, round-1 profile), which
+// is what a device's share of a frame costs altogether once the frame is split eight ways.  prepass_width * prepass_height may
+// be 0 (metrics without a prepass): the launch is then the camera set-up alone.
+extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
+gr_camera_prepass(const float4* __restrict__ position_cart_in, float flip, float speed_x, float speed_y, float speed_z,
+                  float4* __restrict__ position_generic_out, float4* __restrict__ e0_out, float4* __restrict__ e1_out,
+                  float4* __restrict__ e2_out, float4* __restrict__ e3_out, const float4* __restrict__ g_camera_quat,
+                  int* __restrict__ termination_buffer, int prepass_width, int prepass_height, cfg_t cfg_in, dfg_t dfg_in,
+                  int image_height, int block_rows, int strip_rank, int strip_count) {
+    GR_PARAMETERS_IN_REGISTERS
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const float4 in = *position_cart_in;
+    float3 polar = cartesian_to_polar(yzw(in));
+    if (flip > 0) polar.x = -polar.x;
+    const float4 camera = gm::spherical_to_generic(f4(in.x, polar), cfg);
+    tetrad t;
+    calculate_tetrads(camera, f3(speed_x, speed_y, speed_z), t, cfg, 1);
+    if (id == 0) {
+        *position_generic_out = camera;
+        *e0_out = t.e[0];
+        *e1_out = t.e[1];
+        *e2_out = t.e[2];
+        *e3_out = t.e[3];
+    }
+    prepass_cell(id, camera, *g_camera_quat, t.e[0], t.e[1], t.e[2], t.e[3], termination_buffer, prepass_width, prepass_height, cfg, dfg,
+                 image_height, block_rows, strip_rank, strip_count);
 }
 
 // ------------------------------------------------------------------------------------------------

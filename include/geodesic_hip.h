@@ -257,6 +257,15 @@ int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_gene
                             const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg,
                             int image_height, int block_rows, int strip_rank, int strip_count);
 
+/* gr_cart_to_generic + gr_init_basis_vectors + gr_prepass_fused_strips in one launch: the camera's metric coordinates and tetrad
+ * are computed from the Cartesian camera inside the launch (and stored to position_generic_out / e*_out for gr_trace_fused), then
+ * the prepass cells are traced.  prepass_width * prepass_height may be 0: camera set-up only.  Removes two single-lane launches
+ * from every frame's chain. */
+int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, float flip, const float basis_speed[3],
+                      void* position_generic_out, void* e0_out, void* e1_out, void* e2_out, void* e3_out, const void* camera_quat,
+                      void* termination_buffer, int prepass_width, int prepass_height, const void* cfg, const void* dfg,
+                      int image_height, int block_rows, int strip_rank, int strip_count);
+
 /* init -> integrate -> render-data in one launch; writes only render_data[sy*width+sx] (32 B per pixel).
  * Rows are dealt to devices block-cyclically: global block b (block_rows rows, multiple of 8) belongs to device
  * b % strip_count; each block additionally traces the one row below it (texture-filter halo).  strip_count <= 1
