@@ -83,11 +83,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_prepass", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_prepass", "gr_adaptive_refine", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_PREPASS, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_PREPASS, K_ADAPTIVE_REFINE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -664,9 +664,11 @@ int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, co
 static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const void* camera_generic, const void* camera_quat, void* rdata,
                         int width, int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
                         int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
-                        const void* dfg, void* attempt_counter) {
+                        const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
+    if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && (rays_per_lane != 1 || strip_count > 1)))
+        return fail(GR_ERROR_INVALID_ARGUMENT, "lattice / pending_only: gr_trace_fused on a whole image only");
     if (rays_per_lane == 2 && !p->fn[K_TRACE_PAIR])
         return fail(GR_ERROR_INVALID_ARGUMENT, "this program has no gr_trace_pair kernel (its expressions do not instantiate on pairs)");
     if (strip_count <= 1) {   // one block covering the image
@@ -680,6 +682,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         return fail(GR_ERROR_INVALID_ARGUMENT, "the last image row must not start a block (its filter reads the row above)");
     int local_blocks = gr_strip_local_blocks(height, block_rows, strip_rank, strip_count);
     long long waves_per_block = (long long)((width + T - 1) / T) * (block_rows / T) + (strip_count > 1 ? (width + 63) / 64 : 0);
+    if (lattice == 2) waves_per_block = (long long)((width / 2 + T - 1) / T) * ((height / 2 + T - 1) / T);   // tiles of the half-resolution grid
     // four tile-waves per workgroup (measured on MI355X, 4K Kerr: 64 -> 7.59 ms, 128 -> 7.43, 256 -> 7.24; one wave per SIMD
     // still leaves the full 512-VGPR budget to the heaviest metrics).  Experiment hooks: GR_TRACE_BLOCK=64|128|256 with the
     // kernel built with the same -DGR_TRACE_BLOCK through GR_EXTRA_FLAGS; GR_TRACE_PERSISTENT=0 launches one wave per tile.
@@ -702,8 +705,22 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         groups = resident_groups;
     }
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
-                    &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves};
+                    &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
+                    &lattice, &pending_only};   // the last two: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
     return launch(p, rays_per_lane == 2 ? K_TRACE_PAIR : K_TRACE_FUSED, stream, (unsigned)groups, 1, wg, 1, args);
+}
+
+int gr_trace_fused_adaptive(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
+                            int height, const void* term, int prepass_width, int prepass_height, const void* e0, const void* e1,
+                            const void* e2, const void* e3, const void* cfg, const void* dfg, void* attempt_counter, int lattice,
+                            int pending_only) {
+    return trace_launch(p, 1, stream, camera_generic, camera_quat, rdata, width, height, 0, 0, 1, term, prepass_width, prepass_height, e0, e1,
+                        e2, e3, cfg, dfg, attempt_counter, lattice, pending_only);
+}
+
+int gr_adaptive_refine(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg) {
+    void* args[] = {&rdata, &pending_count, &width, &height, &dfg};
+    return launch(p, K_ADAPTIVE_REFINE, stream, (unsigned)((width / 2 + 15) / 16), (unsigned)((height / 2 + 15) / 16), 16, 16, args);
 }
 
 int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

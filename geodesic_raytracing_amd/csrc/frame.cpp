@@ -522,14 +522,12 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     else features.max_acceleration_change = info.max_acceleration_change;   // metric_manager.hpp:50
 
     const int width = s->width, height = s->height;
-    // The defaults of gr_features (adaptive_sampling on, as the reference's GUI) and of gr_frame_options (fused mode) must work
-    // together: the fused kernels trace every pixel, so a whole-frame request with adaptive sampling takes the reference-shaped
-    // sequence, which implements it (cl.cl:5223-5345).  Strips are traced in full: adaptive sampling is an approximation of
-    // exactly that frame.
-    if (opt.mode == GR_MODE_FUSED && features.adaptive_sampling != 0 && !features.use_triangle_rendering) {
-        if (opt.strip_count > 1) features.adaptive_sampling = 0;
-        else opt.mode = GR_MODE_REFERENCE;
-    }
+    // The defaults of gr_features (adaptive_sampling on, as the reference's GUI) and of gr_frame_options (fused mode) work
+    // together: a whole frame is sampled adaptively on the fused path (half-resolution lattice, gr_adaptive_refine, second fused
+    // launch over the marked pixels; cl.cl:3234-3250, 5223-5345).  A device's share of a split frame is traced in full:
+    // adaptive sampling is an approximation of exactly that frame.
+    if (opt.mode == GR_MODE_FUSED && features.adaptive_sampling != 0 && !features.use_triangle_rendering && opt.strip_count > 1)
+        features.adaptive_sampling = 0;
     bool use_prepass = opt.use_prepass < 0 ? info.use_prepass != 0 : opt.use_prepass != 0;
     bool adaptive = features.adaptive_sampling != 0 && !features.use_triangle_rendering;
 
@@ -697,12 +695,27 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 if (opt.rays_per_lane == 2) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2: this program has no gr_trace_pair kernel");
                 rays_per_lane = 1;
             }
+            if (adaptive) {
+                // quarter of the primary rays (the pixels (2x, 2y)), then the blocks that need it refined by a second launch
+                const void* term = use_prepass ? s->termination_buffer : nullptr;
+                const int pw = use_prepass ? prepass_width : width, ph = use_prepass ? prepass_height : height;
+                GR_CHECK(gr_trace_fused_adaptive(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, term, pw, ph,
+                                                 s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, 2, 0));
+                GR_CHECK(end(GR_STAGE_TRACE));
+                GR_CHECK(begin(GR_STAGE_ADAPTIVE));
+                HIP_CHECK(hipMemsetAsync(s->rays_adaptive_count, 0, 4, stream));
+                GR_CHECK(gr_adaptive_refine(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg));
+                GR_CHECK(gr_trace_fused_adaptive(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, term, pw, ph,
+                                                 s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, 1, 1));
+                GR_CHECK(end(GR_STAGE_ADAPTIVE));
+            } else {
             GR_CHECK((rays_per_lane == 2 ? gr_trace_pair : gr_trace_fused)(
                 p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows, strip_rank, strip_count,
                 use_prepass ? s->termination_buffer : nullptr, use_prepass ? prepass_width : width, use_prepass ? prepass_height : height,
                 s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
+            }
         }
-        GR_CHECK(end(GR_STAGE_TRACE));
+        if (!adaptive) GR_CHECK(end(GR_STAGE_TRACE));
         for (const auto& r : todo) {
             // a free slot, else the stalest one no current request claims (a camera that was announced but never came)
             gr_render_state::prefetch_slot* slot = nullptr;

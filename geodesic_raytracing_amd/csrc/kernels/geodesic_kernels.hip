@@ -104,6 +104,8 @@ struct dynamic_feature_config {
 #ifndef GR_TILE
 #define GR_TILE 8
 #endif
+// render_data.terminated of a pixel that gr_adaptive_refine wants traced (the reference's values are 0, 1, 2)
+#define GR_PENDING (-1)
 
 // minimum resident waves per SIMD the integrator kernels are register-allocated for (512 VGPRs / N waves each).
 // 1 = no cap: the allocator takes what the metric's expressions need and occupancy follows (substituted Kerr: 92 VGPRs
@@ -1883,7 +1885,12 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            int strip_count, const int* __restrict__ termination_buffer, int prepass_width,
                                            int prepass_height, const float4* __restrict__ e0, const float4* __restrict__ e1,
                                            const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
-                                           unsigned long long* __restrict__ attempt_counter) {
+                                           unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only) {
+    // Adaptive sampling on the fused path (cl.cl:3234-3250, 5223-5345): lattice = 2 traces the pixels (2x, 2y) only - the tiles
+    // then cover the half-resolution grid - and pending_only = 1 traces the pixels gr_adaptive_refine marked (terminated ==
+    // GR_PENDING) and leaves every other record alone.  Neither is combined with a row split (strip_count == 1).
+    const int image_width = width, image_height = height;
+    if (lattice == 2) { width /= 2; height /= 2; block_rows = ((height + 7) / 8) * 8; }
     const int T = GR_TILE;
     const int tiles_x = (width + T - 1) / T;
     const int tile_rows = block_rows / T;
@@ -1902,10 +1909,13 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         cy = r0 + block_rows;
     }
     if (cx >= width || cy >= height) return;
+    cx *= lattice; cy *= lattice;
+    width = image_width; height = image_height;
+    if (pending_only && rdata[cy * width + cx].terminated != GR_PENDING) return;
 
     // the prepass verdict first: a skipped pixel (58 % of the 4K Kerr frame) needs no ray at all
     int terminated = 0;
-    if (termination_buffer && prepass_width != width && prepass_height != height) {
+    if (!pending_only && termination_buffer && prepass_width != width && prepass_height != height) {
         float fx = exact_ratio(cx, width);
         float fy = exact_ratio(cy, height);
         int lx = (int)roundf(fx * prepass_width);
@@ -1965,7 +1975,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
-               int total_waves) {
+               int total_waves, int lattice, int pending_only) {
     GR_PARAMETERS_IN_REGISTERS
     const int lane = threadIdx.x % 64;
     // profiling launches (attempt_counter != NULL) also measure the shader clock they ran at: every wave adds its lifetime in
@@ -1987,7 +1997,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
         // 5 instead of 8 waves per SIMD).  Re-reading 96 bytes through the scalar cache per tile is free by comparison.
         asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
         trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
-                   termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter);
+                   termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only);
 #ifdef GR_TRACE_SINGLE_TILE   // experiment: one tile per wave only (launch with GR_TRACE_PERSISTENT=0)
         break;
 #else
@@ -2300,6 +2310,48 @@ __device__ __forceinline__ render_data interpolate_render_data(render_data r1, r
     out.sy = (r1.sy + r2.sy) / 2;
     out.side = (r1.side + r2.side) / 2;
     return out;
+}
+
+// handle_adaptive_sampling on the fused path: the half-resolution records are already render_data (gr_trace_fused, lattice 2), so
+// the decision is taken on them - the sky angles come back out of the texture coordinates instead of out of 96-byte ray records -
+// and a block that needs its three other pixels marks them GR_PENDING in place for the second fused launch (pending_only) instead
+// of appending rays to a list: the second launch then walks the same 8x8 tiles, neighbouring rays stay in one wave, no atomics
+// order the work.  Same tests as the reference (cl.cl:5242-5282): boundary blocks always refine, differing termination flags
+// refine, otherwise the angular error across the block against the per-pixel angle times the threshold.
+extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, int* __restrict__ pending_count, int width, int height,
+                                              dfg_t dfg) {
+    const int sx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int hw = width / 2, hh = height / 2;
+    if (sx >= hw || sy >= hh) return;
+    const int lsx = 2 * sx, lsy = 2 * sy;
+    auto at = [&](int x, int y) -> render_data& { return rdat[y * width + x]; };
+    bool refine = true;
+    if (sx != 0 && sx != hw - 1 && sy != 0 && sy != hh - 1) {
+        const render_data centre = at(lsx, lsy), left = at(lsx - 2, lsy), right = at(lsx + 2, lsy), up = at(lsx, lsy - 2), down = at(lsx, lsy + 2);
+        const int down_right_flag = at(lsx + 2, lsy + 2).terminated;
+        const float2 la = tex_to_angle(left.tex_coord), ra = tex_to_angle(right.tex_coord), ua = tex_to_angle(up.tex_coord), da = tex_to_angle(down.tex_coord);
+        // tex_to_angle gives (phi, theta); the reference compares (theta, phi) pairs
+        const float x_error = __builtin_fabsf(angle_between_angles(make_float2(la.y, la.x), make_float2(ra.y, ra.x)));
+        const float y_error = __builtin_fabsf(angle_between_angles(make_float2(da.y, da.x), make_float2(ua.y, ua.x)));
+        const float relative_angular_error = (float)((double)(((x_error + x_error + y_error + y_error) / 4.f) / 2) * GR_PI);
+        const float fov = GET_FEATURE(field_of_view, dfg);
+        const float per_pixel = (float)((double)(fov * 2) * GR_PI / (double)360.f) / width;
+        refine = relative_angular_error >= per_pixel * GET_FEATURE(adaptive_sampling_threshold, dfg);
+        const int ct = centre.terminated;
+        if (ct != left.terminated || ct != right.terminated || ct != up.terminated || ct != down.terminated || ct != down_right_flag) refine = true;
+    }
+    if (refine) {
+        at(lsx + 1, lsy).terminated = GR_PENDING;
+        at(lsx, lsy + 1).terminated = GR_PENDING;
+        at(lsx + 1, lsy + 1).terminated = GR_PENDING;
+        if (pending_count) atomicAdd(pending_count, 3);
+    } else {
+        const render_data c = at(lsx, lsy);
+        at(lsx + 1, lsy) = interpolate_render_data(c, at(lsx + 2, lsy));
+        at(lsx, lsy + 1) = interpolate_render_data(c, at(lsx, lsy + 2));
+        at(lsx + 1, lsy + 1) = interpolate_render_data(c, at(lsx + 2, lsy + 2));
+    }
 }
 
 extern "C" __global__ void gr_handle_adaptive_sampling(const lightray* __restrict__ rays_in, const int* __restrict__ rays_in_count,

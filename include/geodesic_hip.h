@@ -276,6 +276,19 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
                    const void* e0, const void* e1, const void* e2, const void* e3,
                    const void* cfg, const void* dfg, void* attempt_counter);
 
+/* Adaptive sampling on the fused path (the reference: init_rays_generic's packing cl.cl:3234-3250 + handle_adaptive_sampling
+ * cl.cl:5223-5345 + a second do_generic_rays / calculate_render_data).  gr_trace_fused_adaptive is gr_trace_fused on a whole image
+ * with lattice = 2: only the pixels (2x, 2y) are traced; or with pending_only = 1: only the pixels whose record says terminated ==
+ * -1 are traced, every other record is left alone.  gr_adaptive_refine decides per 2x2 block from the lattice records (boundary
+ * blocks and blocks whose termination flags differ always refine, otherwise the angular error across the block against the
+ * per-pixel angle times adaptive_sampling_threshold): a block to refine gets its three other records marked -1, any other block
+ * gets them interpolated; pending_count (device int, may be NULL) accumulates 3 per refined block. */
+int gr_trace_fused_adaptive(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* render_data,
+                            int width, int height, const void* termination_buffer, int prepass_width, int prepass_height,
+                            const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg,
+                            void* attempt_counter, int lattice, int pending_only);
+int gr_adaptive_refine(gr_program* p, void* stream, void* render_data, void* pending_count, int width, int height, const void* dfg);
+
 /* gr_trace_fused with two rays per lane: a wave takes two neighbouring 8x8 tiles and every lane integrates one pixel of each,
  * all per-ray arithmetic in packed fp32 (v_pk_fma/mul/add_f32: one instruction, two rays).  Same arguments, same records;
  * each ray's arithmetic is that of gr_trace_fused (results agree to what the compiler contracts differently).  A program has

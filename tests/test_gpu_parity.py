@@ -174,6 +174,28 @@ def test_adaptive_sampling_matches_reference():
     assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
 
 
+def test_adaptive_sampling_on_the_fused_path_matches_reference():
+    """the same golden frame through the fused kernels: half-resolution lattice (gr_trace_fused_adaptive), gr_adaptive_refine on the
+    lattice's render-data records, second fused launch over the marked pixels.  The decision reads the sky angles back out of
+    texture coordinates where the reference reads them off ray records, so a borderline block may fall the other way."""
+    from geodesic_raytracing_amd.pipeline import download
+    meta, z = load_golden("kerr_adaptive_sampling")
+    px, state = _frame(meta, gra.MODE_FUSED)
+    n_new = int(download(0, state.buffer(gra.BUF_RAYS_ADAPTIVE_COUNT), np.int32, 1)[0])
+    assert abs(n_new - meta["adaptive_count"]) <= 12
+    rd = download(0, state.buffer(gra.BUF_RENDER_DATA), gra.pipeline.RENDER_DATA_DTYPE, meta["width"] * meta["height"])
+    assert (rd["terminated"] >= 0).all()             # no record left pending
+    d = px[..., :3] - z["pixels"][..., :3]
+    bad = np.abs(d).max(axis=2) > 1e-3
+    assert bad.mean() <= 0.01
+    assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
+    # ... and the substituted program, with the metric's prepass on as in the GUI
+    px2, _ = _frame(dict(meta, prepass=True), gra.MODE_FUSED, substituted=True)
+    d = px2[..., :3] - z["pixels"][..., :3]
+    bad = np.abs(d).max(axis=2) > 1e-3
+    assert bad.mean() <= 0.01
+
+
 @pytest.mark.parametrize("name", ["kerr", "schwarzschild_redshift", "alcubierre", "kerr_prepass", "kerr_schild_prepass"])
 def test_fused_and_tiled_paths_equal_reference_sequence(name):
     """the 8x8-tiled ray order is bit-identical to the reference order (same kernels); the fused kernel is the same
