@@ -233,11 +233,13 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     int rc = build(opts, code);
     if (rc != GR_OK) return rc;
 
-    // Occupancy of the fused trace kernel.  Measured on MI355X (4K Kerr, substituted program, trace launch alone): the register
-    // allocator, given the whole file, takes 99 VGPRs (4 waves per SIMD) - 6.66 ms; held to 72 (7 waves, 60 bytes of spills, none
-    // of them inside the Verlet loop) - 6.25 ms; 96 / 80 / 64 VGPRs: 6.80 / 6.47 / 6.57 ms.  The loop's dependent chains want more
-    // waves than the allocator's appetite leaves.  Rule: rebuild with the register budget of three quarters of what the free build
-    // took, rounded down to an occupancy step, and keep that build unless it spills more than 64 bytes per lane.
+    // Occupancy of the fused trace kernel.  Measured on MI355X (4K Kerr, substituted program, trace launch on its own): the register
+    // allocator, given the whole file, takes 99 VGPRs (4 waves per SIMD) - 6.66 ms; held to 80 (6 waves, 24 bytes of spills per lane,
+    // none of them inside the Verlet loop) - 6.47 ms; to 72 (7 waves, 60 bytes) - 6.25 ms, but the spills around the loop then add
+    // ~120 MB of scratch traffic per launch to the 265 MB of results; to 96 (5 waves, no spills) - 6.80 ms.  With three frames in
+    // flight the difference disappears (the machine is then full - and power-limited - either way); what the extra waves buy is
+    // the latency of a frame rendered on its own.  Rule: rebuild with the register budget of five sixths of what the free build
+    // took, rounded down to an occupancy step, and keep that build unless it spills more than 32 bytes per lane.
     bool tuned_by_caller = false;
     for (auto& o : opts) tuned_by_caller |= o.rfind("-DGR_FUSED_WAVES", 0) == 0 || o.rfind("-DGR_TRACE_WAVES", 0) == 0;
     const char* tuning = getenv("GR_OCCUPANCY_TUNING");
@@ -245,15 +247,15 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
         int vgprs = 0, scratch = 0;
         if (kernel_resources(code, "gr_trace_fused", vgprs, scratch) && vgprs > 64) {
             auto waves_of = [](int regs) { int w = 512 / (((regs + 7) / 8) * 8); return w > 8 ? 8 : w; };
-            int target_waves = waves_of(vgprs * 3 / 4);
-            while (target_waves > 1 && (512 / target_waves) / 8 * 8 > vgprs * 3 / 4) target_waves++;   // budget of w waves <= 3/4 of the free build
+            int target_waves = waves_of(vgprs * 5 / 6);
+            while (target_waves > 1 && (512 / target_waves) / 8 * 8 > vgprs * 5 / 6) target_waves++;   // budget of w waves <= 5/6 of the free build
             if (target_waves > 8) target_waves = 8;
             if (target_waves > waves_of(vgprs)) {
                 std::vector<std::string> capped = opts;
                 capped.push_back("-DGR_FUSED_WAVES=" + std::to_string(target_waves));
                 std::string code2;
                 int v2 = 0, s2 = 0;
-                if (build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2) && s2 <= scratch + 64) code.swap(code2);
+                if (build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2) && s2 <= scratch + 32) code.swap(code2);
             }
         }
     }
