@@ -65,8 +65,12 @@ def parse():
     ap.add_argument("--lookahead-depth", type=int, default=0, help="frames of prepass look-ahead (1 or 2); default 1 on one GPU, "
                     "2 when the frame is split over several (a strip traces faster than one prepass runs)")
     ap.add_argument("--block-rows", type=int, default=48, help="rows per block of the block-cyclic row split (N > 1); multiple of 8")
+    ap.add_argument("--trace-waves-per-simd", type=int, default=-1, help="persistent waves per SIMD of a trace launch in the timed frames "
+                    "(0 = all that fit, -1 = 4 with three or more frames in flight on one GPU, else all)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="render states / streams cycled through (1 = strictly one frame at a time)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--measure-clock", action="store_true", help="count attempts in the timed frames too, so that the shader clock of the "
+                    "overlapped launches can be read afterwards (two timestamp reads per wave; the counters cost an atomic per tile)")
     return ap.parse_args()
 
 
@@ -151,6 +155,9 @@ def main():
     # cells); the coarser deal is evened out by the rotation of the strips over the frames
     plan = grd.StripPlan(H, world, block_rows=args.block_rows)
     in_flight = max(1, min(args.frames_in_flight, 8)) if fused else 1
+    # with frames in flight a trace launch takes 4 of the SIMDs' wave slots instead of all (6 for the Kerr kernel): the launches
+    # then share the device and one drains while the next is in full swing (measured +2-3 %; one frame at a time: all slots)
+    waves_per_launch = args.trace_waves_per_simd if args.trace_waves_per_simd >= 0 else (4 if (in_flight >= 3 and world == 1) else 0)
 
     # N > 1: the C ABI's gr_render_frame_tiled (csrc/tiled.cpp) - this rank's share of the rows, then per block an ncclSend /
     # ncclRecv straight to the block's rows of rank 0's frame (no staging, no un-permute).  GR_BENCH_GATHER=torch selects the
@@ -216,6 +223,9 @@ def main():
                 opts.next_strip_rank = slot.gather.strip_of(k + in_flight)        # the frames this render state sees next
                 opts.next_strip_rank2 = slot.gather.strip_of(k + 2 * in_flight)
                 target = slot.gather.local_buffer().data_ptr()
+            if args.measure_clock:
+                opts.count_attempts = 1
+            opts.trace_waves_per_simd = waves_per_launch
             if lookahead is not None:
                 opts.next_camera = lookahead
                 if depth == 2:
@@ -263,6 +273,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    overlapped_clock = [round(slot.state.shader_clock_mhz(), 1) for slot in ring] if args.measure_clock else None
     ms_per_step = elapsed / args.steps * 1e3
     mrays = W * H / (elapsed / args.steps) / 1e6
     # every trace launch of the timed region, HIP events on the stream it was launched on
@@ -277,6 +288,8 @@ def main():
     local_pixels = W * H if world == 1 else sum(b - a for a, b in plan.blocks_of(rank)) * W + plan.local_blocks(rank) * W
     alg_bytes = (TRACE_BYTES_PER_RAY if fused else 140) * local_pixels
     extra["fps"] = round(1e3 / ms_per_step, 2)
+    if overlapped_clock:
+        extra["shader_clock_mhz_last_overlapped_launches"] = overlapped_clock
 
     def exclusive_frames(prog, cfgv, n=5):
         """n frames one at a time with per-stage events and the attempt / shader-clock counters: stage ms (means), attempts,
@@ -442,7 +455,7 @@ def main():
                                    f"prepass {'on' if metric.info.use_prepass else 'off'}, tol {metric.info.max_acceleration_change:g}, "
                                    f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
                        "mode": args.mode, "prepass_lookahead": bool(fused and not args.no_lookahead), "prepass_lookahead_depth": depth,
-                       "frames_in_flight": in_flight, "priming_frames": priming, "build_key": program.build_key, "counters_tag": tag, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
+                       "frames_in_flight": in_flight, "trace_waves_per_simd": waves_per_launch, "priming_frames": priming, "build_key": program.build_key, "counters_tag": tag, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
                        "parallelism": f"{plan.block_rows}-row blocks, block-cyclic over {world} GPUs (assignment rotating per frame); {gather_path}" if multi else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -49,7 +49,7 @@ class FrameOptions(ctypes.Structure):
                 ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera)), ("geodesic", c_void_p),
                 ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("parallel_transport_observer", c_int),
                 ("ray_compaction", c_int), ("next_camera2", ctypes.POINTER(Camera)), ("next_geodesic_time2", c_float),
-                ("next_strip_rank", c_int), ("next_strip_rank2", c_int), ("rays_per_lane", c_int)]
+                ("next_strip_rank", c_int), ("next_strip_rank2", c_int), ("rays_per_lane", c_int), ("trace_waves_per_simd", c_int)]
 
 
 MODE_REFERENCE, MODE_FUSED = 0, 1
@@ -98,12 +98,16 @@ _SIGNATURES = {
     "gr_prepass_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
     "gr_prepass_fused_strips": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gr_tile_order_bytes": (ctypes.c_longlong, [c_int, c_int, c_int, c_int, c_int]),
+    "gr_order_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gr_trace_fused_ordered": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "gr_trace_fused_adaptive": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "gr_adaptive_refine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gr_camera_prepass": (c_int, [c_void_p, c_void_p, c_void_p, c_float, ctypes.POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p,
-                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gr_trace_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gr_trace_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
@@ -140,6 +144,8 @@ _SIGNATURES = {
     "gr_render_state_trace_log": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int), c_int]),
     "gr_render_state_attempts": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gr_render_state_shader_clock": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "gr_render_state_counters": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong), c_int]),
+    "gr_render_state_wave_time": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong)]),
     "gr_tiled_unique_id": (c_int, [c_void_p]),
     "gr_tiled_create": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "gr_tiled_create_local": (c_int, [c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),

@@ -83,11 +83,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_prepass", "gr_adaptive_refine", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_prepass", "gr_order_tiles", "gr_adaptive_refine", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_PREPASS, K_ADAPTIVE_REFINE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_PREPASS, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -233,13 +233,13 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     int rc = build(opts, code);
     if (rc != GR_OK) return rc;
 
-    // Occupancy of the fused trace kernel.  Measured on MI355X (4K Kerr, substituted program, trace launch on its own): the register
-    // allocator, given the whole file, takes 99 VGPRs (4 waves per SIMD) - 6.66 ms; held to 80 (6 waves, 24 bytes of spills per lane,
-    // none of them inside the Verlet loop) - 6.47 ms; to 72 (7 waves, 60 bytes) - 6.25 ms, but the spills around the loop then add
-    // ~120 MB of scratch traffic per launch to the 265 MB of results; to 96 (5 waves, no spills) - 6.80 ms.  With three frames in
-    // flight the difference disappears (the machine is then full - and power-limited - either way); what the extra waves buy is
-    // the latency of a frame rendered on its own.  Rule: rebuild with the register budget of five sixths of what the free build
-    // took, rounded down to an occupancy step, and keep that build unless it spills more than 32 bytes per lane.
+    // Occupancy of the fused trace kernel.  Left alone, the register allocator takes what the kernel could use at its widest
+    // point (Kerr, substituted: 108 VGPRs, 4 waves per SIMD); a quarter of that is cold inside the Verlet loop (the registers a
+    // ray's exit state is copied to, set-up and epilogue values).  Measured on MI355X, 4K Kerr, three frames in flight / one
+    // launch on its own: free build 1 400 Mrays/s / 6.7 ms; held to 96 VGPRs (5 waves, nothing spilled) 1 492 / 6.5; to 80 (6
+    // waves, 60 bytes per lane spilled, none of it inside the loop's attempts) 1 535 / 6.2; to 72 (7 waves, 84 bytes) 1 530 / 6.2.
+    // Rule: rebuild with the register budget of five sixths of what the free build took, rounded down to an occupancy step,
+    // and keep that build unless it spills more than 64 bytes per lane.
     bool tuned_by_caller = false;
     for (auto& o : opts) tuned_by_caller |= o.rfind("-DGR_FUSED_WAVES", 0) == 0 || o.rfind("-DGR_TRACE_WAVES", 0) == 0;
     const char* tuning = getenv("GR_OCCUPANCY_TUNING");
@@ -250,12 +250,18 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
             int target_waves = waves_of(vgprs * 5 / 6);
             while (target_waves > 1 && (512 / target_waves) / 8 * 8 > vgprs * 5 / 6) target_waves++;   // budget of w waves <= 5/6 of the free build
             if (target_waves > 8) target_waves = 8;
+            if (target_waves <= waves_of(vgprs) && getenv("GR_VERBOSE_BUILD"))
+                fprintf(stderr, "[gr] gr_trace_fused: free build %d VGPRs / %d B scratch, left alone\n", vgprs, scratch);
             if (target_waves > waves_of(vgprs)) {
                 std::vector<std::string> capped = opts;
                 capped.push_back("-DGR_FUSED_WAVES=" + std::to_string(target_waves));
                 std::string code2;
                 int v2 = 0, s2 = 0;
-                if (build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2) && s2 <= scratch + 32) code.swap(code2);
+                const bool built = build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2);
+                if (getenv("GR_VERBOSE_BUILD"))
+                    fprintf(stderr, "[gr] gr_trace_fused: free build %d VGPRs / %d B scratch; held to %d waves: %d VGPRs / %d B scratch%s\n", vgprs,
+                            scratch, target_waves, v2, s2, built && s2 <= scratch + 64 ? " (kept)" : " (dropped)");
+                if (built && s2 <= scratch + 64) code.swap(code2);
             }
         }
     }
@@ -295,6 +301,7 @@ struct gr_program {
     unsigned int* tickets = nullptr;
     std::atomic<unsigned> next_ticket{0};
     int compute_units = 256;
+    int resident_groups_per_cu[K_COUNT] = {};   // of the trace kernels at the launch's workgroup size: 0 = not asked yet
     std::string arguments;
     std::string key;   // what the code object was built from: kernel source, every compile option, hiprtc version (16 hex digits)
     // identity for caches keyed by program (frame.cpp prefetch slots): an address can be reused by a later program, this cannot
@@ -631,18 +638,20 @@ int gr_internal_fail(int code, const char* msg) { return fail((gr_status)code, m
 
 int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* term,
                             int prepass_width, int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3,
-                            const void* cfg, const void* dfg, int image_height, int block_rows, int strip_rank, int strip_count) {
+                            const void* cfg, const void* dfg, int image_height, int block_rows, int strip_rank, int strip_count,
+                            void* cell_attempts) {
     if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = 8; }
     if (block_rows <= 0 || strip_rank < 0 || strip_rank >= strip_count || image_height <= 0)
         return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
     void* args[] = {&camera_generic, &camera_quat, &term, &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg,
-                    &image_height, &block_rows, &strip_rank, &strip_count};
+                    &image_height, &block_rows, &strip_rank, &strip_count, &cell_attempts};
     return launch(p, K_PREPASS_FUSED, stream, blocks((long long)prepass_width * prepass_height, 64), 1, 64, 1, args);
 }
 
 int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, float flip, const float basis_speed[3], void* position_generic_out,
                       void* e0_out, void* e1_out, void* e2_out, void* e3_out, const void* camera_quat, void* term, int prepass_width,
-                      int prepass_height, const void* cfg, const void* dfg, int image_height, int block_rows, int strip_rank, int strip_count) {
+                      int prepass_height, const void* cfg, const void* dfg, int image_height, int block_rows, int strip_rank, int strip_count,
+                      void* cell_attempts) {
     if (!basis_speed) return fail(GR_ERROR_INVALID_ARGUMENT, "null basis speed");
     if (prepass_width < 0 || prepass_height < 0) return fail(GR_ERROR_INVALID_ARGUMENT, "negative prepass size");
     if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = 8; }
@@ -650,7 +659,7 @@ int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, fl
     if (image_height <= 0) image_height = prepass_height > 0 ? prepass_height * 16 : 16;
     float sx = basis_speed[0], sy = basis_speed[1], sz = basis_speed[2];
     void* args[] = {&position_cart, &flip, &sx, &sy, &sz, &position_generic_out, &e0_out, &e1_out, &e2_out, &e3_out, &camera_quat, &term,
-                    &prepass_width, &prepass_height, &cfg, &dfg, &image_height, &block_rows, &strip_rank, &strip_count};
+                    &prepass_width, &prepass_height, &cfg, &dfg, &image_height, &block_rows, &strip_rank, &strip_count, &cell_attempts};
     long long cells = (long long)prepass_width * prepass_height;
     return launch(p, K_CAMERA_PREPASS, stream, blocks(cells > 0 ? cells : 1, 64), 1, 64, 1, args);
 }
@@ -659,14 +668,49 @@ int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, co
                      int prepass_width, int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3,
                      const void* cfg, const void* dfg) {
     return gr_prepass_fused_strips(p, stream, camera_generic, camera_quat, term, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg,
-                                   prepass_height * 16, 8, 0, 1);
+                                   prepass_height * 16, 8, 0, 1, nullptr);
+}
+
+// tiles (one wave each) a device traces: its row blocks cut into 8x8 tiles + per block the halo row in 64-pixel pieces; 0 when
+// the description is invalid (trace_launch says why)
+static long long device_tile_count(int width, int height, int block_rows, int strip_rank, int strip_count) {
+    const int T = 8;
+    if (width <= 0 || height <= 0) return 0;
+    if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + T - 1) / T) * T; }
+    if (block_rows <= 0 || block_rows % T != 0 || strip_rank < 0 || strip_rank >= strip_count) return 0;
+    long long per_block = (long long)((width + T - 1) / T) * (block_rows / T) + (strip_count > 1 ? (width + 63) / 64 : 0);
+    return per_block * gr_strip_local_blocks(height, block_rows, strip_rank, strip_count);
+}
+
+long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_rank, int strip_count) {
+    return (16 + device_tile_count(width, height, block_rows, strip_rank, strip_count)) * 4;
+}
+
+int gr_order_tiles(gr_program* p, void* stream, const void* term, const void* cell_attempts, int prepass_width, int prepass_height,
+                   int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order) {
+    if (!p || !term || !cell_attempts || !tile_order || prepass_width <= 0 || prepass_height <= 0)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "gr_order_tiles: null argument or no prepass");
+    if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + 7) / 8) * 8; }
+    long long tiles = device_tile_count(width, height, block_rows, strip_rank, strip_count);
+    if (tiles <= 0 || tiles > 0x7fffffff) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_order_tiles: bad image or strip description");
+    int total = (int)tiles;
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipMemsetAsync(tile_order, 0, 64, (hipStream_t)stream));
+    for (int phase = 0; phase < 2; phase++) {
+        void* args[] = {&term, &cell_attempts, &prepass_width, &prepass_height, &width, &height, &block_rows, &strip_rank, &strip_count,
+                        &total, &tile_order, &phase};
+        int rc = launch(p, K_ORDER_TILES, stream, blocks(total, 256), 1, 256, 1, args);
+        if (rc != GR_OK) return rc;
+    }
+    return GR_OK;
 }
 
 // gr_trace_fused (rays_per_lane 1) and gr_trace_pair (2): same tiles, same arguments; a pair wave takes two tile-waves
 static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const void* camera_generic, const void* camera_quat, void* rdata,
                         int width, int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
                         int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
-                        const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0) {
+                        const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0, const void* tile_order = nullptr,
+                        int waves_per_simd = 0) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
     if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && (rays_per_lane != 1 || strip_count > 1)))
@@ -696,10 +740,29 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     int total_waves = (int)waves;
     long long groups = ((waves + rays_per_lane - 1) / rays_per_lane * 64 + wg - 1) / wg;
     unsigned int* tickets = nullptr;
-    // persistent mode only pays when there are more tiles than wave slots (8 per SIMD, 4 SIMDs per CU)
-    // experiment hook: GR_TRACE_WAVES_PER_SIMD=k launches only k persistent waves per SIMD (occupancy scaling studies)
-    static const int waves_per_simd = [] { const char* e = getenv("GR_TRACE_WAVES_PER_SIMD"); int v = e ? atoi(e) : 8; return (v >= 1 && v <= 8) ? v : 8; }();
-    long long resident_groups = (long long)p->compute_units * 4 * waves_per_simd * 64 / wg;
+    // persistent mode only pays when there are more tiles than wave slots.  The launch is exactly as many workgroups as the
+    // kernel's register and scratch footprint lets the device hold (asked of the runtime once per kernel): a larger one
+    // leaves workgroups queued behind the resident ones which start only when the tickets are gone, and which the
+    // dispatcher then has to retire before the next launch's workgroups get the freed slots
+    // experiment hook: GR_TRACE_WAVES_PER_SIMD=k launches k persistent waves per SIMD whatever fits (occupancy studies)
+    static const int forced_waves_per_simd = [] { const char* e = getenv("GR_TRACE_WAVES_PER_SIMD"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 0; }();
+    const int kernel_index = rays_per_lane == 2 ? K_TRACE_PAIR : K_TRACE_FUSED;
+    if (!p->resident_groups_per_cu[kernel_index]) {
+        int n = 0;
+        HIP_CHECK(hipSetDevice(p->device));
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, p->fn[kernel_index], wg, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 4 * 8 * 64 / wg;
+        }
+        p->resident_groups_per_cu[kernel_index] = n;
+    }
+    long long resident_groups = (long long)p->compute_units * p->resident_groups_per_cu[kernel_index];
+    // a caller that keeps several frames in flight may take fewer slots per launch: two smaller launches then share the device
+    // and the one drains while the other is in full swing (gr_frame_options.trace_waves_per_simd)
+    if (forced_waves_per_simd)
+        resident_groups = (long long)p->compute_units * 4 * forced_waves_per_simd * 64 / wg;
+    else if (waves_per_simd >= 1 && waves_per_simd <= 8)
+        resident_groups = std::min(resident_groups, (long long)p->compute_units * 4 * waves_per_simd * 64 / wg);
     if (persistent && groups > resident_groups) {
         tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
         HIP_CHECK(hipSetDevice(p->device));
@@ -708,8 +771,8 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     }
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
-                    &lattice, &pending_only};   // the last two: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
-    return launch(p, rays_per_lane == 2 ? K_TRACE_PAIR : K_TRACE_FUSED, stream, (unsigned)groups, 1, wg, 1, args);
+                    &lattice, &pending_only, &tile_order};   // the last three: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
+    return launch(p, kernel_index, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
 int gr_trace_fused_adaptive(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
@@ -731,6 +794,14 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
                    const void* dfg, void* attempt_counter) {
     return trace_launch(p, 1, stream, camera_generic, camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, term,
                         prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter);
+}
+
+int gr_trace_fused_ordered(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
+                           int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
+                           int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
+                           const void* dfg, void* attempt_counter, const void* tile_order, int waves_per_simd) {
+    return trace_launch(p, 1, stream, camera_generic, camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, term,
+                        prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, 1, 0, tile_order, waves_per_simd);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

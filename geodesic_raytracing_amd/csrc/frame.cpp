@@ -45,12 +45,14 @@ struct gr_render_state {
     void* render_data_count = nullptr;
     void* cfg = nullptr;            // struct dynamic_config (floats in declaration order)
     void* dfg = nullptr;            // struct dynamic_feature_config
-    void* attempts = nullptr;       // uint64[4]: attempts, shader cycles, 100 MHz ticks, waves (the last three: fused trace only)
+    void* attempts = nullptr;       // uint64[128]: attempts, shader cycles, 100 MHz ticks, waves (the last three: fused trace only); the rest: probe builds
     // per-pixel buffers (render_state.hpp:172-196); ray records are allocated on first use
     void* rays_in = nullptr;
     void* rays_adaptive = nullptr;
     void* render_data = nullptr;
     void* termination_buffer = nullptr;
+    void* tile_order = nullptr;      // the order the persistent trace hands its tiles out in (gr_order_tiles)
+    size_t tile_order_bytes = 0;
     size_t ray_capacity = 0;
     hipEvent_t ev_start[GR_STAGE_COUNT] = {};
     hipEvent_t ev_stop[GR_STAGE_COUNT] = {};
@@ -67,6 +69,7 @@ struct gr_render_state {
         void* camera_pos_generic = nullptr;
         void* tetrad[4] = {};
         void* termination_buffer = nullptr;
+        void* tile_order = nullptr;   // gr_order_tiles' list for the frame's trace (the cost estimates sit behind the prepass flags)
     };
     struct prefetch_key {
         gr_camera camera{};
@@ -107,6 +110,7 @@ struct gr_render_state {
         std::swap(camera_pos_generic, o.camera_pos_generic);
         for (int i = 0; i < 4; i++) std::swap(tetrad[i], o.tetrad[i]);
         std::swap(termination_buffer, o.termination_buffer);
+        std::swap(tile_order, o.tile_order);
     }
 };
 
@@ -158,6 +162,7 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->compact_out = 0;
     o->time_kernels = 0;
     o->count_attempts = 0;
+    o->trace_waves_per_simd = 0;
     o->next_camera = nullptr;
     o->geodesic = nullptr;
     o->geodesic_time = 0;
@@ -247,16 +252,21 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
     A(&s->render_data_count, 4);
     A(&s->cfg, CFG_MAX * sizeof(float));
     A(&s->dfg, sizeof(gr_features));
-    A(&s->attempts, 32);
+    A(&s->attempts, 1024);
     size_t px = (size_t)width * height;
     A(&s->render_data, px * sizeof(gr_render_data));
     A(&s->termination_buffer, px * sizeof(int));
+    // one word per tile: 8x8 tiles of the whole image or, split over devices, of at most all its blocks + their halo pieces
+    const size_t order_bytes = (px / 32 + (size_t)width + 4096) * sizeof(unsigned int);
+    A(&s->tile_order, order_bytes);
+    s->tile_order_bytes = order_bytes;
     for (auto& slot : s->pre) {
         A(&slot.set.camera_pos_cart, 16);
         A(&slot.set.camera_quat, 16);
         A(&slot.set.camera_pos_generic, 16);
         for (auto& t : slot.set.tetrad) A(&t, 16);
         A(&slot.set.termination_buffer, px * sizeof(int));
+        A(&slot.set.tile_order, order_bytes);
         A(&slot.velocity, 16);
     }
     if (e == hipSuccess) {
@@ -289,12 +299,13 @@ void gr_render_state_destroy(gr_render_state* s) {
     (void)hipSetDevice(s->device);
     std::vector<void*> ptrs = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
                                s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
-                               s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer};
+                               s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->tile_order};
     for (auto& slot : s->pre) {
         if (slot.stream) { (void)hipStreamSynchronize(slot.stream); (void)hipStreamDestroy(slot.stream); }
         if (slot.ready) (void)hipEventDestroy(slot.ready);
         ptrs.insert(ptrs.end(), {slot.set.camera_pos_cart, slot.set.camera_quat, slot.set.camera_pos_generic, slot.set.tetrad[0],
-                                 slot.set.tetrad[1], slot.set.tetrad[2], slot.set.tetrad[3], slot.set.termination_buffer, slot.velocity});
+                                 slot.set.tetrad[1], slot.set.tetrad[2], slot.set.tetrad[3], slot.set.termination_buffer, slot.set.tile_order,
+                                 slot.velocity});
     }
     if (s->main_mark) (void)hipEventDestroy(s->main_mark);
     for (auto& pr : s->trace_log) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -359,6 +370,23 @@ int gr_render_state_shader_clock(gr_render_state* s, double* mhz) {
     unsigned long long v[4] = {};
     HIP_CHECK(hipMemcpy(v, s->attempts, 32, hipMemcpyDeviceToHost));
     *mhz = v[2] ? 100.0 * (double)v[1] / (double)v[2] : 0.0;   // cycles per tick of the 100 MHz reference clock
+    return GR_OK;
+}
+
+int gr_render_state_wave_time(gr_render_state* s, double* wave_ms, unsigned long long* waves) {
+    if (!s || !wave_ms || !waves) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    HIP_CHECK(hipSetDevice(s->device));
+    unsigned long long v[4] = {};
+    HIP_CHECK(hipMemcpy(v, s->attempts, 32, hipMemcpyDeviceToHost));
+    *wave_ms = (double)v[2] * 1e-5;   // ticks of 10 ns
+    *waves = v[3];
+    return GR_OK;
+}
+
+int gr_render_state_counters(gr_render_state* s, unsigned long long* words, int count) {
+    if (!s || !words || count < 0 || count > 128) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "counters: up to 128 words");
+    HIP_CHECK(hipSetDevice(s->device));
+    HIP_CHECK(hipMemcpy(words, s->attempts, (size_t)count * 8, hipMemcpyDeviceToHost));
     return GR_OK;
 }
 
@@ -613,7 +641,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     };
     void* attempts = nullptr;
     if (opt.count_attempts) {
-        HIP_CHECK(hipMemsetAsync(s->attempts, 0, 32, stream));
+        HIP_CHECK(hipMemsetAsync(s->attempts, 0, 1024, stream));
         attempts = s->attempts;
     }
 
@@ -644,18 +672,31 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         int strip_count = opt.strip_count > 1 ? opt.strip_count : 1;
         int strip_rank = strip_count > 1 ? opt.strip_rank : 0;
         int block_rows = strip_count > 1 ? opt.block_rows : ((height + 7) / 8) * 8;
+        // The prepass rays' costs (kept behind the prepass flags in the termination buffer, which is allocated per pixel) order the
+        // tiles of the trace, longest first (gr_order_tiles); GR_TILE_ORDER=0 keeps image order (A/B experiments)
+        static const bool tile_order_enabled = [] { const char* e = getenv("GR_TILE_ORDER"); return !(e && e[0] == '0'); }();
+        const size_t cells = use_prepass ? (size_t)prepass_width * prepass_height : 0;
+        const bool order_tiles = tile_order_enabled && use_prepass && !adaptive && 2 * cells <= (size_t)width * height &&
+                                 (size_t)gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
+        auto cost_plane = [&](void* termination_buffer) -> void* { return order_tiles ? (void*)((unsigned int*)termination_buffer + cells) : nullptr; };
         if (!prefetched && one_launch_setup) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_camera_prepass(p, stream, s->camera_pos_cart, camera->flip, camera->basis_speed, s->camera_pos_generic, s->tetrad[0],
                                        s->tetrad[1], s->tetrad[2], s->tetrad[3], s->camera_quat, s->termination_buffer,
                                        use_prepass ? prepass_width : 0, use_prepass ? prepass_height : 0, s->cfg, s->dfg, height, block_rows,
-                                       strip_rank, strip_count));
+                                       strip_rank, strip_count, cost_plane(s->termination_buffer)));
+            if (order_tiles)
+                GR_CHECK(gr_order_tiles(p, stream, s->termination_buffer, cost_plane(s->termination_buffer), prepass_width, prepass_height,
+                                        width, height, block_rows, strip_rank, strip_count, s->tile_order));
             GR_CHECK(end(GR_STAGE_PREPASS));
         } else if (use_prepass && !prefetched) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_prepass_fused_strips(p, stream, s->camera_pos_generic, s->camera_quat, s->termination_buffer, prepass_width,
                                              prepass_height, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg,
-                                             height, block_rows, strip_rank, strip_count));
+                                             height, block_rows, strip_rank, strip_count, cost_plane(s->termination_buffer)));
+            if (order_tiles)
+                GR_CHECK(gr_order_tiles(p, stream, s->termination_buffer, cost_plane(s->termination_buffer), prepass_width, prepass_height,
+                                        width, height, block_rows, strip_rank, strip_count, s->tile_order));
             GR_CHECK(end(GR_STAGE_PREPASS));
         }
         // look-ahead requests that are not already sitting in a slot
@@ -709,10 +750,17 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                                  s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, 1, 1));
                 GR_CHECK(end(GR_STAGE_ADAPTIVE));
             } else {
-            GR_CHECK((rays_per_lane == 2 ? gr_trace_pair : gr_trace_fused)(
-                p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows, strip_rank, strip_count,
-                use_prepass ? s->termination_buffer : nullptr, use_prepass ? prepass_width : width, use_prepass ? prepass_height : height,
-                s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
+            if (rays_per_lane == 2)
+                GR_CHECK(gr_trace_pair(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
+                                       strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
+                                       use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
+                                       s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
+            else
+                GR_CHECK(gr_trace_fused_ordered(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
+                                                strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
+                                                use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
+                                                s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts,
+                                                order_tiles ? s->tile_order : nullptr, opt.trace_waves_per_simd));
             }
         }
         if (!adaptive) GR_CHECK(end(GR_STAGE_TRACE));
@@ -736,15 +784,19 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 GR_CHECK(gr_camera_prepass(p, slot->stream, slot->set.camera_pos_cart, r.camera->flip, r.camera->basis_speed,
                                            slot->set.camera_pos_generic, slot->set.tetrad[0], slot->set.tetrad[1], slot->set.tetrad[2],
                                            slot->set.tetrad[3], slot->set.camera_quat, slot->set.termination_buffer, prepass_width,
-                                           prepass_height, s->cfg, s->dfg, height, block_rows, r.strip_rank, strip_count));
+                                           prepass_height, s->cfg, s->dfg, height, block_rows, r.strip_rank, strip_count,
+                                           cost_plane(slot->set.termination_buffer)));
             } else {
                 GR_CHECK(camera_setup(slot->stream, slot->set.camera_pos_cart, slot->set.camera_pos_generic, slot->set.tetrad, r.camera, r.time,
                                       slot->velocity));
                 GR_CHECK(gr_prepass_fused_strips(p, slot->stream, slot->set.camera_pos_generic, slot->set.camera_quat,
                                                  slot->set.termination_buffer, prepass_width, prepass_height, slot->set.tetrad[0],
                                                  slot->set.tetrad[1], slot->set.tetrad[2], slot->set.tetrad[3], s->cfg, s->dfg, height,
-                                                 block_rows, r.strip_rank, strip_count));
+                                                 block_rows, r.strip_rank, strip_count, cost_plane(slot->set.termination_buffer)));
             }
+            if (order_tiles)   // the look-ahead frame's order too: off the frame's critical path like its prepass
+                GR_CHECK(gr_order_tiles(p, slot->stream, slot->set.termination_buffer, cost_plane(slot->set.termination_buffer), prepass_width,
+                                        prepass_height, width, height, block_rows, r.strip_rank, strip_count, slot->set.tile_order));
             HIP_CHECK(hipEventRecord(slot->ready, slot->stream));
             slot->valid = true;
             slot->age = s->frame_counter;

@@ -106,6 +106,12 @@ struct dynamic_feature_config {
 #endif
 // render_data.terminated of a pixel that gr_adaptive_refine wants traced (the reference's values are 0, 1, 2)
 #define GR_PENDING (-1)
+#define GR_TILE_ORDER_HEADER 16   // words in front of gr_order_tiles' list: 8 class counts, 8 class cursors
+#define GR_TILE_CLASSES 8
+#ifndef GR_SCALAR_INTERLEAVE
+#define GR_SCALAR_INTERLEAVE 24   // dummy scalar adds per Verlet attempt woven into the acceleration's vector stretch (0: none)
+#endif
+#define GR_SKIP_CHUNK 32          // tiles of the last class per ticket
 
 // minimum resident waves per SIMD the integrator kernels are register-allocated for (512 VGPRs / N waves each).
 // 1 = no cap: the allocator takes what the metric's expressions need and occupancy follows (substituted Kerr: 92 VGPRs
@@ -1112,18 +1118,6 @@ __device__ __forceinline__ void overwrite(float4& dst, float4 src) {
                  : "+v"(dst.x), "+v"(dst.y), "+v"(dst.z), "+v"(dst.w) : "v"(src.x), "v"(src.y), "v"(src.z), "v"(src.w));
 }
 
-#define GR_INTEGRATOR_MAX_BLOCK 256
-// Fourteen floats of a lane to its LDS slots (component c at byte c * 4 * GR_INTEGRATOR_MAX_BLOCK): opaque stores, so that they stay
-// in the rarely executed block they are written in.  The same lane reads them back; LDS serves a wave's requests in order.
-__device__ __forceinline__ void park(unsigned int lds_byte_address, float4 p, float4 v, float4 a, float e0, float e1) {
-    asm volatile("ds_write_b32 %0, %1 offset:12288\n\tds_write_b32 %0, %2 offset:13312" : : "v"(lds_byte_address), "v"(e0), "v"(e1) : "memory");
-    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:1024\n\tds_write_b32 %0, %3 offset:2048\n\tds_write_b32 %0, %4 offset:3072\n\t"
-                 "ds_write_b32 %0, %5 offset:4096\n\tds_write_b32 %0, %6 offset:5120\n\tds_write_b32 %0, %7 offset:6144\n\tds_write_b32 %0, %8 offset:7168\n\t"
-                 "ds_write_b32 %0, %9 offset:8192\n\tds_write_b32 %0, %10 offset:9216\n\tds_write_b32 %0, %11 offset:10240\n\tds_write_b32 %0, %12 offset:11264"
-                 : : "v"(lds_byte_address), "v"(p.x), "v"(p.y), "v"(p.z), "v"(p.w), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w)
-                 : "memory");
-}
-// largest workgroup of a kernel that integrates rays (the fused trace kernels; gr_do_generic_rays and the prepass use 64)
 // the same with a wave-uniform first operand (a feature value, a literal): no VGPR is spent on it
 __device__ __forceinline__ float min_f32_uniform(float uniform, float x) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(x)); return r; }
 __device__ __forceinline__ float max_f32_uniform(float uniform, float x) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(x)); return r; }
@@ -1261,6 +1255,23 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
 #else
         float4 next_acceleration = gm::geodesic_acceleration_with<decltype(libm)::value>(next_position, predicted, cfg);
 #endif
+#if GR_SCALAR_INTERLEAVE > 0
+        // Scalar interleave.  The acceleration above is ~135 vector instructions in a row; a wave that is let run issues them back
+        // to back, and measured on MI355X the SIMD's vector port then idles a good part of the time (three frames in flight, 4K
+        // Kerr: 1 440 Mrays/s at 1 240 W, no limiter active).  A chain of GR_SCALAR_INTERLEAVE dummy scalar adds placed here is
+        // woven by the instruction scheduler into that stretch - one s_add_u32 every 2-5 vector instructions - and the same
+        // frames run at 1 730 Mrays/s, at the 1 340 W where the power limiter starts to work: dose-response 1 -> +4 %, 4 -> +9 %,
+        // 8 -> +11 %, 12 -> +16 %, 16 -> +17 %, 24..48 -> +18..20 %, 80 and more slower again (the scalar unit becomes the
+        // bottleneck); one launch on its own 6.5 -> 6.05 ms.  The same count of s_nop, which the scheduler leaves in one block,
+        // does nothing, and neither do wave priorities: it is the alternation of scalar and vector issue inside the stretch that
+        // counts (DESIGN.md section 4 has the measurements and what was ruled out).  The adds compute nothing that is used.
+        {
+            int filler = 1;
+#pragma unroll
+            for (int q = 0; q < GR_SCALAR_INTERLEAVE; q++) asm volatile("s_add_u32 %0, %0, 3" : "+s"(filler) : : "scc");
+            asm volatile("" ::"s"(filler));
+        }
+#endif
         float4 next_velocity = velocity + (acceleration + next_acceleration) * half_ds;
         if (reparam) {
             const float md = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(next_velocity.x), __builtin_fabsf(next_velocity.y)),
@@ -1315,8 +1326,14 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
     // The state a ray leaves the fast loop in is parked in LDS - once per ray, its own slot, read back by the same lane after the
     // loop.  Left to the compiler, "whichever set the ray was in when it left" becomes twelve running copies per attempt; kept in
     // registers of its own it costs twelve VGPRs across the loop, i.e. a wave per SIMD.
-    __shared__ float exit_state[14][GR_INTEGRATOR_MAX_BLOCK];
-    const unsigned int slot = (unsigned int)(size_t)(__attribute__((address_space(3))) float*)&exit_state[0][threadIdx.x];
+    // The state a ray leaves the fast loop in gets registers of its own, written - once per ray - where the loop is left, by copies
+    // the compiler cannot move.  Left to the compiler, "whichever set the ray was in when it left" becomes twelve running copies
+    // per attempt.  The 14 registers are cold inside the loop, so when the host holds the kernel to more waves per SIMD than its
+    // free register count allows (capi.cpp, occupancy rule) they are what the allocator spills: the exit state then lives in
+    // scratch memory, touched only in the exit block.  (Parking it in LDS by hand - ds_write in the exit block, 14 KB per
+    // workgroup - measured 6 % slower with three frames in flight: 1 445 against 1 535 Mrays/s at the same occupancy.)
+    float4 position = p0, velocity = v0, acceleration = a0;
+    float exit_ds = 0, exit_running = 1;
     {
         const trig_flavour<false> polynomial;
         for (;;) {
@@ -1324,20 +1341,18 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
             float ds_used, running_before;
             if (attempt(polynomial, p0, v0, a0, p1, v1, a1, ds_used, running_before)) {
                 const bool out = RESUMABLE && pause_wave;
-                park(slot, out ? p1 : p0, out ? v1 : v0, out ? a1 : a0, ds_used, running_before);
+                overwrite(position, out ? p1 : p0); overwrite(velocity, out ? v1 : v0); overwrite(acceleration, out ? a1 : a0);
+                asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "+v"(exit_ds), "+v"(exit_running) : "v"(ds_used), "v"(running_before));
                 break;
             }
             if (attempt(polynomial, p1, v1, a1, p0, v0, a0, ds_used, running_before)) {
                 const bool out = RESUMABLE && pause_wave;
-                park(slot, out ? p0 : p1, out ? v0 : v1, out ? a0 : a1, ds_used, running_before);
+                overwrite(position, out ? p0 : p1); overwrite(velocity, out ? v0 : v1); overwrite(acceleration, out ? a0 : a1);
+                asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "+v"(exit_ds), "+v"(exit_running) : "v"(ds_used), "v"(running_before));
                 break;
             }
         }
     }
-    const int lane_slot = threadIdx.x;
-    float4 position = f4(exit_state[0][lane_slot], exit_state[1][lane_slot], exit_state[2][lane_slot], exit_state[3][lane_slot]);
-    float4 velocity = f4(exit_state[4][lane_slot], exit_state[5][lane_slot], exit_state[6][lane_slot], exit_state[7][lane_slot]);
-    float4 acceleration = f4(exit_state[8][lane_slot], exit_state[9][lane_slot], exit_state[10][lane_slot], exit_state[11][lane_slot]);
 #ifdef IS_CONSTANT_THETA
     position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
 #endif
@@ -1360,10 +1375,10 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         // Left at the bottom of an attempt: degenerate for good, or a sin / cos argument outside the polynomial's range.  The
         // attempt is done again, and the ray integrated on if it was the latter, one attempt per trip with sin / cos from libm.
         // What the loop carries is put back to what it was before the abandoned attempt.
-        const float ds_used = exit_state[12][lane_slot];
+        const float ds_used = exit_ds;
         float4 polar = gm::generic_to_spherical(position, cfg);
         if (__builtin_fabsf(gm::distance_to_object(polar, cfg)) < new_max) next_ds = ds_used;   // min(next_ds, ambient) gives ds_used again
-        running = exit_state[13][lane_slot];
+        running = exit_running;
         budget++;
         const trig_flavour<true> precise;
         for (;;) {
@@ -1975,7 +1990,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
-               int total_waves, int lattice, int pending_only) {
+               int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order) {
     GR_PARAMETERS_IN_REGISTERS
     const int lane = threadIdx.x % 64;
     // profiling launches (attempt_counter != NULL) also measure the shader clock they ran at: every wave adds its lifetime in
@@ -1985,11 +2000,28 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
     // one call site for both modes: the two schedules must run the very same instructions per pixel (strip renders are
     // compared bit for bit with whole-frame renders)
     int wave = blockIdx.x * (GR_TRACE_BLOCK / 64) + threadIdx.x / 64;
+    // With gr_order_tiles' list a ticket is one tile of the classes that trace, or GR_SKIP_CHUNK tiles of the last class (all
+    // pixels skipped by the prepass: a store each).  The tickets come from ONE counter, which the memory system serves at about
+    // 10 ns a ticket whoever asks - nothing next to a tile's 0.1-1 ms of tracing, but the 75 000 skipped tiles of the 4K Kerr
+    // frame, handed out back to back at the end of the list, would add 0.7 ms of pure ticket traffic to the launch.
+    int held = 0, cursor = 0;   // tiles this wave still holds from its last ticket, and where in the list they start
+    const int singles = (tile_counter && tile_order) ? total_waves - (int)tile_order[GR_TILE_CLASSES - 1] : total_waves;
     for (;;) {
         if (tile_counter) {
-            unsigned int ticket = 0;
-            if (lane == 0) ticket = atomicAdd(tile_counter, 1u);
-            wave = (int)__builtin_amdgcn_readfirstlane(ticket);
+            if (held == 0) {
+                unsigned int ticket = 0;
+                if (lane == 0) ticket = atomicAdd(tile_counter, 1u);
+                cursor = (int)__builtin_amdgcn_readfirstlane(ticket);
+                held = 1;
+                if (cursor >= singles) {
+                    cursor = singles + (cursor - singles) * GR_SKIP_CHUNK;
+                    held = total_waves - cursor < GR_SKIP_CHUNK ? total_waves - cursor : GR_SKIP_CHUNK;
+                }
+                if (held <= 0) break;
+            }
+            wave = tile_order ? (int)tile_order[GR_TILE_ORDER_HEADER + cursor] : cursor;
+            cursor++;
+            held--;
         }
         if (wave >= total_waves) break;
         // Launder the camera / tetrad pointers once per tile: otherwise everything in the ray set-up that depends only on
@@ -2008,6 +2040,10 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
         atomicAdd(attempt_counter + 1, (unsigned long long)__builtin_amdgcn_s_memtime() - born_cycles);
         atomicAdd(attempt_counter + 2, (unsigned long long)__builtin_amdgcn_s_memrealtime() - born_ticks);
         atomicAdd(attempt_counter + 3, 1ull);
+#ifdef GR_PROBE_LIFE_HISTOGRAM   // experiment (the frame state's 1 KiB counter block only): wave lifetimes in 0.125 ms bins
+        unsigned long long bin = ((unsigned long long)__builtin_amdgcn_s_memrealtime() - born_ticks) / 12500ull;
+        atomicAdd(attempt_counter + 8 + (bin < 119ull ? bin : 119ull), 1ull);
+#endif
     }
 }
 
@@ -2219,7 +2255,8 @@ gr_trace_compact(const float4* __restrict__ g_generic_camera_in, const float4* _
 // that map to cp - 1 .. cp + 1.  The prepass is otherwise replicated work: 11 % of a device's frame at 8 devices.
 __device__ __forceinline__ void prepass_cell(int id, float4 camera, float4 camera_quat, float4 e0, float4 e1, float4 e2, float4 e3,
                                              int* __restrict__ termination_buffer, int prepass_width, int prepass_height, cfg_t cfg, dfg_t dfg,
-                                             int image_height, int block_rows, int strip_rank, int strip_count) {
+                                             int image_height, int block_rows, int strip_rank, int strip_count,
+                                             unsigned int* __restrict__ cell_attempts) {
     if (id >= prepass_width * prepass_height) return;
     int cx = id % prepass_width, cy = id / prepass_width;
     if (strip_count > 1) {
@@ -2240,18 +2277,21 @@ __device__ __forceinline__ void prepass_cell(int id, float4 camera, float4 camer
     s.position = ray.position;
     s.velocity = ray.velocity;
     s.acceleration = ray.acceleration;
-    int res = integrate_ray(s, cfg, dfg, nullptr);
+    unsigned int tries = 0;
+    int res = integrate_ray(s, cfg, dfg, &tries);
     termination_buffer[id] = res == RAY_TERMINATED ? 0 : 1;
+    if (cell_attempts) cell_attempts[id] = tries;   // what the ray cost: gr_order_tiles' estimate for the tiles around the cell
 }
 
 extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
 gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                  int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                  const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
-                 cfg_t cfg_in, dfg_t dfg_in, int image_height, int block_rows, int strip_rank, int strip_count) {
+                 cfg_t cfg_in, dfg_t dfg_in, int image_height, int block_rows, int strip_rank, int strip_count,
+                 unsigned int* __restrict__ cell_attempts) {
     GR_PARAMETERS_IN_REGISTERS
     prepass_cell(blockIdx.x * blockDim.x + threadIdx.x, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, termination_buffer,
-                 prepass_width, prepass_height, cfg, dfg, image_height, block_rows, strip_rank, strip_count);
+                 prepass_width, prepass_height, cfg, dfg, image_height, block_rows, strip_rank, strip_count, cell_attempts);
 }
 
 // cart_to_generic_kernel + init_basis_vectors + the prepass in ONE launch (the reference: three of its launches and the prepass
@@ -2266,7 +2306,7 @@ gr_camera_prepass(const float4* __restrict__ position_cart_in, float flip, float
                   float4* __restrict__ position_generic_out, float4* __restrict__ e0_out, float4* __restrict__ e1_out,
                   float4* __restrict__ e2_out, float4* __restrict__ e3_out, const float4* __restrict__ g_camera_quat,
                   int* __restrict__ termination_buffer, int prepass_width, int prepass_height, cfg_t cfg_in, dfg_t dfg_in,
-                  int image_height, int block_rows, int strip_rank, int strip_count) {
+                  int image_height, int block_rows, int strip_rank, int strip_count, unsigned int* __restrict__ cell_attempts) {
     GR_PARAMETERS_IN_REGISTERS
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     const float4 in = *position_cart_in;
@@ -2283,7 +2323,69 @@ gr_camera_prepass(const float4* __restrict__ position_cart_in, float flip, float
         *e3_out = t.e[3];
     }
     prepass_cell(id, camera, *g_camera_quat, t.e[0], t.e[1], t.e[2], t.e[3], termination_buffer, prepass_width, prepass_height, cfg, dfg,
-                 image_height, block_rows, strip_rank, strip_count);
+                 image_height, block_rows, strip_rank, strip_count, cell_attempts);
+}
+
+// ---- the order the persistent trace hands its tiles out in -----------------------------------------
+// A persistent launch ends when its slowest wave ends, and a wave that draws a long tile late ends late: with the tiles handed
+// out in image order the 4K Kerr launch spent its last 1.4 of 6.3 ms draining (tickets gone at 4.9 ms; 6 waves share a SIMD,
+// so an average traced tile of ~500 attempts takes 0.6 ms and the tiles on the shadow's edge several times that).  The prepass
+// has already traced one ray per 16x16 pixels: what those rays cost is a fair estimate of what the tiles around them will
+// cost, so the tiles are handed out longest first - classes by the most expensive ray among the 3x3 cells around the tile's
+// centre, tiles that straddle the shadow's edge first of all, tiles the prepass lets skip (a store per pixel) last, where they
+// fill the slots of the draining launch.  Scheduling only: which wave traces a tile and when has no influence on its rays.
+// Two launches over the device's tiles: phase 0 counts the classes, phase 1 deals every tile a place in its class's range
+// (order within a class: as the atomics fall, i.e. roughly image order).  list[0..7] counts, [8..15] cursors, then the tiles.
+__device__ __forceinline__ int tile_cost_class(int tile, int width, int height, int block_rows, int strip_rank, int strip_count,
+                                               const int* __restrict__ termination_buffer, const unsigned int* __restrict__ cell_attempts,
+                                               int prepass_width, int prepass_height) {
+    int cx = 0, cy = 0;
+    if (!trace_slot_to_pixel((unsigned)tile * 64u + 36u, width, height, block_rows, strip_rank, strip_count, cx, cy) &&
+        !trace_slot_to_pixel((unsigned)tile * 64u, width, height, block_rows, strip_rank, strip_count, cx, cy))
+        return GR_TILE_CLASSES - 1;   // padding: nothing to trace
+    const int lx = (int)roundf(exact_ratio(cx, width) * prepass_width), ly = (int)roundf(exact_ratio(cy, height) * prepass_height);
+    // a pixel's stencil reaches one cell beyond the cell it rounds to, and the pixels of a tile round to cells up to one away
+    // from the centre's: shadow flags over 5x5 cells (a tile put in the last class by mistake would be traced as one of
+    // GR_SKIP_CHUNK tiles by a single wave), costs over the 3x3 next to the tile
+    int in_shadow = 0;
+    unsigned int dearest = 0;
+    for (int dy = -2; dy <= 2; dy++)
+        for (int dx = -2; dx <= 2; dx++) {
+            const int x = lx + dx, y = ly + dy;
+            if (x < 0 || y < 0 || x >= prepass_width || y >= prepass_height) continue;   // outside: never "skip" (early_terminate)
+            if (termination_buffer[y * prepass_width + x] == 1) in_shadow++;
+            if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) {
+                const unsigned int a = cell_attempts[y * prepass_width + x];
+                dearest = a > dearest ? a : dearest;
+            }
+        }
+    if (in_shadow == 25) return GR_TILE_CLASSES - 1;
+    if (in_shadow > 0) return 0;
+    return dearest >= 2048u ? 1 : dearest >= 1024u ? 2 : dearest >= 512u ? 3 : dearest >= 256u ? 4 : dearest >= 128u ? 5 : 6;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+gr_order_tiles(const int* __restrict__ termination_buffer, const unsigned int* __restrict__ cell_attempts, int prepass_width,
+               int prepass_height, int width, int height, int block_rows, int strip_rank, int strip_count, int total_tiles,
+               unsigned int* __restrict__ list, int phase) {
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cls = tile < total_tiles ? tile_cost_class(tile, width, height, block_rows, strip_rank, strip_count, termination_buffer,
+                                                          cell_attempts, prepass_width, prepass_height)
+                                       : -1;
+    const int lane = threadIdx.x % 64;
+    unsigned int first = 0;   // where the class's range starts (phase 1)
+    for (int c = 0; c < GR_TILE_CLASSES; c++) {
+        const unsigned long long members = __builtin_amdgcn_ballot_w64(cls == c);
+        if (members) {   // one atomic per wave and class
+            const int leader = __builtin_ctzll(members);
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(list + (phase == 0 ? c : GR_TILE_CLASSES + c), (unsigned int)__builtin_popcountll(members));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (phase == 1 && cls == c)
+                list[GR_TILE_ORDER_HEADER + first + base + (unsigned int)__builtin_popcountll(members & ((1ull << lane) - 1ull))] = (unsigned int)tile;
+        }
+        if (phase == 1) first += list[c];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -313,6 +313,17 @@ class RenderState:
         check(lib.gr_render_state_shader_clock(self.handle, ctypes.byref(v)))
         return v.value
 
+    def wave_time(self):
+        """(summed wave lifetime in ms, waves) of the same launch"""
+        ms, n = ctypes.c_double(0), ctypes.c_ulonglong(0)
+        check(lib.gr_render_state_wave_time(self.handle, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def counters(self, count=128):
+        words = (ctypes.c_ulonglong * count)()
+        check(lib.gr_render_state_counters(self.handle, words, count))
+        return list(words)
+
     def attempts(self):
         v = ctypes.c_ulonglong()
         check(lib.gr_render_state_attempts(self.handle, ctypes.byref(v)))

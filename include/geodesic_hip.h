@@ -251,11 +251,13 @@ int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, co
                      const void* e0, const void* e1, const void* e2, const void* e3,
                      const void* cfg, const void* dfg);
 /* the same for a device that owns only the row blocks strip_rank, strip_rank + strip_count, ... of an image of
- * image_height rows (see gr_trace_fused): cells none of its rows can look at are not traced and keep their old value */
+ * image_height rows (see gr_trace_fused): cells none of its rows can look at are not traced and keep their old value.
+ * cell_attempts (unsigned[prepass_width * prepass_height], may be NULL): the step attempts each cell's ray took, the cost
+ * estimate gr_order_tiles works from */
 int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
                             void* termination_buffer, int prepass_width, int prepass_height,
                             const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg,
-                            int image_height, int block_rows, int strip_rank, int strip_count);
+                            int image_height, int block_rows, int strip_rank, int strip_count, void* cell_attempts);
 
 /* gr_cart_to_generic + gr_init_basis_vectors + gr_prepass_fused_strips in one launch: the camera's metric coordinates and tetrad
  * are computed from the Cartesian camera inside the launch (and stored to position_generic_out / e*_out for gr_trace_fused), then
@@ -264,7 +266,16 @@ int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_gene
 int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, float flip, const float basis_speed[3],
                       void* position_generic_out, void* e0_out, void* e1_out, void* e2_out, void* e3_out, const void* camera_quat,
                       void* termination_buffer, int prepass_width, int prepass_height, const void* cfg, const void* dfg,
-                      int image_height, int block_rows, int strip_rank, int strip_count);
+                      int image_height, int block_rows, int strip_rank, int strip_count, void* cell_attempts);
+
+/* The order in which a persistent gr_trace_fused launch hands out its tiles: longest first, as estimated from what the prepass
+ * rays around each tile cost (cell_attempts of gr_prepass_fused_strips / gr_camera_prepass), tiles on the shadow's edge before
+ * everything, tiles the prepass lets skip last.  A launch lasts as long as its slowest wave, and a long tile drawn late is what
+ * makes a wave slow; which wave traces a tile has no influence on the tile's pixels.  tile_order: gr_tile_order_bytes(...) bytes,
+ * written by two small launches on `stream`; pass it to gr_trace_fused_ordered with the same image and strip description. */
+long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_rank, int strip_count);
+int gr_order_tiles(gr_program* p, void* stream, const void* termination_buffer, const void* cell_attempts, int prepass_width,
+                   int prepass_height, int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order);
 
 /* init -> integrate -> render-data in one launch; writes only render_data[sy*width+sx] (32 B per pixel).
  * Rows are dealt to devices block-cyclically: global block b (block_rows rows, multiple of 8) belongs to device
@@ -275,6 +286,13 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
                    const void* termination_buffer, int prepass_width, int prepass_height,
                    const void* e0, const void* e1, const void* e2, const void* e3,
                    const void* cfg, const void* dfg, void* attempt_counter);
+/* the same with the tiles handed out in gr_order_tiles' order (tile_order NULL: image order, i.e. gr_trace_fused) and, when
+ * waves_per_simd is 1..8, at most that many persistent waves per SIMD (0: as many as the kernel's registers allow) */
+int gr_trace_fused_ordered(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
+                           void* render_data, int width, int height, int block_rows, int strip_rank, int strip_count,
+                           const void* termination_buffer, int prepass_width, int prepass_height,
+                           const void* e0, const void* e1, const void* e2, const void* e3,
+                           const void* cfg, const void* dfg, void* attempt_counter, const void* tile_order, int waves_per_simd);
 
 /* Adaptive sampling on the fused path (the reference: init_rays_generic's packing cl.cl:3234-3250 + handle_adaptive_sampling
  * cl.cl:5223-5345 + a second do_generic_rays / calculate_render_data).  gr_trace_fused_adaptive is gr_trace_fused on a whole image
@@ -370,6 +388,9 @@ typedef struct gr_frame_options {
     int next_strip_rank2;  /*   frame to frame (load balance over ranks); -1 = the same as this frame's */
     int rays_per_lane;     /* fused mode without compaction: 1 = gr_trace_fused, 2 = gr_trace_pair (error if the program lacks it),
                             * 0 = library default: 2 where the program has the pair kernel, else 1 (GR_TRACE_RAYS_PER_LANE=1|2 overrides) */
+    int trace_waves_per_simd;   /* fused mode: persistent waves per SIMD a trace launch takes, 1..8; 0 = as many as fit (best for
+                            * one frame at a time).  With three or more frames in flight on streams of their own, 4 measured
+                            * 2-3 % faster than all: the launches then share the device instead of queueing for it. */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 
@@ -416,6 +437,12 @@ int gr_render_state_attempts(gr_render_state* s, unsigned long long* attempts);
  * same lifetimes in ticks of the constant 100 MHz reference clock (s_memrealtime); 0 when the frame was not traced by
  * gr_trace_fused with count_attempts (synchronises the device) */
 int gr_render_state_shader_clock(gr_render_state* s, double* mhz);
+/* of the same launch: the summed lifetime of its waves in milliseconds and how many waves ran.  Over (wave slots the launch
+ * held) x (launch duration) this is the share of the slots that was occupied - the rest is the launch's ramp and tail */
+int gr_render_state_wave_time(gr_render_state* s, double* wave_ms, unsigned long long* waves);
+/* the first count (<= 128) words of that frame's counter block as the kernels left them: [0] attempts, [1] shader cycles,
+ * [2] reference-clock ticks, [3] waves, [8..127] only written by probe builds of the kernels (tools/README.md) */
+int gr_render_state_counters(gr_render_state* s, unsigned long long* words, int count);
 
 enum { GR_BUF_RAYS_IN = 0, GR_BUF_RAYS_COUNT = 1, GR_BUF_RENDER_DATA = 2, GR_BUF_TERMINATION = 3, GR_BUF_CAMERA_GENERIC = 4,
        GR_BUF_TETRAD0 = 5, GR_BUF_TETRAD1 = 6, GR_BUF_TETRAD2 = 7, GR_BUF_TETRAD3 = 8, GR_BUF_RAYS_ADAPTIVE = 9,

@@ -1,0 +1,94 @@
+"""GPU tests (-m gpu) of what only schedules the fused trace: the order its tiles are handed out in (gr_order_tiles), how many
+tiles a ticket covers, how many wave slots a launch takes.  None of it may change a pixel."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import geodesic_raytracing_amd as gra  # noqa: E402
+from geodesic_raytracing_amd import check, lib  # noqa: E402
+from geodesic_raytracing_amd.pipeline import DeviceBuffer, RENDER_DATA_DTYPE, download  # noqa: E402
+from test_gpu_fullsize import SCRIPTS, background  # noqa: E402
+
+W, H = 1920, 1080   # 32 400 tiles: more than the device's wave slots, so the launch is persistent and draws tickets
+
+
+def traced_state(strip=(0, 1), block_rows=48):
+    """a Kerr frame's camera, tetrad and prepass on the device (a frame is rendered once to fill the state's buffers)"""
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv = metric.cfg_values(a=0.45)
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    state = gra.RenderState(W, H, 0)
+    dbg, levels = background()
+    out = DeviceBuffer(0, W * H * 16)
+    opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=strip[0], strip_count=strip[1], block_rows=block_rows, compact_out=1)
+    state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv, opts)
+    state.synchronize()
+    return prog, state
+
+
+def order_list(prog, state, strip, block_rows, pw, ph):
+    nbytes = lib.gr_tile_order_bytes(W, H, block_rows, strip[0], strip[1])
+    order = DeviceBuffer(0, nbytes)
+    term = state.buffer(gra.BUF_TERMINATION)
+    check(lib.gr_order_tiles(prog.handle, None, term, term + 4 * pw * ph, pw, ph, W, H, block_rows, strip[0], strip[1], order.ptr))
+    check(lib.gr_device_synchronize(0))
+    return order, order.to_numpy(np.uint32, (nbytes // 4,))
+
+
+@pytest.mark.parametrize("strip,block_rows", [((0, 1), 0), ((1, 3), 48), ((7, 8), 16)])
+def test_tile_order_is_a_permutation_of_the_device_tiles(strip, block_rows):
+    """every tile of the device exactly once, the classes' counts add up, and the frame's own list (written by gr_render_frame)
+    holds the same tiles; the order inside a class is whatever the atomics made it"""
+    prog, state = traced_state(strip, block_rows or 48)
+    pw, ph = W // 16, H // 16
+    rows = block_rows or ((H + 7) // 8) * 8
+    _, words = order_list(prog, state, strip, rows, pw, ph)
+    counts, cursors, tiles = words[:8], words[8:16], words[16:]
+    assert counts.sum() == tiles.size and (cursors == counts).all()
+    assert np.array_equal(np.sort(tiles), np.arange(tiles.size, dtype=np.uint32))
+    assert counts[7] > 0 and counts[0] > 0   # the Kerr shadow: tiles to skip, and tiles on its edge
+
+
+def test_ordered_trace_equals_image_order_bit_for_bit():
+    """gr_trace_fused (image order, every slot) against gr_trace_fused_ordered (gr_order_tiles' list, chunked tickets for the
+    skipped tiles, two waves per SIMD): the same render_data records"""
+    prog, state = traced_state()
+    pw, ph = W // 16, H // 16
+    order, _ = order_list(prog, state, (0, 1), ((H + 7) // 8) * 8, pw, ph)
+    b = state.buffer
+    common = (b(gra.BUF_CAMERA_GENERIC), b(gra.BUF_CAMERA_QUAT))
+    tail = (b(gra.BUF_TERMINATION), pw, ph, b(gra.BUF_TETRAD0), b(gra.BUF_TETRAD1), b(gra.BUF_TETRAD2), b(gra.BUF_TETRAD3),
+            b(gra.BUF_CFG), b(gra.BUF_DFG), None)
+    records = []
+    for ordered in (False, True, True):
+        rd = DeviceBuffer(0, W * H * RENDER_DATA_DTYPE.itemsize)
+        if ordered:
+            waves = 2 if len(records) == 1 else 0
+            check(lib.gr_trace_fused_ordered(prog.handle, None, *common, rd.ptr, W, H, 0, 0, 1, *tail, order.ptr, waves))
+        else:
+            check(lib.gr_trace_fused(prog.handle, None, *common, rd.ptr, W, H, 0, 0, 1, *tail))
+        check(lib.gr_device_synchronize(0))
+        records.append(download(0, rd.ptr, RENDER_DATA_DTYPE, W * H))
+    assert records[0].tobytes() == records[1].tobytes()
+    assert records[0].tobytes() == records[2].tobytes()
+    assert (records[0]["terminated"] == 2).any() and (records[0]["terminated"] == 1).any()
+
+
+def test_frame_with_fewer_wave_slots_is_bit_identical():
+    """gr_frame_options.trace_waves_per_simd only sizes the launch"""
+    frames = []
+    for waves in (0, 3):
+        metric = gra.Metric("kerr_boyer", SCRIPTS)
+        cfgv = metric.cfg_values(a=0.45)
+        feats = metric.features(adaptive_sampling=0)
+        prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+        state = gra.RenderState(W, H, 0)
+        dbg, levels = background()
+        out = DeviceBuffer(0, W * H * 16)
+        state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv,
+                     gra.frame_options(mode=gra.MODE_FUSED, trace_waves_per_simd=waves))
+        state.synchronize()
+        frames.append(out.to_numpy(np.float32, (H, W, 4)))
+    assert frames[0].tobytes() == frames[1].tobytes()

@@ -52,7 +52,8 @@ def kernel(name, lines, width=1):
     outs = ", ".join(f'"+v"(a{i})' for i in range(8))
     stmt = f'asm volatile("{block}" : {outs} : "v"(b), "v"(c), "s"(m), "s"(sb) : "vcc");'
     body = "\n".join("        " + stmt for _ in range(16))
-    return f'''__global__ void __launch_bounds__(256) k_{name}(float* out, int iters) {{
+    return f'''__global__ void __launch_bounds__(256) k_{name}(float* out, int iters, unsigned long long* clk) {{
+    const unsigned long long born_cycles = __builtin_amdgcn_s_memtime(), born_ticks = __builtin_amdgcn_s_memrealtime();
     {init}
     {bc}
     unsigned long long m = 0x5555555555555555ull + (unsigned long long)iters;
@@ -62,6 +63,10 @@ def kernel(name, lines, width=1):
     }}
     {fin}
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x % 64 == 0) {{   // every wave: its lifetime in shader cycles and in ticks of the constant 100 MHz clock
+        atomicAdd(clk, (unsigned long long)__builtin_amdgcn_s_memtime() - born_cycles);
+        atomicAdd(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - born_ticks);
+    }}
 }}'''
 
 
@@ -75,14 +80,15 @@ for name, lines in SEQUENCES.items():
     print(kernel(name, lines))
     names.append(name)
 print('''template <typename K>
-static void run(const char* name, K kernel, float* out, int blocks) {
+static void run(const char* name, K kernel, float* out, int blocks, unsigned long long* clk) {
     const int iters = 4096;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    kernel<<<blocks, 256>>>(out, 64);
+    kernel<<<blocks, 256>>>(out, 64, clk);
     hipDeviceSynchronize();
+    hipMemset(clk, 0, 16);
     hipEventRecord(a);
-    kernel<<<blocks, 256>>>(out, iters);
+    kernel<<<blocks, 256>>>(out, iters, clk);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms = 0;
@@ -91,12 +97,18 @@ static void run(const char* name, K kernel, float* out, int blocks) {
     int clk_khz = 0;
     hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
     double cycles = ms * 1e-3 * clk_khz * 1e3;
-    printf("%-12s %8.3f ms  %6.2f cycles per wave64 instruction per SIMD (nominal clock %d MHz)\\n", name, ms, cycles / wave_instr_per_simd, clk_khz / 1000);
+    unsigned long long c[2] = {0, 0};
+    hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost);
+    double mhz = c[1] ? 100.0 * (double)c[0] / (double)c[1] : 0.0;   // shader cycles per tick of the 100 MHz reference clock
+    printf("%-12s %8.3f ms  %6.2f cycles of the nominal %d MHz clock per wave64 instruction per SIMD; shader clock while it ran %6.0f MHz -> %5.2f shader cycles\\n",
+           name, ms, cycles / wave_instr_per_simd, clk_khz / 1000, mhz, ms * 1e-3 * mhz * 1e6 / wave_instr_per_simd);
 }
 int main() {
     const int blocks = 256 * 8;   // 8 workgroups of 4 waves per CU = 8 waves per SIMD
     float* out;
-    hipMalloc(&out, (size_t)blocks * 256 * 4);''')
+    hipMalloc(&out, (size_t)blocks * 256 * 4);
+    unsigned long long* clk;
+    hipMalloc(&clk, 16);''')
 for n in names:
-    print(f'    run("{n}", k_{n}, out, blocks);')
+    print(f'    run("{n}", k_{n}, out, blocks, clk);')
 print("    return 0;\n}")
