@@ -683,7 +683,7 @@ static long long device_tile_count(int width, int height, int block_rows, int st
 }
 
 long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_rank, int strip_count) {
-    return (16 + device_tile_count(width, height, block_rows, strip_rank, strip_count)) * 4;
+    return (16 + 2 * device_tile_count(width, height, block_rows, strip_rank, strip_count)) * 4;   // header, list, classes
 }
 
 int gr_order_tiles(gr_program* p, void* stream, const void* term, const void* cell_attempts, int prepass_width, int prepass_height,
@@ -699,7 +699,7 @@ int gr_order_tiles(gr_program* p, void* stream, const void* term, const void* ce
     for (int phase = 0; phase < 2; phase++) {
         void* args[] = {&term, &cell_attempts, &prepass_width, &prepass_height, &width, &height, &block_rows, &strip_rank, &strip_count,
                         &total, &tile_order, &phase};
-        int rc = launch(p, K_ORDER_TILES, stream, blocks(total, 256), 1, 256, 1, args);
+        int rc = launch(p, K_ORDER_TILES, stream, blocks(total, 1024), 1, 1024, 1, args);
         if (rc != GR_OK) return rc;
     }
     return GR_OK;

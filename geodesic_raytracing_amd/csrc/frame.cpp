@@ -256,8 +256,8 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
     size_t px = (size_t)width * height;
     A(&s->render_data, px * sizeof(gr_render_data));
     A(&s->termination_buffer, px * sizeof(int));
-    // one word per tile: 8x8 tiles of the whole image or, split over devices, of at most all its blocks + their halo pieces
-    const size_t order_bytes = (px / 32 + (size_t)width + 4096) * sizeof(unsigned int);
+    // two words per tile: 8x8 tiles of the whole image or, split over devices, of at most all its blocks + their halo pieces
+    const size_t order_bytes = (px / 16 + 2 * (size_t)width + 8192) * sizeof(unsigned int);
     A(&s->tile_order, order_bytes);
     s->tile_order_bytes = order_bytes;
     for (auto& slot : s->pre) {

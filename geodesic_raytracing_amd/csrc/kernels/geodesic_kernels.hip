@@ -2335,7 +2335,8 @@ gr_camera_prepass(const float4* __restrict__ position_cart_in, float flip, float
 // centre, tiles that straddle the shadow's edge first of all, tiles the prepass lets skip (a store per pixel) last, where they
 // fill the slots of the draining launch.  Scheduling only: which wave traces a tile and when has no influence on its rays.
 // Two launches over the device's tiles: phase 0 counts the classes, phase 1 deals every tile a place in its class's range
-// (order within a class: as the atomics fall, i.e. roughly image order).  list[0..7] counts, [8..15] cursors, then the tiles.
+// (order within a class: as the atomics fall, i.e. roughly image order).  list[0..7] counts, [8..15] cursors, then the tiles,
+// then the tiles' classes (scratch between the two phases).
 __device__ __forceinline__ int tile_cost_class(int tile, int width, int height, int block_rows, int strip_rank, int strip_count,
                                                const int* __restrict__ termination_buffer, const unsigned int* __restrict__ cell_attempts,
                                                int prepass_width, int prepass_height) {
@@ -2349,14 +2350,19 @@ __device__ __forceinline__ int tile_cost_class(int tile, int width, int height, 
     // GR_SKIP_CHUNK tiles by a single wave), costs over the 3x3 next to the tile
     int in_shadow = 0;
     unsigned int dearest = 0;
+    // every cell is read, at clamped coordinates, whether it counts or not: 50 independent loads in flight instead of a chain of
+    // conditional ones (the kernel is nothing but their latency)
+#pragma unroll
     for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
         for (int dx = -2; dx <= 2; dx++) {
-            const int x = lx + dx, y = ly + dy;
-            if (x < 0 || y < 0 || x >= prepass_width || y >= prepass_height) continue;   // outside: never "skip" (early_terminate)
-            if (termination_buffer[y * prepass_width + x] == 1) in_shadow++;
+            const int x = min(max(lx + dx, 0), prepass_width - 1), y = min(max(ly + dy, 0), prepass_height - 1);
+            const bool inside = x == lx + dx && y == ly + dy;   // outside the grid: never "skip" (early_terminate)
+            const int flag = termination_buffer[y * prepass_width + x];
+            in_shadow += (inside && flag == 1) ? 1 : 0;
             if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) {
                 const unsigned int a = cell_attempts[y * prepass_width + x];
-                dearest = a > dearest ? a : dearest;
+                dearest = (inside && a > dearest) ? a : dearest;
             }
         }
     if (in_shadow == 25) return GR_TILE_CLASSES - 1;
@@ -2364,27 +2370,48 @@ __device__ __forceinline__ int tile_cost_class(int tile, int width, int height, 
     return dearest >= 2048u ? 1 : dearest >= 1024u ? 2 : dearest >= 512u ? 3 : dearest >= 256u ? 4 : dearest >= 128u ? 5 : 6;
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(1024)
 gr_order_tiles(const int* __restrict__ termination_buffer, const unsigned int* __restrict__ cell_attempts, int prepass_width,
                int prepass_height, int width, int height, int block_rows, int strip_rank, int strip_count, int total_tiles,
                unsigned int* __restrict__ list, int phase) {
+    // one atomic per class and WORKGROUP on the device-wide counters: they are single addresses that every XCD contends for
+    // (~50 ns an atomic; per wave the 2 000 waves of a 4K frame spent 0.1 ms on them), the waves of a workgroup meet in LDS
+    __shared__ unsigned int group_count[GR_TILE_CLASSES], group_base[GR_TILE_CLASSES];
+    if (threadIdx.x < GR_TILE_CLASSES) group_count[threadIdx.x] = 0;
+    __syncthreads();
     const int tile = blockIdx.x * blockDim.x + threadIdx.x;
-    const int cls = tile < total_tiles ? tile_cost_class(tile, width, height, block_rows, strip_rank, strip_count, termination_buffer,
-                                                          cell_attempts, prepass_width, prepass_height)
-                                       : -1;
+    // phase 0 works the classes out and leaves them behind the list for phase 1
+    unsigned int* classes = list + GR_TILE_ORDER_HEADER + total_tiles;
+    int cls = -1;
+    if (tile < total_tiles) {
+        if (phase == 0) {
+            cls = tile_cost_class(tile, width, height, block_rows, strip_rank, strip_count, termination_buffer, cell_attempts, prepass_width,
+                                  prepass_height);
+            classes[tile] = (unsigned int)cls;
+        } else {
+            cls = (int)classes[tile];
+        }
+    }
     const int lane = threadIdx.x % 64;
-    unsigned int first = 0;   // where the class's range starts (phase 1)
+    unsigned int place = 0;   // of this tile among its workgroup's tiles of the same class
     for (int c = 0; c < GR_TILE_CLASSES; c++) {
         const unsigned long long members = __builtin_amdgcn_ballot_w64(cls == c);
-        if (members) {   // one atomic per wave and class
+        if (members) {
             const int leader = __builtin_ctzll(members);
-            unsigned int base = 0;
-            if (lane == leader) base = atomicAdd(list + (phase == 0 ? c : GR_TILE_CLASSES + c), (unsigned int)__builtin_popcountll(members));
-            base = __builtin_amdgcn_readlane(base, leader);
-            if (phase == 1 && cls == c)
-                list[GR_TILE_ORDER_HEADER + first + base + (unsigned int)__builtin_popcountll(members & ((1ull << lane) - 1ull))] = (unsigned int)tile;
+            unsigned int wave_base = 0;
+            if (lane == leader) wave_base = atomicAdd(&group_count[c], (unsigned int)__builtin_popcountll(members));
+            wave_base = __builtin_amdgcn_readlane(wave_base, leader);
+            if (cls == c) place = wave_base + (unsigned int)__builtin_popcountll(members & ((1ull << lane) - 1ull));
         }
-        if (phase == 1) first += list[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < GR_TILE_CLASSES && group_count[threadIdx.x])
+        group_base[threadIdx.x] = atomicAdd(list + (phase == 0 ? 0 : GR_TILE_CLASSES) + threadIdx.x, group_count[threadIdx.x]);
+    __syncthreads();
+    if (phase == 1 && cls >= 0) {
+        unsigned int first = 0;   // where the class's range starts
+        for (int c = 0; c < cls; c++) first += list[c];
+        list[GR_TILE_ORDER_HEADER + first + group_base[cls] + place] = (unsigned int)tile;
     }
 }
 
