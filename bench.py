@@ -294,7 +294,7 @@ def main():
     def exclusive_frames(prog, cfgv, n=5):
         """n frames one at a time with per-stage events and the attempt / shader-clock counters: stage ms (means), attempts,
         MHz"""
-        stage_sum, attempts, clocks = {}, 0, []
+        stage_sum, attempts, clocks, shares = {}, 0, [], []
         for _ in range(n):
             if multi:
                 opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=rank, strip_count=world, block_rows=plan.block_rows, compact_out=1,
@@ -307,8 +307,13 @@ def main():
             torch.cuda.synchronize()
             attempts = state.attempts()
             clocks.append(state.shader_clock_mhz())
-            for k, v in state.stage_ms().items():
+            stages_now = state.stage_ms()
+            for k, v in stages_now.items():
                 stage_sum.setdefault(k, []).append(v)
+            wave_ms, waves = state.wave_time()   # fused trace only: summed wave lifetimes -> share of the launch's slots occupied
+            if waves and stages_now.get("trace"):
+                shares.append(wave_ms / waves / stages_now["trace"])
+        exclusive_frames.slot_share = float(np.mean(shares[1:])) if len(shares) > 1 else None
         return {k: float(np.mean(v[1:])) for k, v in stage_sum.items()}, attempts, float(np.mean(clocks[1:]))
 
     def roofline_blocks(prog, cfgv, tag, wall_s_per_frame, overlapped_launch_s=None, launches=0):
@@ -323,6 +328,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(launch_s * 1e3, 4),
                 "avg_launch_basis": "launches run one at a time after the timed region (4 frames, HIP events on the launch's stream)",
                 "shader_clock_mhz_during_launch": round(mhz, 1),
+                "wave_slot_occupancy_of_launch": round(exclusive_frames.slot_share, 3) if exclusive_frames.slot_share else None,
                 "note": "register-resident ODE integrator: fp32 VALU bound, see valu_roofline (SURVEY.md 8d)"}
         if overlapped_launch_s is not None:
             roof["avg_launch_ms_overlapped"] = round(overlapped_launch_s * 1e3, 4)
