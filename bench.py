@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--lookahead-depth", type=int, default=0, help="frames of prepass look-ahead (1 or 2); default 1 on one GPU, "
                     "2 when the frame is split over several (a strip traces faster than one prepass runs)")
     ap.add_argument("--block-rows", type=int, default=48, help="rows per block of the block-cyclic row split (N > 1); multiple of 8")
+    ap.add_argument("--fused-shading", type=int, default=-1, help="gr_frame_options.fused_shading of the timed frames (-1 library default, "
+                    "0 separate gr_render pass, 1 shading inside the trace launch + seams)")
     ap.add_argument("--trace-waves-per-simd", type=int, default=-1, help="persistent waves per SIMD of a trace launch in the timed frames "
                     "(0 = all that fit, -1 = 4 with three or more frames in flight on one GPU, else all)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="render states / streams cycled through (1 = strictly one frame at a time)")
@@ -226,6 +228,7 @@ def main():
             if args.measure_clock:
                 opts.count_attempts = 1
             opts.trace_waves_per_simd = waves_per_launch
+            opts.fused_shading = args.fused_shading
             if lookahead is not None:
                 opts.next_camera = lookahead
                 if depth == 2:

@@ -49,7 +49,21 @@ class FrameOptions(ctypes.Structure):
                 ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera)), ("geodesic", c_void_p),
                 ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("parallel_transport_observer", c_int),
                 ("ray_compaction", c_int), ("next_camera2", ctypes.POINTER(Camera)), ("next_geodesic_time2", c_float),
-                ("next_strip_rank", c_int), ("next_strip_rank2", c_int), ("rays_per_lane", c_int), ("trace_waves_per_simd", c_int)]
+                ("next_strip_rank", c_int), ("next_strip_rank2", c_int), ("rays_per_lane", c_int), ("fused_shading", c_int),
+                ("trace_waves_per_simd", c_int)]
+
+
+class TraceShading(ctypes.Structure):
+    _fields_ = [("out", c_void_p), ("background1", c_void_p), ("background2", c_void_p), ("bg_width", c_int), ("bg_height", c_int),
+                ("bg_levels", c_int), ("max_probes", c_int), ("compact_out", c_int)]
+
+
+class TraceFusedArgs(ctypes.Structure):
+    _fields_ = [("camera_generic", c_void_p), ("camera_quat", c_void_p), ("render_data", c_void_p), ("width", c_int), ("height", c_int),
+                ("block_rows", c_int), ("strip_rank", c_int), ("strip_count", c_int), ("termination_buffer", c_void_p),
+                ("prepass_width", c_int), ("prepass_height", c_int), ("e0", c_void_p), ("e1", c_void_p), ("e2", c_void_p),
+                ("e3", c_void_p), ("cfg", c_void_p), ("dfg", c_void_p), ("attempt_counter", c_void_p), ("tile_order", c_void_p),
+                ("waves_per_simd", c_int), ("shading", TraceShading)]
 
 
 MODE_REFERENCE, MODE_FUSED = 0, 1
@@ -101,8 +115,9 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gr_tile_order_bytes": (ctypes.c_longlong, [c_int, c_int, c_int, c_int, c_int]),
     "gr_order_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "gr_trace_fused_ordered": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
-                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "gr_trace_fused_launch": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TraceFusedArgs)]),
+    "gr_render_seams": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_int, c_void_p, c_void_p]),
     "gr_trace_fused_adaptive": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "gr_adaptive_refine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -607,9 +607,9 @@ int gr_handle_adaptive_sampling(gr_program* p, void* stream, const void* rays, c
 int gr_render(gr_program* p, void* stream, const void* rdata, const void* rdata_count, int num_pixels, void* out,
               const void* bg1, const void* bg2, int bg_width, int bg_height, int bg_levels, int width, int height,
               int max_probes, const void* cfg, const void* dfg) {
-    int block_pixels = num_pixels > 0 ? num_pixels : 1, rank = 0, count = 1, compact = 0;
+    int block_pixels = num_pixels > 0 ? num_pixels : 1, rank = 0, count = 1, compact = 0, seams_only = 0;
     void* args[] = {&rdata, &rdata_count, &out, &bg1, &bg2, &bg_width, &bg_height, &bg_levels, &width, &height,
-                    &max_probes, &cfg, &dfg, &num_pixels, &block_pixels, &rank, &count, &compact};
+                    &max_probes, &cfg, &dfg, &num_pixels, &block_pixels, &rank, &count, &compact, &seams_only};
     return launch(p, K_RENDER, stream, blocks(num_pixels, 256), 1, 256, 1, args);
 }
 
@@ -629,8 +629,27 @@ int gr_render_strips(gr_program* p, void* stream, const void* rdata, void* out, 
     int block_pixels = block_rows * width;
     int num = local_blocks * block_pixels;
     const void* rdata_count = p ? p->huge_count : nullptr;
+    int seams_only = 0;
     void* args[] = {&rdata, &rdata_count, &out, &bg1, &bg2, &bg_width, &bg_height, &bg_levels, &width, &height,
-                    &max_probes, &cfg, &dfg, &num, &block_pixels, &strip_rank, &strip_count, &compact_out};
+                    &max_probes, &cfg, &dfg, &num, &block_pixels, &strip_rank, &strip_count, &compact_out, &seams_only};
+    return launch(p, K_RENDER, stream, blocks(num, 256), 1, 256, 1, args);
+}
+
+// the pixels gr_trace_fused_launch's in-tile shading leaves: last column and last row of every 8x8 tile of this device's blocks
+int gr_render_seams(gr_program* p, void* stream, const void* rdata, void* out, const void* bg1, const void* bg2, int bg_width,
+                    int bg_height, int bg_levels, int width, int height, int block_rows, int strip_rank, int strip_count,
+                    int compact_out, int max_probes, const void* cfg, const void* dfg) {
+    if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + 7) / 8) * 8; }
+    if (block_rows <= 0 || block_rows % 8 != 0 || strip_rank < 0 || strip_rank >= strip_count || width <= 0 || width % 8 != 0)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "gr_render_seams: width and block_rows must be multiples of 8");
+    int local_blocks = gr_strip_local_blocks(height, block_rows, strip_rank, strip_count);
+    int block_pixels = block_rows * width;
+    long long items = (long long)local_blocks * (width / 8) * (block_rows / 8) * 15;
+    if (items > 0x7fffffff) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_render_seams: image too large");
+    int num = (int)items, seams_only = 1;
+    const void* rdata_count = p ? p->huge_count : nullptr;
+    void* args[] = {&rdata, &rdata_count, &out, &bg1, &bg2, &bg_width, &bg_height, &bg_levels, &width, &height,
+                    &max_probes, &cfg, &dfg, &num, &block_pixels, &strip_rank, &strip_count, &compact_out, &seams_only};
     return launch(p, K_RENDER, stream, blocks(num, 256), 1, 256, 1, args);
 }
 
@@ -710,7 +729,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
                         int width, int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
                         int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
                         const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0, const void* tile_order = nullptr,
-                        int waves_per_simd = 0) {
+                        int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
     if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && (rays_per_lane != 1 || strip_count > 1)))
@@ -769,9 +788,18 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
         groups = resident_groups;
     }
+    // the kernel's trace_shading, by value (same layout)
+    struct { void* out; const void* bg1; const void* bg2; int bg_width, bg_height, bg_levels, most_probes, compact_out; } shading = {};
+    if (shading_in && shading_in->out) {
+        if (rays_per_lane != 1 || lattice != 1 || pending_only || width % T != 0 || height % T != 0)
+            return fail(GR_ERROR_INVALID_ARGUMENT, "in-tile shading: gr_trace_fused on every pixel of an image whose sides are multiples of 8");
+        shading.out = shading_in->out; shading.bg1 = shading_in->background1; shading.bg2 = shading_in->background2;
+        shading.bg_width = shading_in->bg_width; shading.bg_height = shading_in->bg_height; shading.bg_levels = shading_in->bg_levels;
+        shading.most_probes = shading_in->max_probes; shading.compact_out = strip_count > 1 ? shading_in->compact_out : 0;
+    }
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
-                    &lattice, &pending_only, &tile_order};   // the last three: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
+                    &lattice, &pending_only, &tile_order, &shading};   // the last four: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
     return launch(p, kernel_index, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
@@ -796,12 +824,11 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
                         prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter);
 }
 
-int gr_trace_fused_ordered(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
-                           int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
-                           int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
-                           const void* dfg, void* attempt_counter, const void* tile_order, int waves_per_simd) {
-    return trace_launch(p, 1, stream, camera_generic, camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, term,
-                        prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, 1, 0, tile_order, waves_per_simd);
+int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args* a) {
+    if (!a) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    return trace_launch(p, 1, stream, a->camera_generic, a->camera_quat, a->render_data, a->width, a->height, a->block_rows, a->strip_rank,
+                        a->strip_count, a->termination_buffer, a->prepass_width, a->prepass_height, a->e0, a->e1, a->e2, a->e3, a->cfg, a->dfg,
+                        a->attempt_counter, 1, 0, a->tile_order, a->waves_per_simd, &a->shading);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

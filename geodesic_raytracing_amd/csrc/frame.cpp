@@ -163,6 +163,7 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->time_kernels = 0;
     o->count_attempts = 0;
     o->trace_waves_per_simd = 0;
+    o->fused_shading = -1;
     o->next_camera = nullptr;
     o->geodesic = nullptr;
     o->geodesic_time = 0;
@@ -718,6 +719,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         }
         if (!todo.empty()) HIP_CHECK(hipEventRecord(s->main_mark, stream));   // everything up to here is older than the prefetches
         // every device runs the (tiny) prepass itself; its own row blocks (+ one halo row each) are traced here
+        bool shade_in_trace = false;
         GR_CHECK(begin(GR_STAGE_TRACE));
         // library default: no compaction (the benchmark workloads keep > 95 % of their lanes busy without it); experiments can
         // switch it on for every frame with GR_TRACE_COMPACT=<keep_lanes>
@@ -755,12 +757,27 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                        strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
                                        use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
                                        s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts));
-            else
-                GR_CHECK(gr_trace_fused_ordered(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
-                                                strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
-                                                use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
-                                                s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts,
-                                                order_tiles ? s->tile_order : nullptr, opt.trace_waves_per_simd));
+            else {
+                gr_trace_fused_args a{};
+                a.camera_generic = s->camera_pos_generic; a.camera_quat = s->camera_quat; a.render_data = s->render_data;
+                a.width = width; a.height = height; a.block_rows = block_rows; a.strip_rank = strip_rank; a.strip_count = strip_count;
+                a.termination_buffer = use_prepass ? s->termination_buffer : nullptr;
+                a.prepass_width = use_prepass ? prepass_width : width; a.prepass_height = use_prepass ? prepass_height : height;
+                a.e0 = s->tetrad[0]; a.e1 = s->tetrad[1]; a.e2 = s->tetrad[2]; a.e3 = s->tetrad[3]; a.cfg = s->cfg; a.dfg = s->dfg;
+                a.attempt_counter = attempts;
+                a.tile_order = order_tiles ? s->tile_order : nullptr;
+                a.waves_per_simd = opt.trace_waves_per_simd;
+                // the trace shades the pixels whose filter neighbours are in their own tile; gr_render_seams below does the rest
+                shade_in_trace = out && opt.fused_shading == 1 && width % 8 == 0 && height % 8 == 0;   // default: off, on measurement
+                if (opt.fused_shading == 1 && !shade_in_trace && out)
+                    return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused_shading = 1: width and height must be multiples of 8");
+                if (shade_in_trace) {
+                    a.shading.out = out; a.shading.background1 = bg1; a.shading.background2 = bg2; a.shading.bg_width = bg_width;
+                    a.shading.bg_height = bg_height; a.shading.bg_levels = bg_levels; a.shading.max_probes = opt.max_probes;
+                    a.shading.compact_out = strip_count > 1 ? opt.compact_out : 0;
+                }
+                GR_CHECK(gr_trace_fused_launch(p, stream, &a));
+            }
             }
         }
         if (!adaptive) GR_CHECK(end(GR_STAGE_TRACE));
@@ -804,9 +821,13 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         }
         if (out) {
             GR_CHECK(begin(GR_STAGE_RENDER));
-            GR_CHECK(gr_render_strips(p, stream, s->render_data, out, bg1, bg2, bg_width, bg_height, bg_levels, width, height,
-                                      strip_count > 1 ? block_rows : height, strip_rank, strip_count,
-                                      strip_count > 1 ? opt.compact_out : 0, opt.max_probes, s->cfg, s->dfg));
+            if (shade_in_trace)
+                GR_CHECK(gr_render_seams(p, stream, s->render_data, out, bg1, bg2, bg_width, bg_height, bg_levels, width, height, block_rows,
+                                         strip_rank, strip_count, strip_count > 1 ? opt.compact_out : 0, opt.max_probes, s->cfg, s->dfg));
+            else
+                GR_CHECK(gr_render_strips(p, stream, s->render_data, out, bg1, bg2, bg_width, bg_height, bg_levels, width, height,
+                                          strip_count > 1 ? block_rows : height, strip_rank, strip_count,
+                                          strip_count > 1 ? opt.compact_out : 0, opt.max_probes, s->cfg, s->dfg));
             GR_CHECK(end(GR_STAGE_RENDER));
         }
         return GR_OK;

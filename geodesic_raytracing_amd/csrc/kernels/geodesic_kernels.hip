@@ -1895,12 +1895,26 @@ __device__ __forceinline__ unsigned int wave_slots(unsigned int trips, unsigned 
 // global block gb belongs to device gb % strip_count); a block is tiles_x * block_rows/8 tile-waves, and, when the image is
 // split, 64x1 "halo" waves tracing the row just below it, which the texture filter of the block's last row reads
 // (cl.cl:5509-5520).  strip_count == 1: one block covering the whole image.
+// Shading inside the trace launch.  Of the 64 pixels of a tile, the 49 that are not in its last column or row have both neighbours
+// the texture filter looks at (the pixel to the right and the pixel below, cl.cl:5509-5546) in the same wave: their sky coordinates
+// come over by ds_bpermute and the wave writes the finished float4 pixels itself, straight from the registers the render-data
+// record was built in.  The 15 pixels of the last column and row need records other waves write; gr_render shades those in a
+// second, small launch (seams_only).  out == NULL: no shading here (gr_render does all of it).
+struct trace_shading {
+    float4* out;
+    const uchar4* bg1_texels;
+    const uchar4* bg2_texels;
+    int bg_width, bg_height, bg_levels, most_probes, compact_out;
+};
+__device__ __attribute__((noinline)) float4 shade_pixel_in_tile(const render_data& self, float2 beside, float2 below, const trace_shading& shading, dfg_t dfg);
+
 __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __restrict__ camera, const float4* __restrict__ camera_quat,
                                            render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank,
                                            int strip_count, const int* __restrict__ termination_buffer, int prepass_width,
                                            int prepass_height, const float4* __restrict__ e0, const float4* __restrict__ e1,
                                            const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
-                                           unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only) {
+                                           unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
+                                           const trace_shading& shading) {
     // Adaptive sampling on the fused path (cl.cl:3234-3250, 5223-5345): lattice = 2 traces the pixels (2x, 2y) only - the tiles
     // then cover the half-resolution grid - and pending_only = 1 traces the pixels gr_adaptive_refine marked (terminated ==
     // GR_PENDING) and leaves every other record alone.  Neither is combined with a row split (strip_count == 1).
@@ -1968,6 +1982,23 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                dfg, GET_FEATURE(redshift, dfg) != 0);
     }
     rdata[cy * width + cx] = dat;
+#ifndef GR_NO_TILE_SHADING   // experiment: the kernel without its shading part (shading.out must then be NULL)
+    if (shading.out && lattice == 1 && !pending_only && within < tiles_x * tile_rows) {
+        // every lane of the tile that holds a pixel hands its sky coordinates to the lanes left of and above it
+        const float2 beside = make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) * 4, __float_as_int(dat.tex_coord.x))),
+                                          __int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) * 4, __float_as_int(dat.tex_coord.y))));
+        const float2 below = make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute((lane + T) * 4, __float_as_int(dat.tex_coord.x))),
+                                         __int_as_float(__builtin_amdgcn_ds_bpermute((lane + T) * 4, __float_as_int(dat.tex_coord.y))));
+        if (lane % T < T - 1 && lane / T < T - 1 && cx < width - 1 && cy < height - 1) {
+            long long out_index = (long long)cy * width + cx;
+            if (shading.compact_out) {   // the device's blocks back to back (gr_render's compact_out)
+                const int block = cy / block_rows;
+                out_index = ((long long)(block / strip_count) * block_rows + (cy - block * block_rows)) * width + cx;
+            }
+            shading.out[out_index] = shade_pixel_in_tile(dat, beside, below, shading, dfg);
+        }
+    }
+#endif
 #ifdef GR_COUNT_WAVE_SLOTS
     // experiment (tools/README.md): count the lane slots the wave spent in the Verlet loop - 64 x the trip count of its longest
     // ray - instead of the attempts; attempts / slots = the fraction of the lanes doing useful work
@@ -1990,7 +2021,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
-               int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order) {
+               int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading) {
     GR_PARAMETERS_IN_REGISTERS
     const int lane = threadIdx.x % 64;
     // profiling launches (attempt_counter != NULL) also measure the shader clock they ran at: every wave adds its lifetime in
@@ -2029,7 +2060,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
         // 5 instead of 8 waves per SIMD).  Re-reading 96 bytes through the scalar cache per tile is free by comparison.
         asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
         trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
-                   termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only);
+                   termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading);
 #ifdef GR_TRACE_SINGLE_TILE   // experiment: one tile per wave only (launch with GR_TRACE_PERSISTENT=0)
         break;
 #else
@@ -2717,6 +2748,12 @@ __device__ float4 shade_pixel(const render_data& self, float2 beside, bool besid
     return f4(rgb.x, rgb.y, rgb.z, colour.w);
 }
 
+__device__ __attribute__((noinline)) float4 shade_pixel_in_tile(const render_data& self, float2 beside, float2 below, const trace_shading& shading, dfg_t dfg) {
+    const sky_sampler near_sky{shading.bg1_texels, shading.bg_width, shading.bg_height, shading.bg_levels},
+                      far_sky{shading.bg2_texels, shading.bg_width, shading.bg_height, shading.bg_levels};
+    return shade_pixel(self, beside, false, below, false, near_sky, far_sky, shading.most_probes, dfg);
+}
+
 // The launch of the reference (num_pixels = block_pixels = width * height, strip_rank 0, strip_count 1, compact_out 0) shades the
 // whole image; the extension shades one device's row blocks of a split image: work item gid is pixel `off` of local block `lb`,
 // the global block being lb * strip_count + strip_rank, and with compact_out the device's blocks are written back to back.
@@ -2724,11 +2761,24 @@ extern "C" __global__ void gr_render(const render_data* __restrict__ rdata, cons
                                      const uchar4* __restrict__ bg1_texels, const uchar4* __restrict__ bg2_texels,
                                      int bg_width, int bg_height, int bg_levels,
                                      int width, int height, int most_probes, cfg_t cfg, dfg_t dfg,
-                                     int num_pixels, int block_pixels, int strip_rank, int strip_count, int compact_out) {
+                                     int num_pixels, int block_pixels, int strip_rank, int strip_count, int compact_out, int seams_only) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= num_pixels) return;
-    const int lb = gid / block_pixels;
-    const int off = gid - lb * block_pixels;
+    int lb, off;
+    if (seams_only) {
+        // the pixels a fused trace launch left (trace_shading): last column and last row of every 8x8 tile, 15 work items per tile,
+        // tiles numbered block by block as the trace numbers them.  Records are indexed by pixel; width is a multiple of 8.
+        const int tiles_x = width / GR_TILE, tiles_per_block = tiles_x * (block_pixels / width / GR_TILE);
+        const int tile = gid / 15, k = gid - tile * 15;
+        lb = tile / tiles_per_block;
+        const int within = tile - lb * tiles_per_block;
+        const int x = (within % tiles_x) * GR_TILE + (k < GR_TILE ? GR_TILE - 1 : k - GR_TILE);
+        const int y = (within / tiles_x) * GR_TILE + (k < GR_TILE ? k : GR_TILE - 1);
+        off = y * width + x;
+    } else {
+        lb = gid / block_pixels;
+        off = gid - lb * block_pixels;
+    }
     const int id = (lb * strip_count + strip_rank) * block_pixels + off;
     if (id >= *rdata_count || id >= width * height) return;
     const render_data self = rdata[id];

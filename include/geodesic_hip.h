@@ -286,13 +286,39 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
                    const void* termination_buffer, int prepass_width, int prepass_height,
                    const void* e0, const void* e1, const void* e2, const void* e3,
                    const void* cfg, const void* dfg, void* attempt_counter);
-/* the same with the tiles handed out in gr_order_tiles' order (tile_order NULL: image order, i.e. gr_trace_fused) and, when
- * waves_per_simd is 1..8, at most that many persistent waves per SIMD (0: as many as the kernel's registers allow) */
-int gr_trace_fused_ordered(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
-                           void* render_data, int width, int height, int block_rows, int strip_rank, int strip_count,
-                           const void* termination_buffer, int prepass_width, int prepass_height,
-                           const void* e0, const void* e1, const void* e2, const void* e3,
-                           const void* cfg, const void* dfg, void* attempt_counter, const void* tile_order, int waves_per_simd);
+/* gr_trace_fused with everything that only schedules it or rides along, by name:
+ *   tile_order      gr_order_tiles' list (NULL: image order)
+ *   waves_per_simd  1..8: at most that many persistent waves per SIMD (0: as many as the kernel's registers allow)
+ *   shading.out     not NULL: the launch also SHADES the pixels whose two filter neighbours lie in the same 8x8 tile - 49 of every
+ *                   64 - from the registers their records were built in (the neighbours' sky coordinates come over by
+ *                   ds_bpermute) and writes them to shading.out as gr_render would (compact_out as in gr_render_strips);
+ *                   gr_render_seams then shades the last column and row of every tile from the records.  Width and height
+ *                   must be multiples of 8.  The records are written either way. */
+typedef struct gr_trace_shading {
+    void* out;                       /* float4 per pixel; NULL = no shading in the trace launch */
+    const void* background1;
+    const void* background2;
+    int bg_width, bg_height, bg_levels, max_probes, compact_out;
+} gr_trace_shading;
+typedef struct gr_trace_fused_args {
+    const void* camera_generic;
+    const void* camera_quat;
+    void* render_data;
+    int width, height, block_rows, strip_rank, strip_count;
+    const void* termination_buffer;
+    int prepass_width, prepass_height;
+    const void *e0, *e1, *e2, *e3, *cfg, *dfg;
+    void* attempt_counter;
+    const void* tile_order;
+    int waves_per_simd;
+    gr_trace_shading shading;
+} gr_trace_fused_args;
+int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args* args);
+/* the pixels such a launch leaves to shade: same arguments as gr_render_strips (strip_count <= 1: the whole image) */
+int gr_render_seams(gr_program* p, void* stream, const void* render_data, void* out_rgba_f32,
+                    const void* background1, const void* background2, int bg_width, int bg_height, int bg_levels,
+                    int width, int height, int block_rows, int strip_rank, int strip_count, int compact_out,
+                    int max_probes, const void* cfg, const void* dfg);
 
 /* Adaptive sampling on the fused path (the reference: init_rays_generic's packing cl.cl:3234-3250 + handle_adaptive_sampling
  * cl.cl:5223-5345 + a second do_generic_rays / calculate_render_data).  gr_trace_fused_adaptive is gr_trace_fused on a whole image
@@ -388,6 +414,12 @@ typedef struct gr_frame_options {
     int next_strip_rank2;  /*   frame to frame (load balance over ranks); -1 = the same as this frame's */
     int rays_per_lane;     /* fused mode without compaction: 1 = gr_trace_fused, 2 = gr_trace_pair (error if the program lacks it),
                             * 0 = library default: 2 where the program has the pair kernel, else 1 (GR_TRACE_RAYS_PER_LANE=1|2 overrides) */
+    int fused_shading;     /* fused mode: 1 = the trace launch shades the 49 of every 64 pixels whose filter neighbours are in the same
+                            * tile and gr_render_seams the rest (needs width and height to be multiples of 8, one ray per lane, no
+                            * compaction, no adaptive sampling); 0 or -1 (library default) = gr_render shades every pixel.  Off by
+                            * default on measurement: 4K Kerr, three frames in flight, 1 723 against 1 743 Mrays/s - the shading
+                            * arithmetic moves into the trace launch, and the separate pass was already hidden behind the next
+                            * frame's trace */
     int trace_waves_per_simd;   /* fused mode: persistent waves per SIMD a trace launch takes, 1..8; 0 = as many as fit (best for
                             * one frame at a time).  With three or more frames in flight on streams of their own, 4 measured
                             * 2-3 % faster than all: the launches then share the device instead of queueing for it. */

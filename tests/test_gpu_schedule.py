@@ -1,5 +1,7 @@
 """GPU tests (-m gpu) of what only schedules the fused trace: the order its tiles are handed out in (gr_order_tiles), how many
 tiles a ticket covers, how many wave slots a launch takes.  None of it may change a pixel."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -55,23 +57,26 @@ def test_tile_order_is_a_permutation_of_the_device_tiles(strip, block_rows):
 
 
 def test_ordered_trace_equals_image_order_bit_for_bit():
-    """gr_trace_fused (image order, every slot) against gr_trace_fused_ordered (gr_order_tiles' list, chunked tickets for the
-    skipped tiles, two waves per SIMD): the same render_data records"""
+    """gr_trace_fused (image order, every slot) against gr_trace_fused_launch with gr_order_tiles' list (chunked tickets for the
+    skipped tiles), two waves per SIMD and all: the same render_data records"""
     prog, state = traced_state()
     pw, ph = W // 16, H // 16
     order, _ = order_list(prog, state, (0, 1), ((H + 7) // 8) * 8, pw, ph)
     b = state.buffer
-    common = (b(gra.BUF_CAMERA_GENERIC), b(gra.BUF_CAMERA_QUAT))
     tail = (b(gra.BUF_TERMINATION), pw, ph, b(gra.BUF_TETRAD0), b(gra.BUF_TETRAD1), b(gra.BUF_TETRAD2), b(gra.BUF_TETRAD3),
             b(gra.BUF_CFG), b(gra.BUF_DFG), None)
     records = []
     for ordered in (False, True, True):
         rd = DeviceBuffer(0, W * H * RENDER_DATA_DTYPE.itemsize)
         if ordered:
-            waves = 2 if len(records) == 1 else 0
-            check(lib.gr_trace_fused_ordered(prog.handle, None, *common, rd.ptr, W, H, 0, 0, 1, *tail, order.ptr, waves))
+            a = gra.TraceFusedArgs(camera_generic=b(gra.BUF_CAMERA_GENERIC), camera_quat=b(gra.BUF_CAMERA_QUAT), render_data=rd.ptr,
+                                   width=W, height=H, block_rows=0, strip_rank=0, strip_count=1, termination_buffer=b(gra.BUF_TERMINATION),
+                                   prepass_width=pw, prepass_height=ph, e0=b(gra.BUF_TETRAD0), e1=b(gra.BUF_TETRAD1),
+                                   e2=b(gra.BUF_TETRAD2), e3=b(gra.BUF_TETRAD3), cfg=b(gra.BUF_CFG), dfg=b(gra.BUF_DFG),
+                                   tile_order=order.ptr, waves_per_simd=2 if len(records) == 1 else 0)
+            check(lib.gr_trace_fused_launch(prog.handle, None, ctypes.byref(a)))
         else:
-            check(lib.gr_trace_fused(prog.handle, None, *common, rd.ptr, W, H, 0, 0, 1, *tail))
+            check(lib.gr_trace_fused(prog.handle, None, b(gra.BUF_CAMERA_GENERIC), b(gra.BUF_CAMERA_QUAT), rd.ptr, W, H, 0, 0, 1, *tail))
         check(lib.gr_device_synchronize(0))
         records.append(download(0, rd.ptr, RENDER_DATA_DTYPE, W * H))
     assert records[0].tobytes() == records[1].tobytes()
@@ -95,3 +100,39 @@ def test_frame_with_fewer_wave_slots_is_bit_identical():
         state.synchronize()
         frames.append(out.to_numpy(np.float32, (H, W, 4)))
     assert frames[0].tobytes() == frames[1].tobytes()
+
+
+def kerr_frame(**options):
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv = metric.cfg_values(a=0.45)
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    state = gra.RenderState(W, H, 0)
+    dbg, levels = background()
+    rows = options.pop("out_rows", H)
+    out = DeviceBuffer.from_numpy(0, np.full((rows, W, 4), np.nan, dtype=np.float32))   # a pixel nobody writes stays NaN
+    state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv,
+                 gra.frame_options(mode=gra.MODE_FUSED, **options))
+    state.synchronize()
+    return out.to_numpy(np.float32, (rows, W, 4))
+
+
+def test_shading_inside_the_trace_launch_gives_the_frame_of_the_separate_pass():
+    """fused_shading = 1: 49 of every 64 pixels are shaded by the trace launch from registers, the last column and row of every tile by
+    gr_render_seams; fused_shading = 0: gr_render shades every pixel from the records.  The same function on the same values,
+    compiled into two kernels: equal up to what the compiler contracts differently (measured: bit-identical or 1 ulp)."""
+    fused = kerr_frame(fused_shading=1)
+    separate = kerr_frame(fused_shading=0)
+    assert np.isfinite(fused).all() and np.isfinite(separate).all()   # every pixel was written by one of the two launches
+    assert np.abs(fused - separate).max() <= 2e-6
+    assert (fused[..., :3].max(axis=2) > 0).mean() > 0.3   # a picture, not a black frame
+
+
+def test_shading_inside_the_trace_launch_on_a_split_frame():
+    """a device's share of a frame split three ways, compact output: in-tile shading + seams equal the separate pass there too"""
+    blocks = [b for b in range((H + 47) // 48) if b % 3 == 1]
+    rows = sum(min(48, H - b * 48) for b in blocks)
+    fused = kerr_frame(fused_shading=1, strip_rank=1, strip_count=3, block_rows=48, compact_out=1, out_rows=rows)
+    separate = kerr_frame(fused_shading=0, strip_rank=1, strip_count=3, block_rows=48, compact_out=1, out_rows=rows)
+    assert np.isfinite(fused).all() and np.isfinite(separate).all()
+    assert np.abs(fused - separate).max() <= 2e-6
