@@ -198,6 +198,54 @@ def main():
 
     ring = [Slot(i == 0) for i in range(in_flight)]
     state, out, stream = ring[0].state, ring[0].out, ring[0].stream.cuda_stream
+
+    # The RCCL exchange of gr_render_frame_tiled cannot be exercised with two ranks before the first multi-GPU run (RCCL refuses
+    # two ranks on one device), so the first thing an N > 1 run does is check it: one frame through it, compared on rank 0 with the
+    # frame rank 0 renders on its own (a device's share of a split frame equals those rows of the whole frame bit for bit, tests/).
+    # A frame that differs sends every rank to the round-1 gather; a frame that does not come back within two minutes ends the run
+    # with a message instead of hanging it.
+    if tiled is not None and world > 1:
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(120.0):
+                print(f"[bench] rank {rank}: the first gr_render_frame_tiled frame did not complete in 120 s (RCCL send/recv); "
+                      "re-run with GR_BENCH_GATHER=torch", file=sys.stderr, flush=True)
+                os._exit(17)
+        threading.Thread(target=watchdog, daemon=True).start()
+        ok = 1
+        try:
+            o = gra.frame_options(mode=gra.MODE_FUSED)
+            tiled.render(state, program, metric, camera, out.data_ptr() if rank == 0 else None, (bg.data_ptr(), 4096, 2048, levels),
+                         features, cfg_values, o, stream, rotation=0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            if rank == 0:
+                alone = torch.zeros((H, W, 4), dtype=torch.float32, device=device)
+                check_state = gra.RenderState(W, H, local_rank)
+                check_state.render(program, metric, camera, alone.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features, cfg_values,
+                                   gra.frame_options(mode=gra.MODE_FUSED), stream)
+                torch.cuda.synchronize()
+                ok = int(torch.equal(alone, out))
+                del alone, check_state
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] rank {rank}: gr_render_frame_tiled failed on its first frame ({e})", file=sys.stderr)
+            ok = 0
+        done.set()
+        flag = torch.tensor([ok], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if rank == 0:
+                print("[bench] the frame assembled by gr_render_frame_tiled differs from rank 0's own frame; using the "
+                      "torch.distributed gather", file=sys.stderr)
+            tiled, gather_path = None, "torch.distributed.gather + un-permute (gr_render_frame_tiled failed its self-check)"
+            for slot in ring:
+                if rank == 0:
+                    slot.out = slot.gather.frame_buffer(device)
+            out = ring[0].out
+        else:
+            gather_path += "; first frame checked against rank 0's own frame"
     frame_index = [0]
 
     # a batch renderer knows the next frames' cameras: their tetrad + prepass (1.2 ms of pure latency, 507 waves) run on
@@ -365,6 +413,13 @@ def main():
     tag = ("kerr_a045_4k" if abs(args.spin - 0.45) < 1e-9 else "kerr_a09_4k" if abs(args.spin - 0.9) < 1e-9 else None) if kerr_4k else None
     tag = tag or f"{args.metric}_{W}x{H}"
     roofline, valu, stages = roofline_blocks(program, cfg_values, tag, elapsed / args.steps, avg_launch_s, launches)
+    if world > 1:   # every rank's trace launch: as timed in the overlapped region, and on its own
+        mine = torch.tensor([avg_launch_s * 1e3, stages.get("trace", 0.0), stages.get("prepass", 0.0)], dtype=torch.float64, device=device)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        extra["per_rank_trace_launch_ms"] = {"overlapped": [round(float(t[0]), 4) for t in everyone],
+                                             "one_at_a_time": [round(float(t[1]), 4) for t in everyone],
+                                             "prepass_one_at_a_time": [round(float(t[2]), 4) for t in everyone]}
     extra["valu_roofline"] = valu
     extra["stage_ms_sequential_frame"] = {k: round(v, 4) for k, v in stages.items()}
     if multi:

@@ -658,19 +658,20 @@ int gr_internal_fail(int code, const char* msg) { return fail((gr_status)code, m
 int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* term,
                             int prepass_width, int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3,
                             const void* cfg, const void* dfg, int image_height, int block_rows, int strip_rank, int strip_count,
-                            void* cell_attempts) {
+                            void* cell_attempts, int row_margin) {
     if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = 8; }
     if (block_rows <= 0 || strip_rank < 0 || strip_rank >= strip_count || image_height <= 0)
         return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
     void* args[] = {&camera_generic, &camera_quat, &term, &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg,
-                    &image_height, &block_rows, &strip_rank, &strip_count, &cell_attempts};
+                    &image_height, &block_rows, &strip_rank, &strip_count, &cell_attempts, &row_margin};
+    if (row_margin < 0) return fail(GR_ERROR_INVALID_ARGUMENT, "negative row margin");
     return launch(p, K_PREPASS_FUSED, stream, blocks((long long)prepass_width * prepass_height, 64), 1, 64, 1, args);
 }
 
 int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, float flip, const float basis_speed[3], void* position_generic_out,
                       void* e0_out, void* e1_out, void* e2_out, void* e3_out, const void* camera_quat, void* term, int prepass_width,
                       int prepass_height, const void* cfg, const void* dfg, int image_height, int block_rows, int strip_rank, int strip_count,
-                      void* cell_attempts) {
+                      void* cell_attempts, int row_margin) {
     if (!basis_speed) return fail(GR_ERROR_INVALID_ARGUMENT, "null basis speed");
     if (prepass_width < 0 || prepass_height < 0) return fail(GR_ERROR_INVALID_ARGUMENT, "negative prepass size");
     if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = 8; }
@@ -678,7 +679,9 @@ int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, fl
     if (image_height <= 0) image_height = prepass_height > 0 ? prepass_height * 16 : 16;
     float sx = basis_speed[0], sy = basis_speed[1], sz = basis_speed[2];
     void* args[] = {&position_cart, &flip, &sx, &sy, &sz, &position_generic_out, &e0_out, &e1_out, &e2_out, &e3_out, &camera_quat, &term,
-                    &prepass_width, &prepass_height, &cfg, &dfg, &image_height, &block_rows, &strip_rank, &strip_count, &cell_attempts};
+                    &prepass_width, &prepass_height, &cfg, &dfg, &image_height, &block_rows, &strip_rank, &strip_count, &cell_attempts,
+                    &row_margin};
+    if (row_margin < 0) return fail(GR_ERROR_INVALID_ARGUMENT, "negative row margin");
     long long cells = (long long)prepass_width * prepass_height;
     return launch(p, K_CAMERA_PREPASS, stream, blocks(cells > 0 ? cells : 1, 64), 1, 64, 1, args);
 }
@@ -687,7 +690,7 @@ int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, co
                      int prepass_width, int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3,
                      const void* cfg, const void* dfg) {
     return gr_prepass_fused_strips(p, stream, camera_generic, camera_quat, term, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg,
-                                   prepass_height * 16, 8, 0, 1, nullptr);
+                                   prepass_height * 16, 8, 0, 1, nullptr, 0);
 }
 
 // tiles (one wave each) a device traces: its row blocks cut into 8x8 tiles + per block the halo row in 64-pixel pieces; 0 when
@@ -732,8 +735,8 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
                         int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
-    if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && (rays_per_lane != 1 || strip_count > 1)))
-        return fail(GR_ERROR_INVALID_ARGUMENT, "lattice / pending_only: gr_trace_fused on a whole image only");
+    if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && rays_per_lane != 1))
+        return fail(GR_ERROR_INVALID_ARGUMENT, "lattice / pending_only: gr_trace_fused only");
     if (rays_per_lane == 2 && !p->fn[K_TRACE_PAIR])
         return fail(GR_ERROR_INVALID_ARGUMENT, "this program has no gr_trace_pair kernel (its expressions do not instantiate on pairs)");
     if (strip_count <= 1) {   // one block covering the image
@@ -747,7 +750,10 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         return fail(GR_ERROR_INVALID_ARGUMENT, "the last image row must not start a block (its filter reads the row above)");
     int local_blocks = gr_strip_local_blocks(height, block_rows, strip_rank, strip_count);
     long long waves_per_block = (long long)((width + T - 1) / T) * (block_rows / T) + (strip_count > 1 ? (width + 63) / 64 : 0);
-    if (lattice == 2) waves_per_block = (long long)((width / 2 + T - 1) / T) * ((height / 2 + T - 1) / T);   // tiles of the half-resolution grid
+    if (lattice == 2) {   // tiles of the whole half-resolution grid, whoever owns the rows (the kernel leaves the rows of others alone)
+        waves_per_block = (long long)((width / 2 + T - 1) / T) * ((height / 2 + T - 1) / T);
+        local_blocks = 1;
+    }
     // four tile-waves per workgroup (measured on MI355X, 4K Kerr: 64 -> 7.59 ms, 128 -> 7.43, 256 -> 7.24; one wave per SIMD
     // still leaves the full 512-VGPR budget to the heaviest metrics).  Experiment hooks: GR_TRACE_BLOCK=64|128|256 with the
     // kernel built with the same -DGR_TRACE_BLOCK through GR_EXTRA_FLAGS; GR_TRACE_PERSISTENT=0 launches one wave per tile.
@@ -811,9 +817,17 @@ int gr_trace_fused_adaptive(gr_program* p, void* stream, const void* camera_gene
                         e2, e3, cfg, dfg, attempt_counter, lattice, pending_only);
 }
 
-int gr_adaptive_refine(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg) {
-    void* args[] = {&rdata, &pending_count, &width, &height, &dfg};
+int gr_adaptive_refine_strips(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg,
+                              int block_rows, int strip_rank, int strip_count) {
+    if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + 7) / 8) * 8; }
+    if (block_rows <= 0 || block_rows % 8 != 0 || strip_rank < 0 || strip_rank >= strip_count)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
+    void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count};
     return launch(p, K_ADAPTIVE_REFINE, stream, (unsigned)((width / 2 + 15) / 16), (unsigned)((height / 2 + 15) / 16), 16, 16, args);
+}
+
+int gr_adaptive_refine(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg) {
+    return gr_adaptive_refine_strips(p, stream, rdata, pending_count, width, height, dfg, 0, 0, 1);
 }
 
 int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
@@ -828,7 +842,7 @@ int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args
     if (!a) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
     return trace_launch(p, 1, stream, a->camera_generic, a->camera_quat, a->render_data, a->width, a->height, a->block_rows, a->strip_rank,
                         a->strip_count, a->termination_buffer, a->prepass_width, a->prepass_height, a->e0, a->e1, a->e2, a->e3, a->cfg, a->dfg,
-                        a->attempt_counter, 1, 0, a->tile_order, a->waves_per_simd, &a->shading);
+                        a->attempt_counter, a->lattice == 2 ? 2 : 1, a->pending_only ? 1 : 0, a->tile_order, a->waves_per_simd, &a->shading);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

@@ -552,11 +552,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
 
     const int width = s->width, height = s->height;
     // The defaults of gr_features (adaptive_sampling on, as the reference's GUI) and of gr_frame_options (fused mode) work
-    // together: a whole frame is sampled adaptively on the fused path (half-resolution lattice, gr_adaptive_refine, second fused
-    // launch over the marked pixels; cl.cl:3234-3250, 5223-5345).  A device's share of a split frame is traced in full:
-    // adaptive sampling is an approximation of exactly that frame.
-    if (opt.mode == GR_MODE_FUSED && features.adaptive_sampling != 0 && !features.use_triangle_rendering && opt.strip_count > 1)
-        features.adaptive_sampling = 0;
+    // together: a frame is sampled adaptively on the fused path (half-resolution lattice, gr_adaptive_refine, second fused
+    // launch over the marked pixels; cl.cl:3234-3250, 5223-5345) - a device's share of a split frame too: it traces the lattice
+    // rows its blocks' decisions read (two rows of halo either side) and its rows come out as those of the whole frame.
     bool use_prepass = opt.use_prepass < 0 ? info.use_prepass != 0 : opt.use_prepass != 0;
     bool adaptive = features.adaptive_sampling != 0 && !features.use_triangle_rendering;
 
@@ -679,13 +677,14 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         const size_t cells = use_prepass ? (size_t)prepass_width * prepass_height : 0;
         const bool order_tiles = tile_order_enabled && use_prepass && !adaptive && 2 * cells <= (size_t)width * height &&
                                  (size_t)gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
+        const int prepass_margin = adaptive ? 2 : 0;   // the lattice rows beyond a block that its 2x2 decisions read
         auto cost_plane = [&](void* termination_buffer) -> void* { return order_tiles ? (void*)((unsigned int*)termination_buffer + cells) : nullptr; };
         if (!prefetched && one_launch_setup) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_camera_prepass(p, stream, s->camera_pos_cart, camera->flip, camera->basis_speed, s->camera_pos_generic, s->tetrad[0],
                                        s->tetrad[1], s->tetrad[2], s->tetrad[3], s->camera_quat, s->termination_buffer,
                                        use_prepass ? prepass_width : 0, use_prepass ? prepass_height : 0, s->cfg, s->dfg, height, block_rows,
-                                       strip_rank, strip_count, cost_plane(s->termination_buffer)));
+                                       strip_rank, strip_count, cost_plane(s->termination_buffer), prepass_margin));
             if (order_tiles)
                 GR_CHECK(gr_order_tiles(p, stream, s->termination_buffer, cost_plane(s->termination_buffer), prepass_width, prepass_height,
                                         width, height, block_rows, strip_rank, strip_count, s->tile_order));
@@ -694,7 +693,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_prepass_fused_strips(p, stream, s->camera_pos_generic, s->camera_quat, s->termination_buffer, prepass_width,
                                              prepass_height, s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg,
-                                             height, block_rows, strip_rank, strip_count, cost_plane(s->termination_buffer)));
+                                             height, block_rows, strip_rank, strip_count, cost_plane(s->termination_buffer), prepass_margin));
             if (order_tiles)
                 GR_CHECK(gr_order_tiles(p, stream, s->termination_buffer, cost_plane(s->termination_buffer), prepass_width, prepass_height,
                                         width, height, block_rows, strip_rank, strip_count, s->tile_order));
@@ -742,14 +741,22 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 // quarter of the primary rays (the pixels (2x, 2y)), then the blocks that need it refined by a second launch
                 const void* term = use_prepass ? s->termination_buffer : nullptr;
                 const int pw = use_prepass ? prepass_width : width, ph = use_prepass ? prepass_height : height;
-                GR_CHECK(gr_trace_fused_adaptive(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, term, pw, ph,
-                                                 s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, 2, 0));
+                gr_trace_fused_args a{};
+                a.camera_generic = s->camera_pos_generic; a.camera_quat = s->camera_quat; a.render_data = s->render_data;
+                a.width = width; a.height = height; a.block_rows = block_rows; a.strip_rank = strip_rank; a.strip_count = strip_count;
+                a.termination_buffer = term; a.prepass_width = pw; a.prepass_height = ph;
+                a.e0 = s->tetrad[0]; a.e1 = s->tetrad[1]; a.e2 = s->tetrad[2]; a.e3 = s->tetrad[3]; a.cfg = s->cfg; a.dfg = s->dfg;
+                a.attempt_counter = attempts;
+                a.lattice = 2;
+                GR_CHECK(gr_trace_fused_launch(p, stream, &a));
                 GR_CHECK(end(GR_STAGE_TRACE));
                 GR_CHECK(begin(GR_STAGE_ADAPTIVE));
                 HIP_CHECK(hipMemsetAsync(s->rays_adaptive_count, 0, 4, stream));
-                GR_CHECK(gr_adaptive_refine(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg));
-                GR_CHECK(gr_trace_fused_adaptive(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, term, pw, ph,
-                                                 s->tetrad[0], s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, 1, 1));
+                GR_CHECK(gr_adaptive_refine_strips(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows,
+                                                   strip_rank, strip_count));
+                a.lattice = 1;
+                a.pending_only = 1;
+                GR_CHECK(gr_trace_fused_launch(p, stream, &a));
                 GR_CHECK(end(GR_STAGE_ADAPTIVE));
             } else {
             if (rays_per_lane == 2)
@@ -802,14 +809,14 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                            slot->set.camera_pos_generic, slot->set.tetrad[0], slot->set.tetrad[1], slot->set.tetrad[2],
                                            slot->set.tetrad[3], slot->set.camera_quat, slot->set.termination_buffer, prepass_width,
                                            prepass_height, s->cfg, s->dfg, height, block_rows, r.strip_rank, strip_count,
-                                           cost_plane(slot->set.termination_buffer)));
+                                           cost_plane(slot->set.termination_buffer), prepass_margin));
             } else {
                 GR_CHECK(camera_setup(slot->stream, slot->set.camera_pos_cart, slot->set.camera_pos_generic, slot->set.tetrad, r.camera, r.time,
                                       slot->velocity));
                 GR_CHECK(gr_prepass_fused_strips(p, slot->stream, slot->set.camera_pos_generic, slot->set.camera_quat,
                                                  slot->set.termination_buffer, prepass_width, prepass_height, slot->set.tetrad[0],
                                                  slot->set.tetrad[1], slot->set.tetrad[2], slot->set.tetrad[3], s->cfg, s->dfg, height,
-                                                 block_rows, r.strip_rank, strip_count, cost_plane(slot->set.termination_buffer)));
+                                                 block_rows, r.strip_rank, strip_count, cost_plane(slot->set.termination_buffer), prepass_margin));
             }
             if (order_tiles)   // the look-ahead frame's order too: off the frame's critical path like its prepass
                 GR_CHECK(gr_order_tiles(p, slot->stream, slot->set.termination_buffer, cost_plane(slot->set.termination_buffer), prepass_width,

@@ -1895,6 +1895,17 @@ __device__ __forceinline__ unsigned int wave_slots(unsigned int trips, unsigned 
 // global block gb belongs to device gb % strip_count); a block is tiles_x * block_rows/8 tile-waves, and, when the image is
 // split, 64x1 "halo" waves tracing the row just below it, which the texture filter of the block's last row reads
 // (cl.cl:5509-5520).  strip_count == 1: one block covering the whole image.
+// Adaptive sampling on a split frame (halo of two rows).  A device that owns the row blocks strip_rank, strip_rank +
+// strip_count, ... needs the block decisions of the pixel-block rows y (even) with r0 <= y <= r0 + B for each of its blocks [r0, r0 + B)
+// - the row r0 + B is the halo row under the block that the texture filter reads - and for those the lattice rows y - 2 ... y + 2.
+__device__ __forceinline__ bool own_block_within(int y, int margin, int height, int block_rows, int strip_rank, int strip_count) {
+    // is there an own block b (b % strip_count == strip_rank, b * B < height) with b * B - margin <= y <= (b + 1) * B + margin ?
+    const int last = (y + margin) / block_rows;
+    for (int b = last; b >= 0 && (b + 1) * block_rows + margin >= y; b--)
+        if (b % strip_count == strip_rank && b * block_rows < height) return true;
+    return false;
+}
+
 // Shading inside the trace launch.  Of the 64 pixels of a tile, the 49 that are not in its last column or row have both neighbours
 // the texture filter looks at (the pixel to the right and the pixel below, cl.cl:5509-5546) in the same wave: their sky coordinates
 // come over by ds_bpermute and the wave writes the finished float4 pixels itself, straight from the registers the render-data
@@ -1917,9 +1928,13 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            const trace_shading& shading) {
     // Adaptive sampling on the fused path (cl.cl:3234-3250, 5223-5345): lattice = 2 traces the pixels (2x, 2y) only - the tiles
     // then cover the half-resolution grid - and pending_only = 1 traces the pixels gr_adaptive_refine marked (terminated ==
-    // GR_PENDING) and leaves every other record alone.  Neither is combined with a row split (strip_count == 1).
+    // GR_PENDING) and leaves every other record alone.  On a split frame (strip_count > 1) the lattice launch traces the lattice
+    // rows this device's decisions read, the second launch the marked pixels of its own rows and halo rows.
     const int image_width = width, image_height = height;
-    if (lattice == 2) { width /= 2; height /= 2; block_rows = ((height + 7) / 8) * 8; }
+    const int device_block_rows = block_rows, device_rank = strip_rank, device_count = strip_count;
+    // the lattice launch walks the tiles of the whole half-resolution grid whoever owns the rows; a device of a split frame
+    // traces the lattice rows its blocks' decisions read and leaves the others alone (below)
+    if (lattice == 2) { width /= 2; height /= 2; block_rows = ((height + 7) / 8) * 8; strip_rank = 0; strip_count = 1; }
     const int T = GR_TILE;
     const int tiles_x = (width + T - 1) / T;
     const int tile_rows = block_rows / T;
@@ -1940,6 +1955,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     if (cx >= width || cy >= height) return;
     cx *= lattice; cy *= lattice;
     width = image_width; height = image_height;
+    if (lattice == 2 && device_count > 1 && !own_block_within(cy, 2, height, device_block_rows, device_rank, device_count)) return;
     if (pending_only && rdata[cy * width + cx].terminated != GR_PENDING) return;
 
     // the prepass verdict first: a skipped pixel (58 % of the 4K Kerr frame) needs no ray at all
@@ -2287,14 +2303,16 @@ gr_trace_compact(const float4* __restrict__ g_generic_camera_in, const float4* _
 __device__ __forceinline__ void prepass_cell(int id, float4 camera, float4 camera_quat, float4 e0, float4 e1, float4 e2, float4 e3,
                                              int* __restrict__ termination_buffer, int prepass_width, int prepass_height, cfg_t cfg, dfg_t dfg,
                                              int image_height, int block_rows, int strip_rank, int strip_count,
-                                             unsigned int* __restrict__ cell_attempts) {
+                                             unsigned int* __restrict__ cell_attempts, int row_margin) {
     if (id >= prepass_width * prepass_height) return;
     int cx = id % prepass_width, cy = id / prepass_width;
     if (strip_count > 1) {
         // pixel rows whose stencil can touch cell row cy: round(y * ph / H) in [cy - 1, cy + 1], one row of slack either side for
         // the float rounding of that quotient (tests/test_distributed_cpu.py checks the rule by brute force)
-        long long lo = ((long long)(2 * cy - 3) * image_height) / (2 * prepass_height) - 1;
-        long long hi = ((long long)(2 * cy + 3) * image_height + 2 * prepass_height - 1) / (2 * prepass_height) + 1;
+        // row_margin: pixel rows beyond its blocks and halo rows the device also looks from (adaptive sampling: 2, the lattice rows
+        // its block decisions read)
+        long long lo = ((long long)(2 * cy - 3) * image_height) / (2 * prepass_height) - 1 - row_margin;
+        long long hi = ((long long)(2 * cy + 3) * image_height + 2 * prepass_height - 1) / (2 * prepass_height) + 1 + row_margin;
         if (lo < 0) lo = 0;
         if (hi > image_height - 1) hi = image_height - 1;
         // blocks b (rows b*B .. (b+1)*B inclusive of the halo row) that meet [lo, hi]: (b+1)*B >= lo and b*B <= hi
@@ -2319,10 +2337,10 @@ gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* _
                  int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                  const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                  cfg_t cfg_in, dfg_t dfg_in, int image_height, int block_rows, int strip_rank, int strip_count,
-                 unsigned int* __restrict__ cell_attempts) {
+                 unsigned int* __restrict__ cell_attempts, int row_margin) {
     GR_PARAMETERS_IN_REGISTERS
     prepass_cell(blockIdx.x * blockDim.x + threadIdx.x, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, termination_buffer,
-                 prepass_width, prepass_height, cfg, dfg, image_height, block_rows, strip_rank, strip_count, cell_attempts);
+                 prepass_width, prepass_height, cfg, dfg, image_height, block_rows, strip_rank, strip_count, cell_attempts, row_margin);
 }
 
 // cart_to_generic_kernel + init_basis_vectors + the prepass in ONE launch (the reference: three of its launches and the prepass
@@ -2337,7 +2355,8 @@ gr_camera_prepass(const float4* __restrict__ position_cart_in, float flip, float
                   float4* __restrict__ position_generic_out, float4* __restrict__ e0_out, float4* __restrict__ e1_out,
                   float4* __restrict__ e2_out, float4* __restrict__ e3_out, const float4* __restrict__ g_camera_quat,
                   int* __restrict__ termination_buffer, int prepass_width, int prepass_height, cfg_t cfg_in, dfg_t dfg_in,
-                  int image_height, int block_rows, int strip_rank, int strip_count, unsigned int* __restrict__ cell_attempts) {
+                  int image_height, int block_rows, int strip_rank, int strip_count, unsigned int* __restrict__ cell_attempts,
+                  int row_margin) {
     GR_PARAMETERS_IN_REGISTERS
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     const float4 in = *position_cart_in;
@@ -2354,7 +2373,7 @@ gr_camera_prepass(const float4* __restrict__ position_cart_in, float flip, float
         *e3_out = t.e[3];
     }
     prepass_cell(id, camera, *g_camera_quat, t.e[0], t.e[1], t.e[2], t.e[3], termination_buffer, prepass_width, prepass_height, cfg, dfg,
-                 image_height, block_rows, strip_rank, strip_count, cell_attempts);
+                 image_height, block_rows, strip_rank, strip_count, cell_attempts, row_margin);
 }
 
 // ---- the order the persistent trace hands its tiles out in -----------------------------------------
@@ -2479,12 +2498,14 @@ __device__ __forceinline__ render_data interpolate_render_data(render_data r1, r
 // order the work.  Same tests as the reference (cl.cl:5242-5282): boundary blocks always refine, differing termination flags
 // refine, otherwise the angular error across the block against the per-pixel angle times the threshold.
 extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, int* __restrict__ pending_count, int width, int height,
-                                              dfg_t dfg) {
+                                              dfg_t dfg, int block_rows, int strip_rank, int strip_count) {
     const int sx = blockIdx.x * blockDim.x + threadIdx.x;
     const int sy = blockIdx.y * blockDim.y + threadIdx.y;
     const int hw = width / 2, hh = height / 2;
     if (sx >= hw || sy >= hh) return;
     const int lsx = 2 * sx, lsy = 2 * sy;
+    // split frame: only the pixel blocks whose rows this device shades or reads as a halo row (their lattice neighbours were traced)
+    if (strip_count > 1 && !own_block_within(lsy, 0, height, block_rows, strip_rank, strip_count)) return;
     auto at = [&](int x, int y) -> render_data& { return rdat[y * width + x]; };
     bool refine = true;
     if (sx != 0 && sx != hw - 1 && sy != 0 && sy != hh - 1) {

@@ -253,11 +253,12 @@ int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, co
 /* the same for a device that owns only the row blocks strip_rank, strip_rank + strip_count, ... of an image of
  * image_height rows (see gr_trace_fused): cells none of its rows can look at are not traced and keep their old value.
  * cell_attempts (unsigned[prepass_width * prepass_height], may be NULL): the step attempts each cell's ray took, the cost
- * estimate gr_order_tiles works from */
+ * estimate gr_order_tiles works from.  row_margin: how many pixel rows beyond its blocks and their halo rows the device also
+ * traces from (0; adaptive sampling on a split frame: 2) */
 int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
                             void* termination_buffer, int prepass_width, int prepass_height,
                             const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg,
-                            int image_height, int block_rows, int strip_rank, int strip_count, void* cell_attempts);
+                            int image_height, int block_rows, int strip_rank, int strip_count, void* cell_attempts, int row_margin);
 
 /* gr_cart_to_generic + gr_init_basis_vectors + gr_prepass_fused_strips in one launch: the camera's metric coordinates and tetrad
  * are computed from the Cartesian camera inside the launch (and stored to position_generic_out / e*_out for gr_trace_fused), then
@@ -266,7 +267,7 @@ int gr_prepass_fused_strips(gr_program* p, void* stream, const void* camera_gene
 int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, float flip, const float basis_speed[3],
                       void* position_generic_out, void* e0_out, void* e1_out, void* e2_out, void* e3_out, const void* camera_quat,
                       void* termination_buffer, int prepass_width, int prepass_height, const void* cfg, const void* dfg,
-                      int image_height, int block_rows, int strip_rank, int strip_count, void* cell_attempts);
+                      int image_height, int block_rows, int strip_rank, int strip_count, void* cell_attempts, int row_margin);
 
 /* The order in which a persistent gr_trace_fused launch hands out its tiles: longest first, as estimated from what the prepass
  * rays around each tile cost (cell_attempts of gr_prepass_fused_strips / gr_camera_prepass), tiles on the shadow's edge before
@@ -289,6 +290,7 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
 /* gr_trace_fused with everything that only schedules it or rides along, by name:
  *   tile_order      gr_order_tiles' list (NULL: image order)
  *   waves_per_simd  1..8: at most that many persistent waves per SIMD (0: as many as the kernel's registers allow)
+ *   lattice, pending_only   the two launches of adaptive sampling (gr_trace_fused_adaptive), also on a split frame
  *   shading.out     not NULL: the launch also SHADES the pixels whose two filter neighbours lie in the same 8x8 tile - 49 of every
  *                   64 - from the registers their records were built in (the neighbours' sky coordinates come over by
  *                   ds_bpermute) and writes them to shading.out as gr_render would (compact_out as in gr_render_strips);
@@ -312,6 +314,8 @@ typedef struct gr_trace_fused_args {
     const void* tile_order;
     int waves_per_simd;
     gr_trace_shading shading;
+    int lattice;        /* 0 or 1: every pixel; 2: the pixels (2x, 2y) only (first launch of adaptive sampling) */
+    int pending_only;   /* 1: only the pixels gr_adaptive_refine marked (second launch of adaptive sampling) */
 } gr_trace_fused_args;
 int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args* args);
 /* the pixels such a launch leaves to shade: same arguments as gr_render_strips (strip_count <= 1: the whole image) */
@@ -332,6 +336,12 @@ int gr_trace_fused_adaptive(gr_program* p, void* stream, const void* camera_gene
                             const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg,
                             void* attempt_counter, int lattice, int pending_only);
 int gr_adaptive_refine(gr_program* p, void* stream, void* render_data, void* pending_count, int width, int height, const void* dfg);
+/* the same on a device's share of a split frame: only the 2x2 pixel blocks whose rows the device shades or reads as a halo row are
+ * decided.  The lattice launch before it (gr_trace_fused_launch with lattice = 2 and the strip description) traces the lattice
+ * rows those decisions read - two rows of halo either side of a block - and the launch after it (pending_only = 1, same strip
+ * description) the marked pixels of the device's rows; the rows equal those of the whole frame sampled adaptively. */
+int gr_adaptive_refine_strips(gr_program* p, void* stream, void* render_data, void* pending_count, int width, int height,
+                              const void* dfg, int block_rows, int strip_rank, int strip_count);
 
 /* gr_trace_fused with two rays per lane: a wave takes two neighbouring 8x8 tiles and every lane integrates one pixel of each,
  * all per-ray arithmetic in packed fp32 (v_pk_fma/mul/add_f32: one instruction, two rays).  Same arguments, same records;

@@ -211,9 +211,9 @@ def test_strip_prepass_cell_rule_covers_every_cell_a_rank_reads():
     of an own pixel row (or halo row) reads must be kept; and the rule should actually save work."""
     import math
 
-    def kept(cy, H, ph, B, rank, count):
-        lo = int(((2 * cy - 3) * H) / (2 * ph)) - 1          # C truncation towards zero
-        hi = ((2 * cy + 3) * H + 2 * ph - 1) // (2 * ph) + 1
+    def kept(cy, H, ph, B, rank, count, margin=0):
+        lo = int(((2 * cy - 3) * H) / (2 * ph)) - 1 - margin          # C truncation towards zero
+        hi = ((2 * cy + 3) * H + 2 * ph - 1) // (2 * ph) + 1 + margin
         lo, hi = max(lo, 0), min(hi, H - 1)
         b_lo, b_hi = max(int((lo - 1) / B), 0), hi // B      # block b holds rows b*B .. (b+1)*B (halo row included)
         first = b_lo + ((rank - b_lo) % count + count) % count
@@ -236,5 +236,13 @@ def test_strip_prepass_cell_rule_covers_every_cell_a_rank_reads():
                     keep = {c for c in range(ph) if kept(c, H, ph, B, rank, count)}
                     assert need <= keep, (H, B, count, rank, sorted(need - keep)[:5])
                     saved[(H, B, count, rank)] = 1 - len(keep) / ph
+                    # adaptive sampling (row_margin 2): also the lattice rows two beyond each block and its halo row
+                    need2 = set(need)
+                    for b in range(rank, total_blocks, count):
+                        for cy in range(max(b * B - 2, 0), min((b + 1) * B + 2, H - 1) + 1):
+                            ly = int(math.floor(np.float32(np.float32(cy / H) * np.float32(ph)) + 0.5))
+                            need2.update(c for c in (ly - 1, ly, ly + 1) if 0 <= c < ph)
+                    keep2 = {c for c in range(ph) if kept(c, H, ph, B, rank, count, margin=2)}
+                    assert need2 <= keep2, (H, B, count, rank, sorted(need2 - keep2)[:5])
     # 4K, 16-row blocks over 8 devices (the bench layout): a device needs 4 of every 8 cell rows
     assert all(saved[(2160, 16, 8, r)] > 0.45 for r in range(8))
