@@ -73,7 +73,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--measure-clock", action="store_true", help="count attempts in the timed frames too, so that the shader clock of the "
                     "overlapped launches can be read afterwards (two timestamp reads per wave; the counters cost an atomic per tile)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.fused_shading == 1:   # a build option of the programs (part of their cache key)
+        os.environ["GR_EXTRA_FLAGS"] = (os.environ.get("GR_EXTRA_FLAGS", "") + " -DGR_TILE_SHADING").strip()
+    return args
 
 
 def cpu_baseline(metric_name, cfg_values, features_kw, target_seconds):

@@ -130,6 +130,7 @@ _SIGNATURES = {
                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gr_program_has_trace_pair": (c_int, [c_void_p]),
     "gr_program_serial": (ctypes.c_ulonglong, [c_void_p]),
+    "gr_program_has_tile_shading": (c_int, [c_void_p]),
     "gr_program_build_key": (c_char_p, [c_void_p]),
     "gr_trace_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),

@@ -301,6 +301,7 @@ struct gr_program {
     unsigned int* tickets = nullptr;
     std::atomic<unsigned> next_ticket{0};
     int compute_units = 256;
+    bool tile_shading = false;   // built with -DGR_TILE_SHADING: gr_trace_fused can shade the inner pixels of its tiles
     int resident_groups_per_cu[K_COUNT] = {};   // of the trace kernels at the launch's workgroup size: 0 = not asked yet
     std::string arguments;
     std::string key;   // what the code object was built from: kernel source, every compile option, hiprtc version (16 hex digits)
@@ -441,6 +442,10 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
     p->key = key;
     p->device = device;
     p->arguments = argument_string;
+    {
+        const char* extra = getenv("GR_EXTRA_FLAGS");
+        p->tile_shading = p->arguments.find("-DGR_TILE_SHADING") != std::string::npos || (extra && strstr(extra, "-DGR_TILE_SHADING"));
+    }
     static std::atomic<unsigned long long> next_serial{1};
     p->serial = next_serial.fetch_add(1);
     HIP_CHECK(hipModuleLoadData(&p->module, code.data()));
@@ -797,6 +802,8 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     // the kernel's trace_shading, by value (same layout)
     struct { void* out; const void* bg1; const void* bg2; int bg_width, bg_height, bg_levels, most_probes, compact_out; } shading = {};
     if (shading_in && shading_in->out) {
+        if (!p->tile_shading)
+            return fail(GR_ERROR_INVALID_ARGUMENT, "in-tile shading: the program was built without -DGR_TILE_SHADING in its argument string");
         if (rays_per_lane != 1 || lattice != 1 || pending_only || width % T != 0 || height % T != 0)
             return fail(GR_ERROR_INVALID_ARGUMENT, "in-tile shading: gr_trace_fused on every pixel of an image whose sides are multiples of 8");
         shading.out = shading_in->out; shading.bg1 = shading_in->background1; shading.bg2 = shading_in->background2;
@@ -854,6 +861,7 @@ int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const
 }
 
 int gr_program_has_trace_pair(const gr_program* p) { return p && p->fn[K_TRACE_PAIR] ? 1 : 0; }
+int gr_program_has_tile_shading(const gr_program* p) { return p && p->tile_shading ? 1 : 0; }
 
 int gr_trace_compact(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
                      int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,

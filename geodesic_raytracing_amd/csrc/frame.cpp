@@ -775,9 +775,10 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.tile_order = order_tiles ? s->tile_order : nullptr;
                 a.waves_per_simd = opt.trace_waves_per_simd;
                 // the trace shades the pixels whose filter neighbours are in their own tile; gr_render_seams below does the rest
-                shade_in_trace = out && opt.fused_shading == 1 && width % 8 == 0 && height % 8 == 0;   // default: off, on measurement
-                if (opt.fused_shading == 1 && !shade_in_trace && out)
-                    return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused_shading = 1: width and height must be multiples of 8");
+                shade_in_trace = out && opt.fused_shading == 1 && width % 8 == 0 && height % 8 == 0 && gr_program_has_tile_shading(p);
+                if (opt.fused_shading == 1 && !shade_in_trace && out)   // default: off, on measurement
+                    return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT,
+                                            "fused_shading = 1: needs a program built with -DGR_TILE_SHADING and width, height multiples of 8");
                 if (shade_in_trace) {
                     a.shading.out = out; a.shading.background1 = bg1; a.shading.background2 = bg2; a.shading.bg_width = bg_width;
                     a.shading.bg_height = bg_height; a.shading.bg_levels = bg_levels; a.shading.max_probes = opt.max_probes;

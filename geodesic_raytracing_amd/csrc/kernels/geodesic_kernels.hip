@@ -1910,7 +1910,8 @@ __device__ __forceinline__ bool own_block_within(int y, int margin, int height, 
 // the texture filter looks at (the pixel to the right and the pixel below, cl.cl:5509-5546) in the same wave: their sky coordinates
 // come over by ds_bpermute and the wave writes the finished float4 pixels itself, straight from the registers the render-data
 // record was built in.  The 15 pixels of the last column and row need records other waves write; gr_render shades those in a
-// second, small launch (seams_only).  out == NULL: no shading here (gr_render does all of it).
+// second, small launch (seams_only).  out == NULL: no shading here (gr_render does all of it).  Compiled into programs whose
+// argument string carries -DGR_TILE_SHADING (gr_program_has_tile_shading); measured slower than the separate pass, DESIGN.md 4.
 struct trace_shading {
     float4* out;
     const uchar4* bg1_texels;
@@ -1998,7 +1999,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                dfg, GET_FEATURE(redshift, dfg) != 0);
     }
     rdata[cy * width + cx] = dat;
-#ifndef GR_NO_TILE_SHADING   // experiment: the kernel without its shading part (shading.out must then be NULL)
+#ifdef GR_TILE_SHADING   // programs built with -DGR_TILE_SHADING only: carried along unused, the call's spills add 0.12 GB of scratch traffic per 4K launch
     if (shading.out && lattice == 1 && !pending_only && within < tiles_x * tile_rows) {
         // every lane of the tile that holds a pixel hands its sky coordinates to the lanes left of and above it
         const float2 beside = make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) * 4, __float_as_int(dat.tex_coord.x))),

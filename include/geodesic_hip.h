@@ -295,7 +295,8 @@ int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, cons
  *                   64 - from the registers their records were built in (the neighbours' sky coordinates come over by
  *                   ds_bpermute) and writes them to shading.out as gr_render would (compact_out as in gr_render_strips);
  *                   gr_render_seams then shades the last column and row of every tile from the records.  Width and height
- *                   must be multiples of 8.  The records are written either way. */
+ *                   must be multiples of 8, and the program must have been built with -DGR_TILE_SHADING appended to its argument
+ *                   string (gr_program_has_tile_shading).  The records are written either way. */
 typedef struct gr_trace_shading {
     void* out;                       /* float4 per pixel; NULL = no shading in the trace launch */
     const void* background1;
@@ -355,6 +356,8 @@ int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const
                   const void* e0, const void* e1, const void* e2, const void* e3,
                   const void* cfg, const void* dfg, void* attempt_counter);
 int gr_program_has_trace_pair(const gr_program* p);   /* 1 / 0 */
+/* 1 when the program's argument string (or GR_EXTRA_FLAGS) carried -DGR_TILE_SHADING: its gr_trace_fused can shade (gr_trace_shading) */
+int gr_program_has_tile_shading(const gr_program* p);
 /* Process-unique identity of a program object (never reused, unlike its address); 0 for NULL. */
 unsigned long long gr_program_serial(const gr_program* p);
 /* What the program's code object was built from - kernel source, every compile option, hiprtc version - as 16 hex digits (the
@@ -425,8 +428,9 @@ typedef struct gr_frame_options {
     int rays_per_lane;     /* fused mode without compaction: 1 = gr_trace_fused, 2 = gr_trace_pair (error if the program lacks it),
                             * 0 = library default: 2 where the program has the pair kernel, else 1 (GR_TRACE_RAYS_PER_LANE=1|2 overrides) */
     int fused_shading;     /* fused mode: 1 = the trace launch shades the 49 of every 64 pixels whose filter neighbours are in the same
-                            * tile and gr_render_seams the rest (needs width and height to be multiples of 8, one ray per lane, no
-                            * compaction, no adaptive sampling); 0 or -1 (library default) = gr_render shades every pixel.  Off by
+                            * tile and gr_render_seams the rest (needs a program built with -DGR_TILE_SHADING, width and height
+                            * multiples of 8, one ray per lane, no compaction, no adaptive sampling; an error otherwise);
+                            * 0 or -1 (library default) = gr_render shades every pixel.  Off by
                             * default on measurement: 4K Kerr, three frames in flight, 1 723 against 1 743 Mrays/s - the shading
                             * arithmetic moves into the trace launch, and the separate pass was already hidden behind the next
                             * frame's trace */

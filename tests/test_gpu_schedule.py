@@ -106,7 +106,9 @@ def kerr_frame(adaptive=0, **options):
     metric = gra.Metric("kerr_boyer", SCRIPTS)
     cfgv = metric.cfg_values(a=0.45)
     feats = metric.features(adaptive_sampling=adaptive)
-    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    # shading inside the trace launch is a build option of the program
+    extra = " -DGR_TILE_SHADING" if options.get("fused_shading") == 1 else ""
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv) + extra, 0)
     state = gra.RenderState(W, H, 0)
     dbg, levels = background()
     rows = options.pop("out_rows", H)
@@ -152,3 +154,16 @@ def test_adaptive_sampling_on_a_split_frame_gives_the_rows_of_the_whole_frame(co
         rows = np.concatenate([np.arange(b * block_rows, min((b + 1) * block_rows, H)) for b in blocks])
         share = kerr_frame(adaptive=1, strip_rank=rank, strip_count=count, block_rows=block_rows, compact_out=1, out_rows=len(rows))
         assert share.tobytes() == whole[rows].tobytes(), (count, block_rows, rank)
+
+
+def test_shading_inside_the_trace_launch_needs_a_program_built_for_it():
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    feats, cfgv = metric.features(adaptive_sampling=0), metric.cfg_values(a=0.45)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    assert lib.gr_program_has_tile_shading(prog.handle) == 0
+    state = gra.RenderState(W, H, 0)
+    dbg, levels = background()
+    out = DeviceBuffer(0, W * H * 16)
+    with pytest.raises(gra.GeodesicError):
+        state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv,
+                     gra.frame_options(mode=gra.MODE_FUSED, fused_shading=1))
