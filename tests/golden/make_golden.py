@@ -97,6 +97,12 @@ POLAR_CASES = {
                                     camera_pos=[0.9053243236344846, 0.34132324238627365, -7.772548711815563, 5.744398311974292],
                                     camera_quat=[-0.41112675071678806, 0.2556906394720302, 0.05289661426400266, 0.873383672809863],
                                     features=dict(redshift=1, universe_size=30.0, max_precision_radius=14.0)),
+    # round-2 soak (seed 21, 297 cases on the ping-pong loop): the one case over the 1 % mask
+    "kerr_axis_21_122": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(64, 36), cfg=dict(a=0.1381855720874321),
+                             camera_pos=[0.8371838318614235, -4.5378246441429795, -4.083357545045045, -3.509221548845313],
+                             camera_quat=[-0.8104286000020418, -0.1529374610823953, 0.3350814866343691, 0.45556120841364733],
+                             basis_speed=[-0.1830985419023946, 0.24267198206320056, 0.11756292491315451],
+                             features=dict(field_of_view=110.0, universe_size=30.0)),
 }
 
 # camera riding a timelike geodesic (boost_tetrad .. handle_interpolating_geodesic): name -> spec
