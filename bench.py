@@ -161,8 +161,11 @@ def main():
     plan = grd.StripPlan(H, world, block_rows=args.block_rows)
     in_flight = max(1, min(args.frames_in_flight, 8)) if fused else 1
     # with frames in flight a trace launch takes 4 of the SIMDs' wave slots instead of all (6 for the Kerr kernel): the launches
-    # then share the device and one drains while the next is in full swing (measured +2-3 %; one frame at a time: all slots)
-    waves_per_launch = args.trace_waves_per_simd if args.trace_waves_per_simd >= 0 else (4 if (in_flight >= 3 and world == 1) else 0)
+    # then share the device and one drains while the next is in full swing (measured +2-3 %; one frame at a time: all slots).
+    # A rank's share of a frame split 4 or 8 ways is so few tiles that 2 slots are best (tools/strip_probe.py, one of 8 ranks:
+    # 0.760 ms per frame with all slots, 0.732 with 4, 0.711 with 3, 0.703 with 2; one of 4: 1.327 / 1.339 / 1.338 / 1.309)
+    waves_per_launch = args.trace_waves_per_simd if args.trace_waves_per_simd >= 0 else (
+        0 if in_flight < 3 else 4 if world == 1 else 2 if world >= 4 else 0)
 
     # N > 1: the C ABI's gr_render_frame_tiled (csrc/tiled.cpp) - this rank's share of the rows, then per block an ncclSend /
     # ncclRecv straight to the block's rows of rank 0's frame (no staging, no un-permute).  GR_BENCH_GATHER=torch selects the

@@ -30,7 +30,8 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             counter[0] += 1
             state, out, stream = states[k], outs[k], streams[k].cuda_stream
             kf = counter[0] - 1
-            o = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=(kf % world) if rotate else 0, strip_count=world, block_rows=BLOCK, compact_out=1)
+            o = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=(kf % world) if rotate else 0, strip_count=world, block_rows=BLOCK, compact_out=1,
+                                  trace_waves_per_simd=int(os.environ.get("STRIP_PROBE_WAVES", "0")))
             if rotate:
                 o.next_strip_rank = (kf + inflight) % world
                 o.next_strip_rank2 = (kf + 2 * inflight) % world
