@@ -239,7 +239,8 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     // launch on its own: free build 1 400 Mrays/s / 6.7 ms; held to 96 VGPRs (5 waves, nothing spilled) 1 492 / 6.5; to 80 (6
     // waves, 60 bytes per lane spilled, none of it inside the loop's attempts) 1 535 / 6.2; to 72 (7 waves, 84 bytes) 1 530 / 6.2.
     // Rule: rebuild with the register budget of five sixths of what the free build took, rounded down to an occupancy step,
-    // and keep that build unless it spills more than 64 bytes per lane.
+    // and keep that build unless it spills more than 96 bytes per lane (the exit state is 56; the same source compiles to 52-72 B
+    // of spill from one hiprtc run to the next, and a limit next to that number flipped the decision with it).
     bool tuned_by_caller = false;
     for (auto& o : opts) tuned_by_caller |= o.rfind("-DGR_FUSED_WAVES", 0) == 0 || o.rfind("-DGR_TRACE_WAVES", 0) == 0;
     const char* tuning = getenv("GR_OCCUPANCY_TUNING");
@@ -260,8 +261,8 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
                 const bool built = build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2);
                 if (getenv("GR_VERBOSE_BUILD"))
                     fprintf(stderr, "[gr] gr_trace_fused: free build %d VGPRs / %d B scratch; held to %d waves: %d VGPRs / %d B scratch%s\n", vgprs,
-                            scratch, target_waves, v2, s2, built && s2 <= scratch + 64 ? " (kept)" : " (dropped)");
-                if (built && s2 <= scratch + 64) code.swap(code2);
+                            scratch, target_waves, v2, s2, built && s2 <= scratch + 96 ? " (kept)" : " (dropped)");
+                if (built && s2 <= scratch + 96) code.swap(code2);
             }
         }
     }
@@ -710,7 +711,7 @@ static long long device_tile_count(int width, int height, int block_rows, int st
 }
 
 long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_rank, int strip_count) {
-    return (16 + 2 * device_tile_count(width, height, block_rows, strip_rank, strip_count)) * 4;   // header, list, classes
+    return (32 + 2 * device_tile_count(width, height, block_rows, strip_rank, strip_count)) * 4;   // header (2 x 16 classes), list, classes
 }
 
 int gr_order_tiles(gr_program* p, void* stream, const void* term, const void* cell_attempts, int prepass_width, int prepass_height,
@@ -722,7 +723,7 @@ int gr_order_tiles(gr_program* p, void* stream, const void* term, const void* ce
     if (tiles <= 0 || tiles > 0x7fffffff) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_order_tiles: bad image or strip description");
     int total = (int)tiles;
     HIP_CHECK(hipSetDevice(p->device));
-    HIP_CHECK(hipMemsetAsync(tile_order, 0, 64, (hipStream_t)stream));
+    HIP_CHECK(hipMemsetAsync(tile_order, 0, 128, (hipStream_t)stream));
     for (int phase = 0; phase < 2; phase++) {
         void* args[] = {&term, &cell_attempts, &prepass_width, &prepass_height, &width, &height, &block_rows, &strip_rank, &strip_count,
                         &total, &tile_order, &phase};

@@ -106,8 +106,17 @@ struct dynamic_feature_config {
 #endif
 // render_data.terminated of a pixel that gr_adaptive_refine wants traced (the reference's values are 0, 1, 2)
 #define GR_PENDING (-1)
-#define GR_TILE_ORDER_HEADER 16   // words in front of gr_order_tiles' list: 8 class counts, 8 class cursors
-#define GR_TILE_CLASSES 8
+#define GR_TILE_CLASSES 16
+#define GR_TILE_ORDER_HEADER (2 * GR_TILE_CLASSES)   // words in front of gr_order_tiles' list: class counts, class cursors
+#ifndef GR_TILE_COST_REACH
+#define GR_TILE_COST_REACH 1      // cells either side of the tile centre's whose rays' costs count for the tile's class
+#endif
+#ifndef GR_TILE_CLASS_STEPS
+#define GR_TILE_CLASS_STEPS 1     // cost classes of gr_order_tiles per octave of attempts (finer ones measured no better)
+#endif
+#ifndef GR_AGING_PRIORITY
+#define GR_AGING_PRIORITY 0      // experiment: waves that have integrated one tile for long rise in issue priority (measured: no effect)
+#endif
 #ifndef GR_SCALAR_INTERLEAVE
 #define GR_SCALAR_INTERLEAVE 24   // dummy scalar adds per Verlet attempt woven into the acceleration's vector stretch (0: none)
 #endif
@@ -879,6 +888,16 @@ __device__ __forceinline__ int early_terminate(int x, int y, int w, int h, const
     if (x < 0 || y < 0 || x > w - 1 || y > h - 1) return 0;
     return term[y * w + x] == 1;
 }
+// the 5-point stencil of init_rays_generic (cl.cl:3213-3232) with all five cells read at once - clamped coordinates, the verdict
+// of a cell outside the grid discarded afterwards - instead of a chain of conditional loads: a skipped tile is nothing but these
+// loads' latency (measured 45 us per skipped tile with the chain, when few other waves are left to hide it)
+__device__ __forceinline__ bool early_terminate_stencil(int lx, int ly, int w, int h, const int* __restrict__ term) {
+    const int x0 = min(max(lx - 1, 0), w - 1), x1 = min(max(lx, 0), w - 1), x2 = min(max(lx + 1, 0), w - 1);
+    const int y0 = min(max(ly - 1, 0), h - 1), y1 = min(max(ly, 0), h - 1), y2 = min(max(ly + 1, 0), h - 1);
+    const int left = term[y1 * w + x0], centre = term[y1 * w + x1], right = term[y1 * w + x2], up = term[y0 * w + x1], down = term[y2 * w + x1];
+    const bool inside = lx - 1 >= 0 && lx + 1 <= w - 1 && ly - 1 >= 0 && ly + 1 <= h - 1;   // any cell outside: not skipped
+    return inside & (left == 1) & (centre == 1) & (right == 1) & (up == 1) & (down == 1);
+}
 
 // ------------------------------------------------------------------------------------------------
 // the integrator (cl.cl:3273-3346, 3400-3456, 3954-4247)
@@ -1337,6 +1356,22 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
     {
         const trig_flavour<false> polynomial;
         for (;;) {
+#if GR_AGING_PRIORITY
+            // A wave that has been on its tile for long gets issue priority over its neighbours on the SIMD.  A launch (and, for a
+            // device's share of a split frame, the frame) ends when its slowest wave ends, and the slowest waves hold the tiles
+            // with rays next to the shadow's edge: up to ~5 700 attempts, 7 ms when six waves share the SIMD evenly, 2.6 ms for a
+            // wave that need not wait.  The total work is unchanged - the short tiles next to it take a little longer each.
+            // Every 256 trips the wave looks at the step budget of its first live lane (uniform up to the rare rejections).
+            if (!RESUMABLE) {
+                const unsigned int left = (unsigned int)__builtin_amdgcn_readfirstlane((int)budget);
+                if (__builtin_expect((left & 511u) < 2u, 0)) {
+                    const unsigned int done = (unsigned int)loop_limit - left;
+                    if (done >= 3072u) __builtin_amdgcn_s_setprio(3);
+                    else if (done >= 1536u) __builtin_amdgcn_s_setprio(2);
+                    else if (done >= 768u) __builtin_amdgcn_s_setprio(1);
+                }
+            }
+#endif
             float4 p1, v1, a1;
             float ds_used, running_before;
             if (attempt(polynomial, p0, v0, a0, p1, v1, a1, ds_used, running_before)) {
@@ -1926,7 +1961,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            int prepass_height, const float4* __restrict__ e0, const float4* __restrict__ e1,
                                            const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
                                            unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
-                                           const trace_shading& shading) {
+                                           const trace_shading& shading, bool known_skipped) {
     // Adaptive sampling on the fused path (cl.cl:3234-3250, 5223-5345): lattice = 2 traces the pixels (2x, 2y) only - the tiles
     // then cover the half-resolution grid - and pending_only = 1 traces the pixels gr_adaptive_refine marked (terminated ==
     // GR_PENDING) and leaves every other record alone.  On a split frame (strip_count > 1) the lattice launch traces the lattice
@@ -1960,19 +1995,15 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     if (pending_only && rdata[cy * width + cx].terminated != GR_PENDING) return;
 
     // the prepass verdict first: a skipped pixel (58 % of the 4K Kerr frame) needs no ray at all
-    int terminated = 0;
-    if (!pending_only && termination_buffer && prepass_width != width && prepass_height != height) {
+    // known_skipped: a tile of gr_order_tiles' last class - the 5x5 cells around it are all in the shadow, and the stencil of every
+    // one of its pixels lies inside those (a pixel rounds to a cell at most one from the tile centre's) - needs no look-up at all
+    int terminated = known_skipped ? 2 : 0;
+    if (!known_skipped && !pending_only && termination_buffer && prepass_width != width && prepass_height != height) {
         float fx = exact_ratio(cx, width);
         float fy = exact_ratio(cy, height);
         int lx = (int)roundf(fx * prepass_width);
         int ly = (int)roundf(fy * prepass_height);
-        if (early_terminate(lx - 1, ly, prepass_width, prepass_height, termination_buffer) &&
-            early_terminate(lx, ly, prepass_width, prepass_height, termination_buffer) &&
-            early_terminate(lx + 1, ly, prepass_width, prepass_height, termination_buffer) &&
-            early_terminate(lx, ly - 1, prepass_width, prepass_height, termination_buffer) &&
-            early_terminate(lx, ly + 1, prepass_width, prepass_height, termination_buffer)) {
-            terminated = 2;
-        }
+        if (early_terminate_stencil(lx, ly, prepass_width, prepass_height, termination_buffer)) terminated = 2;
     }
     render_data dat;
     unsigned int tries = 0;
@@ -2053,6 +2084,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
     // 10 ns a ticket whoever asks - nothing next to a tile's 0.1-1 ms of tracing, but the 75 000 skipped tiles of the 4K Kerr
     // frame, handed out back to back at the end of the list, would add 0.7 ms of pure ticket traffic to the launch.
     int held = 0, cursor = 0;   // tiles this wave still holds from its last ticket, and where in the list they start
+    bool known_skipped = false;  // the ticket was a chunk of the last class
     const int singles = (tile_counter && tile_order) ? total_waves - (int)tile_order[GR_TILE_CLASSES - 1] : total_waves;
     for (;;) {
         if (tile_counter) {
@@ -2061,6 +2093,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                 if (lane == 0) ticket = atomicAdd(tile_counter, 1u);
                 cursor = (int)__builtin_amdgcn_readfirstlane(ticket);
                 held = 1;
+                known_skipped = tile_order && cursor >= singles;
                 if (cursor >= singles) {
                     cursor = singles + (cursor - singles) * GR_SKIP_CHUNK;
                     held = total_waves - cursor < GR_SKIP_CHUNK ? total_waves - cursor : GR_SKIP_CHUNK;
@@ -2076,8 +2109,24 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
         // them is hoisted out of the tile loop and held in registers across the integrator (94 instead of 64 VGPRs, i.e.
         // 5 instead of 8 waves per SIMD).  Re-reading 96 bytes through the scalar cache per tile is free by comparison.
         asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
+#if GR_AGING_PRIORITY
+        __builtin_amdgcn_s_setprio(0);   // a new tile starts young
+#endif
+#ifdef GR_PROBE_LIFE_HISTOGRAM
+        const unsigned long long tile_began = attempt_counter ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
         trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
-                   termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading);
+                   termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
+                   known_skipped && lattice == 1 && !pending_only);
+#ifdef GR_PROBE_LIFE_HISTOGRAM   // per class of gr_order_tiles: tiles, summed and longest duration (10 ns ticks) in words 128..151 of the block
+        if (attempt_counter && tile_order && tile_counter && lane == 0) {
+            const unsigned long long took = __builtin_amdgcn_s_memrealtime() - tile_began;
+            const unsigned int cls = tile_order[GR_TILE_ORDER_HEADER + total_waves + wave] % GR_TILE_CLASSES;
+            atomicAdd(attempt_counter + 128 + cls * 3, 1ull);
+            atomicAdd(attempt_counter + 129 + cls * 3, took);
+            atomicMax(attempt_counter + 130 + cls * 3, took);
+        }
+#endif
 #ifdef GR_TRACE_SINGLE_TILE   // experiment: one tile per wave only (launch with GR_TRACE_PERSISTENT=0)
         break;
 #else
@@ -2126,11 +2175,7 @@ __device__ __forceinline__ bool prepass_skips_pixel(int cx, int cy, int width, i
     float fy = exact_ratio(cy, height);
     int lx = (int)roundf(fx * prepass_width);
     int ly = (int)roundf(fy * prepass_height);
-    return early_terminate(lx - 1, ly, prepass_width, prepass_height, termination_buffer) &&
-           early_terminate(lx, ly, prepass_width, prepass_height, termination_buffer) &&
-           early_terminate(lx + 1, ly, prepass_width, prepass_height, termination_buffer) &&
-           early_terminate(lx, ly - 1, prepass_width, prepass_height, termination_buffer) &&
-           early_terminate(lx, ly + 1, prepass_width, prepass_height, termination_buffer);
+    return early_terminate_stencil(lx, ly, prepass_width, prepass_height, termination_buffer);
 }
 
 #ifdef GR_TWO_RAYS_PER_LANE
@@ -2382,11 +2427,13 @@ gr_camera_prepass(const float4* __restrict__ position_cart_in, float flip, float
 // out in image order the 4K Kerr launch spent its last 1.4 of 6.3 ms draining (tickets gone at 4.9 ms; 6 waves share a SIMD,
 // so an average traced tile of ~500 attempts takes 0.6 ms and the tiles on the shadow's edge several times that).  The prepass
 // has already traced one ray per 16x16 pixels: what those rays cost is a fair estimate of what the tiles around them will
-// cost, so the tiles are handed out longest first - classes by the most expensive ray among the 3x3 cells around the tile's
-// centre, tiles that straddle the shadow's edge first of all, tiles the prepass lets skip (a store per pixel) last, where they
-// fill the slots of the draining launch.  Scheduling only: which wave traces a tile and when has no influence on its rays.
+// cost, so the tiles are handed out longest first - 16 classes: tiles that straddle the shadow's edge first of all, then by the
+// most expensive ray among the cells around the tile's centre, an octave of attempts per class, tiles no pixel of which needs a
+// ray (a store per pixel) last.  That is for a device's share of a split frame, where a wave slot gets one or two tiles and which
+// comes last decides when the launch ends; on a whole 4K frame (nine traced tiles per slot) image order measured 2 % faster -
+// the longest tiles take 7 ms when six of them share a SIMD from the start, 3.5 ms next to short tiles that keep restarting.  Scheduling only: which wave traces a tile and when has no influence on its rays.
 // Two launches over the device's tiles: phase 0 counts the classes, phase 1 deals every tile a place in its class's range
-// (order within a class: as the atomics fall, i.e. roughly image order).  list[0..7] counts, [8..15] cursors, then the tiles,
+// (order within a class: as the atomics fall, i.e. roughly image order).  list[0..15] counts, [16..31] cursors, then the tiles,
 // then the tiles' classes (scratch between the two phases).
 __device__ __forceinline__ int tile_cost_class(int tile, int width, int height, int block_rows, int strip_rank, int strip_count,
                                                const int* __restrict__ termination_buffer, const unsigned int* __restrict__ cell_attempts,
@@ -2396,9 +2443,13 @@ __device__ __forceinline__ int tile_cost_class(int tile, int width, int height, 
         !trace_slot_to_pixel((unsigned)tile * 64u, width, height, block_rows, strip_rank, strip_count, cx, cy))
         return GR_TILE_CLASSES - 1;   // padding: nothing to trace
     const int lx = (int)roundf(exact_ratio(cx, width) * prepass_width), ly = (int)roundf(exact_ratio(cy, height) * prepass_height);
+    // the halo pieces of a split frame are 64 pixels of one row, not a tile: four cells wide, so the promise of the last class
+    // (below) cannot be made for them
+    const int tiles_in_block = ((width + GR_TILE - 1) / GR_TILE) * (block_rows / GR_TILE);
+    const bool halo_piece = strip_count > 1 && tile % (tiles_in_block + (width + 63) / 64) >= tiles_in_block;
     // a pixel's stencil reaches one cell beyond the cell it rounds to, and the pixels of a tile round to cells up to one away
-    // from the centre's: shadow flags over 5x5 cells (a tile put in the last class by mistake would be traced as one of
-    // GR_SKIP_CHUNK tiles by a single wave), costs over the 3x3 next to the tile
+    // from the centre's: shadow flags over 5x5 cells (the last class promises that no pixel of the tile needs a ray), costs over
+    // the cells within GR_TILE_COST_REACH
     int in_shadow = 0;
     unsigned int dearest = 0;
     // every cell is read, at clamped coordinates, whether it counts or not: 50 independent loads in flight instead of a chain of
@@ -2411,14 +2462,15 @@ __device__ __forceinline__ int tile_cost_class(int tile, int width, int height, 
             const bool inside = x == lx + dx && y == ly + dy;   // outside the grid: never "skip" (early_terminate)
             const int flag = termination_buffer[y * prepass_width + x];
             in_shadow += (inside && flag == 1) ? 1 : 0;
-            if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) {
-                const unsigned int a = cell_attempts[y * prepass_width + x];
-                dearest = (inside && a > dearest) ? a : dearest;
-            }
+            const unsigned int a = cell_attempts[y * prepass_width + x];
+            const bool near = dx >= -GR_TILE_COST_REACH && dx <= GR_TILE_COST_REACH && dy >= -GR_TILE_COST_REACH && dy <= GR_TILE_COST_REACH;
+            dearest = (inside && near && a > dearest) ? a : dearest;
         }
-    if (in_shadow == 25) return GR_TILE_CLASSES - 1;
+    if (in_shadow == 25 && !halo_piece) return GR_TILE_CLASSES - 1;
     if (in_shadow > 0) return 0;
-    return dearest >= 2048u ? 1 : dearest >= 1024u ? 2 : dearest >= 512u ? 3 : dearest >= 256u ? 4 : dearest >= 128u ? 5 : 6;
+    // classes 1 .. 14 by the dearest ray, GR_TILE_CLASS_STEPS classes per octave of attempts, dearest first, < 256 (128) last
+    const int steps = (int)((float)GR_TILE_CLASS_STEPS * __log2f((float)(dearest > 128u ? dearest : 128u) * (1.f / 128.f)));
+    return GR_TILE_CLASSES - 2 - (steps > 13 ? 13 : steps);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)

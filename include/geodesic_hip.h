@@ -271,7 +271,7 @@ int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, fl
 
 /* The order in which a persistent gr_trace_fused launch hands out its tiles: longest first, as estimated from what the prepass
  * rays around each tile cost (cell_attempts of gr_prepass_fused_strips / gr_camera_prepass), tiles on the shadow's edge before
- * everything, tiles the prepass lets skip last.  A launch lasts as long as its slowest wave, and a long tile drawn late is what
+ * everything, tiles no pixel of which needs a ray last (gr_trace_fused_launch then writes their records without looking anything up).  A launch lasts as long as its slowest wave, and a long tile drawn late is what
  * makes a wave slow; which wave traces a tile has no influence on the tile's pixels.  tile_order: gr_tile_order_bytes(...) bytes,
  * written by two small launches on `stream`; pass it to gr_trace_fused_ordered with the same image and strip description. */
 long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_rank, int strip_count);
@@ -486,8 +486,8 @@ int gr_render_state_shader_clock(gr_render_state* s, double* mhz);
 /* of the same launch: the summed lifetime of its waves in milliseconds and how many waves ran.  Over (wave slots the launch
  * held) x (launch duration) this is the share of the slots that was occupied - the rest is the launch's ramp and tail */
 int gr_render_state_wave_time(gr_render_state* s, double* wave_ms, unsigned long long* waves);
-/* the first count (<= 128) words of that frame's counter block as the kernels left them: [0] attempts, [1] shader cycles,
- * [2] reference-clock ticks, [3] waves, [8..127] only written by probe builds of the kernels (tools/README.md) */
+/* the first count (<= 256) words of that frame's counter block as the kernels left them: [0] attempts, [1] shader cycles,
+ * [2] reference-clock ticks, [3] waves, [8..255] only written by probe builds of the kernels (tools/README.md) */
 int gr_render_state_counters(gr_render_state* s, unsigned long long* words, int count);
 
 enum { GR_BUF_RAYS_IN = 0, GR_BUF_RAYS_COUNT = 1, GR_BUF_RENDER_DATA = 2, GR_BUF_TERMINATION = 3, GR_BUF_CAMERA_GENERIC = 4,

@@ -249,7 +249,7 @@ def test_strip_prepass_cell_rule_covers_every_cell_a_rank_reads():
 
 
 def test_tile_list_size_counts_a_devices_tiles():
-    """gr_tile_order_bytes (the list gr_order_tiles writes and gr_trace_fused_launch reads: 16 header words, one id and one class per
+    """gr_tile_order_bytes (the list gr_order_tiles writes and gr_trace_fused_launch reads: 32 header words, one id and one class per
     tile) against a count of the 8x8 tiles and 64-pixel halo pieces of a device's row blocks, restated here"""
     import geodesic_raytracing_amd as gra
     for width, height in ((3840, 2160), (1920, 1080), (1918, 1078), (64, 36), (7680, 4320)):
@@ -262,5 +262,5 @@ def test_tile_list_size_counts_a_devices_tiles():
                         continue
                     blocks = [b for b in range(-(-height // block)) if b % count == rank]
                     tiles = len(blocks) * (-(-width // 8) * (block // 8) + -(-width // 64))
-                assert gra.lib.gr_tile_order_bytes(width, height, block, rank, count) == (16 + 2 * tiles) * 4, (width, height, block, count, rank)
-    assert gra.lib.gr_tile_order_bytes(64, 36, 12, 0, 2) == 16 * 4   # block rows not a multiple of 8: no tiles
+                assert gra.lib.gr_tile_order_bytes(width, height, block, rank, count) == (32 + 2 * tiles) * 4, (width, height, block, count, rank)
+    assert gra.lib.gr_tile_order_bytes(64, 36, 12, 0, 2) == 32 * 4   # block rows not a multiple of 8: no tiles

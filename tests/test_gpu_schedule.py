@@ -47,13 +47,13 @@ def test_tile_order_is_a_permutation_of_the_device_tiles(strip, block_rows):
     pw, ph = W // 16, H // 16
     rows = block_rows or ((H + 7) // 8) * 8
     _, words = order_list(prog, state, strip, rows, pw, ph)
-    n = (words.size - 16) // 2
-    counts, cursors, tiles, classes = words[:8], words[8:16], words[16:16 + n], words[16 + n:]
+    n = (words.size - 32) // 2
+    counts, cursors, tiles, classes = words[:16], words[16:32], words[32:32 + n], words[32 + n:]
     assert counts.sum() == tiles.size and (cursors == counts).all()
-    assert np.array_equal(np.bincount(classes, minlength=8), counts)
+    assert np.array_equal(np.bincount(classes, minlength=16), counts)
     assert (np.diff(classes[tiles].astype(np.int64)) >= 0).all()   # the list runs through the classes in order
     assert np.array_equal(np.sort(tiles), np.arange(tiles.size, dtype=np.uint32))
-    assert counts[7] > 0 and counts[0] > 0   # the Kerr shadow: tiles to skip, and tiles on its edge
+    assert counts[15] > 0 and counts[0] > 0   # the Kerr shadow: tiles no pixel of which needs a ray, and tiles on its edge
 
 
 def test_ordered_trace_equals_image_order_bit_for_bit():

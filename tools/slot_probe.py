@@ -19,5 +19,11 @@ for i in range(5):
     ms, n = state.wave_time(); st = state.stage_ms()
     print("launch %.3f ms  waves %d  wave-ms %.1f  mean life %.3f ms  slot share %.3f  clock %.0f" % (st["trace"], n, ms, ms/n, ms/n/st["trace"], state.shader_clock_mhz()))
 if "LIFE_HISTOGRAM" in os.environ.get("GR_EXTRA_FLAGS", ""):
-    h = state.counters()[8:128]
+    words = state.counters(256)
+    h = words[8:128]
     print("lifetime histogram (0.125 ms bins):", " ".join("%d:%d" % (i, c) for i, c in enumerate(h) if c))
+    for c in range(16):
+        n, total, longest = words[128 + 3 * c: 131 + 3 * c]
+        if n:
+            print("  class %d: %6d tiles, mean %8.1f us, longest %8.1f us, %5.1f %% of the tile time" % (
+                c, n, total / n / 100, longest / 100, 100.0 * total / max(1, sum(words[129 + 3 * k] for k in range(16)))))
