@@ -1342,16 +1342,10 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         return false;
     };
 
-    // The state a ray leaves the fast loop in is parked in LDS - once per ray, its own slot, read back by the same lane after the
-    // loop.  Left to the compiler, "whichever set the ray was in when it left" becomes twelve running copies per attempt; kept in
-    // registers of its own it costs twelve VGPRs across the loop, i.e. a wave per SIMD.
-    // The state a ray leaves the fast loop in gets registers of its own, written - once per ray - where the loop is left, by copies
-    // the compiler cannot move.  Left to the compiler, "whichever set the ray was in when it left" becomes twelve running copies
-    // per attempt.  The 14 registers are cold inside the loop, so when the host holds the kernel to more waves per SIMD than its
-    // free register count allows (capi.cpp, occupancy rule) they are what the allocator spills: the exit state then lives in
-    // scratch memory, touched only in the exit block.  (Parking it in LDS by hand - ds_write in the exit block, 14 KB per
-    // workgroup - measured 6 % slower with three frames in flight: 1 445 against 1 535 Mrays/s at the same occupancy.)
-    float4 position = p0, velocity = v0, acceleration = a0;
+    // The state a ray leaves the fast loop in stays in register set 0 (below): no registers of its own.  (Earlier forms: left to
+    // the compiler, "whichever set the ray was in when it left" becomes twelve running copies per attempt; in twelve registers of
+    // its own it cost a wave per SIMD or, held to six waves, 60 bytes of scratch per lane and 0.1-0.2 GB of scratch traffic per 4K
+    // launch; parked in LDS by hand - 14 KB per workgroup - it measured 6 % slower than the spill.)
     float exit_ds = 0, exit_running = 1;
     {
         const trig_flavour<false> polynomial;
@@ -1374,20 +1368,21 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
 #endif
             float4 p1, v1, a1;
             float ds_used, running_before;
+            // A ray that leaves is left in set 0: lanes that have left are masked off for the rest of the loop, so set 0 keeps their
+            // state with no registers of its own; a ray that leaves from set 1 is copied over first (opaque copies, once per ray).
             if (attempt(polynomial, p0, v0, a0, p1, v1, a1, ds_used, running_before)) {
-                const bool out = RESUMABLE && pause_wave;
-                overwrite(position, out ? p1 : p0); overwrite(velocity, out ? v1 : v0); overwrite(acceleration, out ? a1 : a0);
+                if (RESUMABLE && pause_wave) { overwrite(p0, p1); overwrite(v0, v1); overwrite(a0, a1); }
                 asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "+v"(exit_ds), "+v"(exit_running) : "v"(ds_used), "v"(running_before));
                 break;
             }
             if (attempt(polynomial, p1, v1, a1, p0, v0, a0, ds_used, running_before)) {
-                const bool out = RESUMABLE && pause_wave;
-                overwrite(position, out ? p0 : p1); overwrite(velocity, out ? v0 : v1); overwrite(acceleration, out ? a0 : a1);
+                if (!(RESUMABLE && pause_wave)) { overwrite(p0, p1); overwrite(v0, v1); overwrite(a0, a1); }
                 asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "+v"(exit_ds), "+v"(exit_running) : "v"(ds_used), "v"(running_before));
                 break;
             }
         }
     }
+    float4 position = p0, velocity = v0, acceleration = a0;
 #ifdef IS_CONSTANT_THETA
     position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;
 #endif
