@@ -234,13 +234,14 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     if (rc != GR_OK) return rc;
 
     // Occupancy of the fused trace kernel.  Left alone, the register allocator takes what the kernel could use at its widest
-    // point (Kerr, substituted: 108 VGPRs, 4 waves per SIMD); a quarter of that is cold inside the Verlet loop (the registers a
-    // ray's exit state is copied to, set-up and epilogue values).  Measured on MI355X, 4K Kerr, three frames in flight / one
-    // launch on its own: free build 1 400 Mrays/s / 6.7 ms; held to 96 VGPRs (5 waves, nothing spilled) 1 492 / 6.5; to 80 (6
-    // waves, 60 bytes per lane spilled, none of it inside the loop's attempts) 1 535 / 6.2; to 72 (7 waves, 84 bytes) 1 530 / 6.2.
+    // point (Kerr, substituted: 97 VGPRs, 5 waves per SIMD), part of which is cold inside the Verlet loop (set-up and epilogue
+    // values).  Measured on MI355X, 4K Kerr, three frames in flight / one launch on its own, with the loop that still kept a
+    // finished ray's state in twelve registers of its own (108 VGPRs free): free build 1 400 Mrays/s / 6.7 ms; held to 96 VGPRs (5
+    // waves, nothing spilled) 1 492 / 6.5; to 80 (6 waves, 60 bytes per lane spilled, none of it inside the loop's attempts)
+    // 1 535 / 6.2; to 72 (7 waves, 84 bytes) 1 530 / 6.2.  With today's loop: 6 waves spill 24 bytes; 7 and 8 waves measure the same.
     // Rule: rebuild with the register budget of five sixths of what the free build took, rounded down to an occupancy step,
-    // and keep that build unless it spills more than 96 bytes per lane (the exit state is 56; the same source compiles to 52-72 B
-    // of spill from one hiprtc run to the next, and a limit next to that number flipped the decision with it).
+    // and keep that build unless it spills more than 96 bytes per lane (the same source compiles to a spill that differs by 20 B
+    // from one hiprtc run to the next, and a limit next to the expected number flipped the decision with it).
     bool tuned_by_caller = false;
     for (auto& o : opts) tuned_by_caller |= o.rfind("-DGR_FUSED_WAVES", 0) == 0 || o.rfind("-DGR_TRACE_WAVES", 0) == 0;
     const char* tuning = getenv("GR_OCCUPANCY_TUNING");
