@@ -1,5 +1,5 @@
 """Per-frame time of ONE rank's share of a frame split N ways (no communication), by look-ahead depth: what an N-GPU run
-can reach per frame.   usage: [STRIP_PROBE_INFLIGHT=1,3,5] python tools/strip_probe.py [N ...]"""
+can reach per frame.   usage: [STRIP_PROBE_INFLIGHT=1,3,5] [STRIP_PROBE_BLOCK=48] [STRIP_PROBE_WAVES=2] python tools/strip_probe.py [N ...]"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
