@@ -191,6 +191,9 @@ __device__ __forceinline__ sincos_pair sincos_reduced(float x) {
     // quadrant signs applied to the sign bit directly (xor is full rate, compare + select are not)
     s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, s) ^ ((q & 2u) << 30));
     c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, c) ^ (((q + 1u) & 2u) << 30));
+#ifdef GR_PROBE_SOURCE_BREAKS
+    if (POISON_LARGE) __builtin_amdgcn_s_setprio(0);
+#endif
     return {s, c};
 }
 // the polynomial is evaluated unconditionally (so sin and cos of one angle stay in one basic block and share it);
@@ -306,6 +309,11 @@ __device__ __forceinline__ float4 coordinate_period(cfg_t cfg) {
     auto cos = [&](float x) -> float { return LIBM ? ::cosf(x) : sincos_reduced<true>(x).c; };           \
     (void)sin; (void)cos;
 #endif
+#ifdef GR_PROBE_SOURCE_BREAKS   // experiment: a scalar instruction the scheduler cannot move at the seams of the acceleration
+#define GR_ISSUE_BREAK __builtin_amdgcn_s_setprio(0);
+#else
+#define GR_ISSUE_BREAK
+#endif
 template <bool LIBM>
 __device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 vel, cfg_t cfg) {
 #ifdef GENERIC_CONSTANT_THETA
@@ -316,16 +324,22 @@ __device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 
     const float iv1 = vel.x; const float iv2 = vel.y; const float iv3 = vel.z; const float iv4 = vel.w;
     (void)iv1; (void)iv2; (void)iv3; (void)iv4;
     GR_ACCEL_TRIG(LIBM)
+    GR_ISSUE_BREAK
     float TEMPORARIES0;
+    GR_ISSUE_BREAK
     float4 a;
     a.x = GEO_ACCEL0;
+    GR_ISSUE_BREAK
     a.y = GEO_ACCEL1;
+    GR_ISSUE_BREAK
 #ifndef GENERIC_CONSTANT_THETA
     a.z = GEO_ACCEL2;
+    GR_ISSUE_BREAK
 #else
     a.z = 0.f;
 #endif
     a.w = GEO_ACCEL3;
+    GR_ISSUE_BREAK
     return a;
 }
 // everywhere outside the Verlet loop (ray set-up, geodesic paths): gm::sin / gm::cos with their own large-argument branches

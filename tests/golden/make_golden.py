@@ -103,6 +103,12 @@ POLAR_CASES = {
                              camera_quat=[-0.8104286000020418, -0.1529374610823953, 0.3350814866343691, 0.45556120841364733],
                              basis_speed=[-0.1830985419023946, 0.24267198206320056, 0.11756292491315451],
                              features=dict(field_of_view=110.0, universe_size=30.0)),
+    # second round-2 soak (seed 22, 300 cases): the one case over the 1 % mask
+    "kerr_axis_22_142": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(64, 36), cfg=dict(a=0.24098702551920237),
+                             camera_pos=[0.07883143052852648, 7.311613549431512, -5.060609510417881, -7.144043856092047],
+                             camera_quat=[-0.7659823132455007, -0.28952295048981375, -0.23018925634343776, 0.5257950771914849],
+                             basis_speed=[0.22896019082067293, 0.021257100754642155, -0.20398572550380673],
+                             features=dict(universe_size=30.0)),
 }
 
 # camera riding a timelike geodesic (boost_tetrad .. handle_interpolating_geodesic): name -> spec
