@@ -109,6 +109,12 @@ POLAR_CASES = {
                              camera_quat=[-0.7659823132455007, -0.28952295048981375, -0.23018925634343776, 0.5257950771914849],
                              basis_speed=[0.22896019082067293, 0.021257100754642155, -0.20398572550380673],
                              features=dict(universe_size=30.0)),
+    # third round-2 soak (seed 23, 300 cases): the one case over the 1 % mask
+    "kerr_newman_axis_23_63": dict(metric="kerr_newman_boyer", scripts=True, size=(64, 36), cfg=dict(a=0.03243599252796869, rq=0.1263308864118519),
+                                   camera_pos=[0.026689531860808913, 2.7075304480591424, -3.3584223303336853, -8.219707728680902],
+                                   camera_quat=[-0.7345988591068365, 0.0893395407630169, -0.06763954895833718, 0.6691844693893456],
+                                   basis_speed=[0.15518180300394824, 0.1498653695042953, 0.037818782698535613],
+                                   features=dict(redshift=1)),
 }
 
 # camera riding a timelike geodesic (boost_tetrad .. handle_interpolating_geodesic): name -> spec
