@@ -66,6 +66,14 @@ class TraceFusedArgs(ctypes.Structure):
                 ("waves_per_simd", c_int), ("shading", TraceShading), ("lattice", c_int), ("pending_only", c_int)]
 
 
+class Transport(ctypes.Structure):
+    """gr_transport: the caller's point-to-point calls behind a split frame"""
+    GROUP = ctypes.CFUNCTYPE(c_int, c_void_p)
+    SEND = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
+    RECV = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
+    _fields_ = [("user", c_void_p), ("group_begin", GROUP), ("group_end", GROUP), ("send", SEND), ("recv", RECV)]
+
+
 MODE_REFERENCE, MODE_FUSED = 0, 1
 (STAGE_CAMERA, STAGE_PREPASS, STAGE_INIT, STAGE_TRACE, STAGE_RENDER_DATA, STAGE_ADAPTIVE, STAGE_RENDER) = range(7)
 STAGE_NAMES = ["camera", "prepass", "init", "trace", "render_data", "adaptive", "render"]
@@ -171,6 +179,9 @@ _SIGNATURES = {
                                       ctypes.POINTER(c_float), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                       ctypes.POINTER(FrameOptions), c_int]),
     "gr_tiled_join": (c_int, [c_void_p, c_void_p]),
+    "gr_tiled_create_custom": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_tiled_exchange": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gr_tiled_staging_bytes": (c_size_t, [c_void_p]),
     "gr_tiled_share": (c_int, [c_void_p, c_int]),
     "gr_tiled_block_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gr_tiled_block_rows_of": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

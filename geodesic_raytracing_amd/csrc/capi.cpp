@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "builtin_metrics.hpp"
+#include "codeobject.hpp"
 #include "jsfront.hpp"
 #include "metric_codegen.hpp"
 
@@ -79,6 +80,10 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
     }
     return h;
 }
+
+#ifndef GR_DEFAULT_VECTOR_RUN_LIMIT
+#define GR_DEFAULT_VECTOR_RUN_LIMIT 0
+#endif
 
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
@@ -197,6 +202,11 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
         const char* tuning = getenv("GR_OCCUPANCY_TUNING");   // changes what is built for the same options (see below)
         if (tuning && tuning[0] == '0') h = fnv1a("no occupancy tuning", h);
     }
+    // Pass over the compiled code (codeobject.hpp): no more than `run_limit` vector instructions in a row without a scalar one.
+    // GR_VECTOR_RUN_LIMIT=0 builds through hiprtc alone.
+    int run_limit = GR_DEFAULT_VECTOR_RUN_LIMIT;
+    if (const char* e = getenv("GR_VECTOR_RUN_LIMIT")) run_limit = atoi(e);
+    if (run_limit > 0) h = fnv1a("vector runs <= " + std::to_string(run_limit), h);
     char name[64];
     snprintf(name, sizeof(name), "%016llx.hsaco", (unsigned long long)h);
     if (key_out) key_out->assign(name, 16);
@@ -207,8 +217,22 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     std::string cache_path = cache_dir + "/" + name;
     if (read_file(cache_path, code) && !code.empty()) return GR_OK;
 
-    // one hiprtc build of the kernel source with `options`
+    // one build of the kernel source with `options`: through the assembly pass when it is on and the code-object manager is
+    // there, else through hiprtc (a source error shows up there with its diagnostics)
     auto build = [&](const std::vector<std::string>& options, std::string& out) -> int {
+        if (run_limit > 0) {
+            std::string assembly, log;
+            if (gr::compile_to_assembly(source, options, assembly, log)) {
+                const gr::vector_run_stats st = gr::break_vector_runs(assembly, run_limit);
+                if (gr::assemble_code_object(assembly, out, log)) {
+                    if (getenv("GR_VERBOSE_BUILD"))
+                        fprintf(stderr, "[gr] vector runs: %d longer than %d (longest %d) cut by %d s_nop, longest now %d\n", st.runs_broken,
+                                run_limit, st.longest_before, st.inserted, st.longest_after);
+                    return GR_OK;
+                }
+            }
+            if (getenv("GR_VERBOSE_BUILD")) fprintf(stderr, "[gr] assembly pass not applied (%s): building through hiprtc\n", log.c_str());
+        }
         hiprtcProgram prog;
         if (hiprtcCreateProgram(&prog, source.c_str(), "geodesic_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
             return fail(GR_ERROR_COMPILE, "hiprtcCreateProgram failed");

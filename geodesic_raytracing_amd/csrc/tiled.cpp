@@ -15,9 +15,15 @@
 //     exercise every offset on a one-GPU box): hipMemcpyPeerAsync per block on the owner's stream, events for the root to wait on.
 // The root renders its own blocks directly into the frame (compact_out = 0).  The share a participant renders can rotate with
 // the frame number (`rotation`): shares differ in cost by up to ~9 % and with frames in flight everybody then runs at the mean.
+//   * GR_TRANSPORT_CUSTOM  the caller's own point-to-point calls (a gr_transport table: MPI, sockets - and the recording transport
+//     of tests/test_distributed_cpu.py, which drives the send / receive schedule of every rank of a world on the CPU).  RCCL is
+//     one such table internally.
+// Frames in flight: a participant stages its compact rows in a ring of buffers, one per frame in flight (frame_slot below), so
+// frame k+1 - another stream, another share - never shades into memory frame k's sends still read.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -27,6 +33,7 @@
 #include "../../include/geodesic_hip.h"
 
 extern "C" int gr_internal_fail(int code, const char* msg);
+struct gr_tiled;
 
 namespace {
 
@@ -83,8 +90,18 @@ int rccl_fail(const char* what, int rc) {
 // participants of one process that share a frame through peer copies
 struct peer_group {
     int world = 0;
-    std::vector<hipEvent_t> done;     // one per participant: its blocks have reached the root's frame
-    std::vector<char> pending;
+    std::vector<gr_tiled*> members;   // by rank; nullptr once destroyed
+};
+
+// One frame in flight of one participant: where its compact rows are staged (not on the root, which renders in place) and the
+// event after which they have left that buffer.  gr_render_frame_tiled may be called for the next frame - on another stream, with
+// another share - while this frame's sends still read the buffer, so a participant owns a ring of these and a frame that reuses a
+// slot first waits for the slot's event.
+struct frame_slot {
+    void* buffer = nullptr;
+    hipEvent_t done = nullptr;   // recorded on the frame's stream after its transfers were enqueued
+    bool recorded = false;
+    bool pending = false;        // GR_TRANSPORT_PEER: gr_tiled_join has not waited for it yet
 };
 
 }  // namespace
@@ -93,11 +110,69 @@ struct gr_tiled {
     int transport = GR_TRANSPORT_PEER;
     int world = 1, rank = 0, device = 0, root = 0;
     int width = 0, height = 0, block_rows = 16, blocks_per_share = 0;
-    void* comm = nullptr;                    // ncclComm_t
-    void* local = nullptr;                   // compact strip buffer: blocks_per_share x block_rows x width float4 (not on the root)
+    void* comm = nullptr;                    // ncclComm_t (GR_TRANSPORT_RCCL)
+    gr_transport link{};                     // point-to-point calls of GR_TRANSPORT_RCCL / GR_TRANSPORT_CUSTOM
+    std::vector<frame_slot> ring;
+    unsigned long long frames = 0;
     std::shared_ptr<peer_group> group;       // GR_TRANSPORT_PEER
     int root_device = 0;
+
+    size_t staging_bytes() const { return (size_t)blocks_per_share * block_rows * width * 16; }
+    ~gr_tiled() {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (comm) { rccl_api* r = rccl(); if (r) (void)r->CommDestroy(comm); }
+        for (auto& sl : ring) {
+            if (sl.buffer) (void)hipFree(sl.buffer);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+        }
+        if (group && rank < (int)group->members.size()) group->members[rank] = nullptr;
+    }
 };
+
+namespace {
+
+// RCCL as a gr_transport (user = the gr_tiled that owns the communicator)
+int rccl_group_begin(void*) { int rc = rccl()->GroupStart(); return rc == 0 ? GR_OK : rccl_fail("ncclGroupStart", rc); }
+int rccl_group_end(void*) { int rc = rccl()->GroupEnd(); return rc == 0 ? GR_OK : rccl_fail("ncclGroupEnd", rc); }
+int rccl_send(void* user, const void* data, size_t floats, int peer, void* stream) {
+    int rc = rccl()->Send(data, floats, 7 /* ncclFloat */, peer, ((gr_tiled*)user)->comm, (hipStream_t)stream);
+    return rc == 0 ? GR_OK : rccl_fail("ncclSend", rc);
+}
+int rccl_recv(void* user, void* data, size_t floats, int peer, void* stream) {
+    int rc = rccl()->Recv(data, floats, 7, peer, ((gr_tiled*)user)->comm, (hipStream_t)stream);
+    return rc == 0 ? GR_OK : rccl_fail("ncclRecv", rc);
+}
+
+int ring_size() {
+    int n = 4;   // frames in flight a participant can have before a frame waits for an earlier frame's transfers
+    if (const char* e = getenv("GR_TILED_STAGING")) n = atoi(e);
+    return n < 1 ? 1 : n > 64 ? 64 : n;
+}
+
+int tiled_common(gr_tiled* t, int world, int rank, int device, int width, int height, int block_rows) {
+    if (world < 1 || rank < 0 || rank >= world || width < 1 || height < 1 || block_rows < 8 || block_rows % 8)
+        return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "world >= 1, 0 <= rank < world, block_rows a positive multiple of 8");
+    if (world > 1 && height > 1 && (height - 1) % block_rows == 0)
+        return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "the last image row must not start a block (its filter reads the row above)");
+    t->world = world; t->rank = rank; t->device = device; t->width = width; t->height = height; t->block_rows = block_rows;
+    const int total_blocks = (height + block_rows - 1) / block_rows;
+    t->blocks_per_share = (total_blocks + world - 1) / world;
+    t->ring.assign((size_t)ring_size(), frame_slot());
+    if (device >= 0) HIP_CHECK(hipSetDevice(device));
+    return GR_OK;
+}
+
+// the slot of the next frame, ready to be rendered into on `stream`
+int next_slot(gr_tiled* t, hipStream_t stream, frame_slot** out) {
+    frame_slot& sl = t->ring[(size_t)(t->frames++ % t->ring.size())];
+    if (!sl.done) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (t->rank != t->root && !sl.buffer) HIP_CHECK(hipMalloc(&sl.buffer, t->staging_bytes()));
+    if (sl.recorded) HIP_CHECK(hipStreamWaitEvent(stream, sl.done, 0));   // the frame that used this slot last has left it
+    *out = &sl;
+    return GR_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -109,38 +184,35 @@ int gr_tiled_unique_id(void* id_out_128_bytes) {
     return rc == 0 ? GR_OK : rccl_fail("ncclGetUniqueId", rc);
 }
 
-static int tiled_common(gr_tiled* t, int world, int rank, int device, int width, int height, int block_rows) {
-    if (world < 1 || rank < 0 || rank >= world || width < 1 || height < 1 || block_rows < 8 || block_rows % 8)
-        return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "world >= 1, 0 <= rank < world, block_rows a positive multiple of 8");
-    if (world > 1 && height > 1 && (height - 1) % block_rows == 0)
-        return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "the last image row must not start a block (its filter reads the row above)");
-    t->world = world; t->rank = rank; t->device = device; t->width = width; t->height = height; t->block_rows = block_rows;
-    const int total_blocks = (height + block_rows - 1) / block_rows;
-    t->blocks_per_share = (total_blocks + world - 1) / world;
-    if (rank != t->root) {
-        HIP_CHECK(hipSetDevice(device));
-        HIP_CHECK(hipMalloc(&t->local, (size_t)t->blocks_per_share * block_rows * width * 16));
-    }
-    return GR_OK;
-}
-
 int gr_tiled_create(int world, int rank, int device, const void* unique_id_128_bytes, int width, int height, int block_rows, gr_tiled** out) {
     if (!out) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
-    auto t = std::make_unique<gr_tiled>();
+    if (device < 0) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "device");
+    auto t = std::make_unique<gr_tiled>();   // ~gr_tiled releases whatever exists on every early return below
     t->transport = GR_TRANSPORT_RCCL;
     int rc = tiled_common(t.get(), world, rank, device, width, height, block_rows);
-    if (rc != GR_OK) { if (t->local) (void)hipFree(t->local); return rc; }
+    if (rc != GR_OK) return rc;
     if (world > 1) {
         if (!unique_id_128_bytes) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "world > 1 needs the id of gr_tiled_unique_id");
         rccl_api* r = rccl();
         if (!r) return gr_internal_fail(GR_ERROR_DEVICE, "librccl could not be loaded");
-        HIP_CHECK(hipSetDevice(device));
         unique_id id;
         memcpy(id.bytes, unique_id_128_bytes, sizeof(id.bytes));
         auto init = (int (*)(void**, int, unique_id, int))r->comm_init_rank_raw;   // ncclCommInitRank(comm*, nranks, id BY VALUE, rank)
         int nrc = init(&t->comm, world, id, rank);
-        if (nrc != 0) { if (t->local) (void)hipFree(t->local); return rccl_fail("ncclCommInitRank", nrc); }
+        if (nrc != 0) { t->comm = nullptr; return rccl_fail("ncclCommInitRank", nrc); }
+        t->link = gr_transport{t.get(), rccl_group_begin, rccl_group_end, rccl_send, rccl_recv};
     }
+    *out = t.release();
+    return GR_OK;
+}
+
+int gr_tiled_create_custom(int world, int rank, int device, const gr_transport* transport, int width, int height, int block_rows, gr_tiled** out) {
+    if (!out || !transport || !transport->send || !transport->recv) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    auto t = std::make_unique<gr_tiled>();
+    t->transport = GR_TRANSPORT_CUSTOM;
+    int rc = tiled_common(t.get(), world, rank, device, width, height, block_rows);
+    if (rc != GR_OK) return rc;
+    t->link = *transport;
     *out = t.release();
     return GR_OK;
 }
@@ -149,42 +221,31 @@ int gr_tiled_create_local(int count, const int* devices, int width, int height, 
     if (count < 1 || !devices || !out_array) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
     auto group = std::make_shared<peer_group>();
     group->world = count;
-    group->done.assign(count, nullptr);
-    group->pending.assign(count, 0);
+    group->members.assign(count, nullptr);
     std::vector<std::unique_ptr<gr_tiled>> made;
     for (int r = 0; r < count; r++) {
+        if (devices[r] < 0) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "device");
         auto t = std::make_unique<gr_tiled>();
         t->transport = GR_TRANSPORT_PEER;
-        t->group = group;
         t->root_device = devices[0];
-        int rc = tiled_common(t.get(), count, r, devices[r], width, height, block_rows);
-        if (rc == GR_OK && hipSetDevice(devices[r]) == hipSuccess && hipEventCreateWithFlags(&group->done[r], hipEventDisableTiming) != hipSuccess)
-            rc = gr_internal_fail(GR_ERROR_DEVICE, "hipEventCreate failed");
-        if (rc == GR_OK && devices[r] != devices[0]) {
+        int rc = tiled_common(t.get(), count, r, devices[r], width, height, block_rows);   // selects the device, or fails
+        if (rc != GR_OK) return rc;
+        if (devices[r] != devices[0]) {
             int can = 0;
             (void)hipDeviceCanAccessPeer(&can, devices[r], devices[0]);
             if (can) { hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0); if (e != hipSuccess) (void)hipGetLastError(); }   // already enabled is fine
         }
-        if (rc != GR_OK) {
-            if (t->local) (void)hipFree(t->local);
-            for (auto& m : made) if (m->local) (void)hipFree(m->local);
-            for (auto e : group->done) if (e) (void)hipEventDestroy(e);
-            return rc;
-        }
         made.push_back(std::move(t));
     }
-    for (int r = 0; r < count; r++) out_array[r] = made[r].release();
+    for (int r = 0; r < count; r++) {
+        made[r]->group = group;
+        group->members[r] = made[r].get();
+        out_array[r] = made[r].release();
+    }
     return GR_OK;
 }
 
-void gr_tiled_destroy(gr_tiled* t) {
-    if (!t) return;
-    (void)hipSetDevice(t->device);
-    if (t->comm) { rccl_api* r = rccl(); if (r) (void)r->CommDestroy(t->comm); }
-    if (t->local) (void)hipFree(t->local);
-    if (t->group && t->group->done[t->rank]) { (void)hipEventDestroy(t->group->done[t->rank]); t->group->done[t->rank] = nullptr; }
-    delete t;
-}
+void gr_tiled_destroy(gr_tiled* t) { delete t; }
 
 int gr_tiled_share(const gr_tiled* t, int rotation) { return t ? ((t->rank + (rotation % t->world + t->world)) % t->world) : 0; }
 
@@ -202,10 +263,63 @@ int gr_tiled_block_rows_of(const gr_tiled* t, int share, int local_block, int* r
     return gr_tiled_block_rows(t->height, t->block_rows, t->world, share, local_block, row_begin, row_end);
 }
 
+size_t gr_tiled_staging_bytes(const gr_tiled* t) { return t ? t->staging_bytes() : 0; }
+
+// The transfer of one frame: every block of every other participant's share from its compact place in that participant's
+// `staging` to its rows of the root's frame.  Point-to-point transports: one group per frame, on the owner one send per block in
+// block order, on the root the matching receives peer by peer in the same block order (sends and receives between two ranks
+// match in issue order).
+int gr_tiled_exchange(gr_tiled* t, const void* staging, void* frame_on_root, int rotation, void* stream_v) {
+    if (!t) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (t->world == 1) return GR_OK;
+    hipStream_t stream = (hipStream_t)stream_v;
+    const bool is_root = t->rank == t->root;
+    if (is_root ? !frame_on_root : !staging) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "the root needs the frame, the others their staged rows");
+    const int share = gr_tiled_share(t, rotation);
+    const size_t row_bytes = (size_t)t->width * 16, row_floats = (size_t)t->width * 4;
+    if (t->transport == GR_TRANSPORT_PEER) {
+        if (!frame_on_root) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "peer transport: every participant is given the root's frame buffer");
+        if (is_root) return GR_OK;
+        // peer copies: the owner pushes its blocks into the root's frame on its own stream
+        for (int i = 0; i < t->blocks_per_share; i++) {
+            int a, b;
+            if (gr_tiled_block_rows_of(t, share, i, &a, &b) != 1) continue;
+            void* dst = (char*)frame_on_root + (size_t)a * row_bytes;
+            const void* src = (const char*)staging + (size_t)i * t->block_rows * row_bytes;
+            if (t->device == t->root_device) HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)(b - a) * row_bytes, hipMemcpyDeviceToDevice, stream));
+            else HIP_CHECK(hipMemcpyPeerAsync(dst, t->root_device, src, t->device, (size_t)(b - a) * row_bytes, stream));
+        }
+        return GR_OK;
+    }
+    const gr_transport& link = t->link;
+    int rc = link.group_begin ? link.group_begin(link.user) : GR_OK;
+    if (rc != GR_OK) return rc;
+    if (is_root) {
+        for (int peer = 0; peer < t->world && rc == GR_OK; peer++) {
+            if (peer == t->root) continue;
+            const int peer_share = (peer + (rotation % t->world + t->world)) % t->world;
+            for (int i = 0; i < t->blocks_per_share && rc == GR_OK; i++) {
+                int a, b;
+                if (gr_tiled_block_rows_of(t, peer_share, i, &a, &b) != 1) continue;
+                rc = link.recv(link.user, (char*)frame_on_root + (size_t)a * row_bytes, (size_t)(b - a) * row_floats, peer, stream_v);
+            }
+        }
+    } else {
+        for (int i = 0; i < t->blocks_per_share && rc == GR_OK; i++) {
+            int a, b;
+            if (gr_tiled_block_rows_of(t, share, i, &a, &b) != 1) continue;
+            rc = link.send(link.user, (const char*)staging + (size_t)i * t->block_rows * row_bytes, (size_t)(b - a) * row_floats, t->root, stream_v);
+        }
+    }
+    const int end_rc = link.group_end ? link.group_end(link.user) : GR_OK;
+    return rc != GR_OK ? rc : end_rc;
+}
+
 int gr_render_frame_tiled(gr_tiled* t, gr_render_state* s, gr_program* p, const gr_metric* m, void* stream_v, const gr_camera* camera,
                           const gr_features* features, const float* cfg_values, int num_cfg_values, const void* bg1, const void* bg2,
                           int bg_width, int bg_height, int bg_levels, void* frame_on_root, const gr_frame_options* options, int rotation) {
     if (!t || !s || !p || !m || !camera) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (t->device < 0) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "this participant was created without a device (schedule tests): nothing to render with");
     hipStream_t stream = (hipStream_t)stream_v;
     const bool is_root = t->rank == t->root;
     if (is_root && !frame_on_root) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "the root needs the frame buffer");
@@ -226,62 +340,35 @@ int gr_render_frame_tiled(gr_tiled* t, gr_render_state* s, gr_program* p, const 
         opt.compact_out = 0;
     }
     HIP_CHECK(hipSetDevice(t->device));
-    int rc = gr_render_frame(s, p, m, stream_v, camera, features, cfg_values, num_cfg_values, bg1, bg2, bg_width, bg_height, bg_levels,
-                             is_root ? frame_on_root : t->local, &opt);
-    if (rc != GR_OK || t->world == 1) return rc;
-
-    const size_t row_bytes = (size_t)t->width * 16, row_floats = (size_t)t->width * 4;
-    if (t->transport == GR_TRANSPORT_RCCL) {
-        rccl_api* r = rccl();
-        int nrc = r->GroupStart();
-        if (nrc != 0) return rccl_fail("ncclGroupStart", nrc);
-        if (is_root) {
-            for (int peer = 0; peer < t->world; peer++) {
-                if (peer == t->root) continue;
-                const int peer_share = (peer + (rotation % t->world + t->world)) % t->world;
-                for (int i = 0; i < t->blocks_per_share; i++) {
-                    int a, b;
-                    if (gr_tiled_block_rows_of(t, peer_share, i, &a, &b) != 1) continue;
-                    nrc = r->Recv((char*)frame_on_root + (size_t)a * row_bytes, (size_t)(b - a) * row_floats, 7 /* ncclFloat */, peer, t->comm, stream);
-                    if (nrc != 0) { (void)r->GroupEnd(); return rccl_fail("ncclRecv", nrc); }
-                }
-            }
-        } else {
-            for (int i = 0; i < t->blocks_per_share; i++) {
-                int a, b;
-                if (gr_tiled_block_rows_of(t, share, i, &a, &b) != 1) continue;
-                nrc = r->Send((const char*)t->local + (size_t)i * t->block_rows * row_bytes, (size_t)(b - a) * row_floats, 7, t->root, t->comm, stream);
-                if (nrc != 0) { (void)r->GroupEnd(); return rccl_fail("ncclSend", nrc); }
-            }
-        }
-        nrc = r->GroupEnd();
-        if (nrc != 0) return rccl_fail("ncclGroupEnd", nrc);
-        return GR_OK;
-    }
-    // peer copies: the owner pushes its blocks into the root's frame on its own stream
-    if (!is_root) {
-        for (int i = 0; i < t->blocks_per_share; i++) {
-            int a, b;
-            if (gr_tiled_block_rows_of(t, share, i, &a, &b) != 1) continue;
-            void* dst = (char*)frame_on_root + (size_t)a * row_bytes;
-            const void* src = (const char*)t->local + (size_t)i * t->block_rows * row_bytes;
-            if (t->device == t->root_device) HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)(b - a) * row_bytes, hipMemcpyDeviceToDevice, stream));
-            else HIP_CHECK(hipMemcpyPeerAsync(dst, t->root_device, src, t->device, (size_t)(b - a) * row_bytes, stream));
-        }
-    }
-    HIP_CHECK(hipEventRecord(t->group->done[t->rank], stream));
-    t->group->pending[t->rank] = 1;
-    return GR_OK;
+    if (t->world == 1)
+        return gr_render_frame(s, p, m, stream_v, camera, features, cfg_values, num_cfg_values, bg1, bg2, bg_width, bg_height, bg_levels, frame_on_root, &opt);
+    frame_slot* sl = nullptr;
+    int rc = next_slot(t, stream, &sl);
+    if (rc != GR_OK) return rc;
+    const int render_rc = gr_render_frame(s, p, m, stream_v, camera, features, cfg_values, num_cfg_values, bg1, bg2, bg_width, bg_height, bg_levels,
+                                          is_root ? frame_on_root : sl->buffer, &opt);
+    std::string render_error = render_rc != GR_OK ? gr_last_error() : "";
+    // The transfers are issued even when this participant's render failed: the others have matching sends / receives in their
+    // groups and would wait for ever.  The caller sees the render's error.
+    rc = gr_tiled_exchange(t, sl->buffer, frame_on_root, rotation, stream_v);
+    HIP_CHECK(hipEventRecord(sl->done, stream));
+    sl->recorded = true;
+    sl->pending = t->transport == GR_TRANSPORT_PEER;
+    if (render_rc != GR_OK) return gr_internal_fail(render_rc, render_error.c_str());
+    return rc;
 }
 
 int gr_tiled_join(gr_tiled* root, void* stream_v) {
     if (!root) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
-    if (root->transport != GR_TRANSPORT_PEER || root->world == 1) return GR_OK;   // RCCL: the receives are ordered on the root's stream
+    if (root->transport != GR_TRANSPORT_PEER || root->world == 1) return GR_OK;   // point-to-point: the receives are ordered on the root's stream
     HIP_CHECK(hipSetDevice(root->device));
-    for (int r = 0; r < root->world; r++) {
-        if (!root->group->pending[r]) continue;
-        HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_v, root->group->done[r], 0));
-        root->group->pending[r] = 0;
+    for (gr_tiled* member : root->group->members) {
+        if (!member) continue;
+        for (auto& sl : member->ring) {
+            if (!sl.pending) continue;
+            HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_v, sl.done, 0));
+            sl.pending = false;
+        }
     }
     return GR_OK;
 }

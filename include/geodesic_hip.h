@@ -517,16 +517,33 @@ int gr_device_count(int* count);
  *     owner / ncclRecv on participant 0 at the block's row offset, one group per frame, enqueued on the caller's stream.
  *     librccl is loaded at run time (dlopen), the library has no link dependency on it.
  *   GR_TRANSPORT_PEER: one process driving `count` devices (gr_tiled_create_local; devices may repeat): hipMemcpyPeerAsync per
- *     block on the owner's stream; gr_tiled_join makes participant 0's stream wait for them.
+ *     block on the owner's stream; gr_tiled_join makes participant 0's stream wait for every frame issued so far.
+ *   GR_TRANSPORT_CUSTOM: the caller's point-to-point library behind a gr_transport table (gr_tiled_create_custom); RCCL's call
+ *     pattern with the caller's send / recv: per frame one group, on the owner one send per block in block order, on participant
+ *     0 the matching receives peer by peer.  With device < 0 no device is touched at all: gr_tiled_exchange then runs the
+ *     schedule on host memory (how tests/test_distributed_cpu.py checks order and offsets for every rank of a world).
+ * Frames in flight: each participant stages its rows in a ring of GR_TILED_STAGING (default 4) buffers, one per frame in flight;
+ * gr_render_frame_tiled may be called for frame k+1 on another stream, with another rotation, while frame k's transfers run (a
+ * frame that finds its ring slot still in use makes its stream wait for that frame's transfers).
  * gr_render_frame_tiled = gr_render_frame for this participant's share + the transfer.  `options` as for gr_render_frame (mode,
  * strip_* and compact_out are overridden; next_camera / next_strip_rank look-ahead works as there, see gr_tiled_share).
  * `rotation`: participant r renders share (r + rotation) % world - rotate with the frame number to even out shares of different
  * cost.  frame_on_root: float4[height * width] on participant 0's device; NULL elsewhere with RCCL, the same pointer for every
  * participant with peer copies. */
 typedef struct gr_tiled gr_tiled;
-enum { GR_TRANSPORT_RCCL = 0, GR_TRANSPORT_PEER = 1 };
+enum { GR_TRANSPORT_RCCL = 0, GR_TRANSPORT_PEER = 1, GR_TRANSPORT_CUSTOM = 2 };
+/* the point-to-point calls a split frame needs (the subset of RCCL it uses); every function returns GR_OK or an error code that
+ * gr_render_frame_tiled / gr_tiled_exchange hand back.  group_begin / group_end may be NULL. */
+typedef struct gr_transport {
+    void* user;
+    int (*group_begin)(void* user);
+    int (*group_end)(void* user);
+    int (*send)(void* user, const void* data, size_t float_count, int peer, void* stream);
+    int (*recv)(void* user, void* data, size_t float_count, int peer, void* stream);
+} gr_transport;
 int gr_tiled_unique_id(void* id_out_128_bytes);
 int gr_tiled_create(int world, int rank, int device, const void* unique_id_128_bytes, int width, int height, int block_rows, gr_tiled** out);
+int gr_tiled_create_custom(int world, int rank, int device, const gr_transport* transport, int width, int height, int block_rows, gr_tiled** out);
 int gr_tiled_create_local(int count, const int* devices, int width, int height, int block_rows, gr_tiled** out_array);
 void gr_tiled_destroy(gr_tiled* t);
 int gr_render_frame_tiled(gr_tiled* t, gr_render_state* s, gr_program* p, const gr_metric* m, void* stream, const gr_camera* camera,
@@ -534,6 +551,10 @@ int gr_render_frame_tiled(gr_tiled* t, gr_render_state* s, gr_program* p, const 
                           const void* background1, const void* background2, int bg_width, int bg_height, int bg_levels,
                           void* frame_on_root, const gr_frame_options* options, int rotation);
 int gr_tiled_join(gr_tiled* root, void* stream);
+/* the transfer step of gr_render_frame_tiled on its own: `staging` = this participant's compact rows (blocks back to back,
+ * gr_tiled_staging_bytes; unused on participant 0), frame_on_root as there */
+int gr_tiled_exchange(gr_tiled* t, const void* staging, void* frame_on_root, int rotation, void* stream);
+size_t gr_tiled_staging_bytes(const gr_tiled* t);
 /* the share participant t renders in a frame with this rotation (what to put into options->next_strip_rank for a look-ahead) */
 int gr_tiled_share(const gr_tiled* t, int rotation);
 /* rows [row_begin, row_end) of the local_block-th block of a share; returns 1, 0 for a padding block past the image, -1 on bad

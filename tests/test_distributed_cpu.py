@@ -264,3 +264,128 @@ def test_tile_list_size_counts_a_devices_tiles():
                     tiles = len(blocks) * (-(-width // 8) * (block // 8) + -(-width // 64))
                 assert gra.lib.gr_tile_order_bytes(width, height, block, rank, count) == (32 + 2 * tiles) * 4, (width, height, block, count, rank)
     assert gra.lib.gr_tile_order_bytes(64, 36, 12, 0, 2) == 32 * 4   # block rows not a multiple of 8: no tiles
+
+
+class _Mailbox:
+    """A recording point-to-point transport for gr_tiled_exchange on host memory (gr_transport, GR_TRANSPORT_CUSTOM): every
+    rank's calls are logged; sends and receives between two ranks are matched in issue order - NCCL's rule - once every rank has
+    issued its frame, and the bytes are then moved."""
+
+    def __init__(self):
+        self.sends, self.recvs, self.log = {}, {}, []
+
+    def table(self, gra, rank):
+        import ctypes
+        T = gra.Transport
+
+        def begin(_):
+            self.log.append((rank, "begin"))
+            return 0
+
+        def end(_):
+            self.log.append((rank, "end"))
+            return 0
+
+        def send(_, data, floats, peer, stream):
+            self.log.append((rank, "send", peer, floats, stream))
+            self.sends.setdefault((rank, peer), []).append(ctypes.string_at(data, floats * 4))
+            return 0
+
+        def recv(_, data, floats, peer, stream):
+            self.log.append((rank, "recv", peer, floats, stream))
+            self.recvs.setdefault((peer, rank), []).append((data, floats))
+            return 0
+
+        t = T(None, T.GROUP(begin), T.GROUP(end), T.SEND(send), T.RECV(recv))
+        t._keep = (begin, end, send, recv)
+        return t
+
+    def deliver(self):
+        import ctypes
+        assert set(self.sends) == set(self.recvs)
+        for pair, sent in self.sends.items():
+            want = self.recvs[pair]
+            assert len(sent) == len(want), pair
+            for payload, (dst, floats) in zip(sent, want):
+                assert len(payload) == floats * 4, pair   # a size mismatch hangs or corrupts with the real library
+                ctypes.memmove(dst, payload, len(payload))
+        self.sends.clear()
+        self.recvs.clear()
+
+
+@pytest.mark.parametrize("world,height,block", [(2, 54, 8), (3, 100, 8), (8, 2160, 48), (8, 360, 16), (5, 360, 24)])
+def test_c_abi_exchange_schedule_with_a_recording_transport(world, height, block):
+    """gr_tiled_exchange - the transfer step of gr_render_frame_tiled, the same code path RCCL takes - for every rank of a world
+    on the CPU: three frames issued back to back on three "streams" with the share rotating, then delivered.  Checks: one group
+    per rank and frame bracketing all of its calls; only sends to / receives on the root; per pair as many sends as receives
+    with equal sizes in equal order; every frame assembled on the root equals the frame the shares were cut from."""
+    import ctypes
+    import geodesic_raytracing_amd as gra
+    width, frames = 16, 3
+    plan = StripPlan(height, world, block)
+    box = _Mailbox()
+    tables = [box.table(gra, r) for r in range(world)]
+    parts = []
+    for r in range(world):
+        h = ctypes.c_void_p()
+        gra.check(gra.lib.gr_tiled_create_custom(world, r, -1, ctypes.byref(tables[r]), width, height, block, ctypes.byref(h)))
+        parts.append(h)
+        assert gra.lib.gr_tiled_staging_bytes(h) == plan.blocks_per_rank * block * width * 16
+    rng = np.random.default_rng(world * 1000 + height)
+    truth = [rng.standard_normal((height, width, 4)).astype(np.float32) for _ in range(frames)]
+    assembled = [np.full((height, width, 4), np.nan, np.float32) for _ in range(frames)]
+    staged = {}
+    for k in range(frames):
+        stream = ctypes.c_void_p(0x1000 + k)   # opaque to the schedule: handed through to the transport
+        for r in range(world):
+            share = gra.lib.gr_tiled_share(parts[r], k)
+            assert share == (r + k) % world
+            if r == 0:   # the root renders its own share in place
+                for a, b in plan.blocks_of(share):
+                    assembled[k][a:b] = truth[k][a:b]
+                gra.check(gra.lib.gr_tiled_exchange(parts[r], None, assembled[k].ctypes.data, k, stream))
+            else:
+                buf = np.zeros((plan.blocks_per_rank, block, width, 4), np.float32)
+                for i, (a, b) in enumerate(plan.blocks_of(share)):
+                    buf[i, :b - a] = truth[k][a:b]
+                staged[(k, r)] = buf
+                gra.check(gra.lib.gr_tiled_exchange(parts[r], buf.ctypes.data, None, k, stream))
+    # the schedule as logged: per rank and frame one group, the frame's stream on every call, the root only receives
+    for r in range(world):
+        mine = [e for e in box.log if e[0] == r]
+        assert [e[1] for e in mine].count("begin") == frames and [e[1] for e in mine].count("end") == frames
+        depth, group = 0, -1
+        for e in mine:
+            depth += e[1] == "begin"
+            group += e[1] == "begin"
+            depth -= e[1] == "end"
+            assert depth in (0, 1)
+            if e[1] in ("send", "recv"):
+                assert depth == 1
+                assert e[1] == ("recv" if r == 0 else "send")
+                assert e[2] != r and (r == 0 or e[2] == 0)
+                assert e[4] == 0x1000 + group   # the k-th group's calls are enqueued on the k-th frame's stream
+    box.deliver()
+    for k in range(frames):
+        assert np.array_equal(assembled[k], truth[k]), k
+    # argument checks of the step
+    assert gra.lib.gr_tiled_exchange(parts[0], None, None, 0, None) != 0
+    assert gra.lib.gr_tiled_exchange(parts[1], None, None, 0, None) != 0
+    for h in parts:
+        gra.lib.gr_tiled_destroy(h)
+
+
+def test_c_abi_exchange_hands_a_transport_error_back():
+    import ctypes
+    import geodesic_raytracing_amd as gra
+    T = gra.Transport
+    calls = []
+    fail = T.SEND(lambda u, d, n, p, s: 7)
+    ended = T.GROUP(lambda u: calls.append("end") or 0)
+    t = T(None, T.GROUP(lambda u: 0), ended, fail, T.RECV(lambda u, d, n, p, s: 0))
+    h = ctypes.c_void_p()
+    gra.check(gra.lib.gr_tiled_create_custom(2, 1, -1, ctypes.byref(t), 8, 54, 8, ctypes.byref(h)))
+    buf = np.zeros(gra.lib.gr_tiled_staging_bytes(h) // 4, np.float32)
+    assert gra.lib.gr_tiled_exchange(h, buf.ctypes.data, None, 0, None) == 7
+    assert calls == ["end"]   # the group is closed even then
+    gra.lib.gr_tiled_destroy(h)

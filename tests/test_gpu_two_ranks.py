@@ -124,3 +124,52 @@ def test_c_abi_tiled_frame_rccl_single_participant():
     assert np.array_equal(frame.to_numpy(np.float32, (h, w, 4)), full.to_numpy(np.float32, (h, w, 4)))
     uid = gra.TiledFrame.unique_id()
     assert len(uid) == 128 and any(uid)
+
+
+@pytest.mark.parametrize("staging", [4, 1])
+def test_c_abi_tiled_frames_in_flight_on_several_streams(staging, monkeypatch):
+    """Six frames issued back to back - no synchronisation in between - by three participants, every frame on the next of three
+    streams with the share rotating and a frame buffer of its own, as bench.py's ring of render states does.  Each participant
+    stages a frame in its own ring slot (csrc/tiled.cpp frame_slot); with more frames than slots (and with a ring of one) a frame
+    waits for the transfers of the frame that used its slot before.  Every frame must be the single-GPU frame bit for bit: a
+    shared staging buffer shows up here as rows of the wrong frame or share."""
+    import geodesic_raytracing_amd as gra
+    from geodesic_raytracing_amd.pipeline import DeviceBuffer
+    monkeypatch.setenv("GR_TILED_STAGING", str(staging))
+    w, h, world, block, in_flight = 640, 360, 3, 24, 3
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    feats = metric.features(adaptive_sampling=0)
+    cfg = metric.cfg_values(a=0.45)
+    packed, levels = gra.pack_background(gra.synthetic_background(512, 256))
+    bg = DeviceBuffer.from_numpy(0, packed)
+    cams = [gra.default_camera([0, 0.1 * k, -4 - 0.3 * k, 0.05 * k]) for k in range(6)]
+    full = DeviceBuffer(0, w * h * 16)
+    single = gra.RenderState(w, h, 0)
+    want = []
+    for cam in cams:
+        single.render(prog, metric, cam, full.ptr, (bg.ptr, 512, 256, levels), feats, cfg, gra.frame_options(mode=gra.MODE_FUSED))
+        single.synchronize()
+        want.append(full.to_numpy(np.float32, (h, w, 4)))
+    parts = gra.TiledFrame.local([0] * world, w, h, block)
+    streams = []
+    for _ in range(in_flight):
+        s = ctypes.c_void_p()
+        gra.check(gra.lib.gr_stream_create(0, 0, ctypes.byref(s)))
+        streams.append(s)
+    # a render state per participant and frame in flight (a state's buffers belong to one frame at a time)
+    states = [[gra.RenderState(w, h, 0) for _ in range(in_flight)] for _ in range(world)]
+    frames = [DeviceBuffer(0, w * h * 16) for _ in cams]
+    for k, cam in enumerate(cams):
+        j = k % in_flight
+        for r in range(world):
+            parts[r].render(states[r][j], prog, metric, cam, frames[k].ptr, (bg.ptr, 512, 256, levels), feats, cfg,
+                            gra.frame_options(mode=gra.MODE_FUSED), stream=streams[j], rotation=k)
+    parts[0].join(streams[0])
+    gra.check(gra.lib.gr_device_synchronize(0))
+    for k in range(len(cams)):
+        assert np.array_equal(frames[k].to_numpy(np.float32, (h, w, 4)), want[k]), k
+    for p in parts:
+        p.close()
+    for s in streams:
+        gra.check(gra.lib.gr_stream_destroy(s))
