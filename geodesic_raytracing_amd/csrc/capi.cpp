@@ -82,7 +82,7 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 }
 
 #ifndef GR_DEFAULT_VECTOR_RUN_LIMIT
-#define GR_DEFAULT_VECTOR_RUN_LIMIT 0
+#define GR_DEFAULT_VECTOR_RUN_LIMIT 8
 #endif
 
 const char* const KERNEL_NAMES[] = {
@@ -278,16 +278,19 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
             if (target_waves > 8) target_waves = 8;
             if (target_waves <= waves_of(vgprs) && getenv("GR_VERBOSE_BUILD"))
                 fprintf(stderr, "[gr] gr_trace_fused: free build %d VGPRs / %d B scratch, left alone\n", vgprs, scratch);
-            if (target_waves > waves_of(vgprs)) {
+            // from the rule's target down to one wave more than the free build holds: the first budget that does not spill too much
+            // (double Kerr: 172 VGPRs = 2 waves; held to 4 waves it spills 148 B, held to 3 - 168 VGPRs - nothing)
+            for (int waves = target_waves; waves > waves_of(vgprs); waves--) {
                 std::vector<std::string> capped = opts;
-                capped.push_back("-DGR_FUSED_WAVES=" + std::to_string(target_waves));
+                capped.push_back("-DGR_FUSED_WAVES=" + std::to_string(waves));
                 std::string code2;
                 int v2 = 0, s2 = 0;
                 const bool built = build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2);
+                const bool keep = built && s2 <= scratch + 96;
                 if (getenv("GR_VERBOSE_BUILD"))
                     fprintf(stderr, "[gr] gr_trace_fused: free build %d VGPRs / %d B scratch; held to %d waves: %d VGPRs / %d B scratch%s\n", vgprs,
-                            scratch, target_waves, v2, s2, built && s2 <= scratch + 96 ? " (kept)" : " (dropped)");
-                if (built && s2 <= scratch + 96) code.swap(code2);
+                            scratch, waves, v2, s2, keep ? " (kept)" : " (dropped)");
+                if (keep) { code.swap(code2); break; }
             }
         }
     }
@@ -466,6 +469,14 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
     HIP_CHECK(hipSetDevice(device));
     auto p = std::make_unique<gr_program>();
     p->key = key;
+    {
+        // What was built for this key is not a function of the key alone: the occupancy rule of compile_code_object depends on a
+        // spill size that varies from one compiler run to the next, and a cache directory may hold either outcome.  The key a
+        // caller sees (and the committed hardware counters carry) therefore names the outcome too: registers and scratch of the
+        // fused trace kernel as loaded.
+        int vgprs = 0, scratch = 0;
+        if (kernel_resources(code, "gr_trace_fused", vgprs, scratch)) p->key += "-v" + std::to_string(vgprs) + "s" + std::to_string(scratch);
+    }
     p->device = device;
     p->arguments = argument_string;
     {

@@ -557,6 +557,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     // rows its blocks' decisions read (two rows of halo either side) and its rows come out as those of the whole frame.
     bool use_prepass = opt.use_prepass < 0 ? info.use_prepass != 0 : opt.use_prepass != 0;
     bool adaptive = features.adaptive_sampling != 0 && !features.use_triangle_rendering;
+    // The 2x2 blocks of handle_adaptive_sampling cover 2 (W/2) x 2 (H/2) pixels (cl.cl:5228-5236): with an odd width or height the
+    // last column or row belongs to no block and would keep whatever its record held.  The fused path then traces every pixel.
+    if (opt.mode == GR_MODE_FUSED && ((width | height) & 1)) adaptive = false;
 
     // dynamic_config: $cfg values in declaration order (metric_manager.hpp:60-66)
     std::vector<float> cfg(info.num_dynamic_vars > 0 ? info.num_dynamic_vars : 1, 0.f);
@@ -726,7 +729,16 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // library default: no compaction (the benchmark workloads keep > 95 % of their lanes busy without it); experiments can
         // switch it on for every frame with GR_TRACE_COMPACT=<keep_lanes>
         static const int default_compaction = [] { const char* e = getenv("GR_TRACE_COMPACT"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
-        const int keep_lanes = opt.ray_compaction < 0 ? default_compaction : opt.ray_compaction;
+        int keep_lanes = opt.ray_compaction < 0 ? default_compaction : opt.ray_compaction;
+        // What does not combine is refused, not silently dropped: ray compaction and the two-rays-per-lane kernel trace every
+        // pixel (no lattice / pending-only form), in-tile shading needs every pixel's record in its own tile's wave.
+        if (adaptive && opt.ray_compaction > 0)
+            return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "ray_compaction > 0 with adaptive sampling: gr_trace_compact traces every pixel (switch one of them off)");
+        if (adaptive && opt.rays_per_lane == 2)
+            return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2 with adaptive sampling: gr_trace_pair traces every pixel (switch one of them off)");
+        if (opt.fused_shading == 1 && (adaptive || keep_lanes > 0 || opt.rays_per_lane == 2))
+            return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused_shading = 1 needs one ray per lane, no compaction and no adaptive sampling");
+        if (adaptive) keep_lanes = 0;   // GR_TRACE_COMPACT (an experiment switch for every frame) does not apply to adaptive frames
         if (keep_lanes > 0)
             GR_CHECK(gr_trace_compact(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
                                       strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
@@ -750,6 +762,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.termination_buffer = term; a.prepass_width = pw; a.prepass_height = ph;
                 a.e0 = s->tetrad[0]; a.e1 = s->tetrad[1]; a.e2 = s->tetrad[2]; a.e3 = s->tetrad[3]; a.cfg = s->cfg; a.dfg = s->dfg;
                 a.attempt_counter = attempts;
+                a.waves_per_simd = opt.trace_waves_per_simd;
                 a.lattice = 2;
                 GR_CHECK(gr_trace_fused_launch(p, stream, &a));
                 GR_CHECK(end(GR_STAGE_TRACE));

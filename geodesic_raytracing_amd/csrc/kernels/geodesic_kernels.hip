@@ -117,9 +117,6 @@ struct dynamic_feature_config {
 #ifndef GR_AGING_PRIORITY
 #define GR_AGING_PRIORITY 0      // experiment: waves that have integrated one tile for long rise in issue priority (measured: no effect)
 #endif
-#ifndef GR_SCALAR_INTERLEAVE
-#define GR_SCALAR_INTERLEAVE 24   // dummy scalar adds per Verlet attempt woven into the acceleration's vector stretch (0: none)
-#endif
 #define GR_SKIP_CHUNK 32          // tiles of the last class per ticket
 
 // minimum resident waves per SIMD the integrator kernels are register-allocated for (512 VGPRs / N waves each).
@@ -1288,23 +1285,9 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
 #else
         float4 next_acceleration = gm::geodesic_acceleration_with<decltype(libm)::value>(next_position, predicted, cfg);
 #endif
-#if GR_SCALAR_INTERLEAVE > 0
-        // Scalar interleave.  The acceleration above is ~135 vector instructions in a row; a wave that is let run issues them back
-        // to back, and measured on MI355X the SIMD's vector port then idles a good part of the time (three frames in flight, 4K
-        // Kerr: 1 440 Mrays/s at 1 240 W, no limiter active).  A chain of GR_SCALAR_INTERLEAVE dummy scalar adds placed here is
-        // woven by the instruction scheduler into that stretch - one s_add_u32 every 2-5 vector instructions - and the same
-        // frames run at 1 730 Mrays/s, at the 1 340 W where the power limiter starts to work: dose-response 1 -> +4 %, 4 -> +9 %,
-        // 8 -> +11 %, 12 -> +16 %, 16 -> +17 %, 24..48 -> +18..20 %, 80 and more slower again (the scalar unit becomes the
-        // bottleneck); one launch on its own 6.5 -> 6.05 ms.  The same count of s_nop, which the scheduler leaves in one block,
-        // does nothing, and neither do wave priorities: it is the alternation of scalar and vector issue inside the stretch that
-        // counts (DESIGN.md section 4 has the measurements and what was ruled out).  The adds compute nothing that is used.
-        {
-            int filler = 1;
-#pragma unroll
-            for (int q = 0; q < GR_SCALAR_INTERLEAVE; q++) asm volatile("s_add_u32 %0, %0, 3" : "+s"(filler) : : "scc");
-            asm volatile("" ::"s"(filler));
-        }
-#endif
+        // (The acceleration above is 135 and more vector instructions in a row.  A wave that issues such a stretch back to back
+        // leaves the SIMD's vector port idle part of the time; the host's pass over the compiled code - csrc/codeobject.cpp,
+        // break_vector_runs - puts an s_nop after every 8th vector instruction of a run, which is worth 25 % here.)
         float4 next_velocity = velocity + (acceleration + next_acceleration) * half_ds;
         if (reparam) {
             const float md = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(next_velocity.x), __builtin_fabsf(next_velocity.y)),

@@ -331,10 +331,34 @@ E fn1(Fn f, E a) {
     return intern(FN1, f, 0, "", a, nullptr, nullptr);
 }
 
+// e >= 0 for every real value of its variables, as far as the structure shows it (sums of squares, roots, moduli ...)
+static bool provably_nonnegative(E e, int depth = 0) {
+    if (depth > 64) return false;
+    switch (e->op) {
+        case CONST: return e->c >= 0.0;
+        case MUL: return e->a == e->b || (provably_nonnegative(e->a, depth + 1) && provably_nonnegative(e->b, depth + 1));
+        case ADD:
+        case DIV: return provably_nonnegative(e->a, depth + 1) && provably_nonnegative(e->b, depth + 1);
+        case FN1: return e->fn == F_SQRT || e->fn == F_FABS || e->fn == F_EXP || e->fn == F_COSH;
+        case FN2:
+            if (e->fn == F_MAX) return provably_nonnegative(e->a, depth + 1) || provably_nonnegative(e->b, depth + 1);
+            if (e->fn == F_MIN) return provably_nonnegative(e->a, depth + 1) && provably_nonnegative(e->b, depth + 1);
+            return e->fn == F_CSQRT_RE;
+        default: return false;
+    }
+}
+
 E fn2(Fn f, E a, E b) {
     if (a->op == CONST && b->op == CONST) {
         double r = apply2(f, fl(a->c), fl(b->c));
         if (std::isfinite(r)) return constant(fl(r));
+    }
+    // principal root of a complex number that turns out to be real (a script written for complex parameters, substituted with
+    // values that make them real - the rod half-lengths of double Kerr with sub-extreme constituents): sqrt(a) and 0 on the
+    // non-negative axis, sqrt(max(a, 0)) + i sqrt(max(-a, 0)) where the sign of a is not known
+    if ((f == F_CSQRT_RE || f == F_CSQRT_IM) && is_zero(b)) {
+        if (provably_nonnegative(a)) return f == F_CSQRT_RE ? fn1(F_SQRT, a) : constant(0.0);
+        return fn1(F_SQRT, fn2(F_MAX, f == F_CSQRT_RE ? a : neg(a), constant(0.0)));
     }
     if (f == F_POW && b->op == CONST) {
         double n = b->c;

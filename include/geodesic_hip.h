@@ -360,9 +360,11 @@ int gr_program_has_trace_pair(const gr_program* p);   /* 1 / 0 */
 int gr_program_has_tile_shading(const gr_program* p);
 /* Process-unique identity of a program object (never reused, unlike its address); 0 for NULL. */
 unsigned long long gr_program_serial(const gr_program* p);
-/* What the program's code object was built from - kernel source, every compile option, hiprtc version - as 16 hex digits (the
- * name of its cache file).  Measurements that belong to one build (hardware counters under profiles/) carry it, so that a
- * reader can tell whether they still describe the kernel that runs. */
+/* What the program's code object was built from - kernel source, every compile option, hiprtc version, the setting of the pass
+ * over the compiled code - as 16 hex digits (the name of its cache file), followed by what came out: "-v<VGPRs>s<scratch bytes>"
+ * of gr_trace_fused as loaded (the build-time occupancy rule can go either way for one set of inputs).  Measurements that belong
+ * to one build (hardware counters under profiles/) carry it, so that a reader can tell whether they still describe the kernel
+ * that runs. */
 const char* gr_program_build_key(const gr_program* p);
 
 /* gr_trace_fused with ray compaction (north_star: "wave-level ballots for step-acceptance and ray compaction"): persistent

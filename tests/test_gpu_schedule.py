@@ -167,3 +167,44 @@ def test_shading_inside_the_trace_launch_needs_a_program_built_for_it():
     with pytest.raises(gra.GeodesicError):
         state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv,
                      gra.frame_options(mode=gra.MODE_FUSED, fused_shading=1))
+
+
+def test_options_that_do_not_combine_are_refused():
+    """ray compaction, two rays per lane and in-tile shading have no adaptive form: gr_render_frame says so (INVALID_ARGUMENT)
+    instead of rendering a frame that silently is not what was asked for; the frame's stage timers stay usable afterwards"""
+    metric = gra.Metric("schwarzschild")
+    prog = gra.Program(metric.argument_string(), 0)
+    w, h = 128, 64
+    state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+    dbg, levels = background()
+    adaptive, plain = metric.features(adaptive_sampling=1), metric.features(adaptive_sampling=0)
+    for feats, kw in [(adaptive, dict(ray_compaction=16)), (adaptive, dict(rays_per_lane=2)), (adaptive, dict(fused_shading=1)),
+                      (plain, dict(fused_shading=1, ray_compaction=16)), (plain, dict(fused_shading=1, rays_per_lane=2))]:
+        with pytest.raises(gra.GeodesicError, match="error -1"):
+            state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, metric.cfg_values(),
+                         gra.frame_options(mode=gra.MODE_FUSED, **kw))
+    # ... and a timed adaptive frame closes every stage it opened
+    state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), adaptive, metric.cfg_values(),
+                 gra.frame_options(mode=gra.MODE_FUSED, time_kernels=1, trace_waves_per_simd=2))
+    state.synchronize()
+    ms = state.stage_ms()
+    assert ms["trace"] > 0 and ms["adaptive"] > 0
+
+
+def test_odd_frame_sizes_are_traced_in_full_on_the_fused_path():
+    """the 2x2 blocks of adaptive sampling do not cover the last column / row of an odd-sized frame: the fused path then traces
+    every pixel, so the frame equals the one rendered with adaptive sampling off (and no record is left unwritten)"""
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    dbg, levels = background()
+    for w, h in [(161, 90), (160, 91), (161, 91)]:
+        frames = []
+        for adaptive in (1, 0):
+            state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+            check(lib.gr_device_upload(0, out.ptr, np.full((h, w, 4), -7.0, np.float32).ctypes.data, w * h * 16))
+            state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), metric.features(adaptive_sampling=adaptive),
+                         metric.cfg_values(a=0.45), gra.frame_options(mode=gra.MODE_FUSED))
+            state.synchronize()
+            frames.append(out.to_numpy(np.float32, (h, w, 4)))
+        assert np.array_equal(frames[0], frames[1]), (w, h)
+        assert (frames[0][..., :3] >= 0).all()

@@ -152,11 +152,14 @@ def test_c_abi_tiled_frames_in_flight_on_several_streams(staging, monkeypatch):
         single.synchronize()
         want.append(full.to_numpy(np.float32, (h, w, 4)))
     parts = gra.TiledFrame.local([0] * world, w, h, block)
-    streams = []
-    for _ in range(in_flight):
-        s = ctypes.c_void_p()
-        gra.check(gra.lib.gr_stream_create(0, 0, ctypes.byref(s)))
-        streams.append(s)
+    streams = []   # [participant][frame in flight]
+    for _ in range(world):
+        row = []
+        for _ in range(in_flight):
+            s = ctypes.c_void_p()
+            gra.check(gra.lib.gr_stream_create(0, 0, ctypes.byref(s)))
+            row.append(s)
+        streams.append(row)
     # a render state per participant and frame in flight (a state's buffers belong to one frame at a time)
     states = [[gra.RenderState(w, h, 0) for _ in range(in_flight)] for _ in range(world)]
     frames = [DeviceBuffer(0, w * h * 16) for _ in cams]
@@ -164,12 +167,13 @@ def test_c_abi_tiled_frames_in_flight_on_several_streams(staging, monkeypatch):
         j = k % in_flight
         for r in range(world):
             parts[r].render(states[r][j], prog, metric, cam, frames[k].ptr, (bg.ptr, 512, 256, levels), feats, cfg,
-                            gra.frame_options(mode=gra.MODE_FUSED), stream=streams[j], rotation=k)
-    parts[0].join(streams[0])
+                            gra.frame_options(mode=gra.MODE_FUSED), stream=streams[r][j], rotation=k)
+    parts[0].join(streams[0][0])
     gra.check(gra.lib.gr_device_synchronize(0))
     for k in range(len(cams)):
         assert np.array_equal(frames[k].to_numpy(np.float32, (h, w, 4)), want[k]), k
     for p in parts:
         p.close()
-    for s in streams:
-        gra.check(gra.lib.gr_stream_destroy(s))
+    for row in streams:
+        for s in row:
+            gra.check(gra.lib.gr_stream_destroy(s))

@@ -1,15 +1,15 @@
-"""Sweep of the assembly pass (GR_VECTOR_RUN_LIMIT) against the scalar fillers (GR_SCALAR_INTERLEAVE) on the bench workload.
+"""Sweep of the assembly pass (GR_VECTOR_RUN_LIMIT; 0 = plain hiprtc build) on the bench workload (profiles/r03_run_limit_sweep.txt).
   build container:  python tools/run_limit_sweep.py build      -> code objects of every variant under tools/_variants/cache
   GPU box:          python tools/run_limit_sweep.py run [args] -> one line per variant: pipelined Mrays/s, one-frame-at-a-time ms
 """
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CACHE = os.path.join(ROOT, "tools", "_variants", "cache")
-VARIANTS = [(0, 3), (0, 4), (0, 5), (0, 6), (0, 8), (0, 10), (0, 12), (24, 12), (24, 0)]
+VARIANTS = [0, 4, 6, 8, 10, 12, 16, 24, 32]
 
 
-def env_of(fillers, limit):
-    return dict(os.environ, GR_CACHE_DIR=CACHE, GR_VECTOR_RUN_LIMIT=str(limit), GR_EXTRA_FLAGS=f"-DGR_SCALAR_INTERLEAVE={fillers}")
+def env_of(limit):
+    return dict(os.environ, GR_CACHE_DIR=CACHE, GR_VECTOR_RUN_LIMIT=str(limit))
 
 
 BUILD = r'''
@@ -25,16 +25,16 @@ for a in spins:
 
 if sys.argv[1] == "build":
     os.makedirs(CACHE, exist_ok=True)
-    for f, l in VARIANTS:
-        subprocess.check_call([sys.executable, "-c", BUILD] + sys.argv[2:], env=env_of(f, l))
-        print("built", f, l, flush=True)
+    for l in VARIANTS:
+        subprocess.check_call([sys.executable, "-c", BUILD] + sys.argv[2:], env=env_of(l))
+        print("built", l, flush=True)
 else:
     extra = sys.argv[2:]
-    for f, l in VARIANTS:
-        row = {"fillers": f, "run_limit": l}
+    for l in VARIANTS:
+        row = {"run_limit": l}
         for tag, mode in [("pipelined", []), ("alone", ["--frames-in-flight", "1", "--no-lookahead"])]:
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary", "--steps", "40", "--warmup", "5"] + mode + extra,
-                                 env=env_of(f, l), capture_output=True, text=True)
+                                 env=env_of(l), capture_output=True, text=True)
             try:
                 j = json.loads(out.stdout.strip().splitlines()[-1])
                 row[tag] = {"Mrays_s": round(j["value"], 1), "ms": round(j["ms_per_step"], 3), "trace_ms": j.get("roofline", {}).get("avg_launch_ms")}
