@@ -33,6 +33,13 @@ TRACE_BYTES_PER_RAY = 32       # gr_trace_fused: one 32-byte render_data record 
 STEP_OVERHEAD_FLOPS = 90       # integrator + step controller per Verlet attempt
 
 
+# BASELINE.json configs[3] and configs[4] on one GPU: metric script, frame size, camera, features, tag of their committed counters
+OTHER_CONFIGS = {3: {"label": "config3_double_unequal_kerr_3840x2160", "metric": "double_unequal_kerr", "size": (3840, 2160), "camera": [0, 0, -6, 0.5],
+                     "features": {}, "tag": "double_unequal_kerr_4k"},
+                 4: {"label": "config4_alcubierre_7680x4320_redshift", "metric": "alcubierre", "size": (7680, 4320), "camera": [0, 0, -6, 0.5],
+                     "features": {"redshift": 1}, "tag": "alcubierre_8k_redshift"}}
+
+
 def committed_counters(workload_tag, build_key):
     """Hardware counters of the fused trace kernel collected by tools/final_profiles.sh for one workload (profiles/pmc_<tag>.json).
     They describe ONE build of the kernel: the file carries that build's key (gr_program_build_key) and is only used when the
@@ -57,6 +64,11 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--metric", default="kerr_boyer")
     ap.add_argument("--spin", type=float, default=0.45)
+    ap.add_argument("--config", type=int, default=0, help="3 / 4: BASELINE.json configs[3] (double_unequal_kerr 3840x2160) / configs[4] "
+                    "(alcubierre 7680x4320, redshift on) as the timed workload on this one GPU (profiling runs; the default line reports "
+                    "them under `secondary`)")
+    ap.add_argument("--camera", default="", help="camera position t,x,y,z (default 0,0,-4,0)")
+    ap.add_argument("--redshift", type=int, default=0)
     ap.add_argument("--mode", default="fused", choices=["fused", "reference"])
     ap.add_argument("--program", default="static", choices=["static", "dynamic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,6 +86,9 @@ def parse():
     ap.add_argument("--measure-clock", action="store_true", help="count attempts in the timed frames too, so that the shader clock of the "
                     "overlapped launches can be read afterwards (two timestamp reads per wave; the counters cost an atomic per tile)")
     args = ap.parse_args()
+    if args.config in OTHER_CONFIGS:
+        c = OTHER_CONFIGS[args.config]
+        args.metric, (args.width, args.height), args.camera, args.redshift = c["metric"], c["size"], ",".join(str(x) for x in c["camera"]), c["features"].get("redshift", 0)
     if args.fused_shading == 1:   # a build option of the programs (part of their cache key)
         os.environ["GR_EXTRA_FLAGS"] = (os.environ.get("GR_EXTRA_FLAGS", "") + " -DGR_TILE_SHADING").strip()
     return args
@@ -143,7 +158,7 @@ def main():
     # the metric comes from the script front-end (scripts/kerr_boyer.js + .json), as in the reference
     metric = gra.Metric(args.metric, os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"))
     cfg_values = metric.cfg_values(a=args.spin) if "a" in metric.dynamic_vars else metric.cfg_values()
-    features = metric.features(adaptive_sampling=0)
+    features = metric.features(adaptive_sampling=0, redshift=args.redshift)
     # metric_manager.hpp:19-219: dynamic program first, substituted program (parameters baked in) built in the
     # background and swapped in; the steady state the reference runs in - and the one timed here - is the substituted one
     manager = gra.pipeline.ProgramManager(metric, local_rank, features, cfg_values)
@@ -152,7 +167,7 @@ def main():
         program = manager.dynamic
     bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
     bg = torch.from_numpy(bg_np).to(device)
-    camera = gra.default_camera()
+    camera = gra.default_camera([float(x) for x in args.camera.split(",")] if args.camera else None)
 
     fused = args.mode == "fused"
     # 48-row blocks: measured per-rank frame time at 4K (tools/strip_probe.py, rotating strips, 3 in flight) 16 -> 48 rows:
@@ -343,40 +358,51 @@ def main():
     # region (same program, same frame; HIP events on the launch's own stream) and is reported next to the overlapped average.
     extra = {}
     local_pixels = W * H if world == 1 else sum(b - a for a, b in plan.blocks_of(rank)) * W + plan.local_blocks(rank) * W
-    alg_bytes = (TRACE_BYTES_PER_RAY if fused else 140) * local_pixels
+    headline_alg_bytes = (TRACE_BYTES_PER_RAY if fused else 140) * local_pixels
     extra["fps"] = round(1e3 / ms_per_step, 2)
     if overlapped_clock:
         extra["shader_clock_mhz_last_overlapped_launches"] = overlapped_clock
 
-    def exclusive_frames(prog, cfgv, n=5):
+    class Workload:   # what a roofline block is measured on: the headline's by default, another configuration's under `secondary`
+        def __init__(self, metric, state, camera, features, target, pixels):
+            self.metric, self.state, self.camera, self.features, self.target, self.pixels = metric, state, camera, features, target, pixels
+
+    def exclusive_frames(prog, cfgv, n=5, wl=None):
         """n frames one at a time with per-stage events and the attempt / shader-clock counters: stage ms (means), attempts,
         MHz"""
         stage_sum, attempts, clocks, shares = {}, 0, [], []
         for _ in range(n):
-            if multi:
+            if wl is not None:
+                opts = gra.frame_options(mode=gra.MODE_FUSED, time_kernels=1, count_attempts=1)
+                wl.state.render(prog, wl.metric, wl.camera, wl.target, (bg.data_ptr(), 4096, 2048, levels), wl.features, cfgv, opts, stream)
+            elif multi:
                 opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=rank, strip_count=world, block_rows=plan.block_rows, compact_out=1,
                                          time_kernels=1, count_attempts=1)
                 target = ring[0].gather.local_buffer().data_ptr()
             else:
                 opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=1, count_attempts=1)
                 target = out.data_ptr()
-            state.render(prog, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfgv, opts, stream)
+            if wl is None:
+                state.render(prog, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfgv, opts, stream)
             torch.cuda.synchronize()
-            attempts = state.attempts()
-            clocks.append(state.shader_clock_mhz())
-            stages_now = state.stage_ms()
+            st = wl.state if wl is not None else state
+            attempts = st.attempts()
+            clocks.append(st.shader_clock_mhz())
+            stages_now = st.stage_ms()
             for k, v in stages_now.items():
                 stage_sum.setdefault(k, []).append(v)
-            wave_ms, waves = state.wave_time()   # fused trace only: summed wave lifetimes -> share of the launch's slots occupied
+            wave_ms, waves = st.wave_time()   # fused trace only: summed wave lifetimes -> share of the launch's slots occupied
             if waves and stages_now.get("trace"):
                 shares.append(wave_ms / waves / stages_now["trace"])
         exclusive_frames.slot_share = float(np.mean(shares[1:])) if len(shares) > 1 else None
         return {k: float(np.mean(v[1:])) for k, v in stage_sum.items()}, attempts, float(np.mean(clocks[1:]))
 
-    def roofline_blocks(prog, cfgv, tag, wall_s_per_frame, overlapped_launch_s=None, launches=0):
+    def roofline_blocks(prog, cfgv, tag, wall_s_per_frame, overlapped_launch_s=None, launches=0, wl=None):
         """the contract's HBM roofline object and the binding fp32-VALU one for one workload"""
-        stages, attempts, mhz = exclusive_frames(prog, cfgv)
+        stages, attempts, mhz = exclusive_frames(prog, cfgv, wl=wl)
         launch_s = stages["trace"] * 1e-3
+        alg_bytes = TRACE_BYTES_PER_RAY * wl.pixels if wl is not None else headline_alg_bytes
+        info = (wl.metric if wl is not None else metric).info
         achieved = alg_bytes / launch_s / 1e9
         pmc, pmc_note = committed_counters(tag, prog.build_key) if (fused and world == 1) else (None, "counters are collected on one GPU")
         roof = {"bound": "hbm", "kernel": "gr_trace_fused" if fused else "gr_do_generic_rays", "achieved": round(achieved, 3),
@@ -394,7 +420,7 @@ def main():
         # fp32 FLOP of one trace launch: counted by the hardware (SQ_INSTS_VALU_{ADD,MUL,FMA x2,TRANS}_F32 x 64 lanes) when the
         # committed counters belong to this build; otherwise the code generator's operation count (every DAG node + a fixed 90
         # for integrator and controller: more than the compiled loop executes), and the line says which
-        model_flops_per_attempt = metric.info.accel_ops + metric.info.coord_ops + STEP_OVERHEAD_FLOPS
+        model_flops_per_attempt = info.accel_ops + info.coord_ops + STEP_OVERHEAD_FLOPS
         counted = pmc.get("fp32_flop_per_launch") if pmc else None
         flop_per_frame = counted if counted else model_flops_per_attempt * attempts
         tflops_wall = flop_per_frame / wall_s_per_frame / 1e12        # all stages, the way frames are produced
@@ -417,6 +443,8 @@ def main():
 
     kerr_4k = args.metric == "kerr_boyer" and (W, H) == (3840, 2160) and fused and args.program == "static"
     tag = ("kerr_a045_4k" if abs(args.spin - 0.45) < 1e-9 else "kerr_a09_4k" if abs(args.spin - 0.9) < 1e-9 else None) if kerr_4k else None
+    if args.config in OTHER_CONFIGS:
+        tag = OTHER_CONFIGS[args.config]["tag"]
     tag = tag or f"{args.metric}_{W}x{H}"
     roofline, valu, stages = roofline_blocks(program, cfg_values, tag, elapsed / args.steps, avg_launch_s, launches)
     if world > 1:   # every rank's trace launch: as timed in the overlapped region, and on its own
@@ -484,11 +512,10 @@ def main():
             secondary["reference_kernel_sequence_dynamic_program_fps"] = round(1 / t, 1)
             # the other BASELINE.json configurations, one frame at a time on this one GPU (substituted programs, fused kernel)
             scripts_dir = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
-            for label, name, (cw, ch), cam_pos, feats_kw in (
-                    ("config1_schwarzschild_1920x1080", "schwarzschild", (1920, 1080), None, {}),                  # as shipped: fixed step
-                    ("config1_schwarzschild_adaptive_1920x1080", "schwarzschild_adaptive", (1920, 1080), None, {}),  # as worded: adaptive
-                    ("config3_double_unequal_kerr_3840x2160", "double_unequal_kerr", (3840, 2160), [0, 0, -6, 0.5], {}),
-                    ("config4_alcubierre_7680x4320_redshift", "alcubierre", (7680, 4320), [0, 0, -6, 0.5], {"redshift": 1})):
+            for label, name, (cw, ch), cam_pos, feats_kw, counters_tag in (
+                    ("config1_schwarzschild_1920x1080", "schwarzschild", (1920, 1080), None, {}, None),                  # as shipped: fixed step
+                    ("config1_schwarzschild_adaptive_1920x1080", "schwarzschild_adaptive", (1920, 1080), None, {}, None),  # as worded: adaptive
+                    *[(c["label"], c["metric"], c["size"], c["camera"], c["features"], c["tag"]) for c in OTHER_CONFIGS.values()]):
                 m2 = gra.Metric(name, scripts_dir)
                 f2 = m2.features(adaptive_sampling=0, **feats_kw)
                 p2 = gra.Program(m2.argument_string(features=f2, static=True, cfg_values=m2.cfg_values()), local_rank)
@@ -507,6 +534,11 @@ def main():
                 torch.cuda.synchronize()
                 t = (time.perf_counter() - t) / 3
                 secondary[label] = {"Mrays_per_s": round(cw * ch / t / 1e6, 1), "fps": round(1 / t, 1)}
+                if counters_tag:   # BASELINE configs[3] / [4]: their own roofline objects (one frame at a time on this GPU)
+                    wl = Workload(m2, st2, c2, f2, out2.data_ptr(), cw * ch)
+                    roof2, valu2, stages2 = roofline_blocks(p2, m2.cfg_values(), counters_tag, t, wl=wl)
+                    secondary[label].update({"roofline": roof2, "valu_roofline": valu2, "stage_ms_sequential_frame": {k: round(v, 4) for k, v in stages2.items()},
+                                             "build_key": p2.build_key, "trace_kernel": p2.kernel_info("gr_trace_fused")})
                 del st2, out2
             extra["secondary"] = secondary
 

@@ -19,6 +19,9 @@ if __name__ == "__main__":
     out_txt, out_json, bench_log = sys.argv[1], sys.argv[2], sys.argv[3]
     bench_line = json.loads([ln for ln in open(bench_log).read().splitlines() if ln.startswith("{")][-1])
     build_key, workload = bench_line["config"]["build_key"], bench_line["config"]["workload"]
+    import re
+    size = re.search(r"(\d+)x(\d+)", workload)
+    pixels = int(size.group(1)) * int(size.group(2)) if size else 0
     data = load(sys.argv[4:])
     lines = ["# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --frames-in-flight 1 --no-lookahead   (tools/final_profiles.sh; one pass per counter set)",
              f"# {workload}; build {build_key}; per-dispatch means; FETCH_SIZE / WRITE_SIZE in KiB"]
@@ -34,7 +37,7 @@ if __name__ == "__main__":
                   f"#   VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64) = {lane_util:.3f}",
                   f"#   SQ_INSTS_VALU = {t['SQ_INSTS_VALU']:.4g} wave-instructions per launch",
                   f"#   wave time: WAIT_INST_ANY {t['SQ_WAIT_INST_ANY'] / t['SQ_WAVE_CYCLES']:.2f}, WAIT_ANY {t['SQ_WAIT_ANY'] / t['SQ_WAVE_CYCLES']:.2f} of SQ_WAVE_CYCLES",
-                  f"#   HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE = 2 x {fetch:.4g} + {write:.4g} = {hbm:.4g} B  (algorithmic: 32 B x 8294400 = 2.654e8 B)"]
+                  f"#   HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE = 2 x {fetch:.4g} + {write:.4g} = {hbm:.4g} B  (algorithmic: 32 B x {pixels} = {32 * pixels:.4g} B)"]
         if "SQ_INSTS_VALU_FMA_F32" in t:
             flops = 64 * (t["SQ_INSTS_VALU_ADD_F32"] + t["SQ_INSTS_VALU_MUL_F32"] + 2 * t["SQ_INSTS_VALU_FMA_F32"] + t["SQ_INSTS_VALU_TRANS_F32"])
             other = t["SQ_INSTS_VALU"] - (t["SQ_INSTS_VALU_ADD_F32"] + t["SQ_INSTS_VALU_MUL_F32"] + t["SQ_INSTS_VALU_FMA_F32"] +
