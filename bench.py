@@ -403,6 +403,9 @@ def main():
         launch_s = stages["trace"] * 1e-3
         alg_bytes = TRACE_BYTES_PER_RAY * wl.pixels if wl is not None else headline_alg_bytes
         info = (wl.metric if wl is not None else metric).info
+        accel_ops, coord_ops = info.accel_ops, info.coord_ops
+        if args.program == "static" or wl is not None:   # the substituted program's DAG (parameters folded in) is what runs
+            accel_ops, _, coord_ops = (wl.metric if wl is not None else metric).substituted_op_counts(cfgv)
         achieved = alg_bytes / launch_s / 1e9
         pmc, pmc_note = committed_counters(tag, prog.build_key) if (fused and world == 1) else (None, "counters are collected on one GPU")
         roof = {"bound": "hbm", "kernel": "gr_trace_fused" if fused else "gr_do_generic_rays", "achieved": round(achieved, 3),
@@ -420,7 +423,7 @@ def main():
         # fp32 FLOP of one trace launch: counted by the hardware (SQ_INSTS_VALU_{ADD,MUL,FMA x2,TRANS}_F32 x 64 lanes) when the
         # committed counters belong to this build; otherwise the code generator's operation count (every DAG node + a fixed 90
         # for integrator and controller: more than the compiled loop executes), and the line says which
-        model_flops_per_attempt = info.accel_ops + info.coord_ops + STEP_OVERHEAD_FLOPS
+        model_flops_per_attempt = accel_ops + coord_ops + STEP_OVERHEAD_FLOPS
         counted = pmc.get("fp32_flop_per_launch") if pmc else None
         flop_per_frame = counted if counted else model_flops_per_attempt * attempts
         tflops_wall = flop_per_frame / wall_s_per_frame / 1e12        # all stages, the way frames are produced

@@ -92,6 +92,8 @@ _SIGNATURES = {
     "gr_metric_dynamic_var_default": (c_float, [c_void_p, c_int]),
     "gr_metric_argument_string": (c_int, [c_void_p, ctypes.POINTER(Features), c_int, ctypes.POINTER(c_float), c_int,
                                           c_char_p, c_size_t, ctypes.POINTER(c_size_t)]),
+    "gr_metric_substituted_op_counts": (c_int, [c_void_p, ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                                ctypes.POINTER(c_int)]),
     "gr_program_create": (c_int, [c_char_p, c_int, ctypes.POINTER(c_void_p)]),
     "gr_program_precompile": (c_int, [c_char_p]),
     "gr_program_create_async": (c_int, [c_char_p, c_int, ctypes.POINTER(c_void_p)]),
@@ -165,6 +167,7 @@ _SIGNATURES = {
     "gr_geodesic_camera_interpolate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, ctypes.POINTER(c_float),
                                                ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
     "gr_geodesic_camera_buffer": (c_void_p, [c_void_p, c_int]),
+    "gr_render_state_prepass_policy": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(c_float)]),
     "gr_render_state_stage_ms": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float)]),
     "gr_render_state_trace_log": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int), c_int]),
     "gr_render_state_attempts": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),

@@ -455,6 +455,22 @@ int gr_metric_argument_string(const gr_metric* m, const gr_features* features, i
     GR_TRY_END
 }
 
+int gr_metric_substituted_op_counts(const gr_metric* m, const float* cfg_values, int num_cfg_values, int* accel_ops,
+                                    int* accel_transcendentals, int* coord_ops) {
+    if (!m) return fail(GR_ERROR_INVALID_ARGUMENT, "null metric");
+    GR_TRY_BEGIN
+    std::vector<float> vals(cfg_values, cfg_values + (cfg_values ? num_cfg_values : 0));
+    const gr::MetricImpl concrete = m->desc.concrete(m->vars.substitution(vals));
+    const sym::OpCount accel = sym::count_ops(concrete.accel);
+    std::vector<sym::E> coord = concrete.to_polar;
+    coord.push_back(concrete.distance_function);
+    if (accel_ops) *accel_ops = accel.ops;
+    if (accel_transcendentals) *accel_transcendentals = accel.transcendental;
+    if (coord_ops) *coord_ops = sym::count_ops(coord).ops;
+    return GR_OK;
+    GR_TRY_END
+}
+
 int gr_program_precompile(const char* argument_string) {
     if (!argument_string) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument string");
     std::string code;

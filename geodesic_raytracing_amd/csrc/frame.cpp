@@ -97,8 +97,26 @@ struct gr_render_state {
     };
     static const int LOOKAHEAD = 2;
     prefetch_slot pre[LOOKAHEAD];
+    // Prepass policy (use_prepass = -1, whole frames on the fused path).  The prepass pays for itself through the pixels it lets the
+    // trace skip; where it skips next to nothing (Kerr with a = 0.9 in the script's units: a naked singularity, no shadow - 8.4 ms of
+    // single-ray latency in front of every 4K frame, for nothing) it is left out: its flags are copied to the host after a frame
+    // that ran it, read a frame or two later without waiting, and when fewer than PREPASS_MIN_SKIP of the cells were marked the next
+    // PREPASS_HOLIDAY frames go without one; then it is tried again.  Pixels do not depend on it (a skipped pixel is one whose ray
+    // would have ended in the shadow anyway; tests/test_gpu_fullsize.py holds frames with and without it equal).
+    struct prepass_policy {
+        int* host_flags = nullptr;   // pinned
+        size_t capacity = 0, cells = 0;
+        hipEvent_t copied = nullptr;
+        bool in_flight = false;
+        int holiday = 0;
+        float last_fraction = -1.f;
+        unsigned long long with_prepass = 0, without_prepass = 0;
+    } policy;
+    static constexpr float PREPASS_MIN_SKIP = 0.02f;
+    static const int PREPASS_HOLIDAY = 30;
     hipEvent_t main_mark = nullptr;
     unsigned long long frame_counter = 0;
+    unsigned long long policy_program = 0;
     // time_kernels == 2: one event pair per trace launch, kept until gr_render_state_trace_log collects them (frames of
     // several states overlap on the GPU in pipelined rendering, so "the last frame" is not a representative sample)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_log;
@@ -148,6 +166,15 @@ void gr_camera_default(gr_camera* c) {
     c->quat[0] = std::sin(half); c->quat[1] = 0; c->quat[2] = 0; c->quat[3] = std::cos(half);
     c->basis_speed[0] = c->basis_speed[1] = c->basis_speed[2] = 0;
     c->flip = 0;
+}
+
+int gr_render_state_prepass_policy(gr_render_state* s, unsigned long long* frames_with_prepass, unsigned long long* frames_without,
+                                   float* last_marked_fraction) {
+    if (!s) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (frames_with_prepass) *frames_with_prepass = s->policy.with_prepass;
+    if (frames_without) *frames_without = s->policy.without_prepass;
+    if (last_marked_fraction) *last_marked_fraction = s->policy.last_fraction;
+    return GR_OK;
 }
 
 void gr_frame_options_default(gr_frame_options* o) {
@@ -309,6 +336,8 @@ void gr_render_state_destroy(gr_render_state* s) {
                                  slot.velocity});
     }
     if (s->main_mark) (void)hipEventDestroy(s->main_mark);
+    if (s->policy.copied) (void)hipEventDestroy(s->policy.copied);
+    if (s->policy.host_flags) (void)hipHostFree(s->policy.host_flags);
     for (auto& pr : s->trace_log) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -568,6 +597,28 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     if ((int)cfg.size() > CFG_MAX) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "too many dynamic variables");
     const bool cfg_changed = cfg != s->host_cfg;
     const bool features_changed = !s->features_valid || memcmp(&features, &s->host_features, sizeof(features)) != 0;
+    const bool prepass_by_policy = opt.use_prepass < 0 && use_prepass && opt.mode == GR_MODE_FUSED && opt.strip_count <= 1;
+    if (prepass_by_policy) {
+        auto& pol = s->policy;
+        const unsigned long long serial = gr_program_serial(p);
+        if (cfg_changed || features_changed || serial != s->policy_program) {   // another metric or parameter set: start over
+            pol.holiday = 0;
+            pol.last_fraction = -1.f;
+            if (pol.in_flight) { HIP_CHECK(hipEventSynchronize(pol.copied)); pol.in_flight = false; }
+            s->policy_program = serial;
+        }
+        if (pol.in_flight && hipEventQuery(pol.copied) == hipSuccess) {
+            size_t marked = 0;
+            for (size_t i = 0; i < pol.cells; i++) marked += pol.host_flags[i] == 1;
+            pol.last_fraction = pol.cells ? (float)marked / (float)pol.cells : 0.f;
+            pol.in_flight = false;
+            if (pol.last_fraction < gr_render_state::PREPASS_MIN_SKIP) pol.holiday = gr_render_state::PREPASS_HOLIDAY;
+        } else if (pol.in_flight) {
+            (void)hipGetLastError();   // hipErrorNotReady is not an error
+        }
+        if (pol.holiday > 0) { pol.holiday--; pol.without_prepass++; use_prepass = false; }
+        else pol.with_prepass++;
+    }
     if (cfg_changed || features_changed) {
         // Look-ahead prepasses read s->cfg / s->dfg on their side streams: the upload below must not overtake one that is still
         // running (it would read a mix of old and new parameters), and what the slots hold was computed for the old parameters.
@@ -723,6 +774,21 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             }
         }
         if (!todo.empty()) HIP_CHECK(hipEventRecord(s->main_mark, stream));   // everything up to here is older than the prefetches
+        if (prepass_by_policy && use_prepass && !s->policy.in_flight) {
+            // this frame's prepass flags -> host, behind the prepass on the frame's stream; read when a later frame finds them there
+            auto& pol = s->policy;
+            if (pol.capacity < cells) {
+                if (pol.host_flags) (void)hipHostFree(pol.host_flags);
+                pol.host_flags = nullptr;
+                HIP_CHECK(hipHostMalloc((void**)&pol.host_flags, cells * sizeof(int), hipHostMallocDefault));
+                pol.capacity = cells;
+            }
+            if (!pol.copied) HIP_CHECK(hipEventCreateWithFlags(&pol.copied, hipEventDisableTiming));
+            HIP_CHECK(hipMemcpyAsync(pol.host_flags, s->termination_buffer, cells * sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipEventRecord(pol.copied, stream));
+            pol.cells = cells;
+            pol.in_flight = true;
+        }
         // every device runs the (tiny) prepass itself; its own row blocks (+ one halo row each) are traced here
         bool shade_in_trace = false;
         GR_CHECK(begin(GR_STAGE_TRACE));

@@ -69,6 +69,13 @@ class Metric:
             vals[self.dynamic_vars.index(k)] = float(v)
         return vals
 
+    def substituted_op_counts(self, cfg_values=None):
+        """(acceleration ops, its transcendentals, coordinate ops) of the substituted program for these parameter values"""
+        vals = list(cfg_values) if cfg_values is not None else self.cfg_values()
+        a, t, c = c_int(), c_int(), c_int()
+        check(lib.gr_metric_substituted_op_counts(self.handle, (c_float * len(vals))(*vals), len(vals), ctypes.byref(a), ctypes.byref(t), ctypes.byref(c)))
+        return a.value, t.value, c.value
+
     def features(self, **overrides):
         """feature struct with this metric's error tolerance (metric_manager.hpp:50)."""
         return default_features(max_acceleration_change=self.info.max_acceleration_change, **overrides)
@@ -292,6 +299,12 @@ class RenderState:
         check(lib.gr_render_frame(self.handle, program.handle, metric.handle, stream, ctypes.byref(camera),
                                   ctypes.byref(features), arr, n, bg1, bg2, bw, bh, bl, out_ptr,
                                   ctypes.byref(options) if options is not None else None))
+
+    def prepass_policy(self):
+        """(frames rendered with a prepass, frames the policy rendered without, fraction of cells the last inspected prepass marked)"""
+        a, b, f = ctypes.c_ulonglong(), ctypes.c_ulonglong(), c_float()
+        check(lib.gr_render_state_prepass_policy(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(f)))
+        return a.value, b.value, f.value
 
     def stage_ms(self):
         out = {}

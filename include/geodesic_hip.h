@@ -122,6 +122,11 @@ int gr_metric_argument_string(const gr_metric* m, const gr_features* features, i
                               const float* cfg_values, int num_cfg_values,
                               char* buffer, size_t capacity, size_t* needed);
 
+/* gr_metric_info's operation counts for the substituted program of these parameter values (NULL = defaults): parameters that
+ * make parts of a metric vanish - real rod lengths in the complex-valued double-Kerr family - shrink the DAG a good deal. */
+int gr_metric_substituted_op_counts(const gr_metric* m, const float* cfg_values, int num_cfg_values, int* accel_ops,
+                                    int* accel_transcendentals, int* coord_ops);
+
 /* ---- device program ------------------------------------------------------------------------- */
 
 typedef struct gr_program gr_program;
@@ -402,7 +407,10 @@ typedef struct gr_geodesic_camera gr_geodesic_camera;
 typedef struct gr_frame_options {
     int mode;              /* GR_MODE_* */
     int tiled;             /* reference mode only: 8x8-tile ray order (ignored when adaptive sampling is on) */
-    int use_prepass;       /* -1: per metric config (metric_cfg.use_prepass), 0/1 force */
+    int use_prepass;       /* -1: per metric config (metric_cfg.use_prepass) and - whole frames on the fused path - only while it pays:
+                            * when a frame's prepass marked fewer than 2 % of its cells, the next 30 frames of this render state go
+                            * without one, then it is tried again (pixels do not depend on it; gr_render_state_prepass_policy
+                            * reports).  0 / 1 force it off / on for this frame. */
     int max_probes;        /* anisotropy, graphics_settings.hpp:34 (8) */
     int strip_rank;        /* fused mode, multi-GPU: image rows are dealt in blocks of block_rows rows,          */
     int strip_count;       /*   global block b belongs to device b % strip_count (1 = whole image on this device) */
@@ -470,6 +478,11 @@ int gr_geodesic_camera_interpolate(gr_geodesic_camera* g, gr_program* p, void* s
 enum { GR_GEOBUF_PATH = 0, GR_GEOBUF_VELOCITY = 1, GR_GEOBUF_DS = 2, GR_GEOBUF_COUNT = 3, GR_GEOBUF_TRANSPORTED0 = 4,
        GR_GEOBUF_TRANSPORTED1 = 5, GR_GEOBUF_TRANSPORTED2 = 6, GR_GEOBUF_TRANSPORTED3 = 7 };
 void* gr_geodesic_camera_buffer(gr_geodesic_camera* g, int which);
+
+/* what the prepass policy (gr_frame_options.use_prepass = -1) has done with this state's frames so far, and the fraction of
+ * prepass cells the last inspected prepass marked (-1: none inspected yet); any output may be NULL */
+int gr_render_state_prepass_policy(gr_render_state* s, unsigned long long* frames_with_prepass, unsigned long long* frames_without,
+                                   float* last_marked_fraction);
 
 /* stages for timing / buffer access */
 enum { GR_STAGE_CAMERA = 0, GR_STAGE_PREPASS = 1, GR_STAGE_INIT = 2, GR_STAGE_TRACE = 3, GR_STAGE_RENDER_DATA = 4,

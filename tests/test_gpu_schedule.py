@@ -208,3 +208,33 @@ def test_odd_frame_sizes_are_traced_in_full_on_the_fused_path():
             frames.append(out.to_numpy(np.float32, (h, w, 4)))
         assert np.array_equal(frames[0], frames[1]), (w, h)
         assert (frames[0][..., :3] >= 0).all()
+
+
+def test_prepass_policy_drops_a_prepass_that_skips_nothing():
+    """use_prepass = -1 on whole fused frames: the literal a = 0.9 Kerr (no shadow: the prepass marks no cell) goes without a
+    prepass after the first inspected frame, for 30 frames at a time; a = 0.45 (58 % of the pixels skipped) keeps it; a change of
+    parameters starts over.  Frames are the frames rendered with the prepass forced on, bit for bit."""
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(), 0)
+    w, h = 640, 360
+    dbg, levels = background()
+    state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+    forced, want = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+
+    def run(a, frames):
+        cfgv = metric.cfg_values(a=a)
+        forced.render(prog, metric, gra.default_camera(), want.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv, gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1))
+        forced.synchronize()
+        expect = want.to_numpy(np.float32, (h, w, 4))
+        for _ in range(frames):
+            state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv, gra.frame_options(mode=gra.MODE_FUSED))
+            state.synchronize()
+            assert np.array_equal(out.to_numpy(np.float32, (h, w, 4)), expect)
+        return state.prepass_policy()
+
+    with_a, without_a, frac = run(0.9, 40)
+    assert frac >= 0 and frac < 0.02
+    assert with_a + without_a == 40 and 2 <= with_a <= 3                       # frame 1, 30 frames off, a probe, off again
+    with_b, without_b, frac = run(0.45, 6)                                     # other parameters: the policy starts over
+    assert without_b == without_a and with_b == with_a + 6 and frac > 0.3
