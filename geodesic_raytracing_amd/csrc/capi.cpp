@@ -790,9 +790,17 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
                         int width, int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
                         int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
                         const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0, const void* tile_order = nullptr,
-                        int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr) {
+                        int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr, int inline_prepass = 0) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
+    // the prepass inside the launch: its cell waves are the first tickets (gr_trace_fused's prepass_tickets)
+    int prepass_tickets = 0;
+    if (inline_prepass) {
+        if (rays_per_lane != 1 || lattice != 1 || pending_only || tile_order || strip_count > 1 || !term || prepass_width <= 0 || prepass_height <= 0 ||
+            prepass_width == width || prepass_height == height)
+            return fail(GR_ERROR_INVALID_ARGUMENT, "inline_prepass: gr_trace_fused on every pixel of a whole frame in image order, with a prepass grid");
+        prepass_tickets = (int)(((long long)prepass_width * prepass_height + 63) / 64);
+    }
     if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && rays_per_lane != 1))
         return fail(GR_ERROR_INVALID_ARGUMENT, "lattice / pending_only: gr_trace_fused only");
     if (rays_per_lane == 2 && !p->fn[K_TRACE_PAIR])
@@ -821,7 +829,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     if (waves <= 0) return GR_OK;
     if (waves > 0x7fffffff) return fail(GR_ERROR_INVALID_ARGUMENT, "too many tiles");
     int total_waves = (int)waves;
-    long long groups = ((waves + rays_per_lane - 1) / rays_per_lane * 64 + wg - 1) / wg;
+    long long groups = (((waves + rays_per_lane - 1) / rays_per_lane + prepass_tickets) * 64 + wg - 1) / wg;
     unsigned int* tickets = nullptr;
     // persistent mode only pays when there are more tiles than wave slots.  The launch is exactly as many workgroups as the
     // kernel's register and scratch footprint lets the device hold (asked of the runtime once per kernel): a larger one
@@ -846,12 +854,14 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         resident_groups = (long long)p->compute_units * 4 * forced_waves_per_simd * 64 / wg;
     else if (waves_per_simd >= 1 && waves_per_simd <= 8)
         resident_groups = std::min(resident_groups, (long long)p->compute_units * 4 * waves_per_simd * 64 / wg);
-    if (persistent && groups > resident_groups) {
+    if ((persistent && groups > resident_groups) || prepass_tickets) {   // prepass tickets need the ticket order whatever the size
         tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
         HIP_CHECK(hipSetDevice(p->device));
         HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
-        groups = resident_groups;
+        groups = std::min(groups, resident_groups);
     }
+    if (prepass_tickets)   // every cell unknown (GR_CELL_UNKNOWN = -1) until its ray has been traced
+        HIP_CHECK(hipMemsetAsync(const_cast<void*>(term), 0xff, (size_t)prepass_width * prepass_height * sizeof(int), (hipStream_t)stream));
     // the kernel's trace_shading, by value (same layout)
     struct { void* out; const void* bg1; const void* bg2; int bg_width, bg_height, bg_levels, most_probes, compact_out; } shading = {};
     if (shading_in && shading_in->out) {
@@ -865,7 +875,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     }
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
-                    &lattice, &pending_only, &tile_order, &shading};   // the last four: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
+                    &lattice, &pending_only, &tile_order, &shading, &prepass_tickets};   // the last five: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
     return launch(p, kernel_index, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
@@ -902,7 +912,8 @@ int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args
     if (!a) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
     return trace_launch(p, 1, stream, a->camera_generic, a->camera_quat, a->render_data, a->width, a->height, a->block_rows, a->strip_rank,
                         a->strip_count, a->termination_buffer, a->prepass_width, a->prepass_height, a->e0, a->e1, a->e2, a->e3, a->cfg, a->dfg,
-                        a->attempt_counter, a->lattice == 2 ? 2 : 1, a->pending_only ? 1 : 0, a->tile_order, a->waves_per_simd, &a->shading);
+                        a->attempt_counter, a->lattice == 2 ? 2 : 1, a->pending_only ? 1 : 0, a->tile_order, a->waves_per_simd, &a->shading,
+                        a->inline_prepass ? 1 : 0);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

@@ -191,6 +191,7 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->count_attempts = 0;
     o->trace_waves_per_simd = 0;
     o->fused_shading = -1;
+    o->inline_prepass = -1;
     o->next_camera = nullptr;
     o->geodesic = nullptr;
     o->geodesic_time = 0;
@@ -736,12 +737,40 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                  (size_t)gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
         const int prepass_margin = adaptive ? 2 : 0;   // the lattice rows beyond a block that its 2x2 decisions read
         auto cost_plane = [&](void* termination_buffer) -> void* { return order_tiles ? (void*)((unsigned int*)termination_buffer + cells) : nullptr; };
+        // which trace kernel this frame takes (needed here already: the prepass may ride in the trace launch)
+        // library default: no compaction (the benchmark workloads keep > 95 % of their lanes busy without it); experiments can
+        // switch it on for every frame with GR_TRACE_COMPACT=<keep_lanes>
+        static const int default_compaction = [] { const char* e = getenv("GR_TRACE_COMPACT"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
+        int keep_lanes = opt.ray_compaction < 0 ? default_compaction : opt.ray_compaction;
+        // What does not combine is refused, not silently dropped: ray compaction and the two-rays-per-lane kernel trace every
+        // pixel (no lattice / pending-only form), in-tile shading needs every pixel's record in its own tile's wave.
+        if (adaptive && opt.ray_compaction > 0)
+            return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "ray_compaction > 0 with adaptive sampling: gr_trace_compact traces every pixel (switch one of them off)");
+        if (adaptive && opt.rays_per_lane == 2)
+            return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2 with adaptive sampling: gr_trace_pair traces every pixel (switch one of them off)");
+        if (opt.fused_shading == 1 && (adaptive || keep_lanes > 0 || opt.rays_per_lane == 2))
+            return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused_shading = 1 needs one ray per lane, no compaction and no adaptive sampling");
+        if (adaptive) keep_lanes = 0;   // GR_TRACE_COMPACT (an experiment switch for every frame) does not apply to adaptive frames
+        // two rays per lane (gr_trace_pair) where the program has that kernel, unless told otherwise
+        static const int default_rays_per_lane = [] { const char* e = getenv("GR_TRACE_RAYS_PER_LANE"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : GR_DEFAULT_RAYS_PER_LANE; }();
+        int rays_per_lane = opt.rays_per_lane == 1 || opt.rays_per_lane == 2 ? opt.rays_per_lane : default_rays_per_lane;
+        if (rays_per_lane == 2 && !gr_program_has_trace_pair(p)) {
+            if (opt.rays_per_lane == 2) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2: this program has no gr_trace_pair kernel");
+            rays_per_lane = 1;
+        }
+        // The prepass inside the trace launch (gr_trace_fused_args.inline_prepass): for a frame whose prepass was not computed
+        // ahead of time - an interactive caller does not know the next camera - the prepass's single-ray latency (1.1 ms at 4K
+        // Kerr, 8 ms with a = 0.9) then runs alongside the first tiles instead of in front of the whole trace.
+        static const int inline_default = [] { const char* e = getenv("GR_INLINE_PREPASS"); return !e ? 1 : e[0] != '0'; }();
+        const bool inline_prepass = (opt.inline_prepass < 0 ? inline_default != 0 : opt.inline_prepass != 0) && !prefetched && one_launch_setup && use_prepass &&
+                                    strip_count == 1 && !adaptive && !order_tiles && keep_lanes == 0 && rays_per_lane == 1 &&
+                                    prepass_width != width && prepass_height != height;
         if (!prefetched && one_launch_setup) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_camera_prepass(p, stream, s->camera_pos_cart, camera->flip, camera->basis_speed, s->camera_pos_generic, s->tetrad[0],
                                        s->tetrad[1], s->tetrad[2], s->tetrad[3], s->camera_quat, s->termination_buffer,
-                                       use_prepass ? prepass_width : 0, use_prepass ? prepass_height : 0, s->cfg, s->dfg, height, block_rows,
-                                       strip_rank, strip_count, cost_plane(s->termination_buffer), prepass_margin));
+                                       use_prepass && !inline_prepass ? prepass_width : 0, use_prepass && !inline_prepass ? prepass_height : 0, s->cfg,
+                                       s->dfg, height, block_rows, strip_rank, strip_count, cost_plane(s->termination_buffer), prepass_margin));
             if (order_tiles)
                 GR_CHECK(gr_order_tiles(p, stream, s->termination_buffer, cost_plane(s->termination_buffer), prepass_width, prepass_height,
                                         width, height, block_rows, strip_rank, strip_count, s->tile_order));
@@ -774,7 +803,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             }
         }
         if (!todo.empty()) HIP_CHECK(hipEventRecord(s->main_mark, stream));   // everything up to here is older than the prefetches
-        if (prepass_by_policy && use_prepass && !s->policy.in_flight) {
+        auto inspect_prepass = [&]() -> int {
+            if (!(prepass_by_policy && use_prepass && !s->policy.in_flight)) return GR_OK;
             // this frame's prepass flags -> host, behind the prepass on the frame's stream; read when a later frame finds them there
             auto& pol = s->policy;
             if (pol.capacity < cells) {
@@ -788,36 +818,18 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             HIP_CHECK(hipEventRecord(pol.copied, stream));
             pol.cells = cells;
             pol.in_flight = true;
-        }
+            return GR_OK;
+        };
+        if (!inline_prepass) GR_CHECK(inspect_prepass());   // (with the prepass inside the trace launch: after it)
         // every device runs the (tiny) prepass itself; its own row blocks (+ one halo row each) are traced here
         bool shade_in_trace = false;
         GR_CHECK(begin(GR_STAGE_TRACE));
-        // library default: no compaction (the benchmark workloads keep > 95 % of their lanes busy without it); experiments can
-        // switch it on for every frame with GR_TRACE_COMPACT=<keep_lanes>
-        static const int default_compaction = [] { const char* e = getenv("GR_TRACE_COMPACT"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
-        int keep_lanes = opt.ray_compaction < 0 ? default_compaction : opt.ray_compaction;
-        // What does not combine is refused, not silently dropped: ray compaction and the two-rays-per-lane kernel trace every
-        // pixel (no lattice / pending-only form), in-tile shading needs every pixel's record in its own tile's wave.
-        if (adaptive && opt.ray_compaction > 0)
-            return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "ray_compaction > 0 with adaptive sampling: gr_trace_compact traces every pixel (switch one of them off)");
-        if (adaptive && opt.rays_per_lane == 2)
-            return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2 with adaptive sampling: gr_trace_pair traces every pixel (switch one of them off)");
-        if (opt.fused_shading == 1 && (adaptive || keep_lanes > 0 || opt.rays_per_lane == 2))
-            return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused_shading = 1 needs one ray per lane, no compaction and no adaptive sampling");
-        if (adaptive) keep_lanes = 0;   // GR_TRACE_COMPACT (an experiment switch for every frame) does not apply to adaptive frames
         if (keep_lanes > 0)
             GR_CHECK(gr_trace_compact(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
                                       strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
                                       use_prepass ? prepass_width : width, use_prepass ? prepass_height : height, s->tetrad[0],
                                       s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, keep_lanes));
         else {
-            // two rays per lane (gr_trace_pair) where the program has that kernel, unless told otherwise
-            static const int default_rays_per_lane = [] { const char* e = getenv("GR_TRACE_RAYS_PER_LANE"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : GR_DEFAULT_RAYS_PER_LANE; }();
-            int rays_per_lane = opt.rays_per_lane == 1 || opt.rays_per_lane == 2 ? opt.rays_per_lane : default_rays_per_lane;
-            if (rays_per_lane == 2 && !gr_program_has_trace_pair(p)) {
-                if (opt.rays_per_lane == 2) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2: this program has no gr_trace_pair kernel");
-                rays_per_lane = 1;
-            }
             if (adaptive) {
                 // quarter of the primary rays (the pixels (2x, 2y)), then the blocks that need it refined by a second launch
                 const void* term = use_prepass ? s->termination_buffer : nullptr;
@@ -856,6 +868,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.attempt_counter = attempts;
                 a.tile_order = order_tiles ? s->tile_order : nullptr;
                 a.waves_per_simd = opt.trace_waves_per_simd;
+                a.inline_prepass = inline_prepass ? 1 : 0;
                 // the trace shades the pixels whose filter neighbours are in their own tile; gr_render_seams below does the rest
                 shade_in_trace = out && opt.fused_shading == 1 && width % 8 == 0 && height % 8 == 0 && gr_program_has_tile_shading(p);
                 if (opt.fused_shading == 1 && !shade_in_trace && out)   // default: off, on measurement
@@ -871,6 +884,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             }
         }
         if (!adaptive) GR_CHECK(end(GR_STAGE_TRACE));
+        if (inline_prepass) GR_CHECK(inspect_prepass());
         for (const auto& r : todo) {
             // a free slot, else the stalest one no current request claims (a camera that was announced but never came)
             gr_render_state::prefetch_slot* slot = nullptr;

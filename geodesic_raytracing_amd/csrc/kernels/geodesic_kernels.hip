@@ -910,6 +910,30 @@ __device__ __forceinline__ bool early_terminate_stencil(int lx, int ly, int w, i
     return inside & (left == 1) & (centre == 1) & (right == 1) & (up == 1) & (down == 1);
 }
 
+// The same verdict while the prepass is still running in the SAME launch (gr_trace_fused with prepass_tickets > 0: the first
+// tickets of the persistent launch are the prepass cells, 64 to a wave; the buffer was filled with GR_CELL_UNKNOWN before the
+// launch).  A lane reads its five cells with device-scope loads until none of them is unknown; the wave sleeps between rounds.
+// This cannot hang: tickets are handed out in order, so every prepass ticket is held by a running wave before the first tile
+// ticket is drawn, and prepass waves wait for nothing.
+#define GR_CELL_UNKNOWN (-1)
+__device__ __forceinline__ bool early_terminate_stencil_when_known(int lx, int ly, int w, int h, const int* term) {
+    const int x0 = min(max(lx - 1, 0), w - 1), x1 = min(max(lx, 0), w - 1), x2 = min(max(lx + 1, 0), w - 1);
+    const int y0 = min(max(ly - 1, 0), h - 1), y1 = min(max(ly, 0), h - 1), y2 = min(max(ly + 1, 0), h - 1);
+    int left, centre, right, up, down;
+    for (;;) {
+        left = __hip_atomic_load(term + y1 * w + x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        centre = __hip_atomic_load(term + y1 * w + x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        right = __hip_atomic_load(term + y1 * w + x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        up = __hip_atomic_load(term + y0 * w + x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        down = __hip_atomic_load(term + y2 * w + x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool unknown = (left | centre | right | up | down) < 0;   // GR_CELL_UNKNOWN is the only negative value
+        if (__builtin_amdgcn_ballot_w64(unknown) == 0) break;
+        __builtin_amdgcn_s_sleep(64);   // ~4 k cycles: a prepass ray takes 10^5..10^6
+    }
+    const bool inside = lx - 1 >= 0 && lx + 1 <= w - 1 && ly - 1 >= 0 && ly + 1 <= h - 1;
+    return inside & (left == 1) & (centre == 1) & (right == 1) & (up == 1) & (down == 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // the integrator (cl.cl:3273-3346, 3400-3456, 3954-4247)
 
@@ -1953,7 +1977,10 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            int prepass_height, const float4* __restrict__ e0, const float4* __restrict__ e1,
                                            const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
                                            unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
-                                           const trace_shading& shading, bool known_skipped) {
+                                           const trace_shading& shading, bool known_skipped, int cell_wave, bool cells_in_flight) {
+    // cell_wave >= 0: this "tile" is 64 cells of the low-resolution prepass (prepass_cell, below) traced by the launch itself:
+    // the ray of cell (cx, cy) of the prepass grid, and its verdict goes to the termination buffer instead of a record.
+    // cells_in_flight: the launch has such waves, so a tile waits for the cells its pixels look at.
     // Adaptive sampling on the fused path (cl.cl:3234-3250, 5223-5345): lattice = 2 traces the pixels (2x, 2y) only - the tiles
     // then cover the half-resolution grid - and pending_only = 1 traces the pixels gr_adaptive_refine marked (terminated ==
     // GR_PENDING) and leaves every other record alone.  On a split frame (strip_count > 1) the lattice launch traces the lattice
@@ -1972,6 +1999,15 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     const int within = wave % waves_per_block;
     const int r0 = (local_block * strip_count + strip_rank) * block_rows;
     int cx, cy;
+    int ray_grid_width = image_width, ray_grid_height = image_height;   // the grid the ray's direction is a pixel of
+    if (cell_wave >= 0) {
+        const int cell = cell_wave * 64 + lane;
+        if (cell >= prepass_width * prepass_height) return;
+        cx = cell % prepass_width;
+        cy = cell / prepass_width;
+        ray_grid_width = prepass_width; ray_grid_height = prepass_height;
+        width = image_width; height = image_height;
+    } else {
     if (within < tiles_x * tile_rows) {
         cx = (within % tiles_x) * T + lane % T;
         cy = r0 + (within / tiles_x) * T + lane / T;
@@ -1985,17 +2021,20 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     width = image_width; height = image_height;
     if (lattice == 2 && device_count > 1 && !own_block_within(cy, 2, height, device_block_rows, device_rank, device_count)) return;
     if (pending_only && rdata[cy * width + cx].terminated != GR_PENDING) return;
+    }
 
     // the prepass verdict first: a skipped pixel (58 % of the 4K Kerr frame) needs no ray at all
     // known_skipped: a tile of gr_order_tiles' last class - the 5x5 cells around it are all in the shadow, and the stencil of every
     // one of its pixels lies inside those (a pixel rounds to a cell at most one from the tile centre's) - needs no look-up at all
     int terminated = known_skipped ? 2 : 0;
-    if (!known_skipped && !pending_only && termination_buffer && prepass_width != width && prepass_height != height) {
+    if (cell_wave < 0 && !known_skipped && !pending_only && termination_buffer && prepass_width != width && prepass_height != height) {
         float fx = exact_ratio(cx, width);
         float fy = exact_ratio(cy, height);
         int lx = (int)roundf(fx * prepass_width);
         int ly = (int)roundf(fy * prepass_height);
-        if (early_terminate_stencil(lx, ly, prepass_width, prepass_height, termination_buffer)) terminated = 2;
+        const bool skip = cells_in_flight ? early_terminate_stencil_when_known(lx, ly, prepass_width, prepass_height, termination_buffer)
+                                          : early_terminate_stencil(lx, ly, prepass_width, prepass_height, termination_buffer);
+        if (skip) terminated = 2;
     }
     render_data dat;
     unsigned int tries = 0;
@@ -2009,13 +2048,21 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     } else {
         // camera and tetrad are re-read (scalar loads) for every tile: 24 wave-uniform values held across the integrator
         // loop would spill scalar registers
-        lightray ray = make_pixel_ray(cx, cy, width, height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        lightray ray = make_pixel_ray(cx, cy, ray_grid_width, ray_grid_height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
         ray_state s;
         s.position = ray.position;
         s.velocity = ray.velocity;
         s.acceleration = ray.acceleration;
         s.running_dlambda_dnew = 1;
         int res = integrate_ray(s, cfg, dfg, &tries);
+        if (cell_wave >= 0) {
+            // calculate_singularities (cl.cl:5008-5020): 1 = the ray did not reach the boundary.  Device scope: tiles on other
+            // XCDs (each with an L2 of its own) are polling for it.
+            __hip_atomic_store(const_cast<int*>(termination_buffer) + cy * prepass_width + cx, res == RAY_TERMINATED ? 0 : 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);
+            return;
+        }
         if (res == RAY_TERMINATED) terminated = 1;
         else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
         dat = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated, cx, cy, cfg,
@@ -2061,7 +2108,12 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
-               int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading) {
+               int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
+               int prepass_tickets) {
+    // prepass_tickets > 0 (persistent launches in image order only): the first prepass_tickets tickets are the waves of the
+    // low-resolution prepass, then come the tiles, which wait for the cells they look at (trace_tile).  A frame whose camera was not
+    // known in advance then pays the prepass's single-ray latency once per cell wave alongside the first tiles instead of as a
+    // launch of its own in front of the trace.
     GR_PARAMETERS_IN_REGISTERS
     const int lane = threadIdx.x % 64;
     // profiling launches (attempt_counter != NULL) also measure the shader clock they ran at: every wave adds its lifetime in
@@ -2077,7 +2129,8 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
     // frame, handed out back to back at the end of the list, would add 0.7 ms of pure ticket traffic to the launch.
     int held = 0, cursor = 0;   // tiles this wave still holds from its last ticket, and where in the list they start
     bool known_skipped = false;  // the ticket was a chunk of the last class
-    const int singles = (tile_counter && tile_order) ? total_waves - (int)tile_order[GR_TILE_CLASSES - 1] : total_waves;
+    const int tickets_total = total_waves + (prepass_tickets > 0 ? prepass_tickets : 0);   // (no tile order with prepass tickets)
+    const int singles = (tile_counter && tile_order) ? total_waves - (int)tile_order[GR_TILE_CLASSES - 1] : tickets_total;
     for (;;) {
         if (tile_counter) {
             if (held == 0) {
@@ -2088,13 +2141,18 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                 known_skipped = tile_order && cursor >= singles;
                 if (cursor >= singles) {
                     cursor = singles + (cursor - singles) * GR_SKIP_CHUNK;
-                    held = total_waves - cursor < GR_SKIP_CHUNK ? total_waves - cursor : GR_SKIP_CHUNK;
+                    held = tickets_total - cursor < GR_SKIP_CHUNK ? tickets_total - cursor : GR_SKIP_CHUNK;
                 }
                 if (held <= 0) break;
             }
             wave = tile_order ? (int)tile_order[GR_TILE_ORDER_HEADER + cursor] : cursor;
             cursor++;
             held--;
+        }
+        int cell_wave = -1;
+        if (prepass_tickets > 0) {
+            if (wave < prepass_tickets) { cell_wave = wave; wave = 0; }
+            else wave -= prepass_tickets;
         }
         if (wave >= total_waves) break;
         // Launder the camera / tetrad pointers once per tile: otherwise everything in the ray set-up that depends only on
@@ -2109,7 +2167,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
 #endif
         trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
                    termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
-                   known_skipped && lattice == 1 && !pending_only);
+                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0);
 #ifdef GR_PROBE_LIFE_HISTOGRAM   // per class of gr_order_tiles: tiles, summed and longest duration (10 ns ticks) in words 128..151 of the block
         if (attempt_counter && tile_order && tile_counter && lane == 0) {
             const unsigned long long took = __builtin_amdgcn_s_memrealtime() - tile_began;

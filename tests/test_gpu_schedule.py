@@ -238,3 +238,32 @@ def test_prepass_policy_drops_a_prepass_that_skips_nothing():
     assert with_a + without_a == 40 and 2 <= with_a <= 3                       # frame 1, 30 frames off, a probe, off again
     with_b, without_b, frac = run(0.45, 6)                                     # other parameters: the policy starts over
     assert without_b == without_a and with_b == with_a + 6 and frac > 0.3
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (320, 180), (656, 360)])
+def test_prepass_inside_the_trace_launch_changes_nothing(size):
+    """gr_frame_options.inline_prepass: the prepass cells as the first tickets of the persistent trace launch, tiles waiting for the
+    cells they look at.  Records, prepass flags and pixels are those of the prepass launched on its own - also for a frame small
+    enough that the launch is not persistent, and one whose prepass grid does not divide the image evenly."""
+    w, h = size
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv = metric.cfg_values(a=0.45)
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    dbg, levels = background()
+    got = []
+    for inline in (0, 1):
+        state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+        for cam in (gra.default_camera(), gra.default_camera([0, 0.3, -4.5, 0.2])):   # the second frame re-uses the state's flag buffer
+            state.render(prog, metric, cam, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv,
+                         gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1, inline_prepass=inline, count_attempts=1))
+            state.synchronize()
+        pw, ph = w // 16, h // 16
+        got.append((download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h), download(0, state.buffer(gra.BUF_TERMINATION), np.int32, pw * ph),
+                    out.to_numpy(np.float32, (h, w, 4)), state.attempts()))
+    (rd0, term0, px0, att0), (rd1, term1, px1, att1) = got
+    assert set(np.unique(term1)) <= {0, 1} and np.array_equal(term0, term1)
+    assert rd0.tobytes() == rd1.tobytes()
+    assert np.array_equal(px0, px1)
+    assert (rd1["terminated"] == 2).mean() > 0.2   # the shadow was skipped, i.e. the tiles did see the flags
+    assert att1 > att0                             # the launch's attempt count now includes the prepass rays

@@ -144,6 +144,153 @@ def radius(t, r, theta, phi):                # scripts/origins/at_origin.js
     return r
 
 
+def cylindrical_to_polar(t, p, phi, z):      # scripts/coordinates/cylindrical_to_polar.js
+    return [t, sp.sqrt(p * p + z * z), sp.atan2(p, z), phi]
+
+
+def polar_to_cylindrical(t, r, theta, phi):  # scripts/coordinates/polar_to_cylindrical.js
+    return [t, r * sp.sin(theta), phi, r * sp.cos(theta)]
+
+
+def kerr_schild(t, x, y, z):                 # scripts/kerr_schild.js (https://arxiv.org/pdf/0706.0622.pdf)
+    a, rs = cfg_symbol("a"), cfg_symbol("rs")
+    R2 = x * x + y * y + z * z
+    Rm2 = x * x + y * y - z * z
+    r2 = (-a * a + sp.sqrt(a ** 4 - 2 * a * a * Rm2 + R2 * R2) + R2) / 2
+    r = sp.sqrt(r2)
+    lv = [1, (r * x + a * y) / (r2 + a * a), (r * y - a * x) / (r2 + a * a), z / r]
+    f = rs * r2 * r / (r2 * r2 + a * a * z * z)
+    eta = sp.diag(-1, 1, 1, 1)
+    return sp.Matrix(4, 4, lambda i, j: eta[i, j] + f * lv[i] * lv[j])
+
+
+class Cx:
+    """complex numbers as pairs of real sympy expressions (the role of the reference's dual_complex, js_interop.cpp:506-616)"""
+
+    def __init__(self, re, im=0):
+        self.re, self.im = sp.sympify(re), sp.sympify(im)
+
+    @staticmethod
+    def of(x):
+        return x if isinstance(x, Cx) else Cx(x)
+
+    def __add__(self, o):
+        o = Cx.of(o)
+        return Cx(self.re + o.re, self.im + o.im)
+    __radd__ = __add__
+
+    def __neg__(self):
+        return Cx(-self.re, -self.im)
+
+    def __sub__(self, o):
+        return self + (-Cx.of(o))
+
+    def __rsub__(self, o):
+        return Cx.of(o) + (-self)
+
+    def __mul__(self, o):
+        o = Cx.of(o)
+        return Cx(self.re * o.re - self.im * o.im, self.re * o.im + self.im * o.re)
+    __rmul__ = __mul__
+
+    def conj(self):
+        return Cx(self.re, -self.im)
+
+    def abs2(self):                          # self_conjugate_multiply
+        return self.re * self.re + self.im * self.im
+
+    def __truediv__(self, o):
+        o = Cx.of(o)
+        d = o.abs2()
+        n = self * o.conj()
+        return Cx(n.re / d, n.im / d)
+
+    def __rtruediv__(self, o):
+        return Cx.of(o) / self
+
+
+def csqrt_real(x):
+    """CMath.csqrt (js_interop.cpp:690-732: purely real argument): the root of a real that may be negative"""
+    x = sp.nsimplify(x) if x.is_Number else x
+    if x.is_Number:
+        return Cx(sp.sqrt(x)) if x >= 0 else Cx(0, sp.sqrt(-x))
+    raise ValueError("csqrt of a symbolic value: give the parameters as numbers")
+
+
+def psqrt(zc):
+    """CMath.psqrt of a complex number: principal root; real and non-negative when the argument is"""
+    zc = Cx.of(zc)
+    if zc.im == 0:
+        return Cx(sp.sqrt(zc.re))            # sums of squares here
+    mod = sp.sqrt(zc.abs2())
+    return Cx(sp.sqrt((mod + zc.re) / 2), sp.sign(zc.im) * sp.sqrt((mod - zc.re) / 2))
+
+
+DOUBLE_KERR_PARAMETERS = dict(m1=0.15, m2=0.3, fa1=1.0, fa2=-0.3, R=4.0)    # the script's $default values (= the fixture's cfg)
+
+
+def double_unequal_kerr(t, p, phi, z):       # scripts/double_unequal_kerr.js (Manko & Ruiz 2019), parameters as numbers
+    import numpy as np
+    q = {k: sp.Float(float(np.float32(val)), 30) for k, val in DOUBLE_KERR_PARAMETERS.items()}   # the values the device holds
+    m1, m2, R = q["m1"], q["m2"], q["R"]
+    a1, a2 = q["fa1"] * m1, q["fa2"] * m2
+    i = Cx(0, 1)
+    J = m1 * a1 + m2 * a2
+    M = m1 + m2
+    k = a1 + a2
+    B = R * R - M * M
+    C = 2 * (R + M)
+    lin = 18 * B * k + 27 * C * J - 9 * C * k * M + 2 * k ** 3
+    inner = sp.real_root(sp.sqrt(lin ** 2 + 4 * (3 * B + 3 * C * M - k * k) ** 3) + lin, 3)
+    c2 = sp.real_root(sp.Float(2, 30), 3)
+    a = inner / (3 * c2) - c2 * (3 * B + 3 * C * M - k * k) / (3 * inner) + k / 3
+    a = sp.N(a, 30)
+    Q = (R + M) ** 2 + a * a
+    d1 = ((m1 * (a1 - a2 + a) + R * a) * Q + m2 * a1 * a * a) / Q ** 2
+    d2 = ((m2 * (a2 - a1 + a) + R * a) * Q + m1 * a2 * a * a) / Q ** 2
+    s1 = csqrt_real(sp.N(m1 * m1 - a1 * a1 + 4 * m2 * a1 * d1, 30))
+    s2 = csqrt_real(sp.N(m2 * m2 - a2 * a2 + 4 * m1 * a2 * d2, 30))
+
+    def shifted(off):                        # p^2 + (z + off)^2 with a complex offset
+        w = Cx(z) + off
+        return Cx(p * p) + w * w
+    Rsp, Rsn = psqrt(shifted(R / 2 + s2)), psqrt(shifted(R / 2 - s2))
+    rsp, rsn = psqrt(shifted(-R / 2 + s1)), psqrt(shifted(-R / 2 - s1))
+    mu0 = (Cx(R + M) - i * a) / (Cx(R + M) + i * a)
+    iMS = i * (M * (R + M))
+
+    def lower(sign):
+        return (1 / mu0) * (((sign * s1 - m1 - i * a1) * Q + 2 * a1 * (m1 * a + iMS)) / ((sign * s1 - m1 + i * a1) * Q + 2 * a1 * (m1 * a - iMS)))
+
+    def upper(sign):
+        return -mu0 * (((sign * s2 + m2 - i * a2) * Q - 2 * a2 * (m2 * a - iMS)) / ((sign * s2 + m2 + i * a2) * Q - 2 * a2 * (m2 * a + iMS)))
+
+    def num(c):                              # constants to numbers: keeps the expressions small
+        return Cx(sp.N(c.re, 30), sp.N(c.im, 30))
+    rp, rn = num(lower(1)) * rsp, num(lower(-1)) * rsn
+    Rp, Rn = num(upper(1)) * Rsp, num(upper(-1)) * Rsn
+    s12 = num(s1 * s2)
+    w1 = num(s1 * (R * R - s1 * s1 + s2 * s2))
+    w2 = num(s2 * (R * R + s1 * s1 - s2 * s2))
+    A = num(Cx(R * R) - (s1 + s2) * (s1 + s2)) * (Rp - Rn) * (rp - rn) - 4 * s12 * (Rp - rn) * (Rn - rp)
+    Bc = 2 * w1 * (Rn - Rp) + 2 * w2 * (rn - rp) + 4 * R * s12 * (Rp + Rn - rp - rn)
+    G = (-z) * Bc + w1 * (Rn - Rp) * (rp + rn + R) + w2 * (rn - rp) * (Rp + Rn - R) \
+        - 2 * s12 * (2 * R * (rp * rn - Rp * Rn - s1 * (rn - rp) + s2 * (Rn - Rp)) + num(s1 * s1 - s2 * s2) * (rp + rn - Rp - Rn))
+    K0 = sp.N((Q * (R * R - (m1 - m2) ** 2 + a * a) - 4 * m1 * m1 * m2 * m2 * a * a) / (m1 * m2 * Q), 30)
+    norm = A.abs2() - Bc.abs2()
+    AB = A.conj() + Bc.conj()
+    w = 2 * a - 2 * (G * AB).im / norm
+    f = norm / ((A + Bc) * AB).re
+    e2g = norm / (16 * sp.N(s1.abs2() * s2.abs2(), 30) * K0 * K0 * (Rsp * Rsn * rsp * rsn).re)
+    g = sp.zeros(4, 4)
+    g[0, 0] = -f
+    g[2, 2] = p * p / f - f * w * w
+    g[0, 2] = g[2, 0] = f * w
+    g[1, 1] = e2g / f
+    g[3, 3] = e2g / f
+    return g
+
+
 # settings resolved from scripts/<name>.json + the base it inherits (polar_base.json / cartesian_base.json)
 METRICS = {
     "schwarzschild": dict(g=schwarzschild, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
@@ -153,6 +300,12 @@ METRICS = {
     "alcubierre": dict(g=alcubierre, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=alcubierre_distance,
                        system="CARTESIAN", periodicity=None, singular=None, adaptive=True, detect=False,
                        dynvars=["velocity", "sigma", "R"], nonsingular=True),
+    "kerr_schild": dict(g=kerr_schild, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=radius, system="CARTESIAN",
+                        periodicity=None, singular=None, adaptive=True, detect=True, dynvars=["a", "rs"]),
+    # parameters baked in as numbers (csqrt of a symbolic value has no closed real form); the kernel is still the dynamic one
+    "double_unequal_kerr": dict(g=double_unequal_kerr, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius,
+                                system="CYLINDRICAL", periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True,
+                                dynvars=["m1", "m2", "fa1", "fa2", "R"]),
 }
 
 
@@ -180,8 +333,9 @@ def block_inverse(g):
         elif len(b) == 2:
             det = sub[0, 0] * sub[1, 1] - sub[0, 1] * sub[1, 0]
             si = sp.Matrix([[sub[1, 1], -sub[0, 1]], [-sub[1, 0], sub[0, 0]]]) / det
-        else:
-            si = sub.inv(method="ADJ")
+        else:   # adjugate / determinant on placeholder symbols, then the entries put back (a dense block of big expressions)
+            ph = sp.Matrix(len(b), len(b), lambda i, j: sp.Symbol("m_%d_%d" % (min(i, j), max(i, j))))
+            si = (ph.adjugate() / ph.det()).subs({ph[i, j]: sub[i, j] for i in range(len(b)) for j in range(i, len(b))})
         for a, i in enumerate(b):
             for c, j in enumerate(b):
                 inv[i, j] = si[a, c]
@@ -262,6 +416,8 @@ def argument_string(name):
             out.append("-DSINGULARITY_DETECTION")
     if m["system"] == "X_Y_THETA_PHI":
         out += ["-DW_V1=1", "-DW_V2=1", "-DW_V3=8", "-DW_V4=8" if symmetric else "-DW_V4=32"]
+    elif m["system"] == "CYLINDRICAL":      # metric.hpp:860-864: t, p, phi, z
+        out += ["-DW_V1=1", "-DW_V2=1", "-DW_V3=8", "-DW_V4=1"]
     else:
         out += ["-DW_V1=1", "-DW_V2=1", "-DW_V3=1", "-DW_V4=1"]
     if m.get("nonsingular"):
