@@ -4,6 +4,7 @@
 
 #include <amd_comgr/amd_comgr.h>
 #include <dlfcn.h>
+#include <link.h>
 #include <hip/hip_version.h>
 
 #include <cstring>
@@ -42,9 +43,24 @@ const comgr_api& comgr() {
     static comgr_api api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"libamd_comgr.so.3", "libamd_comgr.so"})
-            if ((api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
-        if (!api.lib) { api.error = "libamd_comgr.so not loadable"; return; }
+        // hiprtc's built-in header first, then the code-object manager FROM THE SAME DIRECTORY, by path and bound to itself: a
+        // process may hold a second ROCm stack (PyTorch wheels bundle their own libamd_comgr.so.3, an older one, which a load by
+        // soname would hand back - and which neither understands this header nor encodes every gfx950 instruction the kernels
+        // compile to).  The two copies do not share symbols (RTLD_LOCAL | RTLD_DEEPBIND).
+        void* builtins = nullptr;
+        for (const char* name : {"libhiprtc-builtins.so.7", "libhiprtc-builtins.so"})
+            if ((builtins = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (builtins) {
+            api.header = (const char*)dlsym(builtins, "__hipRTC_header");
+            const unsigned* size = (const unsigned*)dlsym(builtins, "__hipRTC_header_size");
+            if (size) api.header_size = *size;
+        }
+        if (!api.header || !api.header_size) { api.error = "libhiprtc-builtins.so (hiprtc's built-in header) not loadable"; return; }
+        char origin[4096] = "";
+        if (dlinfo(builtins, RTLD_DI_ORIGIN, origin) == 0 && origin[0])
+            for (const char* name : {"/libamd_comgr.so.3", "/libamd_comgr.so"})
+                if ((api.lib = dlopen((std::string(origin) + name).c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND))) break;
+        if (!api.lib) { api.error = std::string("libamd_comgr.so not loadable from ") + origin; return; }
         bool ok = true;
 #define GR_COMGR_FN(name) ok &= (api.name = (decltype(api.name))dlsym(api.lib, "amd_comgr_" #name)) != nullptr
         GR_COMGR_FN(status_string); GR_COMGR_FN(create_data); GR_COMGR_FN(release_data); GR_COMGR_FN(set_data);
@@ -54,15 +70,6 @@ const comgr_api& comgr() {
         GR_COMGR_FN(do_action); GR_COMGR_FN(action_data_count); GR_COMGR_FN(action_data_get_data);
 #undef GR_COMGR_FN
         if (!ok) { api.error = "libamd_comgr.so lacks an expected entry point"; api.lib = nullptr; return; }
-        void* builtins = nullptr;
-        for (const char* name : {"libhiprtc-builtins.so.7", "libhiprtc-builtins.so"})
-            if ((builtins = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
-        if (builtins) {
-            api.header = (const char*)dlsym(builtins, "__hipRTC_header");
-            const unsigned* size = (const unsigned*)dlsym(builtins, "__hipRTC_header_size");
-            if (size) api.header_size = *size;
-        }
-        if (!api.header || !api.header_size) { api.error = "libhiprtc-builtins.so (hiprtc's built-in header) not loadable"; api.lib = nullptr; }
     });
     return api;
 }
