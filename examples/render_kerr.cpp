@@ -49,13 +49,15 @@ int main(int argc, char** argv) {
     features.adaptive_sampling = 0;
     features.max_acceleration_change = info.max_acceleration_change;   // metric_manager.hpp:50
 
-    // 2. the substituted program (parameters and features baked in, metric_manager.hpp:153-166)
-    size_t need = 0;
-    CHECK(gr_metric_argument_string(metric, &features, 1, cfg.data(), info.num_dynamic_vars, nullptr, 0, &need));
-    std::string arguments(need, '\0');
-    CHECK(gr_metric_argument_string(metric, &features, 1, cfg.data(), info.num_dynamic_vars, arguments.data(), need, &need));
+    // 2. programs, the reference's way (metric_manager.hpp:19-219): the dynamic program is there at once, the substituted one
+    //    (parameters and features baked in) builds in the background; an interactive host would call
+    //    gr_program_manager_current(manager, 0, ...) once per frame and render with whatever it hands back - a one-frame program
+    //    waits for the substituted build
+    gr_program_manager* manager = nullptr;
+    CHECK(gr_program_manager_create(metric, 0, &features, cfg.data(), info.num_dynamic_vars, &manager));
     gr_program* program = nullptr;
-    CHECK(gr_program_create(arguments.c_str(), 0, &program));
+    int substituted = 0;
+    CHECK(gr_program_manager_current(manager, 1, &program, &substituted));
 
     // 3. background: a procedural equirectangular sky (10-degree grid on a gradient), packed with its mip chain
     const int bw = 2048, bh = 1024;
@@ -97,13 +99,13 @@ int main(int argc, char** argv) {
     std::vector<float> frame((size_t)width * height * 4);
     CHECK(gr_device_download(0, frame.data(), d_frame, frame.size() * sizeof(float)));
     CHECK(gr_write_frame_png(out_path, frame.data(), width, height));
-    std::printf("%s %dx%d: trace %.3f ms, wrote %s\n", name, width, height, trace_ms, out_path);
+    std::printf("%s %dx%d (%s program): trace %.3f ms, wrote %s\n", name, width, height, substituted ? "substituted" : "dynamic", trace_ms, out_path);
 
     gr_stream_destroy(stream);
     gr_render_state_destroy(state);
     gr_device_free(0, d_frame);
     gr_device_free(0, d_background);
-    gr_program_destroy(program);
+    gr_program_manager_destroy(manager);   // owns the programs
     gr_metric_destroy(metric);
     return 0;
 }

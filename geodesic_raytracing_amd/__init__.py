@@ -100,6 +100,11 @@ _SIGNATURES = {
     "gr_program_future_poll": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "gr_program_future_destroy": (None, [c_void_p]),
     "gr_program_destroy": (None, [c_void_p]),
+    "gr_program_manager_create": (c_int, [c_void_p, c_int, ctypes.POINTER(Features), ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_void_p)]),
+    "gr_program_manager_update": (c_int, [c_void_p, ctypes.POINTER(Features), ctypes.POINTER(c_float), c_int]),
+    "gr_program_manager_current": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int)]),
+    "gr_program_manager_dynamic": (c_void_p, [c_void_p]),
+    "gr_program_manager_destroy": (None, [c_void_p]),
     "gr_program_kernel_info": (c_int, [c_void_p, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gr_cart_to_generic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "gr_init_basis_vectors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float), c_void_p, c_void_p,

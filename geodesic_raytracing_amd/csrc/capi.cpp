@@ -12,6 +12,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <algorithm>
@@ -565,6 +566,123 @@ void gr_program_future_destroy(gr_program_future* f) {
     if (!f) return;
     if (f->worker.joinable()) f->worker.join();
     delete f;
+}
+
+// ---- metric_manager (metric_manager.hpp:19-219): which program to launch this frame -----------------------------------------
+// The dynamic program (parameters read from memory) is built first and is usable whatever the parameters; the substituted one
+// (parameters and features folded into the code) builds on a worker thread and is swapped in by the first gr_program_manager_current
+// call that finds it finished (check_substitution, :172-219).  Changing a parameter puts the dynamic program back at once
+// (check_recompile's soft recompile, :129-166) and starts a new substituted build; the finished one is retired, not destroyed,
+// because frames launched with it may still be in flight on the caller's streams.
+struct gr_program_manager {
+    const gr_metric* metric = nullptr;
+    int device = 0;
+    gr_program* dynamic = nullptr;
+    gr_program* substituted = nullptr;       // swapped in (using_swapped)
+    gr_program_future* pending = nullptr;    // substituted_program_opt
+    std::vector<gr_program*> retired;
+    gr_features features{};
+    std::vector<float> cfg;
+    unsigned long long swaps = 0, updates = 0;
+};
+
+static int manager_start_build(gr_program_manager* pm) {
+    size_t need = 0;
+    int rc = gr_metric_argument_string(pm->metric, &pm->features, 1, pm->cfg.data(), (int)pm->cfg.size(), nullptr, 0, &need);
+    if (rc != GR_OK) return rc;
+    std::string arguments(need, '\0');
+    rc = gr_metric_argument_string(pm->metric, &pm->features, 1, pm->cfg.data(), (int)pm->cfg.size(), &arguments[0], need, &need);
+    if (rc != GR_OK) return rc;
+    return gr_program_create_async(arguments.c_str(), pm->device, &pm->pending);
+}
+
+static void manager_retire(gr_program_manager* pm, gr_program* p) {
+    if (!p) return;
+    pm->retired.push_back(p);
+    while (pm->retired.size() > 2) {   // the oldest is two parameter changes old: nothing launched with it can still be queued
+        (void)hipSetDevice(pm->device);
+        (void)hipDeviceSynchronize();
+        gr_program_destroy(pm->retired.front());
+        pm->retired.erase(pm->retired.begin());
+    }
+}
+
+int gr_program_manager_create(const gr_metric* m, int device, const gr_features* features, const float* cfg_values, int num_cfg_values,
+                              gr_program_manager** out) {
+    if (!m || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    auto pm = std::make_unique<gr_program_manager>();
+    pm->metric = m;
+    pm->device = device;
+    gr_features_default(&pm->features);
+    pm->features.max_acceleration_change = m->cfg.max_acceleration_change;   // metric_manager.hpp:50
+    if (features) pm->features = *features;
+    const int n = (int)m->vars.names.size();
+    for (int i = 0; i < n; i++) pm->cfg.push_back(cfg_values && i < num_cfg_values ? cfg_values[i] : m->vars.defaults[i]);
+    size_t need = 0;
+    int rc = gr_metric_argument_string(m, nullptr, 0, nullptr, 0, nullptr, 0, &need);
+    if (rc != GR_OK) return rc;
+    std::string arguments(need, '\0');
+    rc = gr_metric_argument_string(m, nullptr, 0, nullptr, 0, &arguments[0], need, &need);
+    if (rc != GR_OK) return rc;
+    rc = gr_program_create(arguments.c_str(), device, &pm->dynamic);   // the first program of a metric is waited for (should_block)
+    if (rc != GR_OK) return rc;
+    rc = manager_start_build(pm.get());
+    if (rc != GR_OK) { gr_program_destroy(pm->dynamic); return rc; }
+    *out = pm.release();
+    return GR_OK;
+}
+
+int gr_program_manager_update(gr_program_manager* pm, const gr_features* features, const float* cfg_values, int num_cfg_values) {
+    if (!pm) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    gr_features f = pm->features;
+    if (features) f = *features;
+    std::vector<float> cfg = pm->cfg;
+    for (size_t i = 0; i < cfg.size(); i++)
+        if (cfg_values && (int)i < num_cfg_values) cfg[i] = cfg_values[i];
+    if (memcmp(&f, &pm->features, sizeof(f)) == 0 && cfg == pm->cfg) return GR_OK;   // nothing changed: keep what is running or building
+    pm->features = f;
+    pm->cfg = cfg;
+    pm->updates++;
+    manager_retire(pm, pm->substituted);   // the substituted program is invalid for the new values: the dynamic one again
+    pm->substituted = nullptr;
+    if (pm->pending) { gr_program_future_destroy(pm->pending); pm->pending = nullptr; }   // joins the abandoned build
+    return manager_start_build(pm);
+}
+
+int gr_program_manager_current(gr_program_manager* pm, int wait, gr_program** program, int* is_substituted) {
+    if (!pm || !program) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    while (pm->pending) {
+        gr_program* ready = nullptr;
+        const int rc = gr_program_future_poll(pm->pending, &ready);
+        if (rc < 0) {   // the substituted build failed: the dynamic program goes on serving, the error is reported once
+            gr_program_future_destroy(pm->pending);
+            pm->pending = nullptr;
+            return rc;
+        }
+        if (rc == 1) {
+            gr_program_future_destroy(pm->pending);
+            pm->pending = nullptr;
+            pm->substituted = ready;
+            pm->swaps++;
+            break;
+        }
+        if (!wait) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    }
+    *program = pm->substituted ? pm->substituted : pm->dynamic;
+    if (is_substituted) *is_substituted = pm->substituted ? 1 : 0;
+    return GR_OK;
+}
+
+gr_program* gr_program_manager_dynamic(gr_program_manager* pm) { return pm ? pm->dynamic : nullptr; }
+
+void gr_program_manager_destroy(gr_program_manager* pm) {
+    if (!pm) return;
+    if (pm->pending) gr_program_future_destroy(pm->pending);
+    for (gr_program* p : pm->retired) gr_program_destroy(p);
+    gr_program_destroy(pm->substituted);
+    gr_program_destroy(pm->dynamic);
+    delete pm;
 }
 
 void gr_program_destroy(gr_program* p) {

@@ -2060,8 +2060,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
             // XCDs (each with an L2 of its own) are polling for it.
             __hip_atomic_store(const_cast<int*>(termination_buffer) + cy * prepass_width + cx, res == RAY_TERMINATED ? 0 : 1, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);
-            return;
+            return;   // (the prepass rays' attempts are not counted: gr_render_state_attempts is the frame's pixels', as with the prepass launched on its own)
         }
         if (res == RAY_TERMINATED) terminated = 1;
         else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }

@@ -121,7 +121,7 @@ class Program:
         return bool(lib.gr_program_has_trace_pair(self.handle))
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and not getattr(self, "borrowed", False):
             lib.gr_program_destroy(self.handle)
             self.handle = None
 
@@ -190,52 +190,58 @@ class TiledFrame:
 
 
 class ProgramManager:
-    """metric_manager (metric_manager.hpp:19-219): the "dynamic" program (reads $cfg / features from memory) is usable at
-    once; the "substituted" program with every parameter baked in is built in the background and swapped in when ready.
-    Changing a parameter (`update`) falls back to the dynamic program until the new substituted one is built."""
+    """metric_manager (metric_manager.hpp:19-219) - a thin caller of gr_program_manager_* (csrc/capi.cpp): the "dynamic" program
+    (reads $cfg / features from memory) is usable at once; the "substituted" program with every parameter baked in is built in
+    the background and swapped in when ready.  Changing a parameter (`update`) falls back to the dynamic program until the new
+    substituted one is built."""
 
     def __init__(self, metric, device=0, features=None, cfg_values=None):
         self.metric, self.device = metric, device
-        self.dynamic = Program(metric.argument_string(), device)
-        self.static = None
-        self._future = None
-        self.update(features, cfg_values)
+        self.handle = c_void_p()
+        arr, n = self._values(cfg_values)
+        check(lib.gr_program_manager_create(metric.handle, device, ctypes.byref(features) if features is not None else None, arr, n,
+                                            ctypes.byref(self.handle)))
+        self.dynamic = self._borrowed(c_void_p(lib.gr_program_manager_dynamic(self.handle)))
+        self.features = features if features is not None else metric.features()
+        self.cfg_values = list(cfg_values) if cfg_values is not None else metric.cfg_values()
+        self.is_substituted = False
+
+    @staticmethod
+    def _values(cfg_values):
+        if cfg_values is None:
+            return None, 0
+        return (c_float * len(cfg_values))(*cfg_values), len(cfg_values)
+
+    def _borrowed(self, handle):
+        p = Program.__new__(Program)          # the manager owns the program: no gr_program_destroy from this wrapper
+        p.handle, p.device, p.borrowed = handle, self.device, True
+        return p
 
     def update(self, features=None, cfg_values=None):
-        self.features = features if features is not None else self.metric.features()
-        self.cfg_values = list(cfg_values) if cfg_values is not None else self.metric.cfg_values()
-        self.static = None
-        self._drop_future()
-        args = self.metric.argument_string(features=self.features, static=True, cfg_values=self.cfg_values)
-        self._future = c_void_p()
-        check(lib.gr_program_create_async(args.encode(), self.device, ctypes.byref(self._future)))
-
-    def _drop_future(self):
-        if self._future:
-            lib.gr_program_future_destroy(self._future)
-            self._future = None
+        arr, n = self._values(cfg_values)
+        check(lib.gr_program_manager_update(self.handle, ctypes.byref(features) if features is not None else None, arr, n))
+        if features is not None:
+            self.features = features
+        if cfg_values is not None:
+            self.cfg_values = list(cfg_values)
 
     def current(self, wait=False):
         """the program to launch this frame"""
-        while self.static is None and self._future:
-            handle = c_void_p()
-            rc = lib.gr_program_future_poll(self._future, ctypes.byref(handle))
-            if rc < 0:
-                check(rc)
-            if rc == 1:
-                p = Program.__new__(Program)
-                p.handle, p.device = handle, self.device
-                self.static = p
-                self._drop_future()
-                break
-            if not wait:
-                break
-            import time
-            time.sleep(0.01)
-        return self.static if self.static is not None else self.dynamic
+        handle, swapped = c_void_p(), c_int()
+        check(lib.gr_program_manager_current(self.handle, int(bool(wait)), ctypes.byref(handle), ctypes.byref(swapped)))
+        self.is_substituted = bool(swapped.value)
+        return self._borrowed(handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib.gr_program_manager_destroy(self.handle)
+            self.handle = None
 
     def __del__(self):
-        self._drop_future()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

@@ -150,6 +150,22 @@ void gr_program_future_destroy(gr_program_future* f);
 
 void gr_program_destroy(gr_program* p);
 
+/* metric_manager (metric_manager.hpp:19-219) as an object: which program to launch this frame.  gr_program_manager_create builds
+ * the dynamic program of `m` (blocking, as the reference does for a newly selected metric) and starts the substituted build for
+ * `features` / `cfg_values` (NULL = the metric's defaults) on a worker thread.  gr_program_manager_current is check_substitution:
+ * called once per frame, it swaps the substituted program in as soon as its build has finished (wait != 0: waits for it) and hands
+ * back the program to launch - owned by the manager, valid until the manager is destroyed or two later updates have retired it.
+ * gr_program_manager_update is the soft recompile: values that differ from the current ones put the dynamic program back at
+ * once, abandon a pending build and start the new one; equal values change nothing.  The metric must outlive the manager.
+ * One thread at a time. */
+typedef struct gr_program_manager gr_program_manager;
+int gr_program_manager_create(const gr_metric* m, int device, const gr_features* features, const float* cfg_values, int num_cfg_values,
+                              gr_program_manager** out);
+int gr_program_manager_update(gr_program_manager* pm, const gr_features* features, const float* cfg_values, int num_cfg_values);
+int gr_program_manager_current(gr_program_manager* pm, int wait, gr_program** program, int* is_substituted);
+gr_program* gr_program_manager_dynamic(gr_program_manager* pm);
+void gr_program_manager_destroy(gr_program_manager* pm);
+
 /* registers / scratch of a kernel as recorded in the code object (0 if unknown) */
 int gr_program_kernel_info(const gr_program* p, const char* kernel_name, int* vgprs, int* sgprs, int* scratch_bytes);
 

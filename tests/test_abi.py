@@ -146,7 +146,15 @@ def test_cpp_example_builds_against_the_header_alone():
     r = subprocess.run([exe, os.path.join(root, "geodesic_raytracing_amd", "scripts"), "kerr_boyer", "64", "36", "/tmp/never.png"],
                        capture_output=True, text=True)
     if r.returncode != 0:              # no GPU here: the first device call must say so
+        assert "gr_program_manager_create" in r.stderr and "device" in r.stderr.lower()
+    # ... and the N-process example (one rank per GPU, RCCL, communicator id through a file)
+    exe = os.path.join(root, "examples", "render_tiled")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "--world", "1", "--rank", "0", os.path.join(root, "geodesic_raytracing_amd", "scripts"), "kerr_boyer", "64", "36",
+                        "/tmp/never.png"], capture_output=True, text=True)
+    if r.returncode != 0:
         assert "gr_program_create" in r.stderr and "device" in r.stderr.lower()
+    assert subprocess.run([exe, "--world", "2", "--rank", "1", "a", "b", "8", "8", "c"], capture_output=True).returncode == 2   # no --id-file
 
 
 def test_pair_kernel_is_built_for_fixed_step_programs_only(tmp_path, monkeypatch):

@@ -441,6 +441,27 @@ def test_cpp_example_renders_a_png(tmp_path):
     assert ((want[..., :3].max(axis=2) == 0) == (img[..., :3].max(axis=2) == 0)).mean() > 0.999
 
 
+def test_cpp_tiled_example_renders_a_png(tmp_path):
+    """examples/render_tiled.cpp - the N-process host of a split frame written against the C ABI alone - with the one participant
+    a one-GPU box allows (RCCL refuses two ranks on a device): communicator-less gr_tiled_create, frames in flight on three
+    streams through gr_render_frame_tiled, PNG from rank 0; through --spawn (the fork-per-GPU launcher) as well"""
+    import os
+    import subprocess
+    from geodesic_raytracing_amd import render as cli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
+    want, _, _ = render("kerr_boyer", 640, 360, cfg=dict(a=0.45), options=dict(mode=gra.MODE_FUSED), scripts=SCRIPTS)
+    for tag, launch in (("rank", ["--world", "1", "--rank", "0"]), ("spawn", ["--spawn", "1"])):
+        out = str(tmp_path / f"tiled_{tag}.png")
+        r = subprocess.run([os.path.join(root, "examples", "render_tiled")] + launch + [SCRIPTS, "kerr_boyer", "640", "360", out, "5", "a=0.45"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "frames/s with the transfer" in r.stdout
+        img = cli.read_png(out)
+        assert img.shape == (360, 640, 4)
+        assert ((want[..., :3].max(axis=2) == 0) == (img[..., :3].max(axis=2) == 0)).mean() > 0.999
+
+
 @pytest.mark.parametrize("name,size", [("schwarzschild", (1920, 1080)), ("minkowski", (1000, 500)), ("wormhole", (1280, 720))])
 def test_two_rays_per_lane_computes_the_same_frame(name, size):
     """gr_trace_pair (two rays per lane, packed fp32; the library default where a program has it) integrates every ray as

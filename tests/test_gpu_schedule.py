@@ -266,4 +266,43 @@ def test_prepass_inside_the_trace_launch_changes_nothing(size):
     assert rd0.tobytes() == rd1.tobytes()
     assert np.array_equal(px0, px1)
     assert (rd1["terminated"] == 2).mean() > 0.2   # the shadow was skipped, i.e. the tiles did see the flags
-    assert att1 > att0                             # the launch's attempt count now includes the prepass rays
+    assert att1 == att0                            # the pixels' attempts (the prepass rays are not counted either way)
+
+
+def test_program_manager_swaps_and_falls_back():
+    """gr_program_manager_* (metric_manager.hpp:19-219 in the C ABI): the dynamic program serves until the substituted build is
+    finished, then the substituted one; the same values again change nothing; other values put the dynamic program back at once
+    and the new substituted program follows; frames of the two programs agree to rounding."""
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    feats = metric.features(adaptive_sampling=0)
+    w, h = 320, 180
+    dbg, levels = background()
+    state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+
+    def frame(prog, cfgv):
+        state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv, gra.frame_options(mode=gra.MODE_FUSED))
+        state.synchronize()
+        return out.to_numpy(np.float32, (h, w, 4))
+
+    a45, a30 = metric.cfg_values(a=0.45), metric.cfg_values(a=0.3)
+    manager = gra.pipeline.ProgramManager(metric, 0, feats, a45)
+    dynamic_key = manager.dynamic.build_key
+    first = manager.current()                      # whichever is there: never blocks
+    assert first.build_key == dynamic_key or manager.is_substituted
+    substituted = manager.current(wait=True)
+    assert manager.is_substituted and substituted.build_key != dynamic_key
+    d = frame(manager.dynamic, a45) - frame(substituted, a45)
+    assert np.sqrt((d[..., :3] ** 2).mean()) < 2e-4
+    manager.update(feats, a45)                     # nothing changed
+    again = manager.current()
+    assert manager.is_substituted and again.handle.value == substituted.handle.value
+    manager.update(feats, a30)                     # soft recompile: the dynamic program at once
+    fallback = manager.current()
+    if not manager.is_substituted:                 # (a cached build may already be there)
+        assert fallback.handle.value == manager.dynamic.handle.value
+    other = manager.current(wait=True)
+    assert manager.is_substituted and other.build_key not in (dynamic_key, substituted.build_key)
+    d = frame(manager.dynamic, a30) - frame(other, a30)
+    assert np.sqrt((d[..., :3] ** 2).mean()) < 2e-4
+    frame(substituted, a45)                        # a retired program stays usable (frames launched with it may be in flight)
+    manager.close()
