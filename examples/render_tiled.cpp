@@ -213,7 +213,11 @@ int main(int argc, char** argv) {
         std::vector<pid_t> children;
         for (int r = 0; r < spawn; r++) {
             const pid_t pid = fork();
-            if (pid == 0) _exit(worker(spawn, r, r, id_file, argc - a, argv + a));
+            if (pid == 0) {
+                const int rc = worker(spawn, r, r, id_file, argc - a, argv + a);
+                std::fflush(nullptr);   // _exit does not flush stdio
+                _exit(rc);
+            }
             if (pid < 0) { std::perror("fork"); return 1; }
             children.push_back(pid);
         }

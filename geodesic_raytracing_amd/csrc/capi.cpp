@@ -163,11 +163,27 @@ bool kernel_resources(const std::string& code, const char* kernel, int& vgprs, i
 
 // Compiles (or fetches from the on-disk cache) the code object for one macro string.
 int compile_code_object(const std::string& argument_string, std::string& code, std::string* key_out = nullptr) {
-    std::string source_path;
-    if (const char* env = getenv("GR_KERNEL_SOURCE")) source_path = env;
-    else source_path = library_dir() + "/csrc/kernels/geodesic_kernels.hip";
+    // the kernel source: the parts under csrc/kernels/ in this order, as one translation unit (GR_KERNEL_SOURCE: one file instead)
+    static const char* const KERNEL_PARTS[] = {"program.hip",       // structs of the boundary, build switches
+                                               "probes.inc",        // measurement hooks (all off by default)
+                                               "metric.hip",        // hosts of the generated expressions
+                                               "setup.hip",         // tetrads, ray set-up
+                                               "integrator.hip",    // the Verlet loop, one and two rays per lane
+                                               "trace.hip",         // render-data, the reference-shaped and the fused kernels, prepass, tile order, adaptive sampling
+                                               "shading.hip",       // texture sampling, gr_render
+                                               "geodesic_camera.hip"};
     std::string source;
-    if (!read_file(source_path, source)) return fail(GR_ERROR_COMPILE, "cannot read kernel source " + source_path);
+    if (const char* env = getenv("GR_KERNEL_SOURCE")) {
+        if (!read_file(env, source)) return fail(GR_ERROR_COMPILE, std::string("cannot read kernel source ") + env);
+    } else {
+        for (const char* part : KERNEL_PARTS) {
+            std::string text;
+            const std::string path = library_dir() + "/csrc/kernels/" + part;
+            if (!read_file(path, text)) return fail(GR_ERROR_COMPILE, "cannot read kernel source " + path);
+            source += text;
+            if (!text.empty() && text.back() != '\n') source += '\n';
+        }
+    }
 
     std::vector<std::string> opts = {
         "--offload-arch=gfx950", "-O3", "-std=c++17",
@@ -224,15 +240,23 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
         if (run_limit > 0) {
             std::string assembly, log;
             if (gr::compile_to_assembly(source, options, assembly, log)) {
-                const gr::vector_run_stats st = gr::break_vector_runs(assembly, run_limit);
-                if (gr::assemble_code_object(assembly, out, log)) {
+                // the kernels that hold a Verlet loop; the others (set-up, shading, tile order ...) are left as compiled
+                static const std::vector<std::string> integrators = {"gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused",
+                                                                     "gr_camera_prepass", "gr_do_generic_rays", "gr_get_geodesic_path"};
+                std::string patched = assembly;
+                const gr::vector_run_stats st = gr::break_vector_runs(patched, run_limit, integrators);
+                if (gr::assemble_code_object(patched, out, log)) {
                     if (getenv("GR_VERBOSE_BUILD"))
                         fprintf(stderr, "[gr] vector runs: %d longer than %d (longest %d) cut by %d s_nop, longest now %d\n", st.runs_broken,
                                 run_limit, st.longest_before, st.inserted, st.longest_after);
                     return GR_OK;
                 }
+                // The compiler sized its branches for the code it emitted; in a very large function the added instructions can push
+                // one past the 16-bit branch offset ("branch size exceeds simm16").  Then the code as compiled.
+                if (getenv("GR_VERBOSE_BUILD")) fprintf(stderr, "[gr] assembly pass not applied (%s)\n", log.c_str());
+                if (gr::assemble_code_object(assembly, out, log)) return GR_OK;
             }
-            if (getenv("GR_VERBOSE_BUILD")) fprintf(stderr, "[gr] assembly pass not applied (%s): building through hiprtc\n", log.c_str());
+            if (getenv("GR_VERBOSE_BUILD")) fprintf(stderr, "[gr] building through hiprtc (%s)\n", log.c_str());
         }
         hiprtcProgram prog;
         if (hiprtcCreateProgram(&prog, source.c_str(), "geodesic_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)

@@ -1,0 +1,341 @@
+// ------------------------------------------------------------------------------------------------
+// math used by the generated expressions.  Everything generated is evaluated inside namespace gm,
+// so unqualified sin/cos/... bind to these fp32 versions.
+namespace gm {
+
+#if defined(GR_FAST_TRIG)
+// hardware v_sin_f32 / v_cos_f32: ~1e-6 absolute error (poor relative accuracy next to the zeros), opt-in only
+__device__ __forceinline__ float sin(float x) { return __sinf(x); }
+__device__ __forceinline__ float cos(float x) { return __cosf(x); }
+#elif defined(GR_LIBM_TRIG)
+__device__ __forceinline__ float sin(float x) { return ::sinf(x); }
+__device__ __forceinline__ float cos(float x) { return ::cosf(x); }
+#else
+// sin and cos of the same angle share one Cody-Waite reduction and both minimax polynomials (the common
+// sub-expressions of the two inlined calls merge), ~1 ulp for |x| < 8192; larger arguments take the libm path.
+// The metric expressions evaluate sin(theta) and cos(theta) together every Verlet step, where the two separate libm
+// calls (each with its own large-argument branch) were ~25 % of the step's instructions.
+struct sincos_pair { float s, c; };
+// POISON_LARGE: an argument outside the polynomial's range (|x| >= 8192) returns NaN for both - two full-rate instructions, no
+// compare, no branch, no flag to carry: x * 4.154e34 overflows exactly then, and fma(inf, 0, r) is NaN while fma(finite, 0, r) is r
+template <bool POISON_LARGE = false>
+__device__ __forceinline__ sincos_pair sincos_reduced(float x) {
+#pragma clang fp reassociate(off)
+    // nearest multiple of pi/2 by the 1.5 * 2^23 trick: the rounded quotient lands in the low mantissa bits of t (so the
+    // quadrant needs no v_cvt_i32_f32) and j = t - magic is exact; both are full-rate ops where v_rndne_f32 and
+    // v_cvt_i32_f32 issue at half rate.  Valid for |x| < 2^21 (callers only trust the result below 8192).  Re-association
+    // (allowed by the build flags elsewhere) is off in this function so that the two constants are not cancelled.
+    float t = __builtin_fmaf(x, 0.636619772367581343f, 12582912.f);
+    float j = t - 12582912.f;
+    unsigned int q = __builtin_bit_cast(unsigned int, t);
+    float r = __builtin_fmaf(-j, 1.57079637050628662109375f, x);   // pi/2 = hi + lo, fma keeps the product exact
+    r = __builtin_fmaf(-j, -4.37113900018624283e-8f, r);
+    if (POISON_LARGE) r = __builtin_fmaf(x * 4.1539e34f, 0.f, r);
+    float r2 = r * r;
+    float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+    float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
+                              r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+    float s = (q & 1) ? cp : sp;
+    float c = (q & 1) ? sp : cp;
+    // quadrant signs applied to the sign bit directly (xor is full rate, compare + select are not)
+    s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, s) ^ ((q & 2u) << 30));
+    c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, c) ^ (((q + 1u) & 2u) << 30));
+    return {s, c};
+}
+// the polynomial is evaluated unconditionally (so sin and cos of one angle stay in one basic block and share it);
+// the libm call only overrides the result in the never-in-practice large-argument case
+__device__ __forceinline__ float sin(float x) {
+    float s = sincos_reduced(x).s;
+    if (__builtin_expect(!(__builtin_fabsf(x) < 8192.f), 0)) s = ::sinf(x);
+    return s;
+}
+__device__ __forceinline__ float cos(float x) {
+    float c = sincos_reduced(x).c;
+    if (__builtin_expect(!(__builtin_fabsf(x) < 8192.f), 0)) c = ::cosf(x);
+    return c;
+}
+#endif
+__device__ __forceinline__ float tan(float x) { return ::tanf(x); }
+__device__ __forceinline__ float asin(float x) { return ::asinf(x); }
+__device__ __forceinline__ float acos(float x) { return ::acosf(x); }
+__device__ __forceinline__ float atan(float x) { return ::atanf(x); }
+__device__ __forceinline__ float atan2(float y, float x) { return ::atan2f(y, x); }
+__device__ __forceinline__ float exp(float x) { return ::expf(x); }
+__device__ __forceinline__ float log(float x) { return ::logf(x); }
+__device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float fabs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ float sinh(float x) { return ::sinhf(x); }
+__device__ __forceinline__ float cosh(float x) { return ::coshf(x); }
+__device__ __forceinline__ float tanh(float x) { return ::tanhf(x); }
+__device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
+__device__ __forceinline__ float fmod(float x, float y) { return ::fmodf(x, y); }
+__device__ __forceinline__ float fmin(float x, float y) { return __builtin_fminf(x, y); }
+__device__ __forceinline__ float fmax(float x, float y) { return __builtin_fmaxf(x, y); }
+__device__ __forceinline__ float sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// --- generated-expression hosts (cl.cl:969-1355, 3377-3387) ---------------------------------------
+
+#define GR_POSITION_VARS(p) \
+    const float v1 = (p).x; const float v2 = (p).y; const float v3 = (p).z; const float v4 = (p).w; \
+    const float rs = RS_IMPL; const float c = C_IMPL; (void)v1; (void)v2; (void)v3; (void)v4; (void)rs; (void)c;
+
+// g_metric_out has 4 (diagonal) or 16 entries
+__device__ __forceinline__ void metric_at(float4 pos, float* g, cfg_t cfg) {
+    GR_POSITION_VARS(pos)
+    float TEMPORARIES0;
+#ifndef GENERIC_BIG_METRIC
+    g[0] = F1_I; g[1] = F2_I; g[2] = F3_I; g[3] = F4_I;
+#else
+    g[0] = F1_I; g[1] = F2_I; g[2] = F3_I; g[3] = F4_I;
+    g[4] = g[1]; g[5] = F6_I; g[6] = F7_I; g[7] = F8_I;
+    g[8] = g[2]; g[9] = g[6]; g[10] = F11_I; g[11] = F12_I;
+    g[12] = g[3]; g[13] = g[7]; g[14] = g[11]; g[15] = F16_I;
+#endif
+}
+
+// always the full symmetric 4x4
+__device__ __forceinline__ void metric_big_at(float4 pos, float* g, cfg_t cfg) {
+#ifndef GENERIC_BIG_METRIC
+    float d[4];
+    metric_at(pos, d, cfg);
+    for (int i = 0; i < 16; i++) g[i] = 0.f;
+    g[0] = d[0]; g[5] = d[1]; g[10] = d[2]; g[15] = d[3];
+#else
+    metric_at(pos, g, cfg);
+#endif
+}
+
+// d g_ij / d v_k as dg[k*16 + i*4 + j] (calculate_partial_derivatives_generic(_big), cl.cl:987-1015, 1053-1199).
+// Only the geodesic-camera kernels (parallel transport) use it; the ray kernels never need the partials at run time.
+__device__ void partials_big_at(float4 pos, float* dg, cfg_t cfg) {
+    GR_POSITION_VARS(pos)
+    float TEMPORARIES0;
+    for (int i = 0; i < 64; i++) dg[i] = 0.f;
+#ifndef GENERIC_BIG_METRIC
+    const float p[16] = {F1_P, F2_P, F3_P, F4_P, F5_P, F6_P, F7_P, F8_P, F9_P, F10_P, F11_P, F12_P, F13_P, F14_P, F15_P, F16_P};
+    for (int var = 0; var < 4; var++)
+        for (int wrt = 0; wrt < 4; wrt++) dg[wrt * 16 + var * 4 + var] = p[var * 4 + wrt];
+#else
+    const float p[64] = {F1_P, F2_P, F3_P, F4_P, 0, F6_P, F7_P, F8_P, 0, 0, F11_P, F12_P, 0, 0, 0, F16_P,
+                         F17_P, F18_P, F19_P, F20_P, 0, F22_P, F23_P, F24_P, 0, 0, F27_P, F28_P, 0, 0, 0, F32_P,
+                         F33_P, F34_P, F35_P, F36_P, 0, F38_P, F39_P, F40_P, 0, 0, F43_P, F44_P, 0, 0, 0, F48_P,
+                         F49_P, F50_P, F51_P, F52_P, 0, F54_P, F55_P, F56_P, 0, 0, F59_P, F60_P, 0, 0, 0, F64_P};
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < 4; i++)
+            for (int j = i; j < 4; j++) {
+                dg[k * 16 + i * 4 + j] = p[k * 16 + i * 4 + j];
+                dg[k * 16 + j * 4 + i] = p[k * 16 + i * 4 + j];
+            }
+#endif
+}
+
+// get_coordinate_period, cl.cl:1338-1355
+__device__ __forceinline__ float4 coordinate_period(cfg_t cfg) {
+#ifdef HAS_COORDINATE_PERIODICITY
+    const float4 zero = make_float4(0, 0, 0, 0);
+    GR_POSITION_VARS(zero)
+    return make_float4(COORDINATE_PERIODICITY1, COORDINATE_PERIODICITY2, COORDINATE_PERIODICITY3, COORDINATE_PERIODICITY4);
+#else
+    return make_float4(0, 0, 0, 0);
+#endif
+}
+
+// closed-form geodesic acceleration (GEO_ACCELn; step_verlet cl.cl:3279-3309)
+#if defined(GR_FAST_TRIG) || defined(GR_LIBM_TRIG)
+#define GR_ACCEL_TRIG(LIBM)
+#else
+// Inside the Verlet loop the expressions' sin / cos are the bare polynomial, which answers an argument outside its range with
+// NaN.  The step controller then treats the attempt like any other that ends in a degenerate velocity - the ray leaves the fast
+// loop - and whoever left that way has the attempt redone by a loop that calls libm (integrate_pingpong): a genuinely
+// degenerate step is found degenerate again, a large argument - never seen in practice - is integrated on.  libm's argument
+// reduction, two copies of it per evaluation, stays out of the loop body every ray runs and out of its register budget, and
+// the fast loop carries no flag for it.
+#define GR_ACCEL_TRIG(LIBM)                                                                              \
+    auto sin = [&](float x) -> float { return LIBM ? ::sinf(x) : sincos_reduced<true>(x).s; };           \
+    auto cos = [&](float x) -> float { return LIBM ? ::cosf(x) : sincos_reduced<true>(x).c; };           \
+    (void)sin; (void)cos;
+#endif
+template <bool LIBM>
+__device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 vel, cfg_t cfg) {
+#ifdef GENERIC_CONSTANT_THETA
+    pos.z = GR_PIf / 2;
+    vel.z = 0.f;
+#endif
+    GR_POSITION_VARS(pos)
+    const float iv1 = vel.x; const float iv2 = vel.y; const float iv3 = vel.z; const float iv4 = vel.w;
+    (void)iv1; (void)iv2; (void)iv3; (void)iv4;
+    GR_ACCEL_TRIG(LIBM)
+    float TEMPORARIES0;
+    float4 a;
+    a.x = GEO_ACCEL0;
+    a.y = GEO_ACCEL1;
+#ifndef GENERIC_CONSTANT_THETA
+    a.z = GEO_ACCEL2;
+#else
+    a.z = 0.f;
+#endif
+    a.w = GEO_ACCEL3;
+    return a;
+}
+// everywhere outside the Verlet loop (ray set-up, geodesic paths): gm::sin / gm::cos with their own large-argument branches
+__device__ __forceinline__ float4 geodesic_acceleration(float4 pos, float4 vel, cfg_t cfg) {
+#ifdef GENERIC_CONSTANT_THETA
+    pos.z = GR_PIf / 2;
+    vel.z = 0.f;
+#endif
+    GR_POSITION_VARS(pos)
+    const float iv1 = vel.x; const float iv2 = vel.y; const float iv3 = vel.z; const float iv4 = vel.w;
+    (void)iv1; (void)iv2; (void)iv3; (void)iv4;
+    float TEMPORARIES0;
+    float4 a;
+    a.x = GEO_ACCEL0;
+    a.y = GEO_ACCEL1;
+#ifndef GENERIC_CONSTANT_THETA
+    a.z = GEO_ACCEL2;
+#else
+    a.z = 0.f;
+#endif
+    a.w = GEO_ACCEL3;
+    return a;
+}
+
+__device__ __forceinline__ float4 generic_to_spherical(float4 in, cfg_t cfg) {
+    GR_POSITION_VARS(in)
+    return make_float4(TO_COORD1, TO_COORD2, TO_COORD3, TO_COORD4);
+}
+
+__device__ __forceinline__ float4 generic_velocity_to_spherical_velocity(float4 in, float4 inv, cfg_t cfg) {
+    GR_POSITION_VARS(in)
+    const float dv1 = inv.x; const float dv2 = inv.y; const float dv3 = inv.z; const float dv4 = inv.w;
+    (void)dv1; (void)dv2; (void)dv3; (void)dv4;
+    return make_float4(TO_DCOORD1, TO_DCOORD2, TO_DCOORD3, TO_DCOORD4);
+}
+
+__device__ __forceinline__ float4 spherical_to_generic(float4 in, cfg_t cfg) {
+    GR_POSITION_VARS(in)
+    return make_float4(FROM_COORD1, FROM_COORD2, FROM_COORD3, FROM_COORD4);
+}
+
+__device__ __forceinline__ float4 spherical_velocity_to_generic_velocity(float4 in, float4 inv, cfg_t cfg) {
+    GR_POSITION_VARS(in)
+    const float dv1 = inv.x; const float dv2 = inv.y; const float dv3 = inv.z; const float dv4 = inv.w;
+    (void)dv1; (void)dv2; (void)dv3; (void)dv4;
+    return make_float4(FROM_DCOORD1, FROM_DCOORD2, FROM_DCOORD3, FROM_DCOORD4);
+}
+
+__device__ __forceinline__ float distance_to_object(float4 polar, cfg_t cfg) {
+    GR_POSITION_VARS(polar)
+    return DISTANCE_FUNC;
+}
+
+#ifdef GR_TWO_RAYS_PER_LANE
+// --- the same hosts for two rays per lane (gr_trace_pair): every variable of the generated expressions is a pair of
+// floats, one per ray, so their multiplies, adds and fmas become v_pk_mul/add/fma_f32 with nothing to shuffle ------------
+typedef float pairf __attribute__((ext_vector_type(2)));
+typedef unsigned int pairu __attribute__((ext_vector_type(2)));
+struct pair4 { pairf x, y, z, w; };
+
+__device__ __forceinline__ pairf pfma(pairf a, pairf b, pairf c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ pairf splat(float x) { pairf r; r.x = x; r.y = x; return r; }
+struct sincos_pairf { pairf s, c; };
+// sincos_reduced (above), both rays at once; the quadrant select stays per ray (v_cndmask has no packed form)
+__device__ __forceinline__ sincos_pairf sincos_reduced(pairf x) {
+#pragma clang fp reassociate(off)
+    pairf t = pfma(x, splat(0.636619772367581343f), splat(12582912.f));
+    pairf j = t - splat(12582912.f);
+    pairu q = __builtin_bit_cast(pairu, t);
+    pairf r = pfma(-j, splat(1.57079637050628662109375f), x);
+    r = pfma(-j, splat(-4.37113900018624283e-8f), r);
+    pairf r2 = r * r;
+    pairf sp = pfma(pfma(pfma(splat(-1.9515295891e-4f), r2, splat(8.3321608736e-3f)), r2, splat(-1.6666654611e-1f)), r2 * r, r);
+    pairf cp = pfma(pfma(pfma(splat(2.443315711809948e-5f), r2, splat(-1.388731625493765e-3f)), r2, splat(4.166664568298827e-2f)),
+                    r2 * r2, pfma(splat(-0.5f), r2, splat(1.0f)));
+    pairf s, c;
+    s.x = (q.x & 1) ? cp.x : sp.x; s.y = (q.y & 1) ? cp.y : sp.y;
+    c.x = (q.x & 1) ? sp.x : cp.x; c.y = (q.y & 1) ? sp.y : cp.y;
+    pairu two; two.x = 2u; two.y = 2u;
+    pairu one; one.x = 1u; one.y = 1u;
+    pairu sh; sh.x = 30u; sh.y = 30u;
+    s = __builtin_bit_cast(pairf, __builtin_bit_cast(pairu, s) ^ ((q & two) << sh));
+    c = __builtin_bit_cast(pairf, __builtin_bit_cast(pairu, c) ^ (((q + one) & two) << sh));
+    return {s, c};
+}
+// the never-in-practice large-argument case goes through one out-of-line libm call per value: inlined (as in the one-ray
+// kernel) its four copies cost the pair kernel scalar-register spills
+__device__ __attribute__((noinline)) float sin_large(float x) { return ::sinf(x); }
+__device__ __attribute__((noinline)) float cos_large(float x) { return ::cosf(x); }
+__device__ __forceinline__ bool large_finite(float x) { return __builtin_fabsf(x) >= 8192.f && __builtin_fabsf(x) <= 3.402823466e+38f; }
+__device__ __forceinline__ pairf sin(pairf x) {
+#if defined(GR_FAST_TRIG) || defined(GR_LIBM_TRIG)
+    pairf s; s.x = gm::sin(x.x); s.y = gm::sin(x.y);
+#else
+    pairf s = sincos_reduced(x).s;
+    // per half: a ray's value must not depend on what its lane partner holds (a partner frozen at a NaN/Inf final state keeps
+    // being evaluated).  NaN/Inf need no libm either: the polynomial already returns NaN for them.
+    if (__builtin_expect(large_finite(x.x), 0)) s.x = sin_large(x.x);
+    if (__builtin_expect(large_finite(x.y), 0)) s.y = sin_large(x.y);
+#endif
+    return s;
+}
+__device__ __forceinline__ pairf cos(pairf x) {
+#if defined(GR_FAST_TRIG) || defined(GR_LIBM_TRIG)
+    pairf c; c.x = gm::cos(x.x); c.y = gm::cos(x.y);
+#else
+    pairf c = sincos_reduced(x).c;
+    if (__builtin_expect(large_finite(x.x), 0)) c.x = cos_large(x.x);
+    if (__builtin_expect(large_finite(x.y), 0)) c.y = cos_large(x.y);
+#endif
+    return c;
+}
+// everything else the expressions may call: once per ray
+#define GR_PAIR_FN1(name) \
+    __device__ __forceinline__ pairf name(pairf x) { pairf r; r.x = gm::name(x.x); r.y = gm::name(x.y); return r; }
+#define GR_PAIR_FN2(name) \
+    __device__ __forceinline__ pairf name(pairf x, pairf y) { pairf r; r.x = gm::name(x.x, y.x); r.y = gm::name(x.y, y.y); return r; } \
+    __device__ __forceinline__ pairf name(pairf x, float y) { pairf r; r.x = gm::name(x.x, y); r.y = gm::name(x.y, y); return r; }     \
+    __device__ __forceinline__ pairf name(float x, pairf y) { pairf r; r.x = gm::name(x, y.x); r.y = gm::name(x, y.y); return r; }
+GR_PAIR_FN1(tan) GR_PAIR_FN1(asin) GR_PAIR_FN1(acos) GR_PAIR_FN1(atan) GR_PAIR_FN1(exp) GR_PAIR_FN1(log) GR_PAIR_FN1(sqrt)
+GR_PAIR_FN1(fabs) GR_PAIR_FN1(sinh) GR_PAIR_FN1(cosh) GR_PAIR_FN1(tanh) GR_PAIR_FN1(sign)
+GR_PAIR_FN2(atan2) GR_PAIR_FN2(pow) GR_PAIR_FN2(fmod) GR_PAIR_FN2(fmin) GR_PAIR_FN2(fmax)
+#undef GR_PAIR_FN1
+#undef GR_PAIR_FN2
+
+#define GR_POSITION_VARS_PAIR(p) \
+    const pairf v1 = (p).x; const pairf v2 = (p).y; const pairf v3 = (p).z; const pairf v4 = (p).w; \
+    const float rs = RS_IMPL; const float c = C_IMPL; (void)v1; (void)v2; (void)v3; (void)v4; (void)rs; (void)c;
+
+__device__ __forceinline__ pair4 geodesic_acceleration(pair4 pos, pair4 vel, cfg_t cfg) {
+#ifdef GENERIC_CONSTANT_THETA
+    pos.z = splat(GR_PIf / 2);
+    vel.z = splat(0.f);
+#endif
+    GR_POSITION_VARS_PAIR(pos)
+    const pairf iv1 = vel.x; const pairf iv2 = vel.y; const pairf iv3 = vel.z; const pairf iv4 = vel.w;
+    (void)iv1; (void)iv2; (void)iv3; (void)iv4;
+    pairf TEMPORARIES0;
+    pair4 a;
+    a.x = GEO_ACCEL0;
+    a.y = GEO_ACCEL1;
+#ifndef GENERIC_CONSTANT_THETA
+    a.z = GEO_ACCEL2;
+#else
+    a.z = splat(0.f);
+#endif
+    a.w = GEO_ACCEL3;
+    return a;
+}
+__device__ __forceinline__ pair4 generic_to_spherical(pair4 in, cfg_t cfg) {
+    GR_POSITION_VARS_PAIR(in)
+    pair4 r;
+    r.x = TO_COORD1; r.y = TO_COORD2; r.z = TO_COORD3; r.w = TO_COORD4;
+    return r;
+}
+__device__ __forceinline__ pairf distance_to_object(pair4 polar, cfg_t cfg) {
+    GR_POSITION_VARS_PAIR(polar)
+    pairf d = DISTANCE_FUNC;
+    return d;
+}
+#endif  // GR_TWO_RAYS_PER_LANE
+
+}  // namespace gm
+

@@ -1,0 +1,965 @@
+// ------------------------------------------------------------------------------------------------
+// final position -> sky coordinates (cl.cl:211-263, 5024-5100)
+
+__device__ __forceinline__ float3 fix_ray_position_cart(float3 pos, float3 vel, float radius) {
+    vel = normalize3(vel);
+    float b = 2 * dot3(vel, pos);
+    float c = dot3(pos, pos) - radius * radius;
+    float discrim = b * b - 4 * c;
+    if (discrim < 0) return pos;
+    float sq = __builtin_sqrtf(discrim);
+    float t0 = (-b - sq) / 2;
+    float t1 = (-b + sq) / 2;
+    float t = __builtin_fabsf(t0) < __builtin_fabsf(t1) ? t0 : t1;
+    return pos + t * vel;
+}
+
+__device__ __forceinline__ float3 fix_ray_position(float3 polar_pos, float3 polar_vel, float radius) {
+    float sgn = fsign(polar_pos.x);
+    float3 cpos = polar_pos;
+    cpos.x = __builtin_fabsf(cpos.x);
+    polar_vel.x *= sgn;
+    float3 cart_vel = spherical_velocity_to_cartesian_velocity(cpos, polar_vel);
+    float3 cart_pos = polar_to_cartesian(cpos);
+    float3 fixed = cartesian_to_polar(fix_ray_position_cart(cart_pos, cart_vel, radius));
+#ifdef IS_CONSTANT_THETA
+    fixed.y = GR_PIf / 2;
+#endif
+    fixed.x *= sgn;
+    return fixed;
+}
+
+__device__ __forceinline__ float4 intersection_position(float4 ray_position, float4 ray_velocity, float4 initial_quat, cfg_t cfg, dfg_t dfg) {
+    float4 position = gm::generic_to_spherical(ray_position, cfg);
+    float4 velocity = gm::generic_velocity_to_spherical_velocity(ray_position, ray_velocity, cfg);
+#ifdef IS_CONSTANT_THETA
+    position.z = GR_PIf / 2;
+    velocity.z = 0;
+#endif
+    const float universe = GET_FEATURE(universe_size, dfg);
+    if (__builtin_fabsf(position.y) >= universe) {
+        float3 p = fix_ray_position(yzw(position), yzw(velocity), universe);
+        position = f4(position.x, p);
+    }
+#if defined(SINGULAR) && defined(TRAVERSABLE_EVENT_HORIZON)
+    if (__builtin_fabsf(position.y) < SINGULAR_TERMINATOR) {
+        float3 p = fix_ray_position(yzw(position), yzw(velocity), SINGULAR_TERMINATOR);
+        position = f4(position.x, p);
+    }
+#endif
+    float3 npolar = yzw(position);
+#ifdef GENERIC_CONSTANT_THETA
+    npolar = cartesian_to_polar(rot_quat(polar_to_cartesian(yzw(position)), initial_quat));
+#endif
+    (void)initial_quat;
+    return f4(position.x, npolar);
+}
+
+__device__ __forceinline__ float2 angle_to_tex(float theta, float phi) {
+    float thetaf = fmodf(theta, 2 * GR_PIf);
+    float phif = phi;
+    if (thetaf >= GR_PIf) { phif += GR_PIf; thetaf -= GR_PIf; }
+    phif = fmodf(phif, 2 * GR_PIf);
+    return make_float2(phif / (2 * GR_PIf) + 0.5f, thetaf / GR_PIf);
+}
+
+__device__ __forceinline__ float2 tex_to_angle(float2 tex) {
+    return make_float2((tex.x - 0.5f) * (2 * GR_PIf), tex.y * GR_PIf);
+}
+
+// render_data of one finished ray (body of calculate_render_data, cl.cl:5146-5212)
+__device__ __forceinline__ render_data make_render_data(float4 position, float4 velocity, float4 initial_quat, float ku_uobsu,
+                                                        float running, int terminated, int sx, int sy, cfg_t cfg, dfg_t dfg,
+                                                        bool need_redshift) {
+    render_data dat;
+    dat.terminated = terminated;
+    dat.sx = sx;
+    dat.sy = sy;
+    dat.z_shift = 0;
+    dat.tex_coord = make_float2(0, 0);
+    dat.side = 1;
+    if (terminated != 1) return dat;
+
+    float4 ipos = intersection_position(position, velocity, initial_quat, cfg, dfg);
+    float4 generic_velocity = velocity / running;
+    dat.side = gm::generic_to_spherical(position, cfg).y < 0 ? 0 : 1;
+#if !defined(TRAVERSABLE_EVENT_HORIZON)
+    if (__builtin_fabsf(ipos.y) <= 1) return dat;
+#endif
+    if (need_redshift) {
+        tetrad t;
+        calculate_tetrads(position, f3(0, 0, 0), t, cfg, 0);
+        float g[16];
+        gm::metric_big_at(position, g, cfg);
+        float4 obvs_low = lower_index_big(t.e[0], g);
+        float z_shift = (dot4(generic_velocity, obvs_low) / ku_uobsu) - 1;
+        dat.z_shift = __builtin_fmaxf(z_shift, -0.999f);
+    }
+    dat.tex_coord = angle_to_tex(ipos.z, ipos.w);
+    return dat;
+}
+
+// ================================================================================================
+// kernels
+
+extern "C" __global__ void gr_cart_to_generic(const float4* __restrict__ position_cart_in, float4* __restrict__ position_generic_out,
+                                              int count, float flip, cfg_t cfg) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    float4 in = position_cart_in[id];
+    float3 polar = cartesian_to_polar(yzw(in));
+    if (flip > 0) polar.x = -polar.x;
+    position_generic_out[id] = gm::spherical_to_generic(f4(in.x, polar), cfg);
+}
+
+extern "C" __global__ void gr_init_basis_vectors(const float4* __restrict__ generic_in, int count, float speed_x, float speed_y, float speed_z,
+                                                 float4* __restrict__ e0_out, float4* __restrict__ e1_out,
+                                                 float4* __restrict__ e2_out, float4* __restrict__ e3_out, cfg_t cfg) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    tetrad t;
+    calculate_tetrads(generic_in[id], f3(speed_x, speed_y, speed_z), t, cfg, 1);
+    e0_out[id] = t.e[0];
+    e1_out[id] = t.e[1];
+    e2_out[id] = t.e[2];
+    e3_out[id] = t.e[3];
+}
+
+extern "C" __global__ void gr_clear_termination_buffer(int* __restrict__ termination_buffer, int width, int height) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= width * height) return;
+    termination_buffer[id] = 1;
+}
+
+// `tiled` is an extension over the reference signature: 0 = reference slot order (slot = cy*width+cx),
+// 1 = 8x8 tile order (slot count is then rounded up to whole tiles; out-of-image slots get terminated = 2).
+extern "C" __global__ void gr_init_rays_generic(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+                                                lightray* __restrict__ metric_rays, int* __restrict__ metric_ray_count,
+                                                int width, int height, const int* __restrict__ termination_buffer,
+                                                int prepass_width, int prepass_height, int flip_geodesic_direction,
+                                                const float4* __restrict__ e0, const float4* __restrict__ e1,
+                                                const float4* __restrict__ e2, const float4* __restrict__ e3,
+                                                cfg_t cfg, dfg_t dfg, int i_am_prepass, int tiled) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    int cx, cy;
+    const int T = GR_TILE;
+    int slots = tiled ? ((width + T - 1) / T) * ((height + T - 1) / T) * T * T : width * height;
+    if (id >= slots) return;
+    bool inside = slot_to_pixel(id, width, height, tiled, cx, cy);
+
+    bool full = i_am_prepass || !GET_FEATURE(adaptive_sampling, dfg) || GET_FEATURE(use_triangle_rendering, dfg);
+    if (id == 0) *metric_ray_count = full ? slots : (height * width) / 4;
+
+    if (!inside) {
+        lightray dead;
+        dead.position = dead.velocity = dead.acceleration = f4(0, 0, 0, 0);
+        dead.initial_quat = f4(0, 0, 0, 1);
+        dead.ku_uobsu = 1; dead.running_dlambda_dnew = 1; dead.terminated = 2; dead.sx = -1; dead.sy = -1;
+        metric_rays[id] = dead;
+        return;
+    }
+
+    lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3,
+                                  flip_geodesic_direction, cfg, dfg);
+
+    // prepass stencil (cl.cl:3213-3232)
+    if (prepass_width != width && prepass_height != height) {
+        float fx = exact_ratio(cx, width);
+        float fy = exact_ratio(cy, height);
+        int lx = (int)roundf(fx * prepass_width);
+        int ly = (int)roundf(fy * prepass_height);
+        if (early_terminate(lx - 1, ly, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx, ly, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx + 1, ly, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx, ly - 1, prepass_width, prepass_height, termination_buffer) &&
+            early_terminate(lx, ly + 1, prepass_width, prepass_height, termination_buffer)) {
+            ray.terminated = 2;
+        }
+    }
+
+    if (full) {
+        metric_rays[id] = ray;
+    } else {
+        if ((cx % 2) != 0 || (cy % 2) != 0) return;
+        metric_rays[(cy / 2) * (width / 2) + cx / 2] = ray;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
+gr_do_generic_rays(lightray* __restrict__ generic_rays_in, const int* __restrict__ generic_count_in,
+                   int* __restrict__ ray_time_min, int* __restrict__ ray_time_max,
+                   cfg_t cfg_in, dfg_t dfg_in, int width, int height, int mouse_x, int mouse_y,
+                   float4* __restrict__ ray_write, int* __restrict__ ray_write_counts, int max_write,
+                   unsigned long long* __restrict__ attempt_counter) {
+    GR_PARAMETERS_IN_REGISTERS
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= *generic_count_in) return;
+    if (ray_write_counts) ray_write_counts[id] = 0;
+    lightray* ray = &generic_rays_in[id];
+    if (ray->terminated == 2) return;
+
+    ray_state s;
+    s.position = ray->position;
+    s.velocity = ray->velocity;
+    s.acceleration = ray->acceleration;
+    unsigned int tries = 0;
+    int res = integrate_ray(s, cfg, dfg, &tries);
+    if (res == RAY_TERMINATED) {
+        ray->position = s.position;
+        ray->velocity = s.velocity;
+        ray->running_dlambda_dnew = s.running_dlambda_dnew;
+        ray->terminated = 1;
+    }
+    if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);   // one add per wave after compiler coalescing
+}
+
+extern "C" __global__ void gr_calculate_singularities(const lightray* __restrict__ finished_rays, const int* __restrict__ finished_count,
+                                                      int* __restrict__ termination_buffer, int width, int height) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= *finished_count) return;
+    int sx = id % width;
+    int sy = id / width;
+    termination_buffer[sy * width + sx] = !finished_rays[id].terminated;
+}
+
+extern "C" __global__ void gr_calculate_render_data(const lightray* __restrict__ rays_in, const int* __restrict__ rays_in_count,
+                                                    render_data* __restrict__ rdata, int* __restrict__ rdata_count,
+                                                    int width, int height, cfg_t cfg, dfg_t dfg) {
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= *rays_in_count) return;
+    if (gid == 0) *rdata_count = width * height;
+    const lightray* ray = &rays_in[gid];
+    int sx = ray->sx, sy = ray->sy;
+    if (sx < 0 || sy < 0 || sx >= width || sy >= height) return;   // padding slots of the tiled layout
+    render_data dat = make_render_data(ray->position, ray->velocity, ray->initial_quat, ray->ku_uobsu, ray->running_dlambda_dnew,
+                                       ray->terminated, sx, sy, cfg, dfg, true);
+    rdata[sy * width + sx] = dat;
+}
+
+
+// init -> integrate -> render-data for one pixel per lane, 8x8 tiles, nothing but the 32-byte result is stored.
+// `wave` numbers the tile-waves of this device: image rows are dealt to devices in blocks of `block_rows` rows (block-cyclic:
+// global block gb belongs to device gb % strip_count); a block is tiles_x * block_rows/8 tile-waves, and, when the image is
+// split, 64x1 "halo" waves tracing the row just below it, which the texture filter of the block's last row reads
+// (cl.cl:5509-5520).  strip_count == 1: one block covering the whole image.
+// Adaptive sampling on a split frame (halo of two rows).  A device that owns the row blocks strip_rank, strip_rank +
+// strip_count, ... needs the block decisions of the pixel-block rows y (even) with r0 <= y <= r0 + B for each of its blocks [r0, r0 + B)
+// - the row r0 + B is the halo row under the block that the texture filter reads - and for those the lattice rows y - 2 ... y + 2.
+__device__ __forceinline__ bool own_block_within(int y, int margin, int height, int block_rows, int strip_rank, int strip_count) {
+    // is there an own block b (b % strip_count == strip_rank, b * B < height) with b * B - margin <= y <= (b + 1) * B + margin ?
+    const int last = (y + margin) / block_rows;
+    for (int b = last; b >= 0 && (b + 1) * block_rows + margin >= y; b--)
+        if (b % strip_count == strip_rank && b * block_rows < height) return true;
+    return false;
+}
+
+// Shading inside the trace launch.  Of the 64 pixels of a tile, the 49 that are not in its last column or row have both neighbours
+// the texture filter looks at (the pixel to the right and the pixel below, cl.cl:5509-5546) in the same wave: their sky coordinates
+// come over by ds_bpermute and the wave writes the finished float4 pixels itself, straight from the registers the render-data
+// record was built in.  The 15 pixels of the last column and row need records other waves write; gr_render shades those in a
+// second, small launch (seams_only).  out == NULL: no shading here (gr_render does all of it).  Compiled into programs whose
+// argument string carries -DGR_TILE_SHADING (gr_program_has_tile_shading); measured slower than the separate pass, DESIGN.md 4.
+struct trace_shading {
+    float4* out;
+    const uchar4* bg1_texels;
+    const uchar4* bg2_texels;
+    int bg_width, bg_height, bg_levels, most_probes, compact_out;
+};
+__device__ __attribute__((noinline)) float4 shade_pixel_in_tile(const render_data& self, float2 beside, float2 below, const trace_shading& shading, dfg_t dfg);
+
+__device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __restrict__ camera, const float4* __restrict__ camera_quat,
+                                           render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank,
+                                           int strip_count, const int* __restrict__ termination_buffer, int prepass_width,
+                                           int prepass_height, const float4* __restrict__ e0, const float4* __restrict__ e1,
+                                           const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
+                                           unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
+                                           const trace_shading& shading, bool known_skipped, int cell_wave, bool cells_in_flight) {
+    // cell_wave >= 0: this "tile" is 64 cells of the low-resolution prepass (prepass_cell, below) traced by the launch itself:
+    // the ray of cell (cx, cy) of the prepass grid, and its verdict goes to the termination buffer instead of a record.
+    // cells_in_flight: the launch has such waves, so a tile waits for the cells its pixels look at.
+    // Adaptive sampling on the fused path (cl.cl:3234-3250, 5223-5345): lattice = 2 traces the pixels (2x, 2y) only - the tiles
+    // then cover the half-resolution grid - and pending_only = 1 traces the pixels gr_adaptive_refine marked (terminated ==
+    // GR_PENDING) and leaves every other record alone.  On a split frame (strip_count > 1) the lattice launch traces the lattice
+    // rows this device's decisions read, the second launch the marked pixels of its own rows and halo rows.
+    const int image_width = width, image_height = height;
+    const int device_block_rows = block_rows, device_rank = strip_rank, device_count = strip_count;
+    // the lattice launch walks the tiles of the whole half-resolution grid whoever owns the rows; a device of a split frame
+    // traces the lattice rows its blocks' decisions read and leaves the others alone (below)
+    if (lattice == 2) { width /= 2; height /= 2; block_rows = ((height + 7) / 8) * 8; strip_rank = 0; strip_count = 1; }
+    const int T = GR_TILE;
+    const int tiles_x = (width + T - 1) / T;
+    const int tile_rows = block_rows / T;
+    const int halo_waves = strip_count > 1 ? (width + 63) / 64 : 0;
+    const int waves_per_block = tiles_x * tile_rows + halo_waves;
+    const int local_block = wave / waves_per_block;
+    const int within = wave % waves_per_block;
+    const int r0 = (local_block * strip_count + strip_rank) * block_rows;
+    int cx, cy;
+    int ray_grid_width = image_width, ray_grid_height = image_height;   // the grid the ray's direction is a pixel of
+    if (cell_wave >= 0) {
+        const int cell = cell_wave * 64 + lane;
+        if (cell >= prepass_width * prepass_height) return;
+        cx = cell % prepass_width;
+        cy = cell / prepass_width;
+        ray_grid_width = prepass_width; ray_grid_height = prepass_height;
+        width = image_width; height = image_height;
+    } else {
+    if (within < tiles_x * tile_rows) {
+        cx = (within % tiles_x) * T + lane % T;
+        cy = r0 + (within / tiles_x) * T + lane / T;
+        if (cy >= r0 + block_rows) return;
+    } else {
+        cx = (within - tiles_x * tile_rows) * 64 + lane;
+        cy = r0 + block_rows;
+    }
+    if (cx >= width || cy >= height) return;
+    cx *= lattice; cy *= lattice;
+    width = image_width; height = image_height;
+    if (lattice == 2 && device_count > 1 && !own_block_within(cy, 2, height, device_block_rows, device_rank, device_count)) return;
+    if (pending_only && rdata[cy * width + cx].terminated != GR_PENDING) return;
+    }
+
+    // the prepass verdict first: a skipped pixel (58 % of the 4K Kerr frame) needs no ray at all
+    // known_skipped: a tile of gr_order_tiles' last class - the 5x5 cells around it are all in the shadow, and the stencil of every
+    // one of its pixels lies inside those (a pixel rounds to a cell at most one from the tile centre's) - needs no look-up at all
+    int terminated = known_skipped ? 2 : 0;
+    if (cell_wave < 0 && !known_skipped && !pending_only && termination_buffer && prepass_width != width && prepass_height != height) {
+        float fx = exact_ratio(cx, width);
+        float fy = exact_ratio(cy, height);
+        int lx = (int)roundf(fx * prepass_width);
+        int ly = (int)roundf(fy * prepass_height);
+        const bool skip = cells_in_flight ? early_terminate_stencil_when_known(lx, ly, prepass_width, prepass_height, termination_buffer)
+                                          : early_terminate_stencil(lx, ly, prepass_width, prepass_height, termination_buffer);
+        if (skip) terminated = 2;
+    }
+    render_data dat;
+    unsigned int tries = 0;
+    if (terminated == 2) {
+        dat.tex_coord = make_float2(0, 0);
+        dat.z_shift = 0;
+        dat.sx = cx;
+        dat.sy = cy;
+        dat.terminated = 2;
+        dat.side = 1;
+    } else {
+        // camera and tetrad are re-read (scalar loads) for every tile: 24 wave-uniform values held across the integrator
+        // loop would spill scalar registers
+        lightray ray = make_pixel_ray(cx, cy, ray_grid_width, ray_grid_height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        ray_state s;
+        s.position = ray.position;
+        s.velocity = ray.velocity;
+        s.acceleration = ray.acceleration;
+        s.running_dlambda_dnew = 1;
+        int res = integrate_ray(s, cfg, dfg, &tries);
+        if (cell_wave >= 0) {
+            // calculate_singularities (cl.cl:5008-5020): 1 = the ray did not reach the boundary.  Device scope: tiles on other
+            // XCDs (each with an L2 of its own) are polling for it.
+            __hip_atomic_store(const_cast<int*>(termination_buffer) + cy * prepass_width + cx, res == RAY_TERMINATED ? 0 : 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            return;   // (the prepass rays' attempts are not counted: gr_render_state_attempts is the frame's pixels', as with the prepass launched on its own)
+        }
+        if (res == RAY_TERMINATED) terminated = 1;
+        else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
+        dat = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated, cx, cy, cfg,
+                               dfg, GET_FEATURE(redshift, dfg) != 0);
+    }
+    rdata[cy * width + cx] = dat;
+#ifdef GR_TILE_SHADING   // programs built with -DGR_TILE_SHADING only: carried along unused, the call's spills add 0.12 GB of scratch traffic per 4K launch
+    if (shading.out && lattice == 1 && !pending_only && within < tiles_x * tile_rows) {
+        // every lane of the tile that holds a pixel hands its sky coordinates to the lanes left of and above it
+        const float2 beside = make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) * 4, __float_as_int(dat.tex_coord.x))),
+                                          __int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) * 4, __float_as_int(dat.tex_coord.y))));
+        const float2 below = make_float2(__int_as_float(__builtin_amdgcn_ds_bpermute((lane + T) * 4, __float_as_int(dat.tex_coord.x))),
+                                         __int_as_float(__builtin_amdgcn_ds_bpermute((lane + T) * 4, __float_as_int(dat.tex_coord.y))));
+        if (lane % T < T - 1 && lane / T < T - 1 && cx < width - 1 && cy < height - 1) {
+            long long out_index = (long long)cy * width + cx;
+            if (shading.compact_out) {   // the device's blocks back to back (gr_render's compact_out)
+                const int block = cy / block_rows;
+                out_index = ((long long)(block / strip_count) * block_rows + (cy - block * block_rows)) * width + cx;
+            }
+            shading.out[out_index] = shade_pixel_in_tile(dat, beside, below, shading, dfg);
+        }
+    }
+#endif
+    GR_PROBE_WAVE_SLOTS(tries, 64u)
+    if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);
+}
+
+// workgroup size of the fused trace kernel: 4 tile-waves, one per SIMD of a CU (capi.cpp launches with the same number)
+#ifndef GR_TRACE_BLOCK
+#define GR_TRACE_BLOCK 256
+#endif
+// Two scheduling modes.  tile_counter == NULL: wave w of the launch traces tile w (grid = all tiles).  tile_counter != NULL:
+// persistent waves - the launch only fills the machine and every wave keeps drawing the next tile from the device-side
+// counter until total_waves are handed out, so a SIMD slot never idles between the end of a short tile (prepass-skipped
+// tiles finish in a few hundred cycles) and the dispatcher's next workgroup.
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
+gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+               render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
+               const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+               const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+               cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
+               int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
+               int prepass_tickets) {
+    // prepass_tickets > 0 (persistent launches in image order only): the first prepass_tickets tickets are the waves of the
+    // low-resolution prepass, then come the tiles, which wait for the cells they look at (trace_tile).  A frame whose camera was not
+    // known in advance then pays the prepass's single-ray latency once per cell wave alongside the first tiles instead of as a
+    // launch of its own in front of the trace.
+    GR_PARAMETERS_IN_REGISTERS
+    const int lane = threadIdx.x % 64;
+    // profiling launches (attempt_counter != NULL) also measure the shader clock they ran at: every wave adds its lifetime in
+    // shader cycles (s_memtime) and in ticks of the constant 100 MHz reference clock (s_memrealtime) to attempt_counter[1], [2]
+    unsigned long long born_cycles = 0, born_ticks = 0;
+    if (attempt_counter) { born_cycles = __builtin_amdgcn_s_memtime(); born_ticks = __builtin_amdgcn_s_memrealtime(); }
+    // one call site for both modes: the two schedules must run the very same instructions per pixel (strip renders are
+    // compared bit for bit with whole-frame renders)
+    int wave = blockIdx.x * (GR_TRACE_BLOCK / 64) + threadIdx.x / 64;
+    // With gr_order_tiles' list a ticket is one tile of the classes that trace, or GR_SKIP_CHUNK tiles of the last class (all
+    // pixels skipped by the prepass: a store each).  The tickets come from ONE counter, which the memory system serves at about
+    // 10 ns a ticket whoever asks - nothing next to a tile's 0.1-1 ms of tracing, but the 75 000 skipped tiles of the 4K Kerr
+    // frame, handed out back to back at the end of the list, would add 0.7 ms of pure ticket traffic to the launch.
+    int held = 0, cursor = 0;   // tiles this wave still holds from its last ticket, and where in the list they start
+    bool known_skipped = false;  // the ticket was a chunk of the last class
+    const int tickets_total = total_waves + (prepass_tickets > 0 ? prepass_tickets : 0);   // (no tile order with prepass tickets)
+    const int singles = (tile_counter && tile_order) ? total_waves - (int)tile_order[GR_TILE_CLASSES - 1] : tickets_total;
+    for (;;) {
+        if (tile_counter) {
+            if (held == 0) {
+                unsigned int ticket = 0;
+                if (lane == 0) ticket = atomicAdd(tile_counter, 1u);
+                cursor = (int)__builtin_amdgcn_readfirstlane(ticket);
+                held = 1;
+                known_skipped = tile_order && cursor >= singles;
+                if (cursor >= singles) {
+                    cursor = singles + (cursor - singles) * GR_SKIP_CHUNK;
+                    held = tickets_total - cursor < GR_SKIP_CHUNK ? tickets_total - cursor : GR_SKIP_CHUNK;
+                }
+                if (held <= 0) break;
+            }
+            wave = tile_order ? (int)tile_order[GR_TILE_ORDER_HEADER + cursor] : cursor;
+            cursor++;
+            held--;
+        }
+        int cell_wave = -1;
+        if (prepass_tickets > 0) {
+            if (wave < prepass_tickets) { cell_wave = wave; wave = 0; }
+            else wave -= prepass_tickets;
+        }
+        if (wave >= total_waves) break;
+        // Launder the camera / tetrad pointers once per tile: otherwise everything in the ray set-up that depends only on
+        // them is hoisted out of the tile loop and held in registers across the integrator (94 instead of 64 VGPRs, i.e.
+        // 5 instead of 8 waves per SIMD).  Re-reading 96 bytes through the scalar cache per tile is free by comparison.
+        asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
+        GR_PROBE_TILE_BEGAN
+        trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
+                   termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
+                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0);
+        GR_PROBE_TILE_ENDED
+        if (!tile_counter) break;
+    }
+    if (attempt_counter && lane == 0) {
+        atomicAdd(attempt_counter + 1, (unsigned long long)__builtin_amdgcn_s_memtime() - born_cycles);
+        atomicAdd(attempt_counter + 2, (unsigned long long)__builtin_amdgcn_s_memrealtime() - born_ticks);
+        atomicAdd(attempt_counter + 3, 1ull);
+        GR_PROBE_WAVE_ENDED
+    }
+}
+
+// ---- ray compaction ------------------------------------------------------------------------------
+// slot t of a device's work list = lane t % 64 of tile-wave t / 64 (the mapping of trace_tile); false for padding slots
+__device__ __forceinline__ bool trace_slot_to_pixel(unsigned int slot, int width, int height, int block_rows, int strip_rank, int strip_count,
+                                                    int& cx, int& cy) {
+    const int T = GR_TILE;
+    const int wave = (int)(slot / 64u), lane = (int)(slot % 64u);
+    const int tiles_x = (width + T - 1) / T;
+    const int tile_rows = block_rows / T;
+    const int halo_waves = strip_count > 1 ? (width + 63) / 64 : 0;
+    const int waves_per_block = tiles_x * tile_rows + halo_waves;
+    const int local_block = wave / waves_per_block;
+    const int within = wave % waves_per_block;
+    const int r0 = (local_block * strip_count + strip_rank) * block_rows;
+    if (within < tiles_x * tile_rows) {
+        cx = (within % tiles_x) * T + lane % T;
+        cy = r0 + (within / tiles_x) * T + lane / T;
+        if (cy >= r0 + block_rows) return false;
+    } else {
+        cx = (within - tiles_x * tile_rows) * 64 + lane;
+        cy = r0 + block_rows;
+    }
+    return cx < width && cy < height;
+}
+
+__device__ __forceinline__ bool prepass_skips_pixel(int cx, int cy, int width, int height, const int* __restrict__ termination_buffer,
+                                                    int prepass_width, int prepass_height) {
+    if (!termination_buffer || prepass_width == width || prepass_height == height) return false;
+    float fx = exact_ratio(cx, width);
+    float fy = exact_ratio(cy, height);
+    int lx = (int)roundf(fx * prepass_width);
+    int ly = (int)roundf(fy * prepass_height);
+    return early_terminate_stencil(lx, ly, prepass_width, prepass_height, termination_buffer);
+}
+
+#ifdef GR_TWO_RAYS_PER_LANE
+// gr_trace_fused with two rays per lane (integrate_pair): a wave takes the tile-waves 2k and 2k+1 of trace_tile's numbering -
+// two horizontally adjacent 8x8 tiles - and lane l owns pixel l of each.  Same arguments, same records written.
+__device__ __forceinline__ void trace_tile_pair(int pair_wave, int lane, const float4* __restrict__ camera, const float4* __restrict__ camera_quat,
+                                                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank,
+                                                int strip_count, const int* __restrict__ termination_buffer, int prepass_width,
+                                                int prepass_height, const float4* __restrict__ e0, const float4* __restrict__ e1,
+                                                const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
+                                                unsigned long long* __restrict__ attempt_counter, int total_waves) {
+    int cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;
+    const bool has0 = trace_slot_to_pixel((unsigned)(2 * pair_wave) * 64u + (unsigned)lane, width, height, block_rows, strip_rank, strip_count, cx0, cy0);
+    const bool has1 = 2 * pair_wave + 1 < total_waves &&
+                      trace_slot_to_pixel((unsigned)(2 * pair_wave + 1) * 64u + (unsigned)lane, width, height, block_rows, strip_rank, strip_count, cx1, cy1);
+    const bool live0 = has0 && !prepass_skips_pixel(cx0, cy0, width, height, termination_buffer, prepass_width, prepass_height);
+    const bool live1 = has1 && !prepass_skips_pixel(cx1, cy1, width, height, termination_buffer, prepass_width, prepass_height);
+    render_data dat0, dat1;
+    dat0.tex_coord = make_float2(0, 0); dat0.z_shift = 0; dat0.sx = cx0; dat0.sy = cy0; dat0.terminated = 2; dat0.side = 1;
+    dat1.tex_coord = make_float2(0, 0); dat1.z_shift = 0; dat1.sx = cx1; dat1.sy = cy1; dat1.terminated = 2; dat1.side = 1;
+    unsigned int tries0 = 0, tries1 = 0;
+    if (live0 | live1) {
+        // a lane with one ray only steps that ray in both halves
+        const int ax = live0 ? cx0 : cx1, ay = live0 ? cy0 : cy1, bx = live1 ? cx1 : cx0, by = live1 ? cy1 : cy0;
+        lightray ray0 = make_pixel_ray(ax, ay, width, height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        lightray ray1 = make_pixel_ray(bx, by, width, height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        pair4 position = pair_of(ray0.position, ray1.position), velocity = pair_of(ray0.velocity, ray1.velocity);
+        pairf running;
+        int res0, res1;
+        integrate_pair(position, velocity, pair_of(ray0.acceleration, ray1.acceleration), running, live0, live1, cfg, dfg, res0, res1,
+                       tries0, tries1);
+        const bool need_redshift = GET_FEATURE(redshift, dfg) != 0;
+        if (live0) dat0 = make_render_data(half_of<0>(position), half_of<0>(velocity), ray0.initial_quat, ray0.ku_uobsu, running.x,
+                                           res0 == RAY_TERMINATED ? 1 : 0, cx0, cy0, cfg, dfg, need_redshift);
+        if (live1) dat1 = make_render_data(half_of<1>(position), half_of<1>(velocity), ray1.initial_quat, ray1.ku_uobsu, running.y,
+                                           res1 == RAY_TERMINATED ? 1 : 0, cx1, cy1, cfg, dfg, need_redshift);
+    }
+    if (has0) rdata[cy0 * width + cx0] = dat0;
+    if (has1) rdata[cy1 * width + cx1] = dat1;
+    GR_PROBE_WAVE_SLOTS_PAIR(tries0, tries1)
+    if (attempt_counter && (has0 | has1)) atomicAdd(attempt_counter, (unsigned long long)tries0 + (unsigned long long)tries1);
+}
+
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
+gr_trace_pair(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+              render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
+              const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+              const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+              cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
+              int total_waves) {
+    GR_PARAMETERS_IN_REGISTERS
+    const int lane = threadIdx.x % 64;
+    const int pair_waves = (total_waves + 1) / 2;
+    int wave = blockIdx.x * (GR_TRACE_BLOCK / 64) + threadIdx.x / 64;
+    for (;;) {
+        if (tile_counter) {
+            unsigned int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(tile_counter, 1u);
+            wave = (int)__builtin_amdgcn_readfirstlane(ticket);
+        }
+        if (wave >= pair_waves) break;
+        asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
+        trace_tile_pair(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
+                        termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, total_waves);
+        if (!tile_counter) break;
+    }
+}
+#endif  // GR_TWO_RAYS_PER_LANE
+
+// gr_trace_fused with ray compaction: a persistent wave keeps one ray per lane and, as soon as fewer than keep_lanes of them
+// are still integrating (wave-level ballot inside the Verlet loop), finishes the rays that ended, draws as many new pixels
+// from the device-side slot counter as it has idle lanes and sets those rays up, then resumes the loop.  The arithmetic of
+// a ray does not depend on which lane or in how many visits it is integrated, so the frame equals gr_trace_fused's up to
+// what the compiler contracts differently in two kernels; what changes is how many lanes of the 64 do useful work when
+// neighbouring rays need very different numbers of steps.  Measured on MI355X (4K Kerr): it does not pay for the workloads
+// of BASELINE.json - 8x8 tiles already keep 97 % (a = 0.45) and 94 % (the a = 0.9 naked singularity) of the lanes busy,
+// and the visits cost more than the idle lanes (7.1 -> 9.6 ms at keep_lanes 16..48) - so the frame driver leaves it off
+// unless asked (gr_frame_options.ray_compaction).
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
+gr_trace_compact(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+                 render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
+                 const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+                 const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+                 cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ slot_counter,
+                 unsigned int total_slots, int keep_lanes) {
+    GR_PARAMETERS_IN_REGISTERS
+    const bool need_redshift = GET_FEATURE(redshift, dfg) != 0;
+    // per-lane ray: pixel, what render-data needs from the set-up, integrator progress
+    int cx = 0, cy = 0;
+    float4 start_position = f4(0, 0, 0, 0), start_velocity = f4(0, 0, 0, 0), initial_quat = f4(0, 0, 0, 1);
+    float ku_uobsu = 1;
+    ray_state s;
+    s.position = s.velocity = s.acceleration = f4(0, 0, 0, 0);
+    s.next_ds = 0; s.running_dlambda_dnew = 1; s.f_in_x = 0; s.steps = 0; s.tries = 0;
+    bool has_ray = false;     // this lane holds a ray
+    bool integrating = false; // ... that has not ended yet
+    int outcome = RAY_LOST;
+    bool exhausted = false;   // wave-uniform: the slot counter ran past the work list
+
+    for (;;) {
+        // 1. rays that ended: render-data record, lane becomes idle
+        if (has_ray && !integrating) {
+            int terminated = 0;
+            float4 p = start_position, v = start_velocity;
+            float running = 1;
+            if (outcome == RAY_TERMINATED) { terminated = 1; p = s.position; v = s.velocity; running = s.running_dlambda_dnew; }
+            rdata[cy * width + cx] = make_render_data(p, v, initial_quat, ku_uobsu, running, terminated, cx, cy, cfg, dfg, need_redshift);
+            if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)s.tries);
+            has_ray = false;
+        }
+        // 2. refill idle lanes (skipped and padding slots use up tickets without giving work, hence the loop)
+        while (!exhausted) {
+            const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has_ray);
+            const int n_idle = __builtin_popcountll(idle);
+            if (n_idle == 0 || (n_idle <= 64 - keep_lanes && n_idle != 64)) break;   // enough rays on board
+            unsigned int base = 0;
+            if (threadIdx.x % 64 == 0) base = atomicAdd(slot_counter, (unsigned int)n_idle);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= total_slots) { exhausted = true; break; }
+            if (base + (unsigned int)n_idle >= total_slots) exhausted = true;
+            const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
+            const unsigned int slot = base + (unsigned int)my_rank;
+            if (!has_ray && slot < total_slots && trace_slot_to_pixel(slot, width, height, block_rows, strip_rank, strip_count, cx, cy)) {
+                if (prepass_skips_pixel(cx, cy, width, height, termination_buffer, prepass_width, prepass_height)) {
+                    render_data dat;
+                    dat.tex_coord = make_float2(0, 0);
+                    dat.z_shift = 0;
+                    dat.sx = cx;
+                    dat.sy = cy;
+                    dat.terminated = 2;
+                    dat.side = 1;
+                    rdata[cy * width + cx] = dat;
+                } else {
+                    lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+                    start_position = ray.position;
+                    start_velocity = ray.velocity;
+                    initial_quat = ray.initial_quat;
+                    ku_uobsu = ray.ku_uobsu;
+                    s.position = ray.position;
+                    s.velocity = ray.velocity;
+                    s.acceleration = ray.acceleration;
+                    integrate_begin(s, dfg);
+                    has_ray = true;
+                    integrating = true;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(has_ray) == 0) break;   // nothing on board and nothing left to draw
+        // 3. integrate until fewer than keep_lanes rays are still going (all of them to the end once the list is exhausted)
+        if (integrating) {
+            bool paused = false;
+            outcome = integrate_pingpong<true>(s, cfg, dfg, nullptr, exhausted ? 1 : keep_lanes, paused);
+            integrating = paused;
+        }
+    }
+}
+
+// termination flags of the low-resolution prepass, straight from a fused trace (role of
+// clear_termination_buffer + init_rays_generic(prepass) + do_generic_rays + calculate_singularities).
+// When the image is split over devices (strip_count > 1) a device only traces the cells its own rows can look at: a pixel
+// row cy reads the cell rows round(cy * ph / H) - 1 .. + 1 (init_rays_generic's 5-point stencil, cl.cl:3213-3232), so
+// cell row cp matters to this device only if one of its blocks (or the halo row under it) intersects the pixel rows
+// that map to cp - 1 .. cp + 1.  The prepass is otherwise replicated work: 11 % of a device's frame at 8 devices.
+__device__ __forceinline__ void prepass_cell(int id, float4 camera, float4 camera_quat, float4 e0, float4 e1, float4 e2, float4 e3,
+                                             int* __restrict__ termination_buffer, int prepass_width, int prepass_height, cfg_t cfg, dfg_t dfg,
+                                             int image_height, int block_rows, int strip_rank, int strip_count,
+                                             unsigned int* __restrict__ cell_attempts, int row_margin) {
+    if (id >= prepass_width * prepass_height) return;
+    int cx = id % prepass_width, cy = id / prepass_width;
+    if (strip_count > 1) {
+        // pixel rows whose stencil can touch cell row cy: round(y * ph / H) in [cy - 1, cy + 1], one row of slack either side for
+        // the float rounding of that quotient (tests/test_distributed_cpu.py checks the rule by brute force)
+        // row_margin: pixel rows beyond its blocks and halo rows the device also looks from (adaptive sampling: 2, the lattice rows
+        // its block decisions read)
+        long long lo = ((long long)(2 * cy - 3) * image_height) / (2 * prepass_height) - 1 - row_margin;
+        long long hi = ((long long)(2 * cy + 3) * image_height + 2 * prepass_height - 1) / (2 * prepass_height) + 1 + row_margin;
+        if (lo < 0) lo = 0;
+        if (hi > image_height - 1) hi = image_height - 1;
+        // blocks b (rows b*B .. (b+1)*B inclusive of the halo row) that meet [lo, hi]: (b+1)*B >= lo and b*B <= hi
+        long long b_lo = (lo - 1) / block_rows, b_hi = hi / block_rows;
+        if (b_lo < 0) b_lo = 0;
+        long long first = b_lo + (((long long)strip_rank - b_lo) % strip_count + strip_count) % strip_count;   // first own block >= b_lo
+        if (first > b_hi) return;
+    }
+    lightray ray = make_pixel_ray(cx, cy, prepass_width, prepass_height, camera, camera_quat, e0, e1, e2, e3, 0, cfg, dfg);
+    ray_state s;
+    s.position = ray.position;
+    s.velocity = ray.velocity;
+    s.acceleration = ray.acceleration;
+    unsigned int tries = 0;
+    int res = integrate_ray(s, cfg, dfg, &tries);
+    termination_buffer[id] = res == RAY_TERMINATED ? 0 : 1;
+    if (cell_attempts) cell_attempts[id] = tries;   // what the ray cost: gr_order_tiles' estimate for the tiles around the cell
+}
+
+extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
+gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+                 int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+                 const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+                 cfg_t cfg_in, dfg_t dfg_in, int image_height, int block_rows, int strip_rank, int strip_count,
+                 unsigned int* __restrict__ cell_attempts, int row_margin) {
+    GR_PARAMETERS_IN_REGISTERS
+    prepass_cell(blockIdx.x * blockDim.x + threadIdx.x, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, termination_buffer,
+                 prepass_width, prepass_height, cfg, dfg, image_height, block_rows, strip_rank, strip_count, cell_attempts, row_margin);
+}
+
+// cart_to_generic_kernel + init_basis_vectors + the prepass in ONE launch (the reference: three of its launches and the prepass
+// sequence, main.cpp:2311, 2329, 2380-2436).  The camera's metric coordinates and tetrad - one lane's worth of work, ~900
+// instructions - are computed by every lane of the launch for itself (same inputs, same instructions, same values), lane 0 of the
+// launch also stores them for gr_trace_fused.  What this buys is the launch chain of a frame: two single-lane kernels with their
+// queue latencies sat in front of every prepass (1.3 ms on average on the look-ahead stream under load, round-1 profile), which
+// is what a device's share of a frame costs altogether once the frame is split eight ways.  prepass_width * prepass_height may
+// be 0 (metrics without a prepass): the launch is then the camera set-up alone.
+extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
+gr_camera_prepass(const float4* __restrict__ position_cart_in, float flip, float speed_x, float speed_y, float speed_z,
+                  float4* __restrict__ position_generic_out, float4* __restrict__ e0_out, float4* __restrict__ e1_out,
+                  float4* __restrict__ e2_out, float4* __restrict__ e3_out, const float4* __restrict__ g_camera_quat,
+                  int* __restrict__ termination_buffer, int prepass_width, int prepass_height, cfg_t cfg_in, dfg_t dfg_in,
+                  int image_height, int block_rows, int strip_rank, int strip_count, unsigned int* __restrict__ cell_attempts,
+                  int row_margin) {
+    GR_PARAMETERS_IN_REGISTERS
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const float4 in = *position_cart_in;
+    float3 polar = cartesian_to_polar(yzw(in));
+    if (flip > 0) polar.x = -polar.x;
+    const float4 camera = gm::spherical_to_generic(f4(in.x, polar), cfg);
+    tetrad t;
+    calculate_tetrads(camera, f3(speed_x, speed_y, speed_z), t, cfg, 1);
+    if (id == 0) {
+        *position_generic_out = camera;
+        *e0_out = t.e[0];
+        *e1_out = t.e[1];
+        *e2_out = t.e[2];
+        *e3_out = t.e[3];
+    }
+    prepass_cell(id, camera, *g_camera_quat, t.e[0], t.e[1], t.e[2], t.e[3], termination_buffer, prepass_width, prepass_height, cfg, dfg,
+                 image_height, block_rows, strip_rank, strip_count, cell_attempts, row_margin);
+}
+
+// ---- the order the persistent trace hands its tiles out in -----------------------------------------
+// A persistent launch ends when its slowest wave ends, and a wave that draws a long tile late ends late: with the tiles handed
+// out in image order the 4K Kerr launch spent its last 1.4 of 6.3 ms draining (tickets gone at 4.9 ms; 6 waves share a SIMD,
+// so an average traced tile of ~500 attempts takes 0.6 ms and the tiles on the shadow's edge several times that).  The prepass
+// has already traced one ray per 16x16 pixels: what those rays cost is a fair estimate of what the tiles around them will
+// cost, so the tiles are handed out longest first - 16 classes: tiles that straddle the shadow's edge first of all, then by the
+// most expensive ray among the cells around the tile's centre, an octave of attempts per class, tiles no pixel of which needs a
+// ray (a store per pixel) last.  That is for a device's share of a split frame, where a wave slot gets one or two tiles and which
+// comes last decides when the launch ends; on a whole 4K frame (nine traced tiles per slot) image order measured 2 % faster -
+// the longest tiles take 7 ms when six of them share a SIMD from the start, 3.5 ms next to short tiles that keep restarting.  Scheduling only: which wave traces a tile and when has no influence on its rays.
+// Two launches over the device's tiles: phase 0 counts the classes, phase 1 deals every tile a place in its class's range
+// (order within a class: as the atomics fall, i.e. roughly image order).  list[0..15] counts, [16..31] cursors, then the tiles,
+// then the tiles' classes (scratch between the two phases).
+__device__ __forceinline__ int tile_cost_class(int tile, int width, int height, int block_rows, int strip_rank, int strip_count,
+                                               const int* __restrict__ termination_buffer, const unsigned int* __restrict__ cell_attempts,
+                                               int prepass_width, int prepass_height) {
+    int cx = 0, cy = 0;
+    if (!trace_slot_to_pixel((unsigned)tile * 64u + 36u, width, height, block_rows, strip_rank, strip_count, cx, cy) &&
+        !trace_slot_to_pixel((unsigned)tile * 64u, width, height, block_rows, strip_rank, strip_count, cx, cy))
+        return GR_TILE_CLASSES - 1;   // padding: nothing to trace
+    const int lx = (int)roundf(exact_ratio(cx, width) * prepass_width), ly = (int)roundf(exact_ratio(cy, height) * prepass_height);
+    // the halo pieces of a split frame are 64 pixels of one row, not a tile: four cells wide, so the promise of the last class
+    // (below) cannot be made for them
+    const int tiles_in_block = ((width + GR_TILE - 1) / GR_TILE) * (block_rows / GR_TILE);
+    const bool halo_piece = strip_count > 1 && tile % (tiles_in_block + (width + 63) / 64) >= tiles_in_block;
+    // a pixel's stencil reaches one cell beyond the cell it rounds to, and the pixels of a tile round to cells up to one away
+    // from the centre's: shadow flags over 5x5 cells (the last class promises that no pixel of the tile needs a ray), costs over
+    // the cells within GR_TILE_COST_REACH
+    int in_shadow = 0;
+    unsigned int dearest = 0;
+    // every cell is read, at clamped coordinates, whether it counts or not: 50 independent loads in flight instead of a chain of
+    // conditional ones (the kernel is nothing but their latency)
+#pragma unroll
+    for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+        for (int dx = -2; dx <= 2; dx++) {
+            const int x = min(max(lx + dx, 0), prepass_width - 1), y = min(max(ly + dy, 0), prepass_height - 1);
+            const bool inside = x == lx + dx && y == ly + dy;   // outside the grid: never "skip" (early_terminate)
+            const int flag = termination_buffer[y * prepass_width + x];
+            in_shadow += (inside && flag == 1) ? 1 : 0;
+            const unsigned int a = cell_attempts[y * prepass_width + x];
+            const bool near = dx >= -GR_TILE_COST_REACH && dx <= GR_TILE_COST_REACH && dy >= -GR_TILE_COST_REACH && dy <= GR_TILE_COST_REACH;
+            dearest = (inside && near && a > dearest) ? a : dearest;
+        }
+    if (in_shadow == 25 && !halo_piece) return GR_TILE_CLASSES - 1;
+    if (in_shadow > 0) return 0;
+    // classes 1 .. 14 by the dearest ray, GR_TILE_CLASS_STEPS classes per octave of attempts, dearest first, < 256 (128) last
+    const int steps = (int)((float)GR_TILE_CLASS_STEPS * __log2f((float)(dearest > 128u ? dearest : 128u) * (1.f / 128.f)));
+    return GR_TILE_CLASSES - 2 - (steps > 13 ? 13 : steps);
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+gr_order_tiles(const int* __restrict__ termination_buffer, const unsigned int* __restrict__ cell_attempts, int prepass_width,
+               int prepass_height, int width, int height, int block_rows, int strip_rank, int strip_count, int total_tiles,
+               unsigned int* __restrict__ list, int phase) {
+    // one atomic per class and WORKGROUP on the device-wide counters: they are single addresses that every XCD contends for
+    // (~50 ns an atomic; per wave the 2 000 waves of a 4K frame spent 0.1 ms on them), the waves of a workgroup meet in LDS
+    __shared__ unsigned int group_count[GR_TILE_CLASSES], group_base[GR_TILE_CLASSES];
+    if (threadIdx.x < GR_TILE_CLASSES) group_count[threadIdx.x] = 0;
+    __syncthreads();
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    // phase 0 works the classes out and leaves them behind the list for phase 1
+    unsigned int* classes = list + GR_TILE_ORDER_HEADER + total_tiles;
+    int cls = -1;
+    if (tile < total_tiles) {
+        if (phase == 0) {
+            cls = tile_cost_class(tile, width, height, block_rows, strip_rank, strip_count, termination_buffer, cell_attempts, prepass_width,
+                                  prepass_height);
+            classes[tile] = (unsigned int)cls;
+        } else {
+            cls = (int)classes[tile];
+        }
+    }
+    const int lane = threadIdx.x % 64;
+    unsigned int place = 0;   // of this tile among its workgroup's tiles of the same class
+    for (int c = 0; c < GR_TILE_CLASSES; c++) {
+        const unsigned long long members = __builtin_amdgcn_ballot_w64(cls == c);
+        if (members) {
+            const int leader = __builtin_ctzll(members);
+            unsigned int wave_base = 0;
+            if (lane == leader) wave_base = atomicAdd(&group_count[c], (unsigned int)__builtin_popcountll(members));
+            wave_base = __builtin_amdgcn_readlane(wave_base, leader);
+            if (cls == c) place = wave_base + (unsigned int)__builtin_popcountll(members & ((1ull << lane) - 1ull));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < GR_TILE_CLASSES && group_count[threadIdx.x])
+        group_base[threadIdx.x] = atomicAdd(list + (phase == 0 ? 0 : GR_TILE_CLASSES) + threadIdx.x, group_count[threadIdx.x]);
+    __syncthreads();
+    if (phase == 1 && cls >= 0) {
+        unsigned int first = 0;   // where the class's range starts
+        for (int c = 0; c < cls; c++) first += list[c];
+        list[GR_TILE_ORDER_HEADER + first + group_base[cls] + place] = (unsigned int)tile;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive sampling (cl.cl:5215-5345)
+
+__device__ __forceinline__ float angle_between_angles(float2 a1, float2 a2) {
+    float3 v1 = polar_to_cartesian(f3(1.f, a1.x, a1.y));
+    float3 v2 = polar_to_cartesian(f3(1.f, a2.x, a2.y));
+    return acosf(clampf(dot3(v1, v2), -1.f, 1.f));
+}
+
+__device__ __forceinline__ render_data interpolate_render_data(render_data r1, render_data r2) {
+    float2 a1 = tex_to_angle(r1.tex_coord);
+    float2 a2 = tex_to_angle(r2.tex_coord);
+    float3 v1 = polar_to_cartesian(f3(1.f, a1.y, a1.x));
+    float3 v2 = polar_to_cartesian(f3(1.f, a2.y, a2.x));
+    float3 vc = (v1 + v2) / 2.f;
+    float3 fangle = cartesian_to_polar(vc);
+    render_data out;
+    out.tex_coord = angle_to_tex(fangle.y, fangle.z);
+    out.z_shift = (r1.z_shift + r2.z_shift) / 2.f;
+    out.terminated = r1.terminated;
+    out.sx = (r1.sx + r2.sx) / 2;
+    out.sy = (r1.sy + r2.sy) / 2;
+    out.side = (r1.side + r2.side) / 2;
+    return out;
+}
+
+// handle_adaptive_sampling on the fused path: the half-resolution records are already render_data (gr_trace_fused, lattice 2), so
+// the decision is taken on them - the sky angles come back out of the texture coordinates instead of out of 96-byte ray records -
+// and a block that needs its three other pixels marks them GR_PENDING in place for the second fused launch (pending_only) instead
+// of appending rays to a list: the second launch then walks the same 8x8 tiles, neighbouring rays stay in one wave, no atomics
+// order the work.  Same tests as the reference (cl.cl:5242-5282): boundary blocks always refine, differing termination flags
+// refine, otherwise the angular error across the block against the per-pixel angle times the threshold.
+extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, int* __restrict__ pending_count, int width, int height,
+                                              dfg_t dfg, int block_rows, int strip_rank, int strip_count) {
+    const int sx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int hw = width / 2, hh = height / 2;
+    if (sx >= hw || sy >= hh) return;
+    const int lsx = 2 * sx, lsy = 2 * sy;
+    // split frame: only the pixel blocks whose rows this device shades or reads as a halo row (their lattice neighbours were traced)
+    if (strip_count > 1 && !own_block_within(lsy, 0, height, block_rows, strip_rank, strip_count)) return;
+    auto at = [&](int x, int y) -> render_data& { return rdat[y * width + x]; };
+    bool refine = true;
+    if (sx != 0 && sx != hw - 1 && sy != 0 && sy != hh - 1) {
+        const render_data centre = at(lsx, lsy), left = at(lsx - 2, lsy), right = at(lsx + 2, lsy), up = at(lsx, lsy - 2), down = at(lsx, lsy + 2);
+        const int down_right_flag = at(lsx + 2, lsy + 2).terminated;
+        const float2 la = tex_to_angle(left.tex_coord), ra = tex_to_angle(right.tex_coord), ua = tex_to_angle(up.tex_coord), da = tex_to_angle(down.tex_coord);
+        // tex_to_angle gives (phi, theta); the reference compares (theta, phi) pairs
+        const float x_error = __builtin_fabsf(angle_between_angles(make_float2(la.y, la.x), make_float2(ra.y, ra.x)));
+        const float y_error = __builtin_fabsf(angle_between_angles(make_float2(da.y, da.x), make_float2(ua.y, ua.x)));
+        const float relative_angular_error = (float)((double)(((x_error + x_error + y_error + y_error) / 4.f) / 2) * GR_PI);
+        const float fov = GET_FEATURE(field_of_view, dfg);
+        const float per_pixel = (float)((double)(fov * 2) * GR_PI / (double)360.f) / width;
+        refine = relative_angular_error >= per_pixel * GET_FEATURE(adaptive_sampling_threshold, dfg);
+        const int ct = centre.terminated;
+        if (ct != left.terminated || ct != right.terminated || ct != up.terminated || ct != down.terminated || ct != down_right_flag) refine = true;
+    }
+    if (refine) {
+        at(lsx + 1, lsy).terminated = GR_PENDING;
+        at(lsx, lsy + 1).terminated = GR_PENDING;
+        at(lsx + 1, lsy + 1).terminated = GR_PENDING;
+        if (pending_count) atomicAdd(pending_count, 3);
+    } else {
+        const render_data c = at(lsx, lsy);
+        at(lsx + 1, lsy) = interpolate_render_data(c, at(lsx + 2, lsy));
+        at(lsx, lsy + 1) = interpolate_render_data(c, at(lsx, lsy + 2));
+        at(lsx + 1, lsy + 1) = interpolate_render_data(c, at(lsx + 2, lsy + 2));
+    }
+}
+
+extern "C" __global__ void gr_handle_adaptive_sampling(const lightray* __restrict__ rays_in, const int* __restrict__ rays_in_count,
+                                                       render_data* __restrict__ rdat, int* __restrict__ rdata_count,
+                                                       lightray* __restrict__ unprocessed_rays_out, int* __restrict__ unprocessed_rays_out_count,
+                                                       const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+                                                       const float4* __restrict__ e0, const float4* __restrict__ e1,
+                                                       const float4* __restrict__ e2, const float4* __restrict__ e3,
+                                                       int width, int height, cfg_t cfg, dfg_t dfg) {
+    int sx = blockIdx.x * blockDim.x + threadIdx.x;
+    int sy = blockIdx.y * blockDim.y + threadIdx.y;
+    int hw = width / 2, hh = height / 2;
+    if (sx >= hw || sy >= hh) return;
+
+    bool should_sample = true;
+    if (sx != 0 && sx != hw - 1 && sy != 0 && sy != hh - 1) {
+        const lightray* centre = &rays_in[sy * hw + sx];
+        const lightray* left = &rays_in[sy * hw + sx - 1];
+        const lightray* right = &rays_in[sy * hw + sx + 1];
+        const lightray* up = &rays_in[(sy - 1) * hw + sx];
+        const lightray* down = &rays_in[(sy + 1) * hw + sx];
+        const lightray* down_right = &rays_in[(sy + 1) * hw + sx + 1];
+
+        float4 lpos = intersection_position(left->position, left->velocity, left->initial_quat, cfg, dfg);
+        float4 rpos = intersection_position(right->position, right->velocity, right->initial_quat, cfg, dfg);
+        float4 upos = intersection_position(up->position, up->velocity, up->initial_quat, cfg, dfg);
+        float4 dpos = intersection_position(down->position, down->velocity, down->initial_quat, cfg, dfg);
+
+        float x_error = __builtin_fabsf(angle_between_angles(make_float2(lpos.z, lpos.w), make_float2(rpos.z, rpos.w)));
+        float y_error = __builtin_fabsf(angle_between_angles(make_float2(dpos.z, dpos.w), make_float2(upos.z, upos.w)));
+        // the reference's expression is ((xe.x+xe.y+ye.x+ye.y)/4.f)/2*M_PI with both lanes of each float2 equal (cl.cl:5272)
+        float relative_angular_error = (float)((double)(((x_error + x_error + y_error + y_error) / 4.f) / 2) * GR_PI);
+        float fov = GET_FEATURE(field_of_view, dfg);
+        float fov_angle_pi = (float)((double)(fov * 2) * GR_PI / (double)360.f);
+        float per_pixel = fov_angle_pi / width;
+        should_sample = relative_angular_error >= per_pixel * GET_FEATURE(adaptive_sampling_threshold, dfg);
+        int ct = centre->terminated;
+        if (ct != left->terminated || ct != right->terminated || ct != up->terminated || ct != down->terminated || ct != down_right->terminated)
+            should_sample = true;
+    }
+
+    if (should_sample) {
+        int base_sx = sx * 2, base_sy = sy * 2;
+        int px[3] = {base_sx + 1, base_sx, base_sx + 1};
+        int py[3] = {base_sy, base_sy + 1, base_sy + 1};
+        int root_id = atomicAdd(unprocessed_rays_out_count, 3);
+        for (int i = 0; i < 3; i++) {
+            unprocessed_rays_out[root_id + i] = make_pixel_ray(px[i], py[i], width, height, *g_generic_camera_in, *g_camera_quat,
+                                                               *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        }
+    } else {
+        int lsx = rays_in[sy * hw + sx].sx;
+        int lsy = rays_in[sy * hw + sx].sy;
+        render_data cdata = rdat[lsy * width + lsx];
+        render_data rdata_ = rdat[lsy * width + lsx + 2];
+        render_data ddata = rdat[(lsy + 2) * width + lsx];
+        render_data drdata = rdat[(lsy + 2) * width + lsx + 2];
+        rdat[lsy * width + lsx + 1] = interpolate_render_data(cdata, rdata_);
+        rdat[(lsy + 1) * width + lsx] = interpolate_render_data(cdata, ddata);
+        rdat[(lsy + 1) * width + lsx + 1] = interpolate_render_data(cdata, drdata);
+    }
+}
+

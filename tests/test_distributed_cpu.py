@@ -207,7 +207,7 @@ def test_single_rank_gather_is_identity():
 
 def test_strip_prepass_cell_rule_covers_every_cell_a_rank_reads():
     """gr_prepass_fused skips the prepass cell rows a device's pixel rows cannot look at (integer rule restated here from
-    geodesic_kernels.hip).  Brute force over image heights, block sizes and device counts: every cell row the 5-point stencil
+    kernels/trace.hip).  Brute force over image heights, block sizes and device counts: every cell row the 5-point stencil
     of an own pixel row (or halo row) reads must be kept; and the rule should actually save work."""
     import math
 

@@ -34,9 +34,12 @@ for name in golden_names():
 ''' % (ROOT, ROOT)
 
 if sys.argv[1] == "build":
-    for name in VARIANTS:
+    procs = []
+    for name in VARIANTS:   # one process per variant, side by side
         os.makedirs(env_of(name)["GR_CACHE_DIR"], exist_ok=True)
-        subprocess.check_call([sys.executable, "-c", BUILD], env=env_of(name))
+        procs.append((name, subprocess.Popen([sys.executable, "-c", BUILD], env=env_of(name))))
+    for name, proc in procs:
+        assert proc.wait() == 0, name
         print("built", name, flush=True)
 else:
     print("# ordinary rays (fewer than twice the median attempts, terminated on both sides) whose final position differs from the reference's by > 1e-3,")
