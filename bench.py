@@ -69,6 +69,7 @@ def parse():
                     "them under `secondary`)")
     ap.add_argument("--camera", default="", help="camera position t,x,y,z (default 0,0,-4,0)")
     ap.add_argument("--redshift", type=int, default=0)
+    ap.add_argument("--use-prepass", type=int, default=-1, help="gr_frame_options.use_prepass of the timed frames: -1 per metric + policy, 0 / 1 forced")
     ap.add_argument("--mode", default="fused", choices=["fused", "reference"])
     ap.add_argument("--program", default="static", choices=["static", "dynamic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -298,6 +299,7 @@ def main():
                 opts.count_attempts = 1
             opts.trace_waves_per_simd = waves_per_launch
             opts.fused_shading = args.fused_shading
+            opts.use_prepass = args.use_prepass
             if lookahead is not None:
                 opts.next_camera = lookahead
                 if depth == 2:
@@ -380,7 +382,8 @@ def main():
                                          time_kernels=1, count_attempts=1)
                 target = ring[0].gather.local_buffer().data_ptr()
             else:
-                opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=1, count_attempts=1)
+                opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=1, count_attempts=1,
+                                         use_prepass=args.use_prepass)
                 target = out.data_ptr()
             if wl is None:
                 state.render(prog, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfgv, opts, stream)

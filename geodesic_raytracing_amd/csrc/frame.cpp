@@ -100,12 +100,14 @@ struct gr_render_state {
     // Prepass policy (use_prepass = -1, whole frames on the fused path).  The prepass pays for itself through the pixels it lets the
     // trace skip; where it skips next to nothing (Kerr with a = 0.9 in the script's units: a naked singularity, no shadow - 8.4 ms of
     // single-ray latency in front of every 4K frame, for nothing) it is left out: its flags are copied to the host after a frame
-    // that ran it, read a frame or two later without waiting, and when fewer than PREPASS_MIN_SKIP of the cells were marked the next
-    // PREPASS_HOLIDAY frames go without one; then it is tried again.  Pixels do not depend on it (a skipped pixel is one whose ray
+    // that ran it, read a frame or two later without waiting, and when fewer than PREPASS_MIN_SKIP of the cells have their whole
+    // 5-point stencil marked (the share of the pixels the trace may skip) the next PREPASS_HOLIDAY frames go without one; then it
+    // is tried again.  Pixels do not depend on it (a skipped pixel is one whose ray
     // would have ended in the shadow anyway; tests/test_gpu_fullsize.py holds frames with and without it equal).
     struct prepass_policy {
         int* host_flags = nullptr;   // pinned
         size_t capacity = 0, cells = 0;
+        int grid_width = 0;
         hipEvent_t copied = nullptr;
         bool in_flight = false;
         int holiday = 0;
@@ -609,9 +611,16 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             s->policy_program = serial;
         }
         if (pol.in_flight && hipEventQuery(pol.copied) == hipSuccess) {
-            size_t marked = 0;
-            for (size_t i = 0; i < pol.cells; i++) marked += pol.host_flags[i] == 1;
-            pol.last_fraction = pol.cells ? (float)marked / (float)pol.cells : 0.f;
+            // the share of the grid whose 5-point stencil is marked throughout: what init_rays_generic's test lets the trace skip
+            // (a pixel is skipped when the cell it rounds to and that cell's four neighbours are all marked, cl.cl:3213-3232)
+            size_t skippable = 0;
+            const int pw = pol.grid_width, ph = pol.cells && pw ? (int)(pol.cells / pw) : 0;
+            for (int y = 1; y + 1 < ph; y++)
+                for (int x = 1; x + 1 < pw; x++) {
+                    const int* c = pol.host_flags + (size_t)y * pw + x;
+                    skippable += c[0] == 1 && c[-1] == 1 && c[1] == 1 && c[-pw] == 1 && c[pw] == 1;
+                }
+            pol.last_fraction = pol.cells ? (float)skippable / (float)pol.cells : 0.f;
             pol.in_flight = false;
             if (pol.last_fraction < gr_render_state::PREPASS_MIN_SKIP) pol.holiday = gr_render_state::PREPASS_HOLIDAY;
         } else if (pol.in_flight) {
@@ -817,6 +826,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             HIP_CHECK(hipMemcpyAsync(pol.host_flags, s->termination_buffer, cells * sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipEventRecord(pol.copied, stream));
             pol.cells = cells;
+            pol.grid_width = prepass_width;
             pol.in_flight = true;
             return GR_OK;
         };

@@ -429,8 +429,8 @@ typedef struct gr_frame_options {
     int mode;              /* GR_MODE_* */
     int tiled;             /* reference mode only: 8x8-tile ray order (ignored when adaptive sampling is on) */
     int use_prepass;       /* -1: per metric config (metric_cfg.use_prepass) and - whole frames on the fused path - only while it pays:
-                            * when a frame's prepass marked fewer than 2 % of its cells, the next 30 frames of this render state go
-                            * without one, then it is tried again (pixels do not depend on it; gr_render_state_prepass_policy
+                            * when a frame's prepass lets the trace skip fewer than 2 % of the pixels (cells with their whole 5-point
+                            * stencil marked), the next 30 frames of this render state go without one, then it is tried again (pixels do not depend on it; gr_render_state_prepass_policy
                             * reports).  0 / 1 force it off / on for this frame. */
     int max_probes;        /* anisotropy, graphics_settings.hpp:34 (8) */
     int strip_rank;        /* fused mode, multi-GPU: image rows are dealt in blocks of block_rows rows,          */
@@ -504,7 +504,7 @@ enum { GR_GEOBUF_PATH = 0, GR_GEOBUF_VELOCITY = 1, GR_GEOBUF_DS = 2, GR_GEOBUF_C
 void* gr_geodesic_camera_buffer(gr_geodesic_camera* g, int which);
 
 /* what the prepass policy (gr_frame_options.use_prepass = -1) has done with this state's frames so far, and the fraction of
- * prepass cells the last inspected prepass marked (-1: none inspected yet); any output may be NULL */
+ * the prepass grid the last inspected prepass made skippable (-1: none inspected yet); any output may be NULL */
 int gr_render_state_prepass_policy(gr_render_state* s, unsigned long long* frames_with_prepass, unsigned long long* frames_without,
                                    float* last_marked_fraction);
 
