@@ -97,13 +97,14 @@ struct gr_render_state {
     };
     static const int LOOKAHEAD = 2;
     prefetch_slot pre[LOOKAHEAD];
-    // Prepass policy (use_prepass = -1, whole frames on the fused path).  The prepass pays for itself through the pixels it lets the
+    // Prepass policy (use_prepass = -2, whole frames on the fused path; opt-in: see the last sentence).  The prepass pays for itself through the pixels it lets the
     // trace skip; where it skips next to nothing (Kerr with a = 0.9 in the script's units: a naked singularity, no shadow - 8.4 ms of
     // single-ray latency in front of every 4K frame, for nothing) it is left out: its flags are copied to the host after a frame
     // that ran it, read a frame or two later without waiting, and when fewer than PREPASS_MIN_SKIP of the cells have their whole
     // 5-point stencil marked (the share of the pixels the trace may skip) the next PREPASS_HOLIDAY frames go without one; then it
-    // is tried again.  Pixels do not depend on it (a skipped pixel is one whose ray
-    // would have ended in the shadow anyway; tests/test_gpu_fullsize.py holds frames with and without it equal).
+    // is tried again.  Not the default, because it is not quite neutral: a pixel the prepass skips is black by decree (its five cells'
+    // rays were lost), and traced on its own its ray may still find a way out in a chaotic region - measured on the a = 0.9 frame:
+    // the pixels that differ are among the < 2 % the prepass would have skipped (tests/test_gpu_schedule.py).
     struct prepass_policy {
         int* host_flags = nullptr;   // pinned
         size_t capacity = 0, cells = 0;
@@ -600,7 +601,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     if ((int)cfg.size() > CFG_MAX) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "too many dynamic variables");
     const bool cfg_changed = cfg != s->host_cfg;
     const bool features_changed = !s->features_valid || memcmp(&features, &s->host_features, sizeof(features)) != 0;
-    const bool prepass_by_policy = opt.use_prepass < 0 && use_prepass && opt.mode == GR_MODE_FUSED && opt.strip_count <= 1;
+    const bool prepass_by_policy = opt.use_prepass == -2 && use_prepass && opt.mode == GR_MODE_FUSED && opt.strip_count <= 1;
     if (prepass_by_policy) {
         auto& pol = s->policy;
         const unsigned long long serial = gr_program_serial(p);

@@ -428,10 +428,12 @@ typedef struct gr_geodesic_camera gr_geodesic_camera;
 typedef struct gr_frame_options {
     int mode;              /* GR_MODE_* */
     int tiled;             /* reference mode only: 8x8-tile ray order (ignored when adaptive sampling is on) */
-    int use_prepass;       /* -1: per metric config (metric_cfg.use_prepass) and - whole frames on the fused path - only while it pays:
-                            * when a frame's prepass lets the trace skip fewer than 2 % of the pixels (cells with their whole 5-point
-                            * stencil marked), the next 30 frames of this render state go without one, then it is tried again (pixels do not depend on it; gr_render_state_prepass_policy
-                            * reports).  0 / 1 force it off / on for this frame. */
+    int use_prepass;       /* -1: per metric config (metric_cfg.use_prepass), 0 / 1 force it off / on for this frame;
+                            * -2: per metric config and - whole frames on the fused path - only while it pays: when a frame's prepass
+                            * lets the trace skip fewer than 2 % of the pixels (cells with their whole 5-point stencil marked), the
+                            * next 30 frames of this render state go without one, then it is tried again
+                            * (gr_render_state_prepass_policy reports).  A pixel the prepass would have skipped is then traced on its
+                            * own, which in chaotic regions (naked singularities) need not come out black as the reference's does. */
     int max_probes;        /* anisotropy, graphics_settings.hpp:34 (8) */
     int strip_rank;        /* fused mode, multi-GPU: image rows are dealt in blocks of block_rows rows,          */
     int strip_count;       /*   global block b belongs to device b % strip_count (1 = whole image on this device) */
@@ -503,7 +505,7 @@ enum { GR_GEOBUF_PATH = 0, GR_GEOBUF_VELOCITY = 1, GR_GEOBUF_DS = 2, GR_GEOBUF_C
        GR_GEOBUF_TRANSPORTED1 = 5, GR_GEOBUF_TRANSPORTED2 = 6, GR_GEOBUF_TRANSPORTED3 = 7 };
 void* gr_geodesic_camera_buffer(gr_geodesic_camera* g, int which);
 
-/* what the prepass policy (gr_frame_options.use_prepass = -1) has done with this state's frames so far, and the fraction of
+/* what the prepass policy (gr_frame_options.use_prepass = -2) has done with this state's frames so far, and the fraction of
  * the prepass grid the last inspected prepass made skippable (-1: none inspected yet); any output may be NULL */
 int gr_render_state_prepass_policy(gr_render_state* s, unsigned long long* frames_with_prepass, unsigned long long* frames_without,
                                    float* last_marked_fraction);
