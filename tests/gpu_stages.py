@@ -167,12 +167,17 @@ def position_err(a, b):
     return np.abs(a - b) / scale
 
 
-def assert_traced_positions(name, got, want, ordinary, chaotic=False, slack=0.015):
+def assert_traced_positions(name, got, want, ordinary, chaotic=False, slack=0.01):
     """the position rule of the trace stage: ordinary rays that terminated on both sides agree to 1e-3
     (position_err) - all but `slack` of them: "fewer than twice the median attempts" does not exclude every ray that passes
-    close to a photon orbit, and those amplify last-place differences past 1e-3.  Measured: the CPU restatement against the
-    reference <= 1 ray per 48x27 fixture; the GPU kernels (approximate v_rcp/v_sqrt, other contraction) <= 6 of 515 (Kerr with
-    reparameterisation, the worst case), 0-3 elsewhere.  The bulk of all terminated rays is held to the same bound."""
+    close to a photon orbit, and those amplify last-place differences past 1e-3.  Measured on MI355X (round 3,
+    profiles/r03_trace_slack_owner.txt): 0 such rays in 21 of the 23 non-chaotic fixtures, 1 of 531 in ingoing_ef, 4 of 515 in
+    kerr_reparameterised (the per-step rescaling of the velocity amplifies differences) - 5 of 22 175 in all, against 1 per
+    fixture for the CPU restatement.  No approximation owns them: rebuilt with IEEE divide / sqrt, without contraction, without
+    reassociation, with libm trigonometry, with all of these, the total moves between 109 and 125 of 23 412 (114 of them in the
+    chaotic naked-singularity fixture every time) - they are rays on which ANY two fp32 evaluation orders part ways.  So the slack
+    is 1 % (5 rays of 515), down from 1.5 %, rather than the 0.2 % of the CPU restatement, which shares the reference's operation
+    order.  The bulk of all terminated rays is held to the same bound."""
     both = (got["terminated"] == 1) & (want["terminated"] == 1)
     err = position_err(got["position"], want["position"]).max(axis=1)
     if chaotic:   # naked singularity: even rays with ordinary step counts are scattered chaotically

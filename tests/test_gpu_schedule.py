@@ -300,8 +300,11 @@ def test_program_manager_swaps_and_falls_back():
     assert first.build_key == dynamic_key or manager.is_substituted
     substituted = manager.current(wait=True)
     assert manager.is_substituted and substituted.build_key != dynamic_key
-    d = frame(manager.dynamic, a45) - frame(substituted, a45)
-    assert np.sqrt((d[..., :3] ** 2).mean()) < 2e-4
+    def same_picture(x, y):   # two programs of one metric: pixels agree to rounding but for the few strongly lensed ones
+        d = np.abs(x[..., :3] - y[..., :3]).max(axis=2)
+        off = d > 1e-3
+        return off.mean() <= 0.01 and np.sqrt((d[~off] ** 2).mean()) < 1e-4
+    assert same_picture(frame(manager.dynamic, a45), frame(substituted, a45))
     manager.update(feats, a45)                     # nothing changed
     again = manager.current()
     assert manager.is_substituted and again.handle.value == substituted.handle.value
@@ -311,7 +314,6 @@ def test_program_manager_swaps_and_falls_back():
         assert fallback.handle.value == manager.dynamic.handle.value
     other = manager.current(wait=True)
     assert manager.is_substituted and other.build_key not in (dynamic_key, substituted.build_key)
-    d = frame(manager.dynamic, a30) - frame(other, a30)
-    assert np.sqrt((d[..., :3] ** 2).mean()) < 2e-4
+    assert same_picture(frame(manager.dynamic, a30), frame(other, a30))
     frame(substituted, a45)                        # a retired program stays usable (frames launched with it may be in flight)
     manager.close()
