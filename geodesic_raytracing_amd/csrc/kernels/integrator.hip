@@ -172,7 +172,7 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
 #ifdef IS_CONSTANT_THETA
         polar.z = GR_PIf / 2;
 #endif
-        const float ar = __builtin_fabsf(gm::distance_to_object(polar, cfg));
+        const float ar = __builtin_fabsf(gm::distance_to_object_from(position, polar, cfg));
         const bool inside = ar < new_max;
 #ifdef ADAPTIVE_PRECISION
         const float near_ds = min_f32_uniform(ambient_precision, next_ds);
@@ -296,7 +296,7 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         // What the loop carries is put back to what it was before the abandoned attempt.
         const float ds_used = exit_ds;
         float4 polar = gm::generic_to_spherical(position, cfg);
-        if (__builtin_fabsf(gm::distance_to_object(polar, cfg)) < new_max) next_ds = ds_used;   // min(next_ds, ambient) gives ds_used again
+        if (__builtin_fabsf(gm::distance_to_object_from(position, polar, cfg)) < new_max) next_ds = ds_used;   // min(next_ds, ambient) gives ds_used again
         running = exit_running;
         budget++;
         const trig_flavour<true> precise;

@@ -66,7 +66,17 @@ __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ float fabs(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ float sinh(float x) { return ::sinhf(x); }
 __device__ __forceinline__ float cosh(float x) { return ::coshf(x); }
-__device__ __forceinline__ float tanh(float x) { return ::tanhf(x); }
+// tanh x = 1 - 2 / (e^{2x} + 1) on the hardware's exp2 and reciprocal: 5 instructions where the library routine (range split,
+// polynomial, selects) compiles to ~40 - the Alcubierre acceleration calls it twice per attempt, a quarter of its loop.  Absolute
+// error <= 1.2e-7 everywhere (the subtraction from 1 costs relative accuracy near 0, where the warp-drive shape function only
+// uses differences of tanh of O(1) arguments); saturates to +-1, NaN stays NaN.  -DGR_LIBM_TANH: the library routine.
+__device__ __forceinline__ float tanh(float x) {
+#ifdef GR_LIBM_TANH
+    return ::tanhf(x);
+#else
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.88539008177792681472f) + 1.f);
+#endif
+}
 __device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
 __device__ __forceinline__ float fmod(float x, float y) { return ::fmodf(x, y); }
 __device__ __forceinline__ float fmin(float x, float y) { return __builtin_fminf(x, y); }
@@ -226,6 +236,20 @@ __device__ __forceinline__ float4 spherical_velocity_to_generic_velocity(float4 
 __device__ __forceinline__ float distance_to_object(float4 polar, cfg_t cfg) {
     GR_POSITION_VARS(polar)
     return DISTANCE_FUNC;
+}
+// The same distance straight from the metric's own coordinates.  The host composes DISTANCE_FUNC with TO_COORDn symbolically and
+// emits GR_DISTANCE_OF_GENERIC when the coordinate round trip cancels completely (csrc/sym.cpp cancel_round_trip: Alcubierre's
+// origin function takes polar coordinates back to Cartesian ones - two atan2, two sin / cos pairs per Verlet attempt, for a
+// distance that is one square root of the position).  A macro string without it (the reference generator's) takes the long way.
+__device__ __forceinline__ float distance_to_object_from(float4 position, float4 polar, cfg_t cfg) {
+#ifdef GR_DISTANCE_OF_GENERIC
+    GR_POSITION_VARS(position)
+    (void)polar;
+    return GR_DISTANCE_OF_GENERIC;
+#else
+    (void)position;
+    return distance_to_object(polar, cfg);
+#endif
 }
 
 #ifdef GR_TWO_RAYS_PER_LANE

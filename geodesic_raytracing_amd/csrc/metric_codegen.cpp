@@ -474,6 +474,15 @@ std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl
     if (cfg.unconditionally_nonsingular) s += "-DUNCONDITIONALLY_NONSINGULAR ";
 
     s += "-DDISTANCE_FUNC=" + to_c(impl.distance_function) + " ";
+    {
+        // DISTANCE_FUNC(TO_COORD(x)) as one expression of the metric's own coordinates - where the trip to polar coordinates and back
+        // cancels completely (no division, no angle left: the rewrite is not an identity where a hypotenuse vanishes).  An extension
+        // of the macro set: the reference's cl.cl ignores it, the fused integrator uses it when it is there.
+        std::map<std::string, E> polar;
+        for (int i = 0; i < 4; i++) polar["v" + std::to_string(i + 1)] = impl.to_polar[i];
+        const E composed = sym::cancel_round_trip(sym::subst(impl.distance_function, polar));
+        if (!sym::contains_division_or_angle(composed)) s += "-DGR_DISTANCE_OF_GENERIC=" + to_c(composed) + " ";
+    }
 
     if (!vars.names.empty()) {
         std::string v;

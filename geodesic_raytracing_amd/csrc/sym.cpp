@@ -531,6 +531,74 @@ E share_reciprocals(E e, std::unordered_map<E, E>& memo) {
     return r;
 }
 
+// ---- coordinates there and back again ------------------------------------------------------------------------------------------
+// Rewrites, bottom-up, the patterns that `from_polar(to_polar(x))` leaves behind: sin / cos of an atan2 become ratios over the
+// hypotenuse, sqrt(A) * sqrt(A) is A, x * (y / x) is y, x / x is 1.  NOT an identity at the points where a hypotenuse vanishes
+// (atan2(0, 0) is 0 by convention, the ratio 0 / 0 is not a number): a caller keeps the result only when every division has
+// cancelled (contains_division).
+namespace {
+E cancel_round_trip_rec(E e, std::unordered_map<E, E>& memo) {
+    if (e->op == CONST || e->op == VAR) return e;
+    auto it = memo.find(e);
+    if (it != memo.end()) return it->second;
+    auto R = [&](E x) { return cancel_round_trip_rec(x, memo); };
+    auto product = [&](E a, E b) -> E {
+        if (a == b && a->op == FN1 && a->fn == F_SQRT) return a->a;                       // sqrt(A) sqrt(A)
+        if (b->op == DIV && b->b == a) return b->a;                                        // a (y / a)
+        if (a->op == DIV && a->b == b) return a->a;                                        // (y / b) b
+        return mul(a, b);
+    };
+    E r = nullptr;
+    switch (e->op) {
+        case ADD: r = add(R(e->a), R(e->b)); break;
+        case SUB: r = sub(R(e->a), R(e->b)); break;
+        case MUL: r = product(R(e->a), R(e->b)); break;
+        case DIV: {
+            E n = R(e->a), d = R(e->b);
+            r = n == d ? constant(1.0) : div(n, d);
+            break;
+        }
+        case NEG: r = neg(R(e->a)); break;
+        case FN1: {
+            E a = R(e->a);
+            if ((e->fn == F_SIN || e->fn == F_COS) && a->op == FN2 && a->fn == F_ATAN2) {
+                E y = a->a, x = a->b;
+                E hyp = fn1(F_SQRT, add(product(y, y), product(x, x)));
+                r = div(e->fn == F_SIN ? y : x, hyp);
+            } else {
+                r = fn1(e->fn, a);
+            }
+            break;
+        }
+        case FN2: r = fn2(e->fn, R(e->a), R(e->b)); break;
+        case SELECT: r = select(R(e->a), R(e->b), R(e->s)); break;
+        default: throw std::runtime_error("cancel_round_trip: bad op");
+    }
+    memo.emplace(e, r);
+    return r;
+}
+bool contains_rec(E e, std::unordered_map<E, bool>& memo, bool (*pred)(E)) {
+    if (pred(e)) return true;
+    if (e->op == CONST || e->op == VAR) return false;
+    auto it = memo.find(e);
+    if (it != memo.end()) return it->second;
+    bool r = (e->a && contains_rec(e->a, memo, pred)) || (e->b && contains_rec(e->b, memo, pred)) || (e->s && contains_rec(e->s, memo, pred));
+    memo.emplace(e, r);
+    return r;
+}
+}  // namespace
+
+E cancel_round_trip(E e) {
+    std::unordered_map<E, E> memo;
+    return cancel_round_trip_rec(e, memo);
+}
+
+bool contains_division_or_angle(E e) {
+    std::unordered_map<E, bool> memo;
+    return contains_rec(e, memo, [](E x) { return x->op == DIV || (x->op == FN2 && x->fn == F_ATAN2) || (x->op == FN1 && (x->fn == F_SIN || x->fn == F_COS || x->fn == F_TAN ||
+                                                                       x->fn == F_ASIN || x->fn == F_ACOS || x->fn == F_ATAN)); });
+}
+
 E subst(E e, const std::map<std::string, E>& m) {
     std::unordered_map<E, E> memo;
     return subst_rec(e, m, memo);

@@ -80,6 +80,12 @@ E diff(E e, const std::string& wrt);
 E subst(E e, const std::map<std::string, E>& m);
 double eval(E e, const std::map<std::string, double>& env);
 
+// The patterns a coordinate round trip from_polar(to_polar(x)) leaves behind, rewritten away: sin / cos of an atan2 as ratios over
+// the hypotenuse, sqrt(A) sqrt(A) = A, x (y / x) = y, x / x = 1.  Not an identity where a hypotenuse vanishes; keep the result
+// only if nothing of the kind is left in it (contains_division_or_angle).
+E cancel_round_trip(E e);
+bool contains_division_or_angle(E e);
+
 // n / (x*x) -> n * ((1/x) * (1/x)): the reciprocal of x is (almost always) needed anyway, and on gfx950 v_rcp_f32
 // issues at a quarter of the v_mul_f32 rate.  `memo` carries the rewritten nodes across calls so that several roots
 // keep sharing sub-expressions.
