@@ -276,7 +276,7 @@ def main():
     lookahead = ctypes.pointer(camera) if (fused and not args.no_lookahead) else None
     depth = 0 if lookahead is None else (args.lookahead_depth if args.lookahead_depth in (1, 2) else (2 if world > 1 else 1))
 
-    def frame(prog=None, cfgv=None):
+    def frame(prog=None, cfgv=None, transfer=True):
         prog = program if prog is None else prog
         cfgv = cfg_values if cfgv is None else cfgv
         slot = ring[frame_index[0] % in_flight]
@@ -304,7 +304,7 @@ def main():
                 opts.next_camera = lookahead
                 if depth == 2:
                     opts.next_camera2 = lookahead
-            if tiled is not None:
+            if tiled is not None and transfer:
                 k = frame_index[0] - 1
                 opts.next_strip_rank = tiled.share(k + in_flight)
                 opts.next_strip_rank2 = tiled.share(k + 2 * in_flight)
@@ -313,7 +313,7 @@ def main():
                 return
             slot.state.render(prog, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfgv, opts,
                               slot.stream.cuda_stream)
-            if multi:
+            if multi and transfer:
                 slot.gather.submit(slot.out, rotation=frame_index[0] - 1)   # asynchronous: overlaps the following frames
 
     def barrier():
@@ -355,6 +355,24 @@ def main():
     launches = sum(n for _, n in logged)
     avg_launch_s = sum(ms for ms, _ in logged) / max(launches, 1) * 1e-3
 
+    without_transfer_s = None
+    if multi:
+        # the same frames with every rank rendering its (rotating) share and nothing sent - what the exchange costs on
+        # the critical path is the difference
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            frame(transfer=False)
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t1
+        t = torch.tensor([mine], dtype=torch.float64, device=device)
+        everyone = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(everyone, t)
+        per_rank_without = [float(x.item()) / args.steps * 1e3 for x in everyone]
+        without_transfer_s = max(per_rank_without) * 1e-3
+        for slot in ring:
+            slot.state.trace_log(reset=True)
+
     # roofline of the dominant kernel.  Launches of frames in flight overlap on the GPU, so their durations say nothing about one
     # launch's cost; the per-launch duration the roofline divides by comes from launches run one at a time right after the timed
     # region (same program, same frame; HIP events on the launch's own stream) and is reported next to the overlapped average.
@@ -362,6 +380,11 @@ def main():
     local_pixels = W * H if world == 1 else sum(b - a for a, b in plan.blocks_of(rank)) * W + plan.local_blocks(rank) * W
     headline_alg_bytes = (TRACE_BYTES_PER_RAY if fused else 140) * local_pixels
     extra["fps"] = round(1e3 / ms_per_step, 2)
+    if without_transfer_s:
+        extra["fps_without_transfer"] = round(1.0 / without_transfer_s, 2)
+        extra["per_rank_ms_per_frame_without_transfer"] = [round(x, 4) for x in per_rank_without]
+        # how long a frame waits for rows to arrive, beyond the slowest rank's rendering: the exchange on the critical path
+        extra["gather_wait_ms_per_frame"] = round(ms_per_step - without_transfer_s * 1e3, 4)
     if overlapped_clock:
         extra["shader_clock_mhz_last_overlapped_launches"] = overlapped_clock
 
@@ -563,7 +586,7 @@ def main():
                                    f"prepass {'on' if metric.info.use_prepass else 'off'}, tol {metric.info.max_acceleration_change:g}, "
                                    f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
                        "mode": args.mode, "prepass_lookahead": bool(fused and not args.no_lookahead), "prepass_lookahead_depth": depth,
-                       "frames_in_flight": in_flight, "trace_waves_per_simd": waves_per_launch, "priming_frames": priming, "build_key": program.build_key, "counters_tag": tag, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
+                       "frames_in_flight": in_flight, "trace_waves_per_simd": waves_per_launch, "prepass": "look-ahead on side streams" if (fused and not args.no_lookahead) else "inside the trace launch (gr_frame_options.inline_prepass)" if fused else "own launches", "priming_frames": priming, "build_key": program.build_key, "counters_tag": tag, "program": "substituted (parameters baked in, metric_manager.hpp:153-166)" if args.program == "static" else "dynamic",
                        "parallelism": f"{plan.block_rows}-row blocks, block-cyclic over {world} GPUs (assignment rotating per frame); {gather_path}" if multi else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
