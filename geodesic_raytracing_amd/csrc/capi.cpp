@@ -1002,6 +1002,14 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
         groups = std::min(groups, resident_groups);
     }
+    // tiles per ticket: one, unless a wave would draw more than 32 tickets (then as many as keep it at 32, at most 8)
+    int ticket_tiles = 1;
+    if (tickets) {
+        const long long launched_waves = groups * (wg / 64);
+        const long long per_wave = (waves + prepass_tickets + launched_waves - 1) / launched_waves;
+        ticket_tiles = (int)std::min<long long>(8, std::max<long long>(1, (per_wave + 31) / 32));
+        if (const char* e = getenv("GR_TICKET_TILES")) { const int v = atoi(e); if (v >= 1 && v <= 64) ticket_tiles = v; }
+    }
     if (prepass_tickets)   // every cell unknown (GR_CELL_UNKNOWN = -1) until its ray has been traced
         HIP_CHECK(hipMemsetAsync(const_cast<void*>(term), 0xff, (size_t)prepass_width * prepass_height * sizeof(int), (hipStream_t)stream));
     // the kernel's trace_shading, by value (same layout)
@@ -1017,7 +1025,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     }
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
-                    &lattice, &pending_only, &tile_order, &shading, &prepass_tickets};   // the last five: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
+                    &lattice, &pending_only, &tile_order, &shading, &prepass_tickets, &ticket_tiles};   // the last six: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
     return launch(p, kernel_index, stream, (unsigned)groups, 1, wg, 1, args);
 }
 

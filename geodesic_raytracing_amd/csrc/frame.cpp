@@ -45,7 +45,7 @@ struct gr_render_state {
     void* render_data_count = nullptr;
     void* cfg = nullptr;            // struct dynamic_config (floats in declaration order)
     void* dfg = nullptr;            // struct dynamic_feature_config
-    void* attempts = nullptr;       // uint64[128]: attempts, shader cycles, 100 MHz ticks, waves (the last three: fused trace only); the rest: probe builds
+    void* attempts = nullptr;       // uint64[GR_COUNTER_WORDS]: attempts, shader cycles, 100 MHz ticks, waves (the last three: fused trace only); [8..255] probe builds; [256..511] the fused trace's attempts, spread
     // per-pixel buffers (render_state.hpp:172-196); ray records are allocated on first use
     void* rays_in = nullptr;
     void* rays_adaptive = nullptr;
@@ -284,7 +284,7 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
     A(&s->render_data_count, 4);
     A(&s->cfg, CFG_MAX * sizeof(float));
     A(&s->dfg, sizeof(gr_features));
-    A(&s->attempts, 2048);
+    A(&s->attempts, GR_COUNTER_WORDS * 8);
     size_t px = (size_t)width * height;
     A(&s->render_data, px * sizeof(gr_render_data));
     A(&s->termination_buffer, px * sizeof(int));
@@ -427,7 +427,11 @@ int gr_render_state_counters(gr_render_state* s, unsigned long long* words, int 
 int gr_render_state_attempts(gr_render_state* s, unsigned long long* attempts) {
     if (!s || !attempts) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
     HIP_CHECK(hipSetDevice(s->device));
-    HIP_CHECK(hipMemcpy(attempts, s->attempts, 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> words(GR_COUNTER_WORDS);
+    HIP_CHECK(hipMemcpy(words.data(), s->attempts, words.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long sum = words[0];   // the reference-shaped, pair and compaction kernels count here
+    for (int i = 256; i < GR_COUNTER_WORDS; i++) sum += words[i];   // gr_trace_fused: spread over 256 words (kernels/program.hip)
+    *attempts = sum;
     return GR_OK;
 }
 
@@ -705,7 +709,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     };
     void* attempts = nullptr;
     if (opt.count_attempts) {
-        HIP_CHECK(hipMemsetAsync(s->attempts, 0, 2048, stream));
+        HIP_CHECK(hipMemsetAsync(s->attempts, 0, GR_COUNTER_WORDS * 8, stream));
         attempts = s->attempts;
     }
 

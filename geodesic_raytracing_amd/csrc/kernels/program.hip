@@ -115,6 +115,10 @@ struct dynamic_feature_config {
 #define GR_TILE_CLASS_STEPS 1     // cost classes of gr_order_tiles per octave of attempts (finer ones measured no better)
 #endif
 #define GR_SKIP_CHUNK 32          // tiles of the last class per ticket
+// the frame's counter block (uint64 words): [0] attempts, [1] shader cycles, [2] 100 MHz ticks, [3] waves, [8..255] probe builds,
+// [256..511] the fused trace's attempts, spread over as many words as keep same-address atomics apart
+#define GR_ATTEMPT_COUNTERS_AT 256
+#define GR_ATTEMPT_COUNTERS 256
 
 // minimum resident waves per SIMD the integrator kernels are register-allocated for (512 VGPRs / N waves each).
 // 1 = no cap: the allocator takes what the metric's expressions need and occupancy follows (substituted Kerr: 92 VGPRs

@@ -382,7 +382,10 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     }
 #endif
     GR_PROBE_WAVE_SLOTS(tries, 64u)
-    if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);
+    // One add per tile-wave after the compiler's wave reduction - into one of GR_ATTEMPT_COUNTERS words chosen by the workgroup,
+    // not into one word: a same-address atomic per tile is a second ticket counter (an 8K Alcubierre frame, 518 400 short tiles,
+    // measured 6.5 ms counted into one word and 3.7 ms uncounted).  The host adds the words up (gr_render_state_attempts).
+    if (attempt_counter) atomicAdd(attempt_counter + GR_ATTEMPT_COUNTERS_AT + (blockIdx.x % GR_ATTEMPT_COUNTERS), (unsigned long long)tries);
 }
 
 // workgroup size of the fused trace kernel: 4 tile-waves, one per SIMD of a CU (capi.cpp launches with the same number)
@@ -400,7 +403,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
                int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
-               int prepass_tickets) {
+               int prepass_tickets, int ticket_tiles) {
     // prepass_tickets > 0 (persistent launches in image order only): the first prepass_tickets tickets are the waves of the
     // low-resolution prepass, then come the tiles, which wait for the cells they look at (trace_tile).  A frame whose camera was not
     // known in advance then pays the prepass's single-ray latency once per cell wave alongside the first tiles instead of as a
@@ -427,11 +430,17 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
             if (held == 0) {
                 unsigned int ticket = 0;
                 if (lane == 0) ticket = atomicAdd(tile_counter, 1u);
-                cursor = (int)__builtin_amdgcn_readfirstlane(ticket);
-                held = 1;
-                known_skipped = tile_order && cursor >= singles;
-                if (cursor >= singles) {
-                    cursor = singles + (cursor - singles) * GR_SKIP_CHUNK;
+                const int drawn = (int)__builtin_amdgcn_readfirstlane(ticket);
+                // a ticket is ticket_tiles consecutive entries of the tiles that trace (1 unless the launch has far more tiles than
+                // waves: the one counter serves ~10^8 tickets a second, and the 518 400 short tiles of an 8K Alcubierre frame
+                // were waiting for it more than they traced), then GR_SKIP_CHUNK entries of the last class
+                const int single_tickets = (singles + ticket_tiles - 1) / ticket_tiles;
+                known_skipped = tile_order && drawn >= single_tickets;
+                if (drawn < single_tickets) {
+                    cursor = drawn * ticket_tiles;
+                    held = singles - cursor < ticket_tiles ? singles - cursor : ticket_tiles;
+                } else {
+                    cursor = singles + (drawn - single_tickets) * GR_SKIP_CHUNK;
                     held = tickets_total - cursor < GR_SKIP_CHUNK ? tickets_total - cursor : GR_SKIP_CHUNK;
                 }
                 if (held <= 0) break;

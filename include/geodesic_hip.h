@@ -299,6 +299,13 @@ long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_r
 int gr_order_tiles(gr_program* p, void* stream, const void* termination_buffer, const void* cell_attempts, int prepass_width,
                    int prepass_height, int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order);
 
+/* Counter block of the fused trace launchers (their `attempt_counter`; NULL = count nothing): GR_COUNTER_WORDS uint64 words on
+ * the device, zeroed by the caller.  [0] attempts of the pair / compaction kernels, [1] summed wave lifetimes in shader cycles,
+ * [2] the same in ticks of the 100 MHz reference clock, [3] waves, [8..255] probe builds only, [256..511] gr_trace_fused's attempts
+ * spread over 256 words by workgroup (one same-address atomic per tile would serialise a frame of many short tiles).  The total
+ * is [0] + sum [256..511]; gr_render_state_attempts does that for a frame's own block. */
+#define GR_COUNTER_WORDS 512
+
 /* init -> integrate -> render-data in one launch; writes only render_data[sy*width+sx] (32 B per pixel).
  * Rows are dealt to devices block-cyclically: global block b (block_rows rows, multiple of 8) belongs to device
  * b % strip_count; each block additionally traces the one row below it (texture-filter halo).  strip_count <= 1
