@@ -22,6 +22,9 @@ METRICS = {  # name -> parameter ranges
     "minkowski": {}, "schwarzschild": {}, "kerr_boyer": {"a": (-0.49, 0.49)}, "alcubierre": {}, "schwarzschild_ingoing_ef": {},
     "wormhole": {}, "cosmic_string": {"mu": (0.0, 0.1)}, "kerr_newman_boyer": {"a": (-0.3, 0.3), "rq": (0.0, 0.3)},
     "kerr_schild": {"a": (-0.45, 0.45)}, "schwarzschild_adaptive": {"rs": (0.5, 2.0)},
+    # sub- and hyper-extreme constituents: the rod half-lengths are real for some draws and complex for others (csrc/sym.cpp folds the
+    # complex roots of the substituted program when they turn out real)
+    "double_unequal_kerr": {"fa1": (-1.2, 1.2), "fa2": (-1.2, 1.2), "R": (3.0, 5.0)},
 }
 
 
@@ -39,15 +42,10 @@ def quat_mul(a, b):
             aw * bw - ax * bx - ay * by - az * bz]
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
-    w, h = 64, 36
-    bg_np, levels = gra.pack_background(gra.synthetic_background(256, 128))
-    bg = DeviceBuffer.from_numpy(0, bg_np)
-    out = DeviceBuffer(0, w * h * 16)
-    state = gra.RenderState(w, h, 0)
-    oracles, worst, failed = {}, 0.0, 0
+def draw_cases(cases, seed):
+    """the soak's cases, drawn from one random stream: (index, metric name, metric, cfg, camera position, orientation, observer speed,
+    feature keywords, camera distance)"""
+    rng = np.random.default_rng(seed)
     names = sorted(METRICS)
     for case in range(cases):
         name = names[case % len(names)]
@@ -61,10 +59,49 @@ def main():
         base = quat_from_axis_angle([1, 0, 0], -np.pi / 2)
         quat = quat_mul(quat_from_axis_angle(rng.normal(size=3), float(rng.uniform(0, 1.0))), base)
         speed = [float(x) for x in rng.uniform(-0.3, 0.3, 3)] if rng.random() < 0.5 else [0.0, 0.0, 0.0]
-        only = int(sys.argv[3]) if len(sys.argv) > 3 else None
         fkw = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change, redshift=int(rng.random() < 0.4),
                    reparameterisation=int(rng.random() < 0.25), field_of_view=float(rng.choice([60.0, 90.0, 110.0])),
                    universe_size=float(rng.choice([20.0, 30.0])), max_precision_radius=float(rng.choice([10.0, 14.0])))
+        yield case, name, metric, cfg, pos, quat, speed, fkw, r
+
+
+def _precompile(argument_string):
+    gra.Program.precompile(argument_string)
+    return True
+
+
+def precompile(cases, seed):
+    """build container: the code objects of every case (dynamic and substituted program) and the CPU oracles, in parallel, so that
+    the soak on the GPU box spends its time rendering"""
+    import multiprocessing
+    strings, oracle_keys = [], []
+    for case, name, metric, cfg, pos, quat, speed, fkw, r in draw_cases(cases, seed):
+        key = metric.argument_string()
+        if key not in oracle_keys:
+            oracle_keys.append(key)
+        for s in (key, metric.argument_string(features=gra.default_features(**fkw), static=True, cfg_values=cfg)):
+            if s not in strings:
+                strings.append(s)
+    with multiprocessing.get_context("spawn").Pool(max(1, (os.cpu_count() or 2) - 1)) as pool:
+        pool.map(_precompile, strings, chunksize=1)
+        pool.map(build_restate.build, oracle_keys, chunksize=1)
+    print(f"precompiled {len(strings)} programs, {len(oracle_keys)} oracles")
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
+    if len(sys.argv) > 3 and sys.argv[3] == "precompile":
+        precompile(cases, seed)
+        return 0
+    w, h = 64, 36
+    bg_np, levels = gra.pack_background(gra.synthetic_background(256, 128))
+    bg = DeviceBuffer.from_numpy(0, bg_np)
+    out = DeviceBuffer(0, w * h * 16)
+    state = gra.RenderState(w, h, 0)
+    oracles, worst, failed = {}, 0.0, 0
+    for case, name, metric, cfg, pos, quat, speed, fkw, r in draw_cases(cases, seed):
+        only = int(sys.argv[3]) if len(sys.argv) > 3 else None
         if only is not None and case != only:
             continue
         feats = gra.default_features(**fkw)
@@ -86,7 +123,11 @@ def main():
             d = px[..., :3] - ref["pixels"][..., :3]
             bad = np.abs(d).max(axis=2) > 1e-3
             rmse = float(np.sqrt((d[~bad] ** 2).mean())) if (~bad).any() else 0.0
-            ok = bad.mean() <= 0.01 and rmse <= 1e-4 and np.isfinite(px).all()
+            # a hyper-extreme constituent of the double-Kerr solution (|a_i / m_i| > 1) is a naked singularity: chaotic orbits around
+            # it, as for the super-extremal Kerr fixture - any two builds differ in a few per cent of the pixels (case 31/46: the
+            # reference's own x86 build and the CPU restatement, same operation order, in 86 of 2304), so the mask is 10 % there
+            chaotic = name == "double_unequal_kerr" and max(abs(cfg[2]), abs(cfg[3])) > 1.0
+            ok = bad.mean() <= (0.10 if chaotic else 0.01) and rmse <= (3e-4 if chaotic else 1e-4) and np.isfinite(px).all()
             failed += not ok
             worst = max(worst, rmse)
             line += f" | {label}: rmse {rmse:.1e} off {bad.mean() * 100:4.1f}%{'' if ok else '  <-- FAIL'}"
