@@ -69,6 +69,8 @@ def parse():
                     "them under `secondary`)")
     ap.add_argument("--camera", default="", help="camera position t,x,y,z (default 0,0,-4,0)")
     ap.add_argument("--redshift", type=int, default=0)
+    ap.add_argument("--inline-prepass", type=int, default=-1, help="gr_frame_options.inline_prepass of the timed frames (-1 library default: a frame "
+                    "whose prepass was not computed ahead traces it inside the trace launch; 0: as a launch of its own)")
     ap.add_argument("--use-prepass", type=int, default=-1, help="gr_frame_options.use_prepass of the timed frames: -1 per metric + policy, 0 / 1 forced")
     ap.add_argument("--mode", default="fused", choices=["fused", "reference"])
     ap.add_argument("--program", default="static", choices=["static", "dynamic"])
@@ -300,6 +302,7 @@ def main():
             opts.trace_waves_per_simd = waves_per_launch
             opts.fused_shading = args.fused_shading
             opts.use_prepass = args.use_prepass
+            opts.inline_prepass = args.inline_prepass
             if lookahead is not None:
                 opts.next_camera = lookahead
                 if depth == 2:
@@ -392,13 +395,15 @@ def main():
         def __init__(self, metric, state, camera, features, target, pixels):
             self.metric, self.state, self.camera, self.features, self.target, self.pixels = metric, state, camera, features, target, pixels
 
-    def exclusive_frames(prog, cfgv, n=5, wl=None):
+    def exclusive_frames(prog, cfgv, n=5, wl=None, inline_prepass=0):
         """n frames one at a time with per-stage events and the attempt / shader-clock counters: stage ms (means), attempts,
-        MHz"""
+        MHz.  inline_prepass = 0: the prepass as a launch of its own, so that the trace stage is the trace kernel's own work (what
+        the roofline blocks describe); -1: as the library renders a frame whose camera was not announced (prepass inside the trace
+        launch)"""
         stage_sum, attempts, clocks, shares = {}, 0, [], []
         for _ in range(n):
             if wl is not None:
-                opts = gra.frame_options(mode=gra.MODE_FUSED, time_kernels=1, count_attempts=1)
+                opts = gra.frame_options(mode=gra.MODE_FUSED, time_kernels=1, count_attempts=1, inline_prepass=inline_prepass)
                 wl.state.render(prog, wl.metric, wl.camera, wl.target, (bg.data_ptr(), 4096, 2048, levels), wl.features, cfgv, opts, stream)
             elif multi:
                 opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=rank, strip_count=world, block_rows=plan.block_rows, compact_out=1,
@@ -406,7 +411,7 @@ def main():
                 target = ring[0].gather.local_buffer().data_ptr()
             else:
                 opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=1, count_attempts=1,
-                                         use_prepass=args.use_prepass)
+                                         use_prepass=args.use_prepass, inline_prepass=inline_prepass)
                 target = out.data_ptr()
             if wl is None:
                 state.render(prog, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfgv, opts, stream)
@@ -468,6 +473,10 @@ def main():
                 "lane_utilisation": pmc.get("valu_lane_utilisation") if pmc else None}
         roof["binding"] = {"bound": "fp32 VALU (no MFMA, no HBM traffic to speak of)", "achieved": round(tflops_wall, 3), "peak": VALU_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(tflops_wall / VALU_PEAK_TFLOPS, 4)}
+        # ... and the frame as the library renders it one at a time when the next camera is not known (prepass inside the trace launch)
+        as_rendered, _, _ = exclusive_frames(prog, cfgv, n=4, wl=wl, inline_prepass=-1)
+        roof["frame_one_at_a_time_ms"] = {"prepass_as_its_own_launch": round(sum(stages.values()), 4),
+                                          "prepass_inside_the_trace_launch": round(sum(as_rendered.values()), 4)}
         return roof, valu, stages
 
     kerr_4k = args.metric == "kerr_boyer" and (W, H) == (3840, 2160) and fused and args.program == "static"

@@ -180,3 +180,48 @@ def test_pair_kernel_is_built_for_fixed_step_programs_only(tmp_path, monkeypatch
     assert symbols(adaptive.argument_string(), "adaptive") == (False, True)
     monkeypatch.setenv("GR_TRACE_PAIR_BUILD", "0")
     assert symbols(fixed.argument_string(), "never") == (False, True)
+
+
+def test_assembly_pass_cuts_the_vector_runs_of_the_integrator(tmp_path, monkeypatch):
+    """host build path (csrc/codeobject.cpp): the program goes through the code-object manager to assembly text, break_vector_runs
+    puts an s_nop after every 8th instruction of a run of vector instructions in the kernels that hold a Verlet loop, and the
+    result is assembled in-process.  Checked on the disassembly of the cached code object (no GPU needed): with the pass no run of
+    vector instructions in gr_trace_fused is longer than 8, without it (GR_VECTOR_RUN_LIMIT=0: plain hiprtc) the acceleration is
+    one run of > 100; set-up kernels are left as compiled."""
+    import glob
+    import os
+    import re
+    import subprocess
+    import geodesic_raytracing_amd as gra
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    metric = gra.Metric("kerr_boyer")
+    args = metric.argument_string(features=metric.features(adaptive_sampling=0), static=True, cfg_values=metric.cfg_values(a=0.45))
+
+    def longest_runs(limit, tag):
+        d = tmp_path / tag
+        d.mkdir()
+        monkeypatch.setenv("GR_CACHE_DIR", str(d))
+        monkeypatch.setenv("GR_VECTOR_RUN_LIMIT", str(limit))
+        gra.Program.precompile(args)
+        (path,) = glob.glob(os.path.join(str(d), "*.hsaco"))
+        text = subprocess.run([objdump, "-d", "--no-show-raw-insn", path], capture_output=True, text=True, check=True).stdout
+        runs, kernel, run = {}, None, 0
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+            if m:
+                kernel, run = m.group(1), 0
+                continue
+            op = line.strip().split(" ")[0] if line.startswith("\t") else ""
+            if op.startswith("v_"):
+                run += 1
+                runs[kernel] = max(runs.get(kernel, 0), run)
+            elif op.startswith("s_"):
+                run = 0
+        return runs
+
+    plain, passed = longest_runs(0, "plain"), longest_runs(8, "pass")
+    assert plain["gr_trace_fused"] > 100
+    assert passed["gr_trace_fused"] <= 8 and passed["gr_camera_prepass"] <= 8 and passed["gr_do_generic_rays"] <= 8
+    assert passed["gr_render"] == plain["gr_render"]          # not an integrator kernel: as compiled

@@ -12,7 +12,7 @@ for W in $WORKLOADS; do
   esac
   for K in stats exclusive_stats; do
     DB=$(find gpurun_out/${TAG}_${W}_${K} -name "*.db" 2>/dev/null | head -1)
-    [ -n "$DB" ] && { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $SEL --steps N --warmup 3 --no-cpu-baseline --no-secondary$( [ $K = exclusive_stats ] && echo ' --frames-in-flight 1 --no-lookahead' )"; python tools/rocprof_summary.py $DB | tail -n +2; echo "# bench line of the profiled run:"; grep '^{"metric"' gpurun_out/${TAG}_${W}_${K}.log | tail -1 | cut -c1-2000; } > profiles/${TAG}_kernel_${K}_${W}.txt
+    [ -n "$DB" ] && { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $SEL --steps N --warmup 3 --no-cpu-baseline --no-secondary$( [ $K = exclusive_stats ] && echo ' --frames-in-flight 1 --no-lookahead --inline-prepass 0' )"; python tools/rocprof_summary.py $DB | tail -n +2; echo "# bench line of the profiled run:"; grep '^{"metric"' gpurun_out/${TAG}_${W}_${K}.log | tail -1 | cut -c1-2000; } > profiles/${TAG}_kernel_${K}_${W}.txt
   done
   [ -d gpurun_out/${TAG}_${W}_pmc1 ] && python tools/pmc_summary.py profiles/${TAG}_pmc_${W}.txt profiles/$JSON gpurun_out/${TAG}_${W}_pmc1.log gpurun_out/${TAG}_${W}_pmc[1-5]
 done
