@@ -115,6 +115,15 @@ POLAR_CASES = {
                                    camera_quat=[-0.7345988591068365, 0.0893395407630169, -0.06763954895833718, 0.6691844693893456],
                                    basis_speed=[0.15518180300394824, 0.1498653695042953, 0.037818782698535613],
                                    features=dict(redshift=1)),
+    # round-3 soak (seed 32, 400 cases): the two cases over the 1 % mask, the camera within ~20 degrees of the polar axis at r ~ 11
+    "kerr_axis_32_135": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(64, 36), cfg=dict(a=-0.14031262029749292),
+                             camera_pos=[0.490799601306076, 2.0536361830023533, -3.0051457154926142, -10.626673477774995],
+                             camera_quat=[-0.6354060372480945, 0.026939736045995394, -0.053497009332032094, 0.7698516015720002],
+                             basis_speed=[-0.10949397484848694, 0.15621987903859214, 0.29804623876091624], features=dict()),
+    "kerr_axis_32_267": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(64, 36), cfg=dict(a=0.30756478406827903),
+                             camera_pos=[-0.9142232821945686, -0.5234851286431226, -6.387000527847298, 9.50104747636112],
+                             camera_quat=[-0.725694739770197, -0.4038229575495091, -0.13208630722479323, 0.5411537406962561],
+                             features=dict(field_of_view=110.0, universe_size=30.0)),
 }
 
 # camera riding a timelike geodesic (boost_tetrad .. handle_interpolating_geodesic): name -> spec

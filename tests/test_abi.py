@@ -223,5 +223,6 @@ def test_assembly_pass_cuts_the_vector_runs_of_the_integrator(tmp_path, monkeypa
 
     plain, passed = longest_runs(0, "plain"), longest_runs(8, "pass")
     assert plain["gr_trace_fused"] > 100
-    assert passed["gr_trace_fused"] <= 8 and passed["gr_camera_prepass"] <= 8 and passed["gr_do_generic_rays"] <= 8
+    # (the pass counts inside basic blocks, the disassembly has no labels: two runs that meet at a fall-through read as one)
+    assert passed["gr_trace_fused"] <= 16 and passed["gr_camera_prepass"] <= 16 and passed["gr_do_generic_rays"] <= 16
     assert passed["gr_render"] == plain["gr_render"]          # not an integrator kernel: as compiled
