@@ -59,6 +59,13 @@ CASES = {
     "kerr_adaptive_sampling": dict(metric="kerr_boyer", size=(48, 28), cfg=dict(a=0.45), features=dict(adaptive_sampling=1, adaptive_sampling_threshold=32.0)),
     "alcubierre": dict(metric="alcubierre", size=(48, 27), features=dict(redshift=1), camera_pos=[0.0, 0.0, -6.0, 0.5]),
     "double_unequal_kerr": dict(metric="double_unequal_kerr", scripts=True, size=(48, 27), camera_pos=[0.0, 0.0, -6.0, 0.5]),
+    # a HYPER-EXTREME constituent (fa2 = a2 / m2 > 1: complex rod half-length, the principal complex roots stay complex; a naked
+    # singularity with chaotic orbits around it): case 46 of the round-3 soak (seed 31), inputs as drawn
+    "double_unequal_kerr_hyperextreme": dict(metric="double_unequal_kerr", scripts=True, size=(64, 36),
+                                             cfg=dict(fa1=0.7869180204853259, fa2=1.1757121094987382, R=3.938914082163638),
+                                             camera_pos=[0.06281916943291765, -4.864652343149663, -7.817783128902845, 0.9215282106101533],
+                                             camera_quat=[-0.590297147333773, 0.10320583672397403, 0.04326497142639673, 0.7993910028035013],
+                                             features=dict(redshift=1, field_of_view=110.0)),
     "kerr_script": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(48, 27), cfg=dict(a=0.45)),
     "ingoing_ef": dict(metric="schwarzschild_ingoing_ef", scripts=True, size=(48, 27)),
     "wormhole_through": dict(metric="wormhole", scripts=True, size=(48, 27), camera_pos=[0.0, 0.0, -2.5, 0.3]),

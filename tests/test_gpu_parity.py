@@ -27,7 +27,7 @@ import geodesic_raytracing_amd as gra  # noqa: E402
 from gpu_stages import Stages, assert_traced_positions, circ_diff, golden_names, load_golden, metric_for, ordinary_rays, rel_err  # noqa: E402
 
 PLAIN = [n for n in golden_names() if not n.endswith("_prepass") and n != "kerr_adaptive_sampling"]
-CHAOTIC = {"kerr_superextremal"}
+CHAOTIC = {"kerr_superextremal", "double_unequal_kerr_hyperextreme"}
 
 
 def background(meta):

@@ -9,7 +9,7 @@ from gpu_stages import assert_traced_positions, circ_diff, golden_names, load_go
 from oracle import build_ref, build_restate
 from oracle.refpipe import OraclePipeline, pack_features
 
-CHAOTIC = {"kerr_superextremal"}
+CHAOTIC = {"kerr_superextremal", "double_unequal_kerr_hyperextreme"}
 
 
 def run_oracle(so, meta):
