@@ -259,7 +259,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
             if (getenv("GR_VERBOSE_BUILD")) fprintf(stderr, "[gr] building through hiprtc (%s)\n", log.c_str());
         }
         hiprtcProgram prog;
-        if (hiprtcCreateProgram(&prog, source.c_str(), "geodesic_kernels.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        if (hiprtcCreateProgram(&prog, source.c_str(), "geodesic_kernels_all_parts.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
             return fail(GR_ERROR_COMPILE, "hiprtcCreateProgram failed");
         std::vector<const char*> copts;
         for (auto& o : options) copts.push_back(o.c_str());

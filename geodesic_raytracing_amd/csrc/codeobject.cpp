@@ -134,7 +134,7 @@ bool compile_to_assembly(const std::string& source, const std::vector<std::strin
     scope sc(c);
     amd_comgr_data_set_t in, out;
     if (!sc.new_set(in) || !sc.new_set(out)) { log = "comgr: data set"; return false; }
-    if (!sc.add(in, AMD_COMGR_DATA_KIND_SOURCE, "geodesic_kernels.hip", source.data(), source.size()) ||
+    if (!sc.add(in, AMD_COMGR_DATA_KIND_SOURCE, "geodesic_kernels_all_parts.hip", source.data(), source.size()) ||
         !sc.add(in, AMD_COMGR_DATA_KIND_INCLUDE, "hiprtc_runtime.h", c.header, c.header_size)) { log = "comgr: inputs"; return false; }
     if (c.create_action_info(&sc.info) != AMD_COMGR_STATUS_SUCCESS) { log = "comgr: action info"; return false; }
     sc.has_info = true;

@@ -344,7 +344,7 @@ __device__ __forceinline__ int integrate_ray(ray_state& s, cfg_t cfg, dfg_t dfg,
 // instructions get through two rays' arithmetic in less issue time than two plain ones, 374 -> 462 G ray-steps/s.  Three
 // quarters of the instructions of a Verlet attempt are such multiplies and fmas, so one lane stepping two rays gets through more
 // attempts per cycle.  What has no packed form (compares, selects, rcp/rsq/sqrt, the commit of an accepted step) is done per
-// half.  The arithmetic of a ray is instruction for instruction that of integrate_core; a ray that has left the loop keeps
+// half.  The arithmetic of a ray is that of the one-ray loop (integrate_pingpong); a ray that has left the loop keeps
 // its state (the commit is per ray) while its partner goes on.
 using gm::pairf;
 using gm::pair4;
@@ -410,7 +410,7 @@ __device__ __forceinline__ void integrate_pair(pair4& position_io, pair4& veloci
     int i0 = 0, i1 = 0;
     bool alive0 = active0, alive1 = active1;
 
-    // the loop-top tests of integrate_core on one ray's numbers
+    // the loop-top tests of the one-ray loop on one ray's numbers
     auto stop_lost = [&](float pos_y, float vel_x_over_run, float acc_x_over_run, float fin, int steps) {
         bool lost = steps >= loop_limit;
 #ifdef HAS_CYLINDRICAL_SINGULARITY
@@ -525,7 +525,7 @@ __device__ __forceinline__ void integrate_pair(pair4& position_io, pair4& veloci
             if (!(poison == 0.f)) alive1 = false;
         }
     }
-    // why each ray left the loop: the loop-top tests on its final state (see integrate_core)
+    // why each ray left the loop: the loop-top tests on its final state (as integrate_pingpong's classify)
     {
         pair4 polar = gm::generic_to_spherical(position, cfg);
 #ifndef UNCONDITIONALLY_NONSINGULAR

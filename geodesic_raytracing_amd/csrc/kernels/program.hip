@@ -1,4 +1,6 @@
-// geodesic_kernels.hip — gfx950 (CDNA4, wave64) kernels of the per-pixel geodesic ray pipeline.
+// kernels/*.hip — gfx950 (CDNA4, wave64) kernels of the per-pixel geodesic ray pipeline.  This is the first of the parts the host
+// concatenates into one translation unit (csrc/capi.cpp KERNEL_PARTS): program, probes.inc, metric, setup, integrator, trace, shading,
+// geodesic_camera.
 //
 // This translation unit is compiled at run time (hiprtc, --offload-arch=gfx950) once per metric,
 // specialised by the same `-D` macro set the reference feeds to its OpenCL program

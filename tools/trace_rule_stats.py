@@ -1,5 +1,5 @@
 """Trace-stage parity statistics per golden case (GPU): how many ordinary rays (fewer than twice the median attempts) miss the 1e-3
-position rule, worst error, attempts against the oracle.  Honour GR_EXTRA_FLAGS (e.g. -DGR_INTEGRATOR_V1) for A/B runs."""
+position rule, worst error, attempts against the oracle.  Honour GR_EXTRA_FLAGS (e.g. -DGR_LIBM_TRIG) for A/B runs."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
