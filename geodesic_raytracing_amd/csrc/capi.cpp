@@ -220,7 +220,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
         if (tuning && tuning[0] == '0') h = fnv1a("no occupancy tuning", h);
     }
     // Pass over the compiled code (codeobject.hpp): no more than `run_limit` vector instructions in a row without a scalar one.
-    // GR_VECTOR_RUN_LIMIT=0 builds through hiprtc alone.
+    // GR_VECTOR_RUN_LIMIT=0: no pass (the build still goes through the code-object manager, see below).
     int run_limit = GR_DEFAULT_VECTOR_RUN_LIMIT;
     if (const char* e = getenv("GR_VECTOR_RUN_LIMIT")) run_limit = atoi(e);
     if (run_limit > 0) h = fnv1a("vector runs <= " + std::to_string(run_limit), h);
@@ -237,9 +237,11 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     // one build of the kernel source with `options`: through the assembly pass when it is on and the code-object manager is
     // there, else through hiprtc (a source error shows up there with its diagnostics)
     auto build = [&](const std::vector<std::string>& options, std::string& out) -> int {
-        if (run_limit > 0) {
+        {   // (GR_VECTOR_RUN_LIMIT=0 goes the same way without the pass: which code-object manager hiprtc would find depends on
+            // what else the process has loaded, and the copy bundled with PyTorch aborts on these kernels)
             std::string assembly, log;
             if (gr::compile_to_assembly(source, options, assembly, log)) {
+                if (run_limit <= 0 && gr::assemble_code_object(assembly, out, log)) return GR_OK;
                 // the kernels that hold a Verlet loop; the others (set-up, shading, tile order ...) are left as compiled
                 static const std::vector<std::string> integrators = {"gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused",
                                                                      "gr_camera_prepass", "gr_do_generic_rays", "gr_get_geodesic_path"};

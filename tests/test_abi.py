@@ -186,7 +186,7 @@ def test_assembly_pass_cuts_the_vector_runs_of_the_integrator(tmp_path, monkeypa
     """host build path (csrc/codeobject.cpp): the program goes through the code-object manager to assembly text, break_vector_runs
     puts an s_nop after every 8th instruction of a run of vector instructions in the kernels that hold a Verlet loop, and the
     result is assembled in-process.  Checked on the disassembly of the cached code object (no GPU needed): with the pass no run of
-    vector instructions in gr_trace_fused is longer than 8, without it (GR_VECTOR_RUN_LIMIT=0: plain hiprtc) the acceleration is
+    vector instructions in gr_trace_fused is longer than 8, without it (GR_VECTOR_RUN_LIMIT=0) the acceleration is
     one run of > 100; set-up kernels are left as compiled."""
     import glob
     import os
