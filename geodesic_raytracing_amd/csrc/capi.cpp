@@ -940,9 +940,9 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     // the prepass inside the launch: its cell waves are the first tickets (gr_trace_fused's prepass_tickets)
     int prepass_tickets = 0;
     if (inline_prepass) {
-        if (rays_per_lane != 1 || lattice != 1 || pending_only || tile_order || strip_count > 1 || !term || prepass_width <= 0 || prepass_height <= 0 ||
+        if (rays_per_lane != 1 || lattice != 1 || pending_only || tile_order || !term || prepass_width <= 0 || prepass_height <= 0 ||
             prepass_width == width || prepass_height == height)
-            return fail(GR_ERROR_INVALID_ARGUMENT, "inline_prepass: gr_trace_fused on every pixel of a whole frame in image order, with a prepass grid");
+            return fail(GR_ERROR_INVALID_ARGUMENT, "inline_prepass: gr_trace_fused on every pixel of its rows in image order, with a prepass grid");
         prepass_tickets = (int)(((long long)prepass_width * prepass_height + 63) / 64);
     }
     if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && rays_per_lane != 1))

@@ -747,10 +747,11 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         static const int tile_order_mode = [] { const char* e = getenv("GR_TILE_ORDER"); return !e ? -1 : e[0] == '0' ? 0 : 1; }();
         const bool tile_order_enabled = tile_order_mode == 1 || (tile_order_mode == -1 && strip_count > 1);
         const size_t cells = use_prepass ? (size_t)prepass_width * prepass_height : 0;
-        const bool order_tiles = tile_order_enabled && use_prepass && !adaptive && 2 * cells <= (size_t)width * height &&
-                                 (size_t)gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
+        // (a frame whose prepass rides in its trace launch - below - has no costs to order by; the frames it announces still do)
+        const bool order_capable = tile_order_enabled && use_prepass && !adaptive && 2 * cells <= (size_t)width * height &&
+                                   (size_t)gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
         const int prepass_margin = adaptive ? 2 : 0;   // the lattice rows beyond a block that its 2x2 decisions read
-        auto cost_plane = [&](void* termination_buffer) -> void* { return order_tiles ? (void*)((unsigned int*)termination_buffer + cells) : nullptr; };
+        auto cost_plane = [&](void* termination_buffer) -> void* { return order_capable ? (void*)((unsigned int*)termination_buffer + cells) : nullptr; };
         // which trace kernel this frame takes (needed here already: the prepass may ride in the trace launch)
         // library default: no compaction (the benchmark workloads keep > 95 % of their lanes busy without it); experiments can
         // switch it on for every frame with GR_TRACE_COMPACT=<keep_lanes>
@@ -776,9 +777,15 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // ahead of time - an interactive caller does not know the next camera - the prepass's single-ray latency (1.1 ms at 4K
         // Kerr, 8 ms with a = 0.9) then runs alongside the first tiles instead of in front of the whole trace.
         static const int inline_default = [] { const char* e = getenv("GR_INLINE_PREPASS"); return !e ? 1 : e[0] != '0'; }();
-        const bool inline_prepass = (opt.inline_prepass < 0 ? inline_default != 0 : opt.inline_prepass != 0) && !prefetched && one_launch_setup && use_prepass &&
-                                    strip_count == 1 && !adaptive && !order_tiles && keep_lanes == 0 && rays_per_lane == 1 &&
+        // By default on whole frames that do not order their tiles (the order needs the prepass rays' costs first).  A device's share
+        // of a split frame can do it too (inline_prepass = 1: it traces the cells its rows look at), but does not by default, on
+        // measurement - one rank of 8 / of 4, one frame at a time, 2 wave slots per SIMD: 2.41 / 3.42 ms against 2.20 / 2.80 with the
+        // prepass in front and the tiles ordered by its costs (tools/strip_probe.py, STRIP_PROBE_DEPTH=0): a share is few tiles, and
+        // which of them start first matters more than the prepass's latency.
+        const bool inline_wanted = opt.inline_prepass < 0 ? (inline_default != 0 && strip_count == 1 && !order_capable) : opt.inline_prepass != 0;
+        const bool inline_prepass = inline_wanted && !prefetched && one_launch_setup && use_prepass && !adaptive && keep_lanes == 0 && rays_per_lane == 1 &&
                                     prepass_width != width && prepass_height != height;
+        const bool order_tiles = order_capable && !inline_prepass;
         if (!prefetched && one_launch_setup) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_camera_prepass(p, stream, s->camera_pos_cart, camera->flip, camera->basis_speed, s->camera_pos_generic, s->tetrad[0],
@@ -930,7 +937,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                                  slot->set.tetrad[1], slot->set.tetrad[2], slot->set.tetrad[3], s->cfg, s->dfg, height,
                                                  block_rows, r.strip_rank, strip_count, cost_plane(slot->set.termination_buffer), prepass_margin));
             }
-            if (order_tiles)   // the look-ahead frame's order too: off the frame's critical path like its prepass
+            if (order_capable)   // the look-ahead frame's order too: off the frame's critical path like its prepass
                 GR_CHECK(gr_order_tiles(p, slot->stream, slot->set.termination_buffer, cost_plane(slot->set.termination_buffer), prepass_width,
                                         prepass_height, width, height, block_rows, r.strip_rank, strip_count, slot->set.tile_order));
             HIP_CHECK(hipEventRecord(slot->ready, slot->stream));

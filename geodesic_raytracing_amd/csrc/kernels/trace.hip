@@ -253,6 +253,25 @@ __device__ __forceinline__ bool own_block_within(int y, int margin, int height, 
     return false;
 }
 
+// Does a device of a split frame (strip_count > 1) need the prepass cells of row cy?  A pixel row y reads the cell rows
+// round(y * ph / H) - 1 .. + 1 (init_rays_generic's 5-point stencil, cl.cl:3213-3232), so cell row cy matters only if one of the
+// device's blocks (or the halo row under it) meets the pixel rows that map to cy - 1 .. cy + 1 - one row of slack either side
+// for the float rounding of that quotient (tests/test_distributed_cpu.py checks the rule by brute force).  row_margin: pixel rows
+// beyond its blocks and halo rows the device also looks from (adaptive sampling: 2, the lattice rows its block decisions read).
+__device__ __forceinline__ bool cell_row_matters(int cy, int prepass_height, int image_height, int block_rows, int strip_rank, int strip_count,
+                                                 int row_margin) {
+    if (strip_count <= 1) return true;
+    long long lo = ((long long)(2 * cy - 3) * image_height) / (2 * prepass_height) - 1 - row_margin;
+    long long hi = ((long long)(2 * cy + 3) * image_height + 2 * prepass_height - 1) / (2 * prepass_height) + 1 + row_margin;
+    if (lo < 0) lo = 0;
+    if (hi > image_height - 1) hi = image_height - 1;
+    // blocks b (rows b*B .. (b+1)*B inclusive of the halo row) that meet [lo, hi]: (b+1)*B >= lo and b*B <= hi
+    long long b_lo = (lo - 1) / block_rows, b_hi = hi / block_rows;
+    if (b_lo < 0) b_lo = 0;
+    const long long first = b_lo + (((long long)strip_rank - b_lo) % strip_count + strip_count) % strip_count;   // first own block >= b_lo
+    return first <= b_hi;
+}
+
 // Shading inside the trace launch.  Of the 64 pixels of a tile, the 49 that are not in its last column or row have both neighbours
 // the texture filter looks at (the pixel to the right and the pixel below, cl.cl:5509-5546) in the same wave: their sky coordinates
 // come over by ds_bpermute and the wave writes the finished float4 pixels itself, straight from the registers the render-data
@@ -301,6 +320,8 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         if (cell >= prepass_width * prepass_height) return;
         cx = cell % prepass_width;
         cy = cell / prepass_width;
+        // a device of a split frame traces the cells its rows look at; the others stay unknown and nobody asks for them
+        if (!cell_row_matters(cy, prepass_height, image_height, device_block_rows, device_rank, device_count, 0)) return;
         ray_grid_width = prepass_width; ray_grid_height = prepass_height;
         width = image_width; height = image_height;
     } else {
@@ -675,21 +696,7 @@ __device__ __forceinline__ void prepass_cell(int id, float4 camera, float4 camer
                                              unsigned int* __restrict__ cell_attempts, int row_margin) {
     if (id >= prepass_width * prepass_height) return;
     int cx = id % prepass_width, cy = id / prepass_width;
-    if (strip_count > 1) {
-        // pixel rows whose stencil can touch cell row cy: round(y * ph / H) in [cy - 1, cy + 1], one row of slack either side for
-        // the float rounding of that quotient (tests/test_distributed_cpu.py checks the rule by brute force)
-        // row_margin: pixel rows beyond its blocks and halo rows the device also looks from (adaptive sampling: 2, the lattice rows
-        // its block decisions read)
-        long long lo = ((long long)(2 * cy - 3) * image_height) / (2 * prepass_height) - 1 - row_margin;
-        long long hi = ((long long)(2 * cy + 3) * image_height + 2 * prepass_height - 1) / (2 * prepass_height) + 1 + row_margin;
-        if (lo < 0) lo = 0;
-        if (hi > image_height - 1) hi = image_height - 1;
-        // blocks b (rows b*B .. (b+1)*B inclusive of the halo row) that meet [lo, hi]: (b+1)*B >= lo and b*B <= hi
-        long long b_lo = (lo - 1) / block_rows, b_hi = hi / block_rows;
-        if (b_lo < 0) b_lo = 0;
-        long long first = b_lo + (((long long)strip_rank - b_lo) % strip_count + strip_count) % strip_count;   // first own block >= b_lo
-        if (first > b_hi) return;
-    }
+    if (!cell_row_matters(cy, prepass_height, image_height, block_rows, strip_rank, strip_count, row_margin)) return;
     lightray ray = make_pixel_ray(cx, cy, prepass_width, prepass_height, camera, camera_quat, e0, e1, e2, e3, 0, cfg, dfg);
     ray_state s;
     s.position = ray.position;

@@ -201,7 +201,7 @@ class ProgramManager:
         arr, n = self._values(cfg_values)
         check(lib.gr_program_manager_create(metric.handle, device, ctypes.byref(features) if features is not None else None, arr, n,
                                             ctypes.byref(self.handle)))
-        self.dynamic = self._borrowed(c_void_p(lib.gr_program_manager_dynamic(self.handle)))
+        self._dynamic_handle = c_void_p(lib.gr_program_manager_dynamic(self.handle))
         self.features = features if features is not None else metric.features()
         self.cfg_values = list(cfg_values) if cfg_values is not None else metric.cfg_values()
         self.is_substituted = False
@@ -215,7 +215,13 @@ class ProgramManager:
     def _borrowed(self, handle):
         p = Program.__new__(Program)          # the manager owns the program: no gr_program_destroy from this wrapper
         p.handle, p.device, p.borrowed = handle, self.device, True
+        p._owner = self                       # ... and lives as long as a program it handed out (ProgramManager(...).current() on a temporary)
         return p
+
+    @property
+    def dynamic(self):
+        """the dynamic program (usable whatever the parameters)"""
+        return self._borrowed(self._dynamic_handle)
 
     def update(self, features=None, cfg_values=None):
         arr, n = self._values(cfg_values)

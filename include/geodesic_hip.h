@@ -347,8 +347,8 @@ typedef struct gr_trace_fused_args {
     int pending_only;   /* 1: only the pixels gr_adaptive_refine marked (second launch of adaptive sampling) */
     int inline_prepass; /* 1: the launch traces the prepass grid itself - its cells are the first tickets of the persistent launch, 64
                          * to a wave, and a tile waits for the cells its pixels look at (device-scope flags in termination_buffer,
-                         * which must be writable and is reset by the call).  Whole frames in image order only (no tile_order, no
-                         * strips, lattice 1).  Camera and tetrad must be on the device already (gr_camera_prepass with a 0 x 0
+                         * which must be writable and is reset by the call).  Image order only (no tile_order), lattice 1; a device's
+                         * share of a split frame traces the cells its rows look at and leaves the others unknown.  Camera and tetrad must be on the device already (gr_camera_prepass with a 0 x 0
                          * grid).  Records and flags are those of the two-launch sequence. */
 } gr_trace_fused_args;
 int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args* args);
@@ -474,9 +474,11 @@ typedef struct gr_frame_options {
                             * default on measurement: 4K Kerr, three frames in flight, 1 723 against 1 743 Mrays/s - the shading
                             * arithmetic moves into the trace launch, and the separate pass was already hidden behind the next
                             * frame's trace */
-    int inline_prepass;    /* fused mode, a frame whose prepass was not computed ahead (next_camera): 1 / -1 (default) = trace the
-                            * prepass grid inside the trace launch (gr_trace_fused_args.inline_prepass) where that applies - whole
-                            * frames, one ray per lane, no adaptive sampling, no compaction; 0 = as a launch of its own in front */
+    int inline_prepass;    /* fused mode, a frame whose prepass was not computed ahead (next_camera): trace the prepass grid inside
+                            * the trace launch (gr_trace_fused_args.inline_prepass; one ray per lane, no adaptive sampling, no
+                            * compaction).  -1 (default): on whole frames that do not order their tiles; 1: also on a device's share
+                            * of a split frame (which then is not ordered - measured slower there); 0: the prepass as a launch of
+                            * its own in front */
     int trace_waves_per_simd;   /* fused mode: persistent waves per SIMD a trace launch takes, 1..8; 0 = as many as fit (best for
                             * one frame at a time).  With three or more frames in flight on streams of their own, 4 measured
                             * 2-3 % faster than all: the launches then share the device instead of queueing for it. */

@@ -22,7 +22,7 @@ look = ctypes.pointer(camera)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
   for rotate in ((True,) if os.environ.get("STRIP_PROBE_INFLIGHT") else (False, True)):
    for inflight in [int(x) for x in os.environ.get("STRIP_PROBE_INFLIGHT", "1,3").split(",")]:
-    for depth in (2,):
+    for depth in [int(x) for x in os.environ.get("STRIP_PROBE_DEPTH", "2").split(",")]:
         counter = [0]
 
         def frame():
