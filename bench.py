@@ -548,6 +548,13 @@ def main():
             secondary["adaptive_sampling_on_threshold32_fps"] = round(1 / t, 1)
             t = timed(camera, features, cfg_values, manager.dynamic, gra.MODE_REFERENCE)
             secondary["reference_kernel_sequence_dynamic_program_fps"] = round(1 / t, 1)
+            # the reference's own speed-up on the fused path with its substituted program: a quarter of the primary rays, the blocks
+            # that need it refined (cl.cl:5223-5345), one frame at a time
+            fa = metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0)
+            pa = gra.Program(metric.argument_string(features=fa, static=True, cfg_values=cfg_values), local_rank)
+            t = timed(camera, fa, cfg_values, pa, gra.MODE_FUSED)
+            secondary["adaptive_sampling_on_threshold32_fused_substituted_fps"] = round(1 / t, 1)
+            del pa
             # the other BASELINE.json configurations, one frame at a time on this one GPU (substituted programs, fused kernel)
             scripts_dir = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
             for label, name, (cw, ch), cam_pos, feats_kw, counters_tag in (
