@@ -184,3 +184,54 @@ def test_argument_string_does_not_depend_on_process_history():
         r = subprocess.run([sys.executable, "-c", prog] + order, capture_output=True, text=True, check=True)
         out.append(dict(line.split() for line in r.stdout.strip().splitlines()))
     assert out[0] == out[1]
+
+
+def _script_metric(name):
+    import os
+    scripts = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geodesic_raytracing_amd", "scripts")
+    return gra.Metric(name, scripts)
+
+
+@pytest.mark.parametrize("params,folds", [(dict(), True), (dict(fa1=0.5, fa2=-0.9, R=3.5), True), (dict(fa2=1.18), False), (dict(fa1=-1.1, fa2=1.05), False)])
+def test_double_kerr_substituted_program_equals_the_dynamic_one(params, folds):
+    """csrc/sym.cpp folds the principal complex roots of the double-Kerr script when the substituted parameters make the rod
+    half-lengths real (sub-extreme constituents) and keeps them when they are complex (hyper-extreme).  Either way the substituted
+    macro set must evaluate - in float64, at points off and near the axis - to what the dynamic one does with the same values."""
+    metric = _script_metric("double_unequal_kerr")
+    cfg = metric.cfg_values(**params)
+    names = dict(zip(metric.dynamic_vars, cfg))
+    dyn = MacroSet(metric.argument_string())
+    sub_string = metric.argument_string(features=metric.features(adaptive_sampling=0), static=True, cfg_values=cfg)
+    sub = MacroSet(sub_string)
+    # a folded program has plain roots of sums of squares; an unfolded principal root prints its sign select (sym.cpp to_c, F_CSQRT_IM)
+    unfolded_roots = sub_string.count("<0.0f)?(-1.0f):1.0f)")
+    assert (unfolded_roots == 0) == folds, unfolded_roots
+    rng = np.random.RandomState(7)
+    for pos in [[0.0, 2.5, 0.3, 1.0], [0.3, 0.02, 1.0, -2.4], [0.0, 5.0, 2.0, 3.1], [0.0, 1.3, 0.1, 0.05]]:
+        vel = list(rng.uniform(-1, 1, 4))
+        g0, g1 = np.array(dyn.metric(pos, names)), np.array(sub.metric(pos))
+        assert np.allclose(g0, g1, rtol=2e-5, atol=1e-6), pos
+        a0, a1 = np.array(dyn.accel(pos, vel, names)), np.array(sub.accel(pos, vel))
+        assert np.allclose(a0, a1, rtol=5e-4, atol=1e-5), (pos, a0, a1)
+
+
+@pytest.mark.parametrize("name", ["alcubierre", "kerr_schild", "kerr_boyer", "double_unequal_kerr", "cosmic_string", "wormhole"])
+def test_distance_of_generic_is_the_distance_of_the_polar_coordinates(name):
+    """-DGR_DISTANCE_OF_GENERIC (csrc/metric_codegen.cpp: DISTANCE_FUNC composed with TO_COORDn, kept only when the coordinate round
+    trip cancels completely) against the long way - TO_COORD1..4, then DISTANCE_FUNC of those - at random points, points on the
+    axes included (where the uncancelled form would divide by a vanishing hypotenuse)."""
+    metric = _script_metric(name)
+    cfg = dict(zip(metric.dynamic_vars, metric.cfg_values()))
+    ms = MacroSet(metric.argument_string())
+    assert ms.has("GR_DISTANCE_OF_GENERIC")
+    text = ms.m["GR_DISTANCE_OF_GENERIC"]
+    assert "atan2" not in text and "sin(" not in text and "cos(" not in text and "/" not in text
+    rng = np.random.RandomState(3)
+    points = [list(rng.uniform(-6, 6, 4)) for _ in range(20)] + [[0.5, 0.0, 0.0, 3.0], [0.5, 0.0, 2.0, 0.0], [-1.0, 3.0, 0.0, 0.0]]
+    for pos in points:
+        if name in ("kerr_boyer", "wormhole", "cosmic_string", "double_unequal_kerr"):
+            pos[1] = abs(pos[1]) + 0.1      # a radius / cylinder radius
+        env = ms.env(pos, cfg=cfg)
+        polar = [ms.value(f"TO_COORD{i + 1}", env) for i in range(4)]
+        long_way = ms.value("DISTANCE_FUNC", ms.env(polar, cfg=cfg))
+        assert ms.value("GR_DISTANCE_OF_GENERIC", env) == pytest.approx(long_way, rel=1e-9, abs=1e-12), pos
