@@ -131,6 +131,17 @@ POLAR_CASES = {
                              camera_pos=[-0.9142232821945686, -0.5234851286431226, -6.387000527847298, 9.50104747636112],
                              camera_quat=[-0.725694739770197, -0.4038229575495091, -0.13208630722479323, 0.5411537406962561],
                              features=dict(field_of_view=110.0, universe_size=30.0)),
+    # third round-3 soak (seed 33, 600 cases): a Kerr camera near the polar axis again, and the double-Kerr camera near the symmetry axis of
+    # the Weyl chart (rho -> 0: the azimuth is as ill-conditioned there as at a Boyer-Lindquist pole)
+    "kerr_axis_33_575": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(64, 36), cfg=dict(a=-0.23229998842858202),
+                             camera_pos=[-0.6079405173160335, -0.49662528519395754, -7.686881752465468, 7.959312228961522],
+                             camera_quat=[-0.5705823453496669, -0.022650100990033926, -0.08471931766927435, 0.8165447919826978],
+                             features=dict(field_of_view=60.0, universe_size=30.0)),
+    "double_kerr_axis_33_541": dict(metric="double_unequal_kerr", scripts=True, size=(64, 36),
+                                    cfg=dict(fa1=0.22269396131436725, fa2=-0.7094257789884395, R=3.2411662334690687),
+                                    camera_pos=[0.10997334765548494, -0.5373825915075183, -2.019667204861688, -11.588137570353418],
+                                    camera_quat=[-0.800403059805112, 0.2303202393915621, -0.002482568913204211, 0.5534449982001999],
+                                    features=dict(redshift=1, reparameterisation=1)),
 }
 
 # camera riding a timelike geodesic (boost_tetrad .. handle_interpolating_geodesic): name -> spec
