@@ -50,7 +50,7 @@ class FrameOptions(ctypes.Structure):
                 ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("parallel_transport_observer", c_int),
                 ("ray_compaction", c_int), ("next_camera2", ctypes.POINTER(Camera)), ("next_geodesic_time2", c_float),
                 ("next_strip_rank", c_int), ("next_strip_rank2", c_int), ("rays_per_lane", c_int), ("fused_shading", c_int),
-                ("inline_prepass", c_int), ("trace_waves_per_simd", c_int)]
+                ("inline_prepass", c_int), ("trace_waves_per_simd", c_int), ("tile_history", c_int)]
 
 
 class TraceShading(ctypes.Structure):
@@ -63,7 +63,8 @@ class TraceFusedArgs(ctypes.Structure):
                 ("block_rows", c_int), ("strip_rank", c_int), ("strip_count", c_int), ("termination_buffer", c_void_p),
                 ("prepass_width", c_int), ("prepass_height", c_int), ("e0", c_void_p), ("e1", c_void_p), ("e2", c_void_p),
                 ("e3", c_void_p), ("cfg", c_void_p), ("dfg", c_void_p), ("attempt_counter", c_void_p), ("tile_order", c_void_p),
-                ("waves_per_simd", c_int), ("shading", TraceShading), ("lattice", c_int), ("pending_only", c_int), ("inline_prepass", c_int)]
+                ("waves_per_simd", c_int), ("shading", TraceShading), ("lattice", c_int), ("pending_only", c_int), ("inline_prepass", c_int),
+                ("tile_cost", c_void_p), ("tile_order_by_history", c_int)]
 
 
 class Transport(ctypes.Structure):
@@ -130,7 +131,9 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "gr_tile_order_bytes": (ctypes.c_longlong, [c_int, c_int, c_int, c_int, c_int]),
     "gr_order_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gr_order_tiles_by_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gr_trace_fused_launch": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TraceFusedArgs)]),
+    "gr_trace_fused_wave_slots": (ctypes.c_longlong, [c_void_p]),
     "gr_render_seams": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_int, c_void_p, c_void_p]),
     "gr_trace_fused_adaptive": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,

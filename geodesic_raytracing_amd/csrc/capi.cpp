@@ -910,23 +910,58 @@ long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_r
     return (32 + 2 * device_tile_count(width, height, block_rows, strip_rank, strip_count)) * 4;   // header (2 x 16 classes), list, classes
 }
 
-int gr_order_tiles(gr_program* p, void* stream, const void* term, const void* cell_attempts, int prepass_width, int prepass_height,
-                   int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order) {
-    if (!p || !term || !cell_attempts || !tile_order || prepass_width <= 0 || prepass_height <= 0)
-        return fail(GR_ERROR_INVALID_ARGUMENT, "gr_order_tiles: null argument or no prepass");
+static int order_tiles_launch(gr_program* p, void* stream, const void* term, const void* cell_attempts, int prepass_width, int prepass_height,
+                              int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order, const void* tile_history) {
     if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + 7) / 8) * 8; }
     long long tiles = device_tile_count(width, height, block_rows, strip_rank, strip_count);
     if (tiles <= 0 || tiles > 0x7fffffff) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_order_tiles: bad image or strip description");
     int total = (int)tiles;
     HIP_CHECK(hipSetDevice(p->device));
     HIP_CHECK(hipMemsetAsync(tile_order, 0, 128, (hipStream_t)stream));
+    // how far (in tiles) a tile looks around itself in the history: the image may have moved by that much since
+    static const int reach_default = [] { const char* e = getenv("GR_TILE_HISTORY_REACH"); int v = e ? atoi(e) : 2; return (v >= 0 && v <= 8) ? v : 2; }();
+    int history_reach = reach_default;
     for (int phase = 0; phase < 2; phase++) {
         void* args[] = {&term, &cell_attempts, &prepass_width, &prepass_height, &width, &height, &block_rows, &strip_rank, &strip_count,
-                        &total, &tile_order, &phase};
+                        &total, &tile_order, &phase, &tile_history, &history_reach};
         int rc = launch(p, K_ORDER_TILES, stream, blocks(total, 1024), 1, 1024, 1, args);
         if (rc != GR_OK) return rc;
     }
     return GR_OK;
+}
+
+int gr_order_tiles(gr_program* p, void* stream, const void* term, const void* cell_attempts, int prepass_width, int prepass_height,
+                   int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order) {
+    if (!p || !term || !cell_attempts || !tile_order || prepass_width <= 0 || prepass_height <= 0)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "gr_order_tiles: null argument or no prepass");
+    return order_tiles_launch(p, stream, term, cell_attempts, prepass_width, prepass_height, width, height, block_rows, strip_rank, strip_count,
+                              tile_order, nullptr);
+}
+
+int gr_order_tiles_by_history(gr_program* p, void* stream, const void* tile_history, int width, int height, int block_rows, int strip_rank,
+                              int strip_count, void* tile_order) {
+    if (!p || !tile_history || !tile_order) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_order_tiles_by_history: null argument");
+    return order_tiles_launch(p, stream, nullptr, nullptr, 0, 0, width, height, block_rows, strip_rank, strip_count, tile_order, tile_history);
+}
+
+// workgroups of `wg` lanes of a trace kernel the device holds at once (asked of the runtime once per kernel); < 0: -error code
+static long long resident_trace_groups(gr_program* p, int kernel_index, int wg) {
+    if (!p->resident_groups_per_cu[kernel_index]) {
+        int n = 0;
+        if (hipSetDevice(p->device) != hipSuccess) return -(long long)fail(GR_ERROR_DEVICE, "hipSetDevice");
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, p->fn[kernel_index], wg, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 4 * 8 * 64 / wg;
+        }
+        p->resident_groups_per_cu[kernel_index] = n;
+    }
+    return (long long)p->compute_units * p->resident_groups_per_cu[kernel_index];
+}
+
+long long gr_trace_fused_wave_slots(gr_program* p) {
+    if (!p) return 0;
+    const long long groups = resident_trace_groups(p, K_TRACE_FUSED, 256);
+    return groups < 0 ? 0 : groups * 4;
 }
 
 // gr_trace_fused (rays_per_lane 1) and gr_trace_pair (2): same tiles, same arguments; a pair wave takes two tile-waves
@@ -934,15 +969,17 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
                         int width, int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,
                         int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
                         const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0, const void* tile_order = nullptr,
-                        int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr, int inline_prepass = 0) {
+                        int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr, int inline_prepass = 0, void* tile_cost = nullptr,
+                        int tile_order_by_history = 0) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
     // the prepass inside the launch: its cell waves are the first tickets (gr_trace_fused's prepass_tickets)
     int prepass_tickets = 0;
     if (inline_prepass) {
-        if (rays_per_lane != 1 || lattice != 1 || pending_only || tile_order || !term || prepass_width <= 0 || prepass_height <= 0 ||
-            prepass_width == width || prepass_height == height)
-            return fail(GR_ERROR_INVALID_ARGUMENT, "inline_prepass: gr_trace_fused on every pixel of its rows in image order, with a prepass grid");
+        if (rays_per_lane != 1 || lattice != 1 || pending_only || (tile_order && !tile_order_by_history) || !term || prepass_width <= 0 ||
+            prepass_height <= 0 || prepass_width == width || prepass_height == height)
+            return fail(GR_ERROR_INVALID_ARGUMENT, "inline_prepass: gr_trace_fused on every pixel of its rows, in image order or the order of "
+                                                   "gr_order_tiles_by_history (gr_order_tiles' needs the prepass first), with a prepass grid");
         prepass_tickets = (int)(((long long)prepass_width * prepass_height + 63) / 64);
     }
     if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && rays_per_lane != 1))
@@ -982,16 +1019,8 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     // experiment hook: GR_TRACE_WAVES_PER_SIMD=k launches k persistent waves per SIMD whatever fits (occupancy studies)
     static const int forced_waves_per_simd = [] { const char* e = getenv("GR_TRACE_WAVES_PER_SIMD"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 0; }();
     const int kernel_index = rays_per_lane == 2 ? K_TRACE_PAIR : K_TRACE_FUSED;
-    if (!p->resident_groups_per_cu[kernel_index]) {
-        int n = 0;
-        HIP_CHECK(hipSetDevice(p->device));
-        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, p->fn[kernel_index], wg, 0) != hipSuccess || n < 1) {
-            (void)hipGetLastError();
-            n = 4 * 8 * 64 / wg;
-        }
-        p->resident_groups_per_cu[kernel_index] = n;
-    }
-    long long resident_groups = (long long)p->compute_units * p->resident_groups_per_cu[kernel_index];
+    long long resident_groups = resident_trace_groups(p, kernel_index, wg);
+    if (resident_groups < 0) return (int)-resident_groups;
     // a caller that keeps several frames in flight may take fewer slots per launch: two smaller launches then share the device
     // and the one drains while the other is in full swing (gr_frame_options.trace_waves_per_simd)
     if (forced_waves_per_simd)
@@ -1025,9 +1054,18 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         shading.bg_width = shading_in->bg_width; shading.bg_height = shading_in->bg_height; shading.bg_levels = shading_in->bg_levels;
         shading.most_probes = shading_in->max_probes; shading.compact_out = strip_count > 1 ? shading_in->compact_out : 0;
     }
+    if (tile_cost) {
+        if (rays_per_lane != 1 || lattice != 1 || pending_only)
+            return fail(GR_ERROR_INVALID_ARGUMENT, "tile_cost: gr_trace_fused on every pixel of its rows");
+        HIP_CHECK(hipSetDevice(p->device));
+        HIP_CHECK(hipMemsetAsync(tile_cost, 0, (size_t)total_waves * sizeof(unsigned int), (hipStream_t)stream));
+    }
+    // gr_order_tiles' last class is a promise (nothing to trace, nothing to look up); gr_order_tiles_by_history's a guess
+    int last_class_is_skipped = (tile_order && !tile_order_by_history) ? 1 : 0;
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
-                    &lattice, &pending_only, &tile_order, &shading, &prepass_tickets, &ticket_tiles};   // the last six: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
+                    &lattice, &pending_only, &tile_order, &shading, &prepass_tickets, &ticket_tiles, &tile_cost,
+                    &last_class_is_skipped};   // the last eight: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
     return launch(p, kernel_index, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
@@ -1065,7 +1103,7 @@ int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args
     return trace_launch(p, 1, stream, a->camera_generic, a->camera_quat, a->render_data, a->width, a->height, a->block_rows, a->strip_rank,
                         a->strip_count, a->termination_buffer, a->prepass_width, a->prepass_height, a->e0, a->e1, a->e2, a->e3, a->cfg, a->dfg,
                         a->attempt_counter, a->lattice == 2 ? 2 : 1, a->pending_only ? 1 : 0, a->tile_order, a->waves_per_simd, &a->shading,
-                        a->inline_prepass ? 1 : 0);
+                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

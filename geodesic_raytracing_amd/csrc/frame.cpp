@@ -4,6 +4,9 @@
 // launches on one in-order queue), execute_kernel main.cpp:139-205.  Everything is asynchronous on
 // the caller's stream; the only host->device traffic per frame is camera (48 B), cfg and features.
 // library default of gr_frame_options.rays_per_lane = 0 (see include/geodesic_hip.h)
+#ifndef GR_DEFAULT_TILE_HISTORY
+#define GR_DEFAULT_TILE_HISTORY 1
+#endif
 #ifndef GR_DEFAULT_RAYS_PER_LANE
 #define GR_DEFAULT_RAYS_PER_LANE 2   /* where the program has gr_trace_pair (capi.cpp: pair_kernel_applies) */
 #endif
@@ -15,6 +18,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
 
 #include "../../include/geodesic_hip.h"
 
@@ -53,6 +57,11 @@ struct gr_render_state {
     void* termination_buffer = nullptr;
     void* tile_order = nullptr;      // the order the persistent trace hands its tiles out in (gr_order_tiles)
     size_t tile_order_bytes = 0;
+    // what each tile of the last fused frame cost (gr_trace_fused_args.tile_cost) and the frame shape that goes with it: the next
+    // frame's tiles are handed out dearest first by it (gr_frame_options.tile_history)
+    void* tile_cost = nullptr;
+    int tile_cost_shape[3] = {0, 0, 0};   // block_rows, strip_rank, strip_count
+    bool tile_cost_valid = false;
     size_t ray_capacity = 0;
     hipEvent_t ev_start[GR_STAGE_COUNT] = {};
     hipEvent_t ev_stop[GR_STAGE_COUNT] = {};
@@ -161,6 +170,39 @@ struct gr_geodesic_camera {
 
 extern "C" {
 
+// Is an earlier fused frame still on this device when the next one is submitted?  (What tile_history's default asks: a frame that
+// has the device to itself ends when its last tile ends, and the order of its tiles decides when that is; frames that overlap fill
+// each other's tails, and there the order measured 3-4 % slower than image order.)  The end of every fused frame is marked with an
+// event; the question is whether the latest such mark has been reached.
+namespace {
+struct device_activity {
+    std::mutex lock;
+    hipEvent_t marks[4] = {};
+    unsigned int used = 0;
+};
+device_activity g_activity[64];
+
+bool earlier_frame_still_running(int device) {
+    if (device < 0 || device >= 64) return false;
+    auto& a = g_activity[device];
+    std::lock_guard<std::mutex> hold(a.lock);
+    if (!a.used) return false;
+    const hipError_t e = hipEventQuery(a.marks[(a.used - 1) % 4]);
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return true; }
+    return false;
+}
+
+void mark_frame_end(int device, hipStream_t stream) {
+    if (device < 0 || device >= 64) return;
+    auto& a = g_activity[device];
+    std::lock_guard<std::mutex> hold(a.lock);
+    hipEvent_t& e = a.marks[a.used % 4];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return; }
+    if (hipEventRecord(e, stream) == hipSuccess) a.used++;
+    else (void)hipGetLastError();
+}
+}   // namespace
+
 void gr_camera_default(gr_camera* c) {
     if (!c) return;
     // camera::camera(), main.cpp:669-673: rot.load_from_axis_angle({1, 0, 0, -pi/2})
@@ -195,6 +237,7 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->trace_waves_per_simd = 0;
     o->fused_shading = -1;
     o->inline_prepass = -1;
+    o->tile_history = -1;
     o->next_camera = nullptr;
     o->geodesic = nullptr;
     o->geodesic_time = 0;
@@ -292,6 +335,7 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
     const size_t order_bytes = (px / 16 + 2 * (size_t)width + 8192) * sizeof(unsigned int);
     A(&s->tile_order, order_bytes);
     s->tile_order_bytes = order_bytes;
+    A(&s->tile_cost, order_bytes / 2);
     for (auto& slot : s->pre) {
         A(&slot.set.camera_pos_cart, 16);
         A(&slot.set.camera_quat, 16);
@@ -331,7 +375,8 @@ void gr_render_state_destroy(gr_render_state* s) {
     (void)hipSetDevice(s->device);
     std::vector<void*> ptrs = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
                                s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
-                               s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->tile_order};
+                               s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->tile_order,
+                               s->tile_cost};
     for (auto& slot : s->pre) {
         if (slot.stream) { (void)hipStreamSynchronize(slot.stream); (void)hipStreamDestroy(slot.stream); }
         if (slot.ready) (void)hipEventDestroy(slot.ready);
@@ -745,7 +790,18 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // Default: on a device's share of a split frame (+8 % with three frames in flight, +35 % one frame at a time, one of 8
         // devices), not on a whole frame (there image order measured 2 % faster); GR_TILE_ORDER=0 never, =1 always.
         static const int tile_order_mode = [] { const char* e = getenv("GR_TILE_ORDER"); return !e ? -1 : e[0] == '0' ? 0 : 1; }();
-        const bool tile_order_enabled = tile_order_mode == 1 || (tile_order_mode == -1 && strip_count > 1);
+        // The other source of an order: what the tiles of this state's previous frame cost (gr_order_tiles_by_history).
+        static const int history_default = [] { const char* e = getenv("GR_TILE_HISTORY"); return !e ? GR_DEFAULT_TILE_HISTORY : e[0] != '0'; }();
+        // Default: whole frames that find the device idle when they are submitted (they record their costs, and follow those of
+        // the frame before if that one did too).
+        // Not frames of more than 32 tiles per wave slot (8K Alcubierre: 72 short tiles of much the same cost; recording and sorting
+        // them measured +3 % on the frame, with nothing to gain).
+        const long long tile_words = gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) / 8;
+        const bool history_wanted = (opt.tile_history < 0 ? history_default != 0 && strip_count == 1 && tile_words <= 32 * gr_trace_fused_wave_slots(p)
+                                                          : opt.tile_history != 0) && !adaptive &&
+                                    (size_t)gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
+        const bool device_busy = history_wanted && opt.tile_history < 0 && earlier_frame_still_running(s->device);
+        const bool tile_order_enabled = !history_wanted && (tile_order_mode == 1 || (tile_order_mode == -1 && strip_count > 1));
         const size_t cells = use_prepass ? (size_t)prepass_width * prepass_height : 0;
         // (a frame whose prepass rides in its trace launch - below - has no costs to order by; the frames it announces still do)
         const bool order_capable = tile_order_enabled && use_prepass && !adaptive && 2 * cells <= (size_t)width * height &&
@@ -786,6 +842,11 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         const bool inline_prepass = inline_wanted && !prefetched && one_launch_setup && use_prepass && !adaptive && keep_lanes == 0 && rays_per_lane == 1 &&
                                     prepass_width != width && prepass_height != height;
         const bool order_tiles = order_capable && !inline_prepass;
+        // (the kernels that record and follow the history are gr_trace_fused's: one ray per lane, no compaction)
+        const bool record_history = history_wanted && !device_busy && keep_lanes == 0 && rays_per_lane == 1;
+        if (history_wanted && !record_history) s->tile_cost_valid = false;   // (what is there would be older than the last frame)
+        const int shape[3] = {block_rows, strip_rank, strip_count};
+        const bool history_order = record_history && s->tile_cost_valid && memcmp(shape, s->tile_cost_shape, sizeof(shape)) == 0;
         if (!prefetched && one_launch_setup) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_camera_prepass(p, stream, s->camera_pos_cart, camera->flip, camera->basis_speed, s->camera_pos_generic, s->tetrad[0],
@@ -889,6 +950,16 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.e0 = s->tetrad[0]; a.e1 = s->tetrad[1]; a.e2 = s->tetrad[2]; a.e3 = s->tetrad[3]; a.cfg = s->cfg; a.dfg = s->dfg;
                 a.attempt_counter = attempts;
                 a.tile_order = order_tiles ? s->tile_order : nullptr;
+                if (history_order) {
+                    GR_CHECK(gr_order_tiles_by_history(p, stream, s->tile_cost, width, height, block_rows, strip_rank, strip_count, s->tile_order));
+                    a.tile_order = s->tile_order;
+                    a.tile_order_by_history = 1;
+                }
+                if (record_history) {
+                    a.tile_cost = s->tile_cost;
+                    memcpy(s->tile_cost_shape, shape, sizeof(shape));
+                    s->tile_cost_valid = true;
+                }
                 a.waves_per_simd = opt.trace_waves_per_simd;
                 a.inline_prepass = inline_prepass ? 1 : 0;
                 // the trace shades the pixels whose filter neighbours are in their own tile; gr_render_seams below does the rest
@@ -956,6 +1027,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                           strip_count > 1 ? opt.compact_out : 0, opt.max_probes, s->cfg, s->dfg));
             GR_CHECK(end(GR_STAGE_RENDER));
         }
+        if (history_wanted) mark_frame_end(s->device, stream);
         return GR_OK;
     }
 

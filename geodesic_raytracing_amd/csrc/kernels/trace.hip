@@ -292,7 +292,8 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            int prepass_height, const float4* __restrict__ e0, const float4* __restrict__ e1,
                                            const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
                                            unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
-                                           const trace_shading& shading, bool known_skipped, int cell_wave, bool cells_in_flight) {
+                                           const trace_shading& shading, bool known_skipped, int cell_wave, bool cells_in_flight,
+                                           unsigned int* __restrict__ tile_cost) {
     // cell_wave >= 0: this "tile" is 64 cells of the low-resolution prepass (prepass_cell, below) traced by the launch itself:
     // the ray of cell (cx, cy) of the prepass grid, and its verdict goes to the termination buffer instead of a record.
     // cells_in_flight: the launch has such waves, so a tile waits for the cells its pixels look at.
@@ -407,6 +408,9 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     // not into one word: a same-address atomic per tile is a second ticket counter (an 8K Alcubierre frame, 518 400 short tiles,
     // measured 6.5 ms counted into one word and 3.7 ms uncounted).  The host adds the words up (gr_render_state_attempts).
     if (attempt_counter) atomicAdd(attempt_counter + GR_ATTEMPT_COUNTERS_AT + (blockIdx.x % GR_ATTEMPT_COUNTERS), (unsigned long long)tries);
+    // what the tile cost - the attempts of its longest ray, which is how long the wave was busy - for the next frame's order
+    // (gr_order_tiles_by_history): again one atomic per tile-wave after the compiler's wave reduction, every tile to a word of its own
+    if (tile_cost) atomicMax(tile_cost + __builtin_amdgcn_readfirstlane(wave), tries);   // (uniform by construction; said so for the reduction)
 }
 
 // workgroup size of the fused trace kernel: 4 tile-waves, one per SIMD of a CU (capi.cpp launches with the same number)
@@ -424,7 +428,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
                int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
-               int prepass_tickets, int ticket_tiles) {
+               int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped) {
     // prepass_tickets > 0 (persistent launches in image order only): the first prepass_tickets tickets are the waves of the
     // low-resolution prepass, then come the tiles, which wait for the cells they look at (trace_tile).  A frame whose camera was not
     // known in advance then pays the prepass's single-ray latency once per cell wave alongside the first tiles instead of as a
@@ -444,8 +448,10 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
     // frame, handed out back to back at the end of the list, would add 0.7 ms of pure ticket traffic to the launch.
     int held = 0, cursor = 0;   // tiles this wave still holds from its last ticket, and where in the list they start
     bool known_skipped = false;  // the ticket was a chunk of the last class
-    const int tickets_total = total_waves + (prepass_tickets > 0 ? prepass_tickets : 0);   // (no tile order with prepass tickets)
-    const int singles = (tile_counter && tile_order) ? total_waves - (int)tile_order[GR_TILE_CLASSES - 1] : tickets_total;
+    // ticket space: the prepass's cell waves, then the tiles - in the list's order if there is one
+    const int cell_tickets = prepass_tickets > 0 ? prepass_tickets : 0;
+    const int tickets_total = total_waves + cell_tickets;
+    const int singles = (tile_counter && tile_order) ? tickets_total - (int)tile_order[GR_TILE_CLASSES - 1] : tickets_total;
     for (;;) {
         if (tile_counter) {
             if (held == 0) {
@@ -456,7 +462,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                 // waves: the one counter serves ~10^8 tickets a second, and the 518 400 short tiles of an 8K Alcubierre frame
                 // were waiting for it more than they traced), then GR_SKIP_CHUNK entries of the last class
                 const int single_tickets = (singles + ticket_tiles - 1) / ticket_tiles;
-                known_skipped = tile_order && drawn >= single_tickets;
+                known_skipped = tile_order && last_class_is_skipped && drawn >= single_tickets;
                 if (drawn < single_tickets) {
                     cursor = drawn * ticket_tiles;
                     held = singles - cursor < ticket_tiles ? singles - cursor : ticket_tiles;
@@ -466,7 +472,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                 }
                 if (held <= 0) break;
             }
-            wave = tile_order ? (int)tile_order[GR_TILE_ORDER_HEADER + cursor] : cursor;
+            wave = (tile_order && cursor >= cell_tickets) ? cell_tickets + (int)tile_order[GR_TILE_ORDER_HEADER + cursor - cell_tickets] : cursor;
             cursor++;
             held--;
         }
@@ -483,7 +489,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
         GR_PROBE_TILE_BEGAN
         trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
                    termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
-                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0);
+                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost);
         GR_PROBE_TILE_ENDED
         if (!tile_counter) break;
     }
@@ -803,10 +809,37 @@ __device__ __forceinline__ int tile_cost_class(int tile, int width, int height, 
     return GR_TILE_CLASSES - 2 - (steps > 13 ? 13 : steps);
 }
 
+// The other estimate: what the tiles cost in the frame before (tile_history: the attempts of each tile's longest ray, left by that
+// frame's gr_trace_fused).  A camera that moves a little per frame - any interactive one - sees nearly the same costs again, and
+// they are exact where the prepass's one ray per 16x16 pixels only samples: the rays that circle the hole many times before they
+// leave are filaments a pixel or two wide, and the tile one of them crosses is ten times its neighbours.  The tile's estimate is
+// the largest cost among itself and the tiles within `reach` of it (the filament may have moved on by a tile or two).  Classes: an octave of
+// attempts each, dearest first; the last class - nothing traced in the tile or around it - is handed out in chunks like the
+// prepass order's, but as a guess, not a promise: its tiles look their pixels up like any other.
+__device__ __forceinline__ int tile_history_class(int tile, int width, int block_rows, int strip_count, const unsigned int* __restrict__ tile_history,
+                                                  int reach) {
+    const int tiles_x = (width + GR_TILE - 1) / GR_TILE, tile_rows = block_rows / GR_TILE;
+    const int per_block = tiles_x * tile_rows + (strip_count > 1 ? (width + 63) / 64 : 0);
+    const int block = tile / per_block, within = tile % per_block;
+    unsigned int dearest = tile_history[tile];
+    if (within < tiles_x * tile_rows) {
+        const int tx = within % tiles_x, ty = within / tiles_x;
+        for (int dy = -reach; dy <= reach; dy++)
+            for (int dx = -reach; dx <= reach; dx++) {
+                const int x = min(max(tx + dx, 0), tiles_x - 1), y = min(max(ty + dy, 0), tile_rows - 1);
+                const unsigned int c = tile_history[block * per_block + y * tiles_x + x];
+                dearest = c > dearest ? c : dearest;
+            }
+    }
+    if (dearest == 0) return GR_TILE_CLASSES - 1;
+    const int octave = 31 - __builtin_clz(dearest);   // 16384 attempts (the step cap) = 14
+    return GR_TILE_CLASSES - 2 - (octave > GR_TILE_CLASSES - 2 ? GR_TILE_CLASSES - 2 : octave);
+}
+
 extern "C" __global__ void __launch_bounds__(1024)
 gr_order_tiles(const int* __restrict__ termination_buffer, const unsigned int* __restrict__ cell_attempts, int prepass_width,
                int prepass_height, int width, int height, int block_rows, int strip_rank, int strip_count, int total_tiles,
-               unsigned int* __restrict__ list, int phase) {
+               unsigned int* __restrict__ list, int phase, const unsigned int* __restrict__ tile_history, int history_reach) {
     // one atomic per class and WORKGROUP on the device-wide counters: they are single addresses that every XCD contends for
     // (~50 ns an atomic; per wave the 2 000 waves of a 4K frame spent 0.1 ms on them), the waves of a workgroup meet in LDS
     __shared__ unsigned int group_count[GR_TILE_CLASSES], group_base[GR_TILE_CLASSES];
@@ -818,8 +851,9 @@ gr_order_tiles(const int* __restrict__ termination_buffer, const unsigned int* _
     int cls = -1;
     if (tile < total_tiles) {
         if (phase == 0) {
-            cls = tile_cost_class(tile, width, height, block_rows, strip_rank, strip_count, termination_buffer, cell_attempts, prepass_width,
-                                  prepass_height);
+            cls = tile_history ? tile_history_class(tile, width, block_rows, strip_count, tile_history, history_reach)
+                               : tile_cost_class(tile, width, height, block_rows, strip_rank, strip_count, termination_buffer, cell_attempts,
+                                                 prepass_width, prepass_height);
             classes[tile] = (unsigned int)cls;
         } else {
             cls = (int)classes[tile];

@@ -298,6 +298,12 @@ int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, fl
 long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_rank, int strip_count);
 int gr_order_tiles(gr_program* p, void* stream, const void* termination_buffer, const void* cell_attempts, int prepass_width,
                    int prepass_height, int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order);
+/* The same list from what the tiles cost in an earlier frame of the same size and strip description (tile_history: the tile_cost a
+ * gr_trace_fused_launch left): exact where the prepass rays sample - the long rays near the photon orbits are filaments a pixel or
+ * two wide - as long as the camera moves little between the two frames (a tile takes the largest cost among itself and its eight
+ * neighbours).  Needs no prepass, so it combines with inline_prepass.  Pass the list with tile_order_by_history = 1. */
+int gr_order_tiles_by_history(gr_program* p, void* stream, const void* tile_history, int width, int height, int block_rows,
+                              int strip_rank, int strip_count, void* tile_order);
 
 /* Counter block of the fused trace launchers (their `attempt_counter`; NULL = count nothing): GR_COUNTER_WORDS uint64 words on
  * the device, zeroed by the caller.  [0] attempts of the pair / compaction kernels, [1] summed wave lifetimes in shader cycles,
@@ -349,9 +355,16 @@ typedef struct gr_trace_fused_args {
                          * to a wave, and a tile waits for the cells its pixels look at (device-scope flags in termination_buffer,
                          * which must be writable and is reset by the call).  Image order only (no tile_order), lattice 1; a device's
                          * share of a split frame traces the cells its rows look at and leaves the others unknown.  Camera and tetrad must be on the device already (gr_camera_prepass with a 0 x 0
-                         * grid).  Records and flags are those of the two-launch sequence. */
+                         * grid).  Records and flags are those of the two-launch sequence.  With tile_order_by_history the tiles
+                         * behind the cell waves follow tile_order. */
+    void* tile_cost;    /* not NULL: unsigned[number of the device's tiles = (gr_tile_order_bytes - 128) / 8]; the launch leaves what
+                         * each tile cost there (the attempts of its longest ray) for gr_order_tiles_by_history.  Every pixel, one ray per lane. */
+    int tile_order_by_history;   /* 1: tile_order is gr_order_tiles_by_history's list (its last class is looked up like any tile) */
 } gr_trace_fused_args;
 int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args* args);
+/* waves of gr_trace_fused the program's device holds at once (what a persistent launch fills it with): a frame of many more tiles than
+ * that has a short tail whatever the order of its tiles */
+long long gr_trace_fused_wave_slots(gr_program* p);
 /* the pixels such a launch leaves to shade: same arguments as gr_render_strips (strip_count <= 1: the whole image) */
 int gr_render_seams(gr_program* p, void* stream, const void* render_data, void* out_rgba_f32,
                     const void* background1, const void* background2, int bg_width, int bg_height, int bg_levels,
@@ -482,6 +495,10 @@ typedef struct gr_frame_options {
     int trace_waves_per_simd;   /* fused mode: persistent waves per SIMD a trace launch takes, 1..8; 0 = as many as fit (best for
                             * one frame at a time).  With three or more frames in flight on streams of their own, 4 measured
                             * 2-3 % faster than all: the launches then share the device instead of queueing for it. */
+    int tile_history;      /* fused mode, one ray per lane: 1 = hand the tiles of this frame out dearest first by what they cost in this
+                            * render state's previous frame (gr_order_tiles_by_history; the first frame, or one of another strip
+                            * description, goes in image order); every such frame records its tiles' costs.  Scheduling only: the
+                            * pixels do not depend on it.  0 = no; -1 = library default */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 

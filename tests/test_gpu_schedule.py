@@ -84,6 +84,90 @@ def test_ordered_trace_equals_image_order_bit_for_bit():
     assert (records[0]["terminated"] == 2).any() and (records[0]["terminated"] == 1).any()
 
 
+def trace_with(prog, state, rd, **extra):
+    b = state.buffer
+    pw, ph = W // 16, H // 16
+    a = gra.TraceFusedArgs(camera_generic=b(gra.BUF_CAMERA_GENERIC), camera_quat=b(gra.BUF_CAMERA_QUAT), render_data=rd.ptr, width=W, height=H,
+                           block_rows=0, strip_rank=0, strip_count=1, termination_buffer=b(gra.BUF_TERMINATION), prepass_width=pw,
+                           prepass_height=ph, e0=b(gra.BUF_TETRAD0), e1=b(gra.BUF_TETRAD1), e2=b(gra.BUF_TETRAD2), e3=b(gra.BUF_TETRAD3),
+                           cfg=b(gra.BUF_CFG), dfg=b(gra.BUF_DFG), **extra)
+    check(lib.gr_trace_fused_launch(prog.handle, None, ctypes.byref(a)))
+    check(lib.gr_device_synchronize(0))
+    return download(0, rd.ptr, RENDER_DATA_DTYPE, W * H)
+
+
+def test_tile_costs_and_the_order_made_from_them():
+    """gr_trace_fused_args.tile_cost: every tile's entry is the attempts of its longest ray (0 where the prepass lets the whole tile be
+    skipped), the records are those of a launch that does not record; gr_order_tiles_by_history: every tile once, classes by the octave
+    of the dearest cost within two tiles, the last class (nothing traced around) not a promise; a launch that follows the list - also
+    with the prepass inside it - writes the same records"""
+    prog, state = traced_state()
+    rows = ((H + 7) // 8) * 8
+    nbytes = lib.gr_tile_order_bytes(W, H, rows, 0, 1)
+    tiles = (nbytes // 4 - 32) // 2
+    assert tiles == (W // 8) * (rows // 8)
+    rd = DeviceBuffer(0, W * H * RENDER_DATA_DTYPE.itemsize)
+    plain = trace_with(prog, state, rd)
+    cost = DeviceBuffer.from_numpy(0, np.full(tiles, 0xdeadbeef, dtype=np.uint32))   # the launch resets it
+    attempts = DeviceBuffer.from_numpy(0, np.zeros(512, dtype=np.uint64))
+    recorded = trace_with(prog, state, rd, tile_cost=cost.ptr, attempt_counter=attempts.ptr)
+    assert recorded.tobytes() == plain.tobytes()
+    costs = cost.to_numpy(np.uint32, (tiles,))
+    counted = attempts.to_numpy(np.uint64, (512,))
+    total_attempts = int(counted[0] + counted[256:].sum())
+    traced = (plain["terminated"].reshape(H, W) != 2)
+    per_tile_traced = np.add.reduceat(np.add.reduceat(np.pad(traced, ((0, rows - H), (0, 0))), np.arange(0, rows, 8), axis=0),
+                                      np.arange(0, W, 8), axis=1).reshape(-1)
+    assert ((costs > 0) == (per_tile_traced > 0)).all()            # a tile costs something exactly when one of its pixels is traced
+    assert costs.max() <= 16384 + 64 and costs.max() > 1000        # the shadow's edge: rays near the step cap
+    assert total_attempts >= int(costs.astype(np.int64).sum())      # the longest ray of every tile is one of its rays
+    assert total_attempts <= int((costs.astype(np.int64) * per_tile_traced).sum())
+    order = DeviceBuffer(0, nbytes)
+    check(lib.gr_order_tiles_by_history(prog.handle, None, cost.ptr, W, H, rows, 0, 1, order.ptr))
+    check(lib.gr_device_synchronize(0))
+    words = order.to_numpy(np.uint32, (nbytes // 4,))
+    counts, listed, classes = words[:16], words[32:32 + tiles], words[32 + tiles:]
+    assert counts.sum() == tiles and np.array_equal(np.sort(listed), np.arange(tiles, dtype=np.uint32))
+    assert (np.diff(classes[listed].astype(np.int64)) >= 0).all()
+    grid = costs.reshape(rows // 8, W // 8)
+    padded = np.pad(grid, 2, mode="edge")
+    dearest = np.max([padded[2 + dy:2 + dy + grid.shape[0], 2 + dx:2 + dx + grid.shape[1]] for dy in range(-2, 3) for dx in range(-2, 3)], axis=0)
+    octave = np.floor(np.log2(np.maximum(dearest, 1))).astype(np.int64)
+    want = np.where(dearest == 0, 15, 14 - np.minimum(octave, 14)).reshape(-1)
+    assert np.array_equal(classes.astype(np.int64), want)
+    assert counts[15] > 0 and counts[:5].sum() > 0
+    for inline in (0, 1):
+        followed = trace_with(prog, state, rd, tile_order=order.ptr, tile_order_by_history=1, inline_prepass=inline, tile_cost=cost.ptr)
+        assert followed.tobytes() == plain.tobytes()
+        assert np.array_equal(cost.to_numpy(np.uint32, (tiles,)), costs)
+
+
+@pytest.mark.parametrize("strip", [(0, 1, 0), (1, 3, 48)])
+def test_frames_that_follow_the_last_frames_costs_are_bit_identical(strip):
+    """gr_frame_options.tile_history: the second and third frame of a render state hand their tiles out by what the frame before
+    cost, with the camera where it was and moved on; the pixels are those of frames in image order (tile_history = 0)"""
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv = metric.cfg_values(a=0.45)
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    dbg, levels = background()
+    out = DeviceBuffer(0, W * H * 16)
+    pictures = {}
+    for history in (0, 1, -1):
+        state = gra.RenderState(W, H, 0)
+        for k, shift in enumerate((0.0, 0.0, 0.05)):
+            camera = gra.default_camera()
+            camera.position[1] += shift
+            o = gra.frame_options(mode=gra.MODE_FUSED, tile_history=history, strip_rank=strip[0], strip_count=strip[1], block_rows=strip[2])
+            state.render(prog, metric, camera, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv, o)
+            state.synchronize()
+            pictures[(history, k)] = out.to_numpy(np.float32, (H, W, 4)).copy()
+    for k in range(3):
+        assert pictures[(1, k)].tobytes() == pictures[(0, k)].tobytes()
+        assert pictures[(-1, k)].tobytes() == pictures[(0, k)].tobytes()
+    assert pictures[(0, 2)].tobytes() != pictures[(0, 1)].tobytes()   # the camera did move
+
+
 def test_frame_with_fewer_wave_slots_is_bit_identical():
     """gr_frame_options.trace_waves_per_simd only sizes the launch"""
     frames = []
