@@ -131,7 +131,7 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),
     "gr_tile_order_bytes": (ctypes.c_longlong, [c_int, c_int, c_int, c_int, c_int]),
     "gr_order_tiles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "gr_order_tiles_by_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gr_order_tiles_by_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int]),
     "gr_trace_fused_launch": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TraceFusedArgs)]),
     "gr_trace_fused_wave_slots": (ctypes.c_longlong, [c_void_p]),
     "gr_render_seams": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

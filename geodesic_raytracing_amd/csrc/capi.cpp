@@ -911,7 +911,8 @@ long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_r
 }
 
 static int order_tiles_launch(gr_program* p, void* stream, const void* term, const void* cell_attempts, int prepass_width, int prepass_height,
-                              int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order, const void* tile_history) {
+                              int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order, const void* tile_history,
+                              int shift_x = 0, int shift_y = 0) {
     if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + 7) / 8) * 8; }
     long long tiles = device_tile_count(width, height, block_rows, strip_rank, strip_count);
     if (tiles <= 0 || tiles > 0x7fffffff) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_order_tiles: bad image or strip description");
@@ -923,7 +924,7 @@ static int order_tiles_launch(gr_program* p, void* stream, const void* term, con
     int history_reach = reach_default;
     for (int phase = 0; phase < 2; phase++) {
         void* args[] = {&term, &cell_attempts, &prepass_width, &prepass_height, &width, &height, &block_rows, &strip_rank, &strip_count,
-                        &total, &tile_order, &phase, &tile_history, &history_reach};
+                        &total, &tile_order, &phase, &tile_history, &history_reach, &shift_x, &shift_y};
         int rc = launch(p, K_ORDER_TILES, stream, blocks(total, 1024), 1, 1024, 1, args);
         if (rc != GR_OK) return rc;
     }
@@ -939,9 +940,10 @@ int gr_order_tiles(gr_program* p, void* stream, const void* term, const void* ce
 }
 
 int gr_order_tiles_by_history(gr_program* p, void* stream, const void* tile_history, int width, int height, int block_rows, int strip_rank,
-                              int strip_count, void* tile_order) {
+                              int strip_count, void* tile_order, int shift_x, int shift_y) {
     if (!p || !tile_history || !tile_order) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_order_tiles_by_history: null argument");
-    return order_tiles_launch(p, stream, nullptr, nullptr, 0, 0, width, height, block_rows, strip_rank, strip_count, tile_order, tile_history);
+    return order_tiles_launch(p, stream, nullptr, nullptr, 0, 0, width, height, block_rows, strip_rank, strip_count, tile_order, tile_history,
+                              shift_x, shift_y);
 }
 
 // workgroups of `wg` lanes of a trace kernel the device holds at once (asked of the runtime once per kernel); < 0: -error code

@@ -62,6 +62,9 @@ struct gr_render_state {
     void* tile_cost = nullptr;
     int tile_cost_shape[3] = {0, 0, 0};   // block_rows, strip_rank, strip_count
     bool tile_cost_valid = false;
+    float tile_cost_anchor[2] = {0, 0};   // the pixel that frame's camera saw the coordinate origin at (origin_on_screen)
+    bool tile_cost_anchored = false;
+    gr_camera tile_cost_camera{};
     size_t ray_capacity = 0;
     hipEvent_t ev_start[GR_STAGE_COUNT] = {};
     hipEvent_t ev_stop[GR_STAGE_COUNT] = {};
@@ -169,6 +172,43 @@ struct gr_geodesic_camera {
 };
 
 extern "C" {
+
+// Where a camera sees the coordinate origin, in pixels, as if space were flat (the inverse of the kernels' pixel_direction).  Between
+// two frames of a moving or turning camera the picture of whatever sits there - the hole, the bubble, the throat, which is where the
+// dear tiles are - moves by about as much as this point does; false if the origin is behind the camera or the camera sits on it.
+static bool origin_on_screen(const gr_camera& c, float fov_degrees, int width, int height, float out[2]) {
+    const double px = c.position[1], py = c.position[2], pz = c.position[3];
+    const double r = std::sqrt(px * px + py * py + pz * pz);
+    double qx = c.quat[0], qy = c.quat[1], qz = c.quat[2], qw = c.quat[3];
+    const double qn = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+    if (!(r > 1e-6) || !(qn > 1e-6)) return false;
+    qx = -qx / qn; qy = -qy / qn; qz = -qz / qn; qw /= qn;   // the inverse rotation: world -> camera
+    const double d[3] = {-px / r, -py / r, -pz / r};
+    const double t[3] = {2 * (qy * d[2] - qz * d[1]), 2 * (qz * d[0] - qx * d[2]), 2 * (qx * d[1] - qy * d[0])};
+    const double v[3] = {d[0] + qw * t[0] + (qy * t[2] - qz * t[1]), d[1] + qw * t[1] + (qz * t[0] - qx * t[2]),
+                         d[2] + qw * t[2] + (qx * t[1] - qy * t[0])};
+    if (!(v[2] > 0.05)) return false;
+    const double f_stop = (width / 2.0) / std::tan(fov_degrees / 360.0 * M_PI);
+    out[0] = (float)(width / 2.0 + f_stop * v[0] / v[2]);
+    out[1] = (float)(height / 2.0 + f_stop * v[1] / v[2]);
+    return std::isfinite(out[0]) && std::isfinite(out[1]);
+}
+
+// An upper estimate of how many pixels the picture moves between two cameras: the angle between the two orientations and the
+// parallax of the origin, at the focal length.  A history the picture has moved more than 48 px away from is not followed: a wrong
+// order is worse than none (a camera rolling 5 degrees a frame, 170 px at the edge: 4K Kerr 7.8 -> 13.4 ms, a = 0.9 27 -> 85 ms following
+// it blindly; up to 43 px - 0.08 units sideways or 1 degree of roll a frame - it measured a gain or nothing).
+static float picture_motion(const gr_camera& a, const gr_camera& b, float fov_degrees, int width) {
+    double dot = 0, na = 0, nb = 0, dp = 0, r = 0;
+    for (int i = 0; i < 4; i++) { dot += (double)a.quat[i] * b.quat[i]; na += (double)a.quat[i] * a.quat[i]; nb += (double)b.quat[i] * b.quat[i]; }
+    for (int i = 1; i < 4; i++) { dp += ((double)a.position[i] - b.position[i]) * ((double)a.position[i] - b.position[i]); r += (double)b.position[i] * b.position[i]; }
+    if (!(na > 0) || !(nb > 0)) return 1e9f;
+    const double c = std::min(1.0, std::fabs(dot) / std::sqrt(na * nb));
+    const double f_stop = (width / 2.0) / std::tan(fov_degrees / 360.0 * M_PI);
+    const double motion = (2 * std::acos(c) + std::sqrt(dp) / std::max(std::sqrt(r), 1e-3)) * f_stop;
+    if (a.flip != b.flip || memcmp(a.basis_speed, b.basis_speed, sizeof(a.basis_speed)) != 0) return 1e9f;
+    return std::isfinite(motion) ? (float)motion : 1e9f;
+}
 
 // Is an earlier fused frame still on this device when the next one is submitted?  (What tile_history's default asks: a frame that
 // has the device to itself ends when its last tile ends, and the order of its tiles decides when that is; frames that overlap fill
@@ -846,7 +886,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         const bool record_history = history_wanted && !device_busy && keep_lanes == 0 && rays_per_lane == 1;
         if (history_wanted && !record_history) s->tile_cost_valid = false;   // (what is there would be older than the last frame)
         const int shape[3] = {block_rows, strip_rank, strip_count};
-        const bool history_order = record_history && s->tile_cost_valid && memcmp(shape, s->tile_cost_shape, sizeof(shape)) == 0;
+        static const float history_max_motion = [] { const char* e = getenv("GR_TILE_HISTORY_MAX_MOTION"); return e ? (float)atof(e) : 48.f; }();
+        const bool history_order = record_history && s->tile_cost_valid && memcmp(shape, s->tile_cost_shape, sizeof(shape)) == 0 && !gc &&
+                                   picture_motion(s->tile_cost_camera, *camera, features.field_of_view, width) <= history_max_motion;
         if (!prefetched && one_launch_setup) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_camera_prepass(p, stream, s->camera_pos_cart, camera->flip, camera->basis_speed, s->camera_pos_generic, s->tetrad[0],
@@ -950,8 +992,17 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.e0 = s->tetrad[0]; a.e1 = s->tetrad[1]; a.e2 = s->tetrad[2]; a.e3 = s->tetrad[3]; a.cfg = s->cfg; a.dfg = s->dfg;
                 a.attempt_counter = attempts;
                 a.tile_order = order_tiles ? s->tile_order : nullptr;
+                float anchor[2] = {0, 0};
+                const bool anchored = record_history && !gc && origin_on_screen(*camera, features.field_of_view, width, height, anchor);
                 if (history_order) {
-                    GR_CHECK(gr_order_tiles_by_history(p, stream, s->tile_cost, width, height, block_rows, strip_rank, strip_count, s->tile_order));
+                    // how far the picture has moved since the costs were recorded, in tiles
+                    int shift[2] = {0, 0};
+                    static const bool follow_camera = [] { const char* e = getenv("GR_TILE_HISTORY_FOLLOW"); return !(e && e[0] == '0'); }();
+                    if (follow_camera && anchored && s->tile_cost_anchored)
+                        for (int i = 0; i < 2; i++)
+                            shift[i] = (int)std::lround(std::max(-4096.f, std::min(4096.f, (anchor[i] - s->tile_cost_anchor[i]) / 8.f)));
+                    GR_CHECK(gr_order_tiles_by_history(p, stream, s->tile_cost, width, height, block_rows, strip_rank, strip_count, s->tile_order,
+                                                       shift[0], shift[1]));
                     a.tile_order = s->tile_order;
                     a.tile_order_by_history = 1;
                 }
@@ -959,6 +1010,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                     a.tile_cost = s->tile_cost;
                     memcpy(s->tile_cost_shape, shape, sizeof(shape));
                     s->tile_cost_valid = true;
+                    s->tile_cost_anchored = anchored;
+                    s->tile_cost_anchor[0] = anchor[0]; s->tile_cost_anchor[1] = anchor[1];
+                    s->tile_cost_camera = *camera;
                 }
                 a.waves_per_simd = opt.trace_waves_per_simd;
                 a.inline_prepass = inline_prepass ? 1 : 0;

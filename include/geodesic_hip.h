@@ -301,9 +301,11 @@ int gr_order_tiles(gr_program* p, void* stream, const void* termination_buffer, 
 /* The same list from what the tiles cost in an earlier frame of the same size and strip description (tile_history: the tile_cost a
  * gr_trace_fused_launch left): exact where the prepass rays sample - the long rays near the photon orbits are filaments a pixel or
  * two wide - as long as the camera moves little between the two frames (a tile takes the largest cost among itself and its eight
- * neighbours).  Needs no prepass, so it combines with inline_prepass.  Pass the list with tile_order_by_history = 1. */
+ * neighbours).  Needs no prepass, so it combines with inline_prepass.  Pass the list with tile_order_by_history = 1.
+ * shift_x, shift_y: how far the picture has moved since, in tiles of 8 pixels (0, 0 if unknown): a tile takes the costs of the
+ * tiles that far back.  gr_render_frame estimates it from where the two cameras see the coordinate origin. */
 int gr_order_tiles_by_history(gr_program* p, void* stream, const void* tile_history, int width, int height, int block_rows,
-                              int strip_rank, int strip_count, void* tile_order);
+                              int strip_rank, int strip_count, void* tile_order, int shift_x, int shift_y);
 
 /* Counter block of the fused trace launchers (their `attempt_counter`; NULL = count nothing): GR_COUNTER_WORDS uint64 words on
  * the device, zeroed by the caller.  [0] attempts of the pair / compaction kernels, [1] summed wave lifetimes in shader cycles,
@@ -496,9 +498,12 @@ typedef struct gr_frame_options {
                             * one frame at a time).  With three or more frames in flight on streams of their own, 4 measured
                             * 2-3 % faster than all: the launches then share the device instead of queueing for it. */
     int tile_history;      /* fused mode, one ray per lane: 1 = hand the tiles of this frame out dearest first by what they cost in this
-                            * render state's previous frame (gr_order_tiles_by_history; the first frame, or one of another strip
-                            * description, goes in image order); every such frame records its tiles' costs.  Scheduling only: the
-                            * pixels do not depend on it.  0 = no; -1 = library default */
+                            * render state's previous frame (gr_order_tiles_by_history, shifted by how far the camera has moved the
+                            * picture since; the first frame, one of another strip description, one whose camera has moved the picture
+                            * by more than 48 px or rides a geodesic goes in image order); every such frame records its tiles' costs.
+                            * Scheduling only: the pixels do not depend on it.  0 = no; -1 = library default: whole frames of at most
+                            * 32 tiles per wave slot that find the device idle when they are submitted (frames in flight fill each
+                            * other's tails, and the order measured slower there) */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 

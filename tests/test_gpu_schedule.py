@@ -99,7 +99,7 @@ def trace_with(prog, state, rd, **extra):
 def test_tile_costs_and_the_order_made_from_them():
     """gr_trace_fused_args.tile_cost: every tile's entry is the attempts of its longest ray (0 where the prepass lets the whole tile be
     skipped), the records are those of a launch that does not record; gr_order_tiles_by_history: every tile once, classes by the octave
-    of the dearest cost within two tiles, the last class (nothing traced around) not a promise; a launch that follows the list - also
+    of the dearest cost within two tiles, the last class (nothing traced within six) not a promise; a launch that follows the list - also
     with the prepass inside it - writes the same records"""
     prog, state = traced_state()
     rows = ((H + 7) // 8) * 8
@@ -123,7 +123,7 @@ def test_tile_costs_and_the_order_made_from_them():
     assert total_attempts >= int(costs.astype(np.int64).sum())      # the longest ray of every tile is one of its rays
     assert total_attempts <= int((costs.astype(np.int64) * per_tile_traced).sum())
     order = DeviceBuffer(0, nbytes)
-    check(lib.gr_order_tiles_by_history(prog.handle, None, cost.ptr, W, H, rows, 0, 1, order.ptr))
+    check(lib.gr_order_tiles_by_history(prog.handle, None, cost.ptr, W, H, rows, 0, 1, order.ptr, 0, 0))
     check(lib.gr_device_synchronize(0))
     words = order.to_numpy(np.uint32, (nbytes // 4,))
     counts, listed, classes = words[:16], words[32:32 + tiles], words[32 + tiles:]
@@ -132,8 +132,11 @@ def test_tile_costs_and_the_order_made_from_them():
     grid = costs.reshape(rows // 8, W // 8)
     padded = np.pad(grid, 2, mode="edge")
     dearest = np.max([padded[2 + dy:2 + dy + grid.shape[0], 2 + dx:2 + dx + grid.shape[1]] for dy in range(-2, 3) for dx in range(-2, 3)], axis=0)
+    wider = np.pad(grid, 6, mode="edge")
+    around = np.max([wider[6 + dy:6 + dy + grid.shape[0], 6 + dx:6 + dx + grid.shape[1]] for dy in range(-6, 7) for dx in range(-6, 7)], axis=0)
     octave = np.floor(np.log2(np.maximum(dearest, 1))).astype(np.int64)
-    want = np.where(dearest == 0, 15, 14 - np.minimum(octave, 14)).reshape(-1)
+    # the last class (32 tiles to a ticket): nothing traced within six tiles; the ring around what was traced: the cheapest single class
+    want = np.where(around == 0, 15, np.where(dearest == 0, 14, 14 - np.minimum(octave, 14))).reshape(-1)
     assert np.array_equal(classes.astype(np.int64), want)
     assert counts[15] > 0 and counts[:5].sum() > 0
     for inline in (0, 1):
