@@ -176,7 +176,7 @@ extern "C" {
 // Where a camera sees the coordinate origin, in pixels, as if space were flat (the inverse of the kernels' pixel_direction).  Between
 // two frames of a moving or turning camera the picture of whatever sits there - the hole, the bubble, the throat, which is where the
 // dear tiles are - moves by about as much as this point does; false if the origin is behind the camera or the camera sits on it.
-static bool origin_on_screen(const gr_camera& c, float fov_degrees, int width, int height, float out[2]) {
+static bool origin_on_screen(const gr_camera& c, float fov_degrees, int width, int height, float out[2]) {   // = gr_camera_origin_on_screen
     const double px = c.position[1], py = c.position[2], pz = c.position[3];
     const double r = std::sqrt(px * px + py * py + pz * pz);
     double qx = c.quat[0], qy = c.quat[1], qz = c.quat[2], qw = c.quat[3];
@@ -208,6 +208,16 @@ static float picture_motion(const gr_camera& a, const gr_camera& b, float fov_de
     const double motion = (2 * std::acos(c) + std::sqrt(dp) / std::max(std::sqrt(r), 1e-3)) * f_stop;
     if (a.flip != b.flip || memcmp(a.basis_speed, b.basis_speed, sizeof(a.basis_speed)) != 0) return 1e9f;
     return std::isfinite(motion) ? (float)motion : 1e9f;
+}
+
+int gr_camera_origin_on_screen(const gr_camera* camera, float field_of_view, int width, int height, float pixel_out[2]) {
+    if (!camera || !pixel_out || width <= 0 || height <= 0) return 0;
+    return origin_on_screen(*camera, field_of_view, width, height, pixel_out) ? 1 : 0;
+}
+
+float gr_picture_motion(const gr_camera* from, const gr_camera* to, float field_of_view, int width) {
+    if (!from || !to || width <= 0) return 1e9f;
+    return picture_motion(*from, *to, field_of_view, width);
 }
 
 // Is an earlier fused frame still on this device when the next one is submitted?  (What tile_history's default asks: a frame that

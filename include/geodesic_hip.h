@@ -506,6 +506,13 @@ typedef struct gr_frame_options {
                             * other's tails, and the order measured slower there) */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
+/* The two estimates tile_history works with (host arithmetic, no device).  gr_camera_origin_on_screen: the pixel at which the
+ * camera sees the coordinate origin as if space were flat - the inverse of the kernels' pixel -> direction map (cl.cl:2015-2059) -
+ * 1 and pixel_out[0..1] = (x, y), or 0 when the origin is behind the camera or the camera sits on it.  gr_picture_motion: an upper
+ * estimate of how many pixels the picture moves between two cameras (angle between the orientations + parallax of the origin, at the
+ * focal length); 1e9 when flip or observer speed differ. */
+int gr_camera_origin_on_screen(const gr_camera* camera, float field_of_view, int width, int height, float pixel_out[2]);
+float gr_picture_motion(const gr_camera* from, const gr_camera* to, float field_of_view, int width);
 
 int gr_render_state_create(int device, int width, int height, gr_render_state** out);
 void gr_render_state_destroy(gr_render_state* s);

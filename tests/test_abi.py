@@ -226,3 +226,58 @@ def test_assembly_pass_cuts_the_vector_runs_of_the_integrator(tmp_path, monkeypa
     # (the pass counts inside basic blocks, the disassembly has no labels: two runs that meet at a fall-through read as one)
     assert passed["gr_trace_fused"] <= 16 and passed["gr_camera_prepass"] <= 16 and passed["gr_do_generic_rays"] <= 16
     assert passed["gr_render"] == plain["gr_render"]          # not an integrator kernel: as compiled
+
+
+def _rot(q, v):
+    """rot_quat (cl.cl:176-191): v rotated by the unit quaternion q = (x, y, z, w)"""
+    qv, w = np.asarray(q[:3], dtype=np.float64), float(q[3])
+    t = 2 * np.cross(qv, v)
+    return v + w * t + np.cross(qv, t)
+
+
+def test_origin_on_screen_inverts_the_pixel_direction_map():
+    """gr_camera_origin_on_screen (what tile_history shifts the last frame's costs by): a camera placed anywhere along the line a
+    pixel looks out through, behind the origin, sees the origin at that pixel - the pixel -> direction map restated from
+    cl.cl:2015-2059 (f_stop = (W/2) / tan(fov/2), direction (x - W/2, y - H/2, f_stop) rotated by the camera quaternion)"""
+    rng = np.random.default_rng(5)
+    W, H = 1920, 1080
+    for _ in range(200):
+        fov = float(rng.choice([60.0, 90.0, 110.0]))
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        x, y = float(rng.uniform(0, W)), float(rng.uniform(0, H))
+        f_stop = (W / 2) / np.tan(np.radians(fov) / 2)
+        d = _rot(q, np.array([x - W / 2, y - H / 2, f_stop]))
+        d /= np.linalg.norm(d)
+        cam = gra.default_camera([float(rng.uniform(-1, 1))] + [float(c) for c in -d * rng.uniform(0.5, 30.0)], [float(c) for c in q])
+        got = (gra.c_float * 2)()
+        assert gra.lib.gr_camera_origin_on_screen(ctypes.byref(cam), fov, W, H, got) == 1
+        assert abs(got[0] - x) < 0.05 and abs(got[1] - y) < 0.05
+        # looking the other way: nothing to follow
+        away = gra.default_camera([0.0] + [float(c) for c in d * 4.0], [float(c) for c in q])
+        assert gra.lib.gr_camera_origin_on_screen(ctypes.byref(away), fov, W, H, got) == 0
+    on_it = gra.default_camera([0.0, 0.0, 0.0, 0.0])
+    assert gra.lib.gr_camera_origin_on_screen(ctypes.byref(on_it), 90.0, W, H, got) == 0
+
+
+def test_picture_motion_estimate():
+    """gr_picture_motion: 0 for the same camera, the focal length times the angle for a turn, times the parallax for a move; a
+    camera whose observer speed or flip changed is another picture altogether"""
+    W, fov = 3840, 90.0
+    f_stop = (W / 2) / np.tan(np.radians(fov) / 2)
+    a = gra.default_camera()
+    assert gra.lib.gr_picture_motion(ctypes.byref(a), ctypes.byref(a), fov, W) == 0.0
+    b = gra.default_camera()
+    b.position[1] += 0.02
+    assert gra.lib.gr_picture_motion(ctypes.byref(a), ctypes.byref(b), fov, W) == pytest.approx(0.02 / 4.0 * f_stop, rel=1e-3)
+    angle = np.radians(1.0)
+    turn = np.array([0.0, np.sin(angle / 2), 0.0, np.cos(angle / 2)])
+    q = np.array([a.quat[i] for i in range(4)])
+    turned = np.concatenate([turn[3] * q[:3] + q[3] * turn[:3] + np.cross(turn[:3], q[:3]), [turn[3] * q[3] - turn[:3] @ q[:3]]])
+    c = gra.default_camera(None, [float(v) for v in turned])
+    assert gra.lib.gr_picture_motion(ctypes.byref(a), ctypes.byref(c), fov, W) == pytest.approx(angle * f_stop, rel=1e-3)
+    minus = gra.default_camera(None, [float(-v) for v in q])   # -q is the same rotation
+    assert gra.lib.gr_picture_motion(ctypes.byref(a), ctypes.byref(minus), fov, W) < 1e-2
+    d = gra.default_camera()
+    d.basis_speed[0] = 0.1
+    assert gra.lib.gr_picture_motion(ctypes.byref(a), ctypes.byref(d), fov, W) > 1e8
