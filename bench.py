@@ -443,7 +443,8 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None, "traffic_source": pmc_note,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(launch_s * 1e3, 4),
-                "avg_launch_basis": "launches run one at a time after the timed region (4 frames, HIP events on the launch's stream)",
+                "avg_launch_basis": "launches run one at a time after the timed region (4 frames, HIP events on the launch's stream); such launches hand "
+                                    "their tiles out dearest first by the previous frame's costs (gr_frame_options.tile_history), launches of frames in flight in image order",
                 "shader_clock_mhz_during_launch": round(mhz, 1),
                 "wave_slot_occupancy_of_launch": round(exclusive_frames.slot_share, 3) if exclusive_frames.slot_share else None,
                 "note": "register-resident ODE integrator: fp32 VALU bound, see valu_roofline (SURVEY.md 8d)"}

@@ -65,6 +65,7 @@ struct gr_render_state {
     float tile_cost_anchor[2] = {0, 0};   // the pixel that frame's camera saw the coordinate origin at (origin_on_screen)
     bool tile_cost_anchored = false;
     gr_camera tile_cost_camera{};
+    unsigned long long tile_cost_program = 0;
     size_t ray_capacity = 0;
     hipEvent_t ev_start[GR_STAGE_COUNT] = {};
     hipEvent_t ev_stop[GR_STAGE_COUNT] = {};
@@ -700,6 +701,11 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     if ((int)cfg.size() > CFG_MAX) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "too many dynamic variables");
     const bool cfg_changed = cfg != s->host_cfg;
     const bool features_changed = !s->features_valid || memcmp(&features, &s->host_features, sizeof(features)) != 0;
+    // another metric, parameter set or field of view: what the last frame's tiles cost says nothing about this one's (tile_history)
+    if (cfg_changed || features_changed || gr_program_serial(p) != s->tile_cost_program) {
+        s->tile_cost_valid = false;
+        s->tile_cost_program = gr_program_serial(p);
+    }
     const bool prepass_by_policy = opt.use_prepass == -2 && use_prepass && opt.mode == GR_MODE_FUSED && opt.strip_count <= 1;
     if (prepass_by_policy) {
         auto& pol = s->policy;
