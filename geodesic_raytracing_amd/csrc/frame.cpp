@@ -228,18 +228,23 @@ float gr_picture_motion(const gr_camera* from, const gr_camera* to, float field_
 namespace {
 struct device_activity {
     std::mutex lock;
-    hipEvent_t marks[4] = {};
+    struct mark { hipEvent_t reached = nullptr; hipStream_t stream = nullptr; bool set = false; } marks[4];
     unsigned int used = 0;
 };
 device_activity g_activity[64];
 
-bool earlier_frame_still_running(int device) {
+// Frames on the caller's own stream do not count: they run one after the other whatever the host does, so a host that submits
+// its next frame while the last one is still running - on the same stream - has the device to itself per frame all the same.
+bool earlier_frame_still_running(int device, hipStream_t stream) {
     if (device < 0 || device >= 64) return false;
     auto& a = g_activity[device];
     std::lock_guard<std::mutex> hold(a.lock);
-    if (!a.used) return false;
-    const hipError_t e = hipEventQuery(a.marks[(a.used - 1) % 4]);
-    if (e == hipErrorNotReady) { (void)hipGetLastError(); return true; }
+    for (auto& m : a.marks) {
+        if (!m.set || m.stream == stream) continue;
+        const hipError_t e = hipEventQuery(m.reached);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); return true; }
+        m.set = false;   // reached (or unusable): nothing to ask again
+    }
     return false;
 }
 
@@ -247,10 +252,22 @@ void mark_frame_end(int device, hipStream_t stream) {
     if (device < 0 || device >= 64) return;
     auto& a = g_activity[device];
     std::lock_guard<std::mutex> hold(a.lock);
-    hipEvent_t& e = a.marks[a.used % 4];
-    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return; }
-    if (hipEventRecord(e, stream) == hipSuccess) a.used++;
-    else (void)hipGetLastError();
+    // the stream's own slot if it has one (one mark per stream is enough: its latest), else the oldest
+    auto* slot = &a.marks[a.used % 4];
+    for (auto& m : a.marks)
+        if (m.set && m.stream == stream) { slot = &m; break; }
+    if (!slot->reached && hipEventCreateWithFlags(&slot->reached, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        slot->reached = nullptr;
+        return;
+    }
+    if (hipEventRecord(slot->reached, stream) == hipSuccess) {
+        if (slot == &a.marks[a.used % 4]) a.used++;
+        slot->stream = stream;
+        slot->set = true;
+    } else {
+        (void)hipGetLastError();
+    }
 }
 }   // namespace
 
@@ -856,7 +873,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         const bool history_wanted = (opt.tile_history < 0 ? history_default != 0 && strip_count == 1 && tile_words <= 32 * gr_trace_fused_wave_slots(p)
                                                           : opt.tile_history != 0) && !adaptive &&
                                     (size_t)gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
-        const bool device_busy = history_wanted && opt.tile_history < 0 && earlier_frame_still_running(s->device);
+        const bool device_busy = history_wanted && opt.tile_history < 0 && earlier_frame_still_running(s->device, stream);
         const bool tile_order_enabled = !history_wanted && (tile_order_mode == 1 || (tile_order_mode == -1 && strip_count > 1));
         const size_t cells = use_prepass ? (size_t)prepass_width * prepass_height : 0;
         // (a frame whose prepass rides in its trace launch - below - has no costs to order by; the frames it announces still do)
