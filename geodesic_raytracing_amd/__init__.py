@@ -134,6 +134,7 @@ _SIGNATURES = {
     "gr_order_tiles_by_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int]),
     "gr_trace_fused_launch": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TraceFusedArgs)]),
     "gr_trace_fused_wave_slots": (ctypes.c_longlong, [c_void_p]),
+    "gr_render_state_tile_history": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(c_int)]),
     "gr_camera_origin_on_screen": (c_int, [ctypes.POINTER(Camera), c_float, c_int, c_int, ctypes.POINTER(c_float)]),
     "gr_picture_motion": (c_float, [ctypes.POINTER(Camera), ctypes.POINTER(Camera), c_float, c_int]),
     "gr_render_seams": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -66,6 +66,8 @@ struct gr_render_state {
     bool tile_cost_anchored = false;
     gr_camera tile_cost_camera{};
     unsigned long long tile_cost_program = 0;
+    unsigned long long history_recorded = 0, history_followed = 0;   // frames (gr_render_state_tile_history)
+    int history_last_shift[2] = {0, 0};
     size_t ray_capacity = 0;
     hipEvent_t ev_start[GR_STAGE_COUNT] = {};
     hipEvent_t ev_stop[GR_STAGE_COUNT] = {};
@@ -209,6 +211,14 @@ static float picture_motion(const gr_camera& a, const gr_camera& b, float fov_de
     const double motion = (2 * std::acos(c) + std::sqrt(dp) / std::max(std::sqrt(r), 1e-3)) * f_stop;
     if (a.flip != b.flip || memcmp(a.basis_speed, b.basis_speed, sizeof(a.basis_speed)) != 0) return 1e9f;
     return std::isfinite(motion) ? (float)motion : 1e9f;
+}
+
+int gr_render_state_tile_history(gr_render_state* s, unsigned long long* frames_recorded, unsigned long long* frames_followed, int last_shift[2]) {
+    if (!s) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (frames_recorded) *frames_recorded = s->history_recorded;
+    if (frames_followed) *frames_followed = s->history_followed;
+    if (last_shift) { last_shift[0] = s->history_last_shift[0]; last_shift[1] = s->history_last_shift[1]; }
+    return GR_OK;
 }
 
 int gr_camera_origin_on_screen(const gr_camera* camera, float field_of_view, int width, int height, float pixel_out[2]) {
@@ -1036,11 +1046,14 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                             shift[i] = (int)std::lround(std::max(-4096.f, std::min(4096.f, (anchor[i] - s->tile_cost_anchor[i]) / 8.f)));
                     GR_CHECK(gr_order_tiles_by_history(p, stream, s->tile_cost, width, height, block_rows, strip_rank, strip_count, s->tile_order,
                                                        shift[0], shift[1]));
+                    s->history_followed++;
+                    s->history_last_shift[0] = shift[0]; s->history_last_shift[1] = shift[1];
                     a.tile_order = s->tile_order;
                     a.tile_order_by_history = 1;
                 }
                 if (record_history) {
                     a.tile_cost = s->tile_cost;
+                    s->history_recorded++;
                     memcpy(s->tile_cost_shape, shape, sizeof(shape));
                     s->tile_cost_valid = true;
                     s->tile_cost_anchored = anchored;

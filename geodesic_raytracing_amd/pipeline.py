@@ -318,6 +318,12 @@ class RenderState:
         check(lib.gr_render_state_prepass_policy(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(f)))
         return a.value, b.value, f.value
 
+    def tile_history(self):
+        """(frames that recorded their tiles' costs, frames that followed the costs of the frame before, the last such frame's shift in tiles)"""
+        a, b, shift = ctypes.c_ulonglong(), ctypes.c_ulonglong(), (ctypes.c_int * 2)()
+        check(lib.gr_render_state_tile_history(self.handle, ctypes.byref(a), ctypes.byref(b), shift))
+        return a.value, b.value, (shift[0], shift[1])
+
     def stage_ms(self):
         out = {}
         for i, name in enumerate(STAGE_NAMES):

@@ -506,6 +506,10 @@ typedef struct gr_frame_options {
                             * other's tails, and the order measured slower there) */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
+/* What tile_history did with this render state's frames so far: how many recorded their tiles' costs, how many of those followed
+ * the costs of the frame before, and the shift (in tiles) the last one that did applied.  Any pointer may be NULL. */
+int gr_render_state_tile_history(gr_render_state* s, unsigned long long* frames_recorded, unsigned long long* frames_followed,
+                                 int last_shift[2]);
 /* The two estimates tile_history works with (host arithmetic, no device).  gr_camera_origin_on_screen: the pixel at which the
  * camera sees the coordinate origin as if space were flat - the inverse of the kernels' pixel -> direction map (cl.cl:2015-2059) -
  * 1 and pixel_out[0..1] = (x, y), or 0 when the origin is behind the camera or the camera sits on it.  gr_picture_motion: an upper

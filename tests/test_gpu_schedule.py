@@ -171,6 +171,66 @@ def test_frames_that_follow_the_last_frames_costs_are_bit_identical(strip):
     assert pictures[(0, 2)].tobytes() != pictures[(0, 1)].tobytes()   # the camera did move
 
 
+def test_which_frames_follow_the_history():
+    """the default (tile_history = -1): a frame records its tiles' costs and follows the last frame's when it finds the device idle or
+    only frames of its own stream in front of it; not when a frame is still running on another stream, not when the camera has moved
+    the picture by more than 48 px, not after another parameter set; the shift is the motion of the origin's picture in tiles"""
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv = metric.cfg_values(a=0.45)
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    dbg, levels = background()
+    out = DeviceBuffer(0, W * H * 16)
+    sky = (dbg.ptr, 1024, 512, levels)
+    o = gra.frame_options(mode=gra.MODE_FUSED)
+    state = gra.RenderState(W, H, 0)
+
+    def frame(state, x=0.0, stream=None, cfg=cfgv):
+        camera = gra.default_camera()
+        camera.position[1] += x
+        state.render(prog, metric, camera, out.ptr, sky, feats, cfg, o, stream)
+
+    frame(state)
+    state.synchronize()
+    assert state.tile_history() == (1, 0, (0, 0))          # the first frame has nothing to follow
+    frame(state)
+    frame(state)                                           # queued behind the last one on the same stream: still follows
+    state.synchronize()
+    assert state.tile_history() == (3, 2, (0, 0))
+    # 0.02 units sideways at 4 units from the origin: 0.005 rad x the focal length 960 px = 4.8 px -> 1 tile (rounded) ... 0.05: 12 px
+    frame(state, x=0.05)
+    state.synchronize()
+    recorded, followed, shift = state.tile_history()
+    assert (recorded, followed) == (4, 3) and shift[1] == 0 and abs(shift[0]) in (1, 2)
+    frame(state, x=0.5)                                    # 120 px: not followed, but recorded for the next
+    state.synchronize()
+    assert state.tile_history()[:2] == (5, 3)
+    frame(state, x=0.5)
+    state.synchronize()
+    assert state.tile_history()[:2] == (6, 4)
+    frame(state, x=0.5, cfg=metric.cfg_values(a=0.3))      # another hole: the costs say nothing
+    state.synchronize()
+    assert state.tile_history()[:2] == (7, 4)
+    # a second render state on a stream of its own while this one's frame is running: neither records nor follows
+    check(lib.gr_device_synchronize(0))
+    side = ctypes.c_void_p()
+    check(lib.gr_stream_create(0, 0, ctypes.byref(side)))
+    other = gra.RenderState(W, H, 0)
+    frame(other, stream=side)
+    other.synchronize()
+    check(lib.gr_device_synchronize(0))
+    assert other.tile_history()[:2] == (1, 0)
+    for _ in range(3):
+        frame(state, x=0.5, cfg=metric.cfg_values(a=0.3))   # queued on the default stream ...
+    frame(other, stream=side)                               # ... and this one finds them running
+    check(lib.gr_device_synchronize(0))
+    assert other.tile_history()[:2] == (1, 0)
+    frame(other, stream=side)                               # idle again: records, and has nothing recent to follow
+    check(lib.gr_device_synchronize(0))
+    assert other.tile_history()[:2] == (2, 0)
+    check(lib.gr_stream_destroy(side))
+
+
 def test_frame_with_fewer_wave_slots_is_bit_identical():
     """gr_frame_options.trace_waves_per_simd only sizes the launch"""
     frames = []
