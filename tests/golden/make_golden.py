@@ -142,6 +142,22 @@ POLAR_CASES = {
                                     camera_pos=[0.10997334765548494, -0.5373825915075183, -2.019667204861688, -11.588137570353418],
                                     camera_quat=[-0.800403059805112, 0.2303202393915621, -0.002482568913204211, 0.5534449982001999],
                                     features=dict(redshift=1, reparameterisation=1)),
+    # fourth round-3 soak (seed 41, 300 cases): three Kerr-Newman cameras outside the precision radius (r ~ 11 > 10) with the widest
+    # view and the larger universe - one of them 8 degrees from the polar axis, the other two with the axis inside their 110 degree view
+    "kerr_newman_axis_41_4": dict(metric="kerr_newman_boyer", scripts=True, size=(64, 36), cfg=dict(a=0.03086185456751156, rq=0.02897490904537001),
+                                  camera_pos=[0.3172054667009572, 4.901889139222192, -8.519887162223535, -6.499761565988149],
+                                  camera_quat=[-0.7053035087399527, -0.020046931759684514, 0.02880658048137977, 0.7080362010569119],
+                                  basis_speed=[0.0918882319995109, 0.054034274168116236, -0.019145882298706618],
+                                  features=dict(field_of_view=110.0, universe_size=30.0)),
+    "kerr_newman_axis_41_48": dict(metric="kerr_newman_boyer", scripts=True, size=(64, 36), cfg=dict(a=0.25509999722187865, rq=0.284957009265189),
+                                   camera_pos=[0.05332062397986603, -0.45034656121899147, -1.5537689748524288, -10.94394741496706],
+                                   camera_quat=[-0.5976367192081851, -0.07642020876815926, 0.2397722125867613, 0.7612487041809375],
+                                   features=dict(reparameterisation=1, field_of_view=110.0, universe_size=30.0)),
+    "kerr_newman_axis_41_114": dict(metric="kerr_newman_boyer", scripts=True, size=(64, 36), cfg=dict(a=0.002148772546230193, rq=0.015098550751060778),
+                                    camera_pos=[-0.7952930639008775, 3.324733824958148, -6.888376605541559, -7.479313416042515],
+                                    camera_quat=[-0.9247459394025275, -0.20264404553430337, -0.05409381449318068, 0.31757549905747684],
+                                    basis_speed=[-0.1071927750937198, 0.26726310449023477, -0.13366769630028333],
+                                    features=dict(field_of_view=110.0, universe_size=30.0)),
 }
 
 # camera riding a timelike geodesic (boost_tetrad .. handle_interpolating_geodesic): name -> spec

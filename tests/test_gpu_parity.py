@@ -278,7 +278,8 @@ def test_randomised_poses_and_features_match_the_oracle():
 
 
 POLAR = ["kerr_newman_axis_13_3", "kerr_axis_14_212", "kerr_newman_axis_14_593", "kerr_axis_21_122", "kerr_axis_22_142", "kerr_newman_axis_23_63",
-         "kerr_axis_32_135", "kerr_axis_32_267", "kerr_axis_33_575", "double_kerr_axis_33_541"]
+         "kerr_axis_32_135", "kerr_axis_32_267", "kerr_axis_33_575", "double_kerr_axis_33_541",
+         "kerr_newman_axis_41_4", "kerr_newman_axis_41_48", "kerr_newman_axis_41_114"]
 
 
 def sky_error(position, position_f64):
@@ -289,7 +290,7 @@ def sky_error(position, position_f64):
 
 @pytest.mark.parametrize("name", POLAR)
 def test_polar_axis_cases_of_the_soak(name):
-    """The cases of the randomised soaks (three of 1 270 in round 1, three of 897 in round 2, four of 1 220 in round 3) in which > 1 % of the pixels were off by > 1e-3 (tests/golden/polar, inputs as
+    """The cases of the randomised soaks (three of 1 270 in round 1, three of 897 in round 2, seven of 1 520 in round 3) in which > 1 % of the pixels were off by > 1e-3 (tests/golden/polar, inputs as
     the soak drew them, expected output from the reference's cl.cl): rays grazing the polar axis of a Boyer-Lindquist chart.  There
     d phi / d lambda ~ 1 / sin^2 theta amplifies every last-place difference, so two fp32 builds agree only as far as they share
     their roundings - the CPU restatement (same operation order as the reference) disagrees with it in 11-30 pixels, the GPU
@@ -299,7 +300,10 @@ def test_polar_axis_cases_of_the_soak(name):
     from the reference's in at most twice as many places as the larger of (CPU restatement vs reference) and (reference vs
     float64) + 4.  Measured (dynamic / substituted program): 13/3 27/24 pixels (CPU 22), 14/212 51/52 (CPU 11, reference vs float64
     48 rays), 14/593 32/29 (CPU 30), 21/122 35-37 (CPU 38, reference vs float64 34 rays), 22/142 55-58 (CPU 58, reference vs float64 75 rays), 23/63 32-37 (CPU 16, reference vs float64 56 rays), 32/135 225-226 (CPU 157), 32/267 102-109 (CPU 95), 33/575 125 (CPU 107), 33/541 28-30 (CPU 25: double Kerr, the camera near the symmetry axis of the Weyl chart) - the round-3 Kerr cases have the camera itself near the axis at r ~ 11, so a tenth
-    of the frame's rays pass it; GR_LIBM_TRIG, correctly rounded divide/sqrt and no contraction change none of it."""
+    of the frame's rays pass it; GR_LIBM_TRIG, correctly rounded divide/sqrt and no contraction change none of it.  Seed 41 (after the tile history went in): three
+    Kerr-Newman cameras at r ~ 11, outside the precision radius, 110 degree view, universe 30 - 41/4 and 41/114 have the axis inside the
+    view (the pixels that differ are one strip three or four columns wide: CPU restatement 22 and 27 pixels, reference vs float64 19 and
+    27 rays), 41/48 sits 8 degrees from it (CPU 29, reference vs float64 111 rays)."""
     from oracle import build_restate
     from oracle.refpipe import OraclePipeline, pack_features
     meta, z = load_golden("polar/" + name)

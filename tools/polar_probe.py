@@ -12,7 +12,8 @@ from oracle import build_restate
 from geodesic_raytracing_amd.pipeline import RENDER_DATA_DTYPE, download
 
 print("flags:", os.environ.get("GR_EXTRA_FLAGS", ""))
-for name in ["kerr_newman_axis_13_3", "kerr_axis_14_212", "kerr_newman_axis_14_593", "kerr_axis_21_122", "kerr_axis_22_142", "kerr_newman_axis_23_63"]:
+for name in ["kerr_newman_axis_13_3", "kerr_axis_14_212", "kerr_newman_axis_14_593", "kerr_axis_21_122", "kerr_axis_22_142", "kerr_newman_axis_23_63",
+             "kerr_newman_axis_41_4", "kerr_newman_axis_41_48", "kerr_newman_axis_41_114"]:
     meta, z = load_golden(os.path.join("polar", name))
     r = run_oracle(build_restate.build(metric_for(meta).argument_string()), meta)
     cpu_bad = (np.abs(r["pixels"][..., :3] - z["pixels"][..., :3]).max(axis=2) > 1e-3)
