@@ -20,7 +20,7 @@ camera = gra.default_camera()
 BLOCK = int(os.environ.get("STRIP_PROBE_BLOCK", "16"))
 look = ctypes.pointer(camera)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
-  for rotate in ((True,) if os.environ.get("STRIP_PROBE_INFLIGHT") else (False, True)):
+  for rotate in ((os.environ.get("STRIP_PROBE_ROTATE", "1") != "0",) if os.environ.get("STRIP_PROBE_INFLIGHT") else (False, True)):
    for inflight in [int(x) for x in os.environ.get("STRIP_PROBE_INFLIGHT", "1,3").split(",")]:
     for depth in [int(x) for x in os.environ.get("STRIP_PROBE_DEPTH", "2").split(",")]:
         counter = [0]
@@ -31,7 +31,8 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             state, out, stream = states[k], outs[k], streams[k].cuda_stream
             kf = counter[0] - 1
             o = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=(kf % world) if rotate else 0, strip_count=world, block_rows=BLOCK, compact_out=1,
-                                  trace_waves_per_simd=int(os.environ.get("STRIP_PROBE_WAVES", "0")))
+                                  trace_waves_per_simd=int(os.environ.get("STRIP_PROBE_WAVES", "0")),
+                                  tile_history=int(os.environ.get("STRIP_PROBE_HISTORY", "-1")), inline_prepass=int(os.environ.get("STRIP_PROBE_INLINE", "-1")))
             if rotate:
                 o.next_strip_rank = (kf + inflight) % world
                 o.next_strip_rank2 = (kf + 2 * inflight) % world
