@@ -1,6 +1,8 @@
 """Randomised parity soak (GPU box): random metric / parameters / camera pose / observer speed / features, small frames, the HIP
 fused kernel (dynamic and substituted program) against the CPU oracle (oracle/restate.cpp, pinned to the reference's kernels).
-Prints one line per case and a summary; exit status 1 if a case is outside the end-to-end tolerance of the parity tests.
+Prints one line per case and a summary; exit status 1 if a case is outside the end-to-end tolerance of the parity tests - unless the
+reference's own x86-64 build (oracle/_ref, built by the `precompile` mode where /root/reference exists) differs from the restatement in
+as many pixels (an ill-conditioned frame; reported, not failed).
 Test infrastructure (it runs the oracle).  usage: PYTHONPATH=. python tests/fuzz_parity.py [cases] [seed] [only_case]
 With only_case the one case is replayed (the random stream is advanced through the earlier ones) and its inputs, the oracle's
 and the GPU's pixels and render-data go to gpurun_out/fuzz_case_<seed>_<case>.npz for a closer look."""
@@ -14,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import geodesic_raytracing_amd as gra  # noqa: E402
 from geodesic_raytracing_amd.pipeline import DeviceBuffer  # noqa: E402
-from oracle import build_restate  # noqa: E402
+from oracle import build_ref, build_restate  # noqa: E402
 from oracle.refpipe import OraclePipeline, pack_features  # noqa: E402
 
 SCRIPTS = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
@@ -85,7 +87,14 @@ def precompile(cases, seed):
     with multiprocessing.get_context("spawn").Pool(max(1, (os.cpu_count() or 2) - 1)) as pool:
         pool.map(_precompile, strings, chunksize=1)
         pool.map(build_restate.build, oracle_keys, chunksize=1)
-    print(f"precompiled {len(strings)} programs, {len(oracle_keys)} oracles")
+    # the reference's own source compiled for x86-64 (oracle/_ref; where /root/reference exists): what a case outside the tolerance is
+    # held against on the GPU box
+    built = 0
+    if build_ref.reference_available():
+        for name in sorted(METRICS):
+            build_ref.build("fuzz_" + name, gra.Metric(name, SCRIPTS).argument_string())
+            built += 1
+    print(f"precompiled {len(strings)} programs, {len(oracle_keys)} oracles, {built} reference builds")
 
 
 def main():
@@ -99,7 +108,7 @@ def main():
     bg = DeviceBuffer.from_numpy(0, bg_np)
     out = DeviceBuffer(0, w * h * 16)
     state = gra.RenderState(w, h, 0)
-    oracles, worst, failed = {}, 0.0, 0
+    oracles, worst, failed, explained = {}, 0.0, 0, 0
     for case, name, metric, cfg, pos, quat, speed, fkw, r in draw_cases(cases, seed):
         only = int(sys.argv[3]) if len(sys.argv) > 3 else None
         if only is not None and case != only:
@@ -128,9 +137,27 @@ def main():
             # reference's own x86 build and the CPU restatement, same operation order, in 86 of 2304), so the mask is 10 % there
             chaotic = name == "double_unequal_kerr" and max(abs(cfg[2]), abs(cfg[3])) > 1.0
             ok = bad.mean() <= (0.10 if chaotic else 0.01) and rmse <= (3e-4 if chaotic else 1e-4) and np.isfinite(px).all()
+            verdict = "" if ok else "  <-- FAIL"
+            if not ok and np.isfinite(px).all() and rmse <= 3e-4:
+                # Too many pixels off: is it the case or the kernel?  The reference's own source compiled for x86-64 against the CPU
+                # restatement (same algorithm, same operation order, another compiler): where those two differ in as many pixels, the
+                # frame is ill-conditioned (rays grazing a chart axis: tests/test_gpu_parity.py::test_polar_axis_cases_of_the_soak,
+                # same rule) and the case is reported as such, not as a failure.
+                so = build_ref.prebuilt("fuzz_" + name, key)
+                if so:
+                    theirs = OraclePipeline(so).frame(w, h, cfg, pack_features(**fkw), camera_pos=pos, camera_quat=quat, basis_speed=speed,
+                                                      background=(bg_np, levels), nthreads=os.cpu_count() or 4)
+                    scatter = int((np.abs(theirs["pixels"][..., :3] - ref["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
+                    against = int((np.abs(px[..., :3] - theirs["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
+                    if against <= 2 * scatter + 4:
+                        verdict = f"  <-- ill-conditioned (reference build vs restatement {scatter} px, GPU vs reference build {against} px)"
+                        explained += 1
+                        ok = True
+                    else:
+                        verdict += f" (reference build vs restatement {scatter} px, GPU vs reference build {against} px)"
             failed += not ok
             worst = max(worst, rmse)
-            line += f" | {label}: rmse {rmse:.1e} off {bad.mean() * 100:4.1f}%{'' if ok else '  <-- FAIL'}"
+            line += f" | {label}: rmse {rmse:.1e} off {bad.mean() * 100:4.1f}%{verdict}"
             if only is not None:
                 from geodesic_raytracing_amd.pipeline import RENDER_DATA_DTYPE, download
                 rd = download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h)
@@ -139,7 +166,8 @@ def main():
                          rd=rd, ref_rd=ref["render_data"], pos=np.array(pos), quat=np.array(quat), speed=np.array(speed), cfg=np.array(cfg),
                          features=np.frombuffer(bytes(pack_features(**fkw)), dtype=np.uint8))
         print(line, flush=True)
-    print(f"{cases} cases x 2 programs: {failed} outside tolerance, worst masked RMSE {worst:.2e}")
+    print(f"{cases} cases x 2 programs: {failed} outside tolerance, {explained} ill-conditioned (the reference's own two builds differ as much), "
+          f"worst masked RMSE {worst:.2e}")
     return 1 if failed else 0
 
 
