@@ -158,6 +158,13 @@ POLAR_CASES = {
                                     camera_quat=[-0.9247459394025275, -0.20264404553430337, -0.05409381449318068, 0.31757549905747684],
                                     basis_speed=[-0.1071927750937198, 0.26726310449023477, -0.13366769630028333],
                                     features=dict(field_of_view=110.0, universe_size=30.0)),
+    # fifth round-3 soak (seed 42, 600 cases): the one case the soak's own check against the reference's x86 build did not explain - a
+    # cosmic-string camera 16 degrees from the string (the axis of its chart) at r ~ 10.4, outside the precision radius
+    "cosmic_string_axis_42_1": dict(metric="cosmic_string", scripts=True, size=(64, 36), cfg=dict(mu=0.006381725610417533),
+                                    camera_pos=[0.9413960487898065, -0.737493886809642, -2.7307436223517505, -10.058532061322971],
+                                    camera_quat=[-0.7318376597075247, -0.021644493729112688, -0.22170552870756433, 0.6440433325992306],
+                                    basis_speed=[-0.2074263047594713, 0.10982937194547276, 0.1468572935446903],
+                                    features=dict(universe_size=30.0)),
 }
 
 # camera riding a timelike geodesic (boost_tetrad .. handle_interpolating_geodesic): name -> spec

@@ -279,7 +279,7 @@ def test_randomised_poses_and_features_match_the_oracle():
 
 POLAR = ["kerr_newman_axis_13_3", "kerr_axis_14_212", "kerr_newman_axis_14_593", "kerr_axis_21_122", "kerr_axis_22_142", "kerr_newman_axis_23_63",
          "kerr_axis_32_135", "kerr_axis_32_267", "kerr_axis_33_575", "double_kerr_axis_33_541",
-         "kerr_newman_axis_41_4", "kerr_newman_axis_41_48", "kerr_newman_axis_41_114"]
+         "kerr_newman_axis_41_4", "kerr_newman_axis_41_48", "kerr_newman_axis_41_114", "cosmic_string_axis_42_1"]
 
 
 def sky_error(position, position_f64):
@@ -290,7 +290,7 @@ def sky_error(position, position_f64):
 
 @pytest.mark.parametrize("name", POLAR)
 def test_polar_axis_cases_of_the_soak(name):
-    """The cases of the randomised soaks (three of 1 270 in round 1, three of 897 in round 2, seven of 1 520 in round 3) in which > 1 % of the pixels were off by > 1e-3 (tests/golden/polar, inputs as
+    """The cases of the randomised soaks (three of 1 270 in round 1, three of 897 in round 2, eight of 2 120 in round 3) in which > 1 % of the pixels were off by > 1e-3 (tests/golden/polar, inputs as
     the soak drew them, expected output from the reference's cl.cl): rays grazing the polar axis of a Boyer-Lindquist chart.  There
     d phi / d lambda ~ 1 / sin^2 theta amplifies every last-place difference, so two fp32 builds agree only as far as they share
     their roundings - the CPU restatement (same operation order as the reference) disagrees with it in 11-30 pixels, the GPU
@@ -303,7 +303,9 @@ def test_polar_axis_cases_of_the_soak(name):
     of the frame's rays pass it; GR_LIBM_TRIG, correctly rounded divide/sqrt and no contraction change none of it.  Seed 41 (after the tile history went in): three
     Kerr-Newman cameras at r ~ 11, outside the precision radius, 110 degree view, universe 30 - 41/4 and 41/114 have the axis inside the
     view (the pixels that differ are one strip three or four columns wide: CPU restatement 22 and 27 pixels, reference vs float64 19 and
-    27 rays), 41/48 sits 8 degrees from it (CPU 29, reference vs float64 111 rays)."""
+    27 rays), 41/48 sits 8 degrees from it (CPU 29, reference vs float64 111 rays).  Seed 42 (600 cases; the soak now holds its outliers
+    against the reference's x86 build and the float64 evaluation itself): two more of the kind, explained on the spot, and a cosmic-string
+    camera 16 degrees from the string - the axis of that chart - at r ~ 10.4: CPU 12 pixels, reference vs float64 65 rays, GPU 46-47."""
     from oracle import build_restate
     from oracle.refpipe import OraclePipeline, pack_features
     meta, z = load_golden("polar/" + name)
