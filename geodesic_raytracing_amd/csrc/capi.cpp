@@ -972,7 +972,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
                         int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
                         const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0, const void* tile_order = nullptr,
                         int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr, int inline_prepass = 0, void* tile_cost = nullptr,
-                        int tile_order_by_history = 0) {
+                        int tile_order_by_history = 0, void* lattice_angles = nullptr) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
     // the prepass inside the launch: its cell waves are the first tickets (gr_trace_fused's prepass_tickets)
@@ -1067,29 +1067,31 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
                     &lattice, &pending_only, &tile_order, &shading, &prepass_tickets, &ticket_tiles, &tile_cost,
-                    &last_class_is_skipped};   // the last eight: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
+                    &last_class_is_skipped, &lattice_angles};   // the last nine: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
     return launch(p, kernel_index, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
 int gr_trace_fused_adaptive(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
                             int height, const void* term, int prepass_width, int prepass_height, const void* e0, const void* e1,
                             const void* e2, const void* e3, const void* cfg, const void* dfg, void* attempt_counter, int lattice,
-                            int pending_only) {
+                            int pending_only, void* lattice_angles) {
     return trace_launch(p, 1, stream, camera_generic, camera_quat, rdata, width, height, 0, 0, 1, term, prepass_width, prepass_height, e0, e1,
-                        e2, e3, cfg, dfg, attempt_counter, lattice, pending_only);
+                        e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, nullptr, 0, nullptr, 0, nullptr, 0,
+                        lattice == 2 ? lattice_angles : nullptr);
 }
 
 int gr_adaptive_refine_strips(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg,
-                              int block_rows, int strip_rank, int strip_count) {
+                              int block_rows, int strip_rank, int strip_count, const void* lattice_angles) {
     if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + 7) / 8) * 8; }
     if (block_rows <= 0 || block_rows % 8 != 0 || strip_rank < 0 || strip_rank >= strip_count)
         return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
-    void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count};
+    void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_angles};
     return launch(p, K_ADAPTIVE_REFINE, stream, (unsigned)((width / 2 + 15) / 16), (unsigned)((height / 2 + 15) / 16), 16, 16, args);
 }
 
-int gr_adaptive_refine(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg) {
-    return gr_adaptive_refine_strips(p, stream, rdata, pending_count, width, height, dfg, 0, 0, 1);
+int gr_adaptive_refine(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg,
+                       const void* lattice_angles) {
+    return gr_adaptive_refine_strips(p, stream, rdata, pending_count, width, height, dfg, 0, 0, 1, lattice_angles);
 }
 
 int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
@@ -1105,7 +1107,7 @@ int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args
     return trace_launch(p, 1, stream, a->camera_generic, a->camera_quat, a->render_data, a->width, a->height, a->block_rows, a->strip_rank,
                         a->strip_count, a->termination_buffer, a->prepass_width, a->prepass_height, a->e0, a->e1, a->e2, a->e3, a->cfg, a->dfg,
                         a->attempt_counter, a->lattice == 2 ? 2 : 1, a->pending_only ? 1 : 0, a->tile_order, a->waves_per_simd, &a->shading,
-                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0);
+                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0, a->lattice == 2 ? a->lattice_angles : nullptr);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

@@ -68,9 +68,11 @@ __device__ __forceinline__ float2 tex_to_angle(float2 tex) {
 }
 
 // render_data of one finished ray (body of calculate_render_data, cl.cl:5146-5212)
+// sky_angles (optional): where the ray meets the sky, (theta, phi) as get_intersection_position gives them - also for a ray whose
+// record stays black (it ended inside r = 1), which is what handle_adaptive_sampling decides on (cl.cl:5260-5268)
 __device__ __forceinline__ render_data make_render_data(float4 position, float4 velocity, float4 initial_quat, float ku_uobsu,
                                                         float running, int terminated, int sx, int sy, cfg_t cfg, dfg_t dfg,
-                                                        bool need_redshift) {
+                                                        bool need_redshift, float2* sky_angles = nullptr) {
     render_data dat;
     dat.terminated = terminated;
     dat.sx = sx;
@@ -81,6 +83,7 @@ __device__ __forceinline__ render_data make_render_data(float4 position, float4 
     if (terminated != 1) return dat;
 
     float4 ipos = intersection_position(position, velocity, initial_quat, cfg, dfg);
+    if (sky_angles) *sky_angles = make_float2(ipos.z, ipos.w);
     float4 generic_velocity = velocity / running;
     dat.side = gm::generic_to_spherical(position, cfg).y < 0 ? 0 : 1;
 #if !defined(TRAVERSABLE_EVENT_HORIZON)
@@ -293,7 +296,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
                                            unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
                                            const trace_shading& shading, bool known_skipped, int cell_wave, bool cells_in_flight,
-                                           unsigned int* __restrict__ tile_cost) {
+                                           unsigned int* __restrict__ tile_cost, float2* __restrict__ lattice_angles) {
     // cell_wave >= 0: this "tile" is 64 cells of the low-resolution prepass (prepass_cell, below) traced by the launch itself:
     // the ray of cell (cx, cy) of the prepass grid, and its verdict goes to the termination buffer instead of a record.
     // cells_in_flight: the launch has such waves, so a tile waits for the cells its pixels look at.
@@ -356,6 +359,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     }
     render_data dat;
     unsigned int tries = 0;
+    float2 sky_angles = make_float2(0, 0);
     if (terminated == 2) {
         dat.tex_coord = make_float2(0, 0);
         dat.z_shift = 0;
@@ -383,8 +387,12 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         if (res == RAY_TERMINATED) terminated = 1;
         else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
         dat = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated, cx, cy, cfg,
-                               dfg, GET_FEATURE(redshift, dfg) != 0);
+                               dfg, GET_FEATURE(redshift, dfg) != 0, &sky_angles);
     }
+    // the lattice launch of adaptive sampling leaves the angles gr_adaptive_refine decides on (a ray that was skipped or did not reach
+    // the sky keeps 0, 0: its flag differs from its neighbours' or, where they are all alike, any equal angles give the reference's
+    // verdict - its rays' untouched initial directions are as smooth as a constant)
+    if (lattice_angles && lattice == 2) lattice_angles[(cy / 2) * (image_width / 2) + cx / 2] = sky_angles;
     rdata[cy * width + cx] = dat;
 #ifdef GR_TILE_SHADING   // programs built with -DGR_TILE_SHADING only: carried along unused, the call's spills add 0.12 GB of scratch traffic per 4K launch
     if (shading.out && lattice == 1 && !pending_only && within < tiles_x * tile_rows) {
@@ -428,7 +436,8 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
                int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
-               int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped) {
+               int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped,
+               float2* __restrict__ lattice_angles) {
     // prepass_tickets > 0 (persistent launches in image order only): the first prepass_tickets tickets are the waves of the
     // low-resolution prepass, then come the tiles, which wait for the cells they look at (trace_tile).  A frame whose camera was not
     // known in advance then pays the prepass's single-ray latency once per cell wave alongside the first tiles instead of as a
@@ -489,7 +498,7 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
         GR_PROBE_TILE_BEGAN
         trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
                    termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
-                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost);
+                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost, lattice_angles);
         GR_PROBE_TILE_ENDED
         if (!tile_counter) break;
     }
@@ -927,7 +936,8 @@ __device__ __forceinline__ render_data interpolate_render_data(render_data r1, r
 // order the work.  Same tests as the reference (cl.cl:5242-5282): boundary blocks always refine, differing termination flags
 // refine, otherwise the angular error across the block against the per-pixel angle times the threshold.
 extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, int* __restrict__ pending_count, int width, int height,
-                                              dfg_t dfg, int block_rows, int strip_rank, int strip_count) {
+                                              dfg_t dfg, int block_rows, int strip_rank, int strip_count,
+                                              const float2* __restrict__ lattice_angles) {
     const int sx = blockIdx.x * blockDim.x + threadIdx.x;
     const int sy = blockIdx.y * blockDim.y + threadIdx.y;
     const int hw = width / 2, hh = height / 2;
@@ -940,10 +950,18 @@ extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, in
     if (sx != 0 && sx != hw - 1 && sy != 0 && sy != hh - 1) {
         const render_data centre = at(lsx, lsy), left = at(lsx - 2, lsy), right = at(lsx + 2, lsy), up = at(lsx, lsy - 2), down = at(lsx, lsy + 2);
         const int down_right_flag = at(lsx + 2, lsy + 2).terminated;
-        const float2 la = tex_to_angle(left.tex_coord), ra = tex_to_angle(right.tex_coord), ua = tex_to_angle(up.tex_coord), da = tex_to_angle(down.tex_coord);
-        // tex_to_angle gives (phi, theta); the reference compares (theta, phi) pairs
-        const float x_error = __builtin_fabsf(angle_between_angles(make_float2(la.y, la.x), make_float2(ra.y, ra.x)));
-        const float y_error = __builtin_fabsf(angle_between_angles(make_float2(da.y, da.x), make_float2(ua.y, ua.x)));
+        // (theta, phi) where each neighbour's ray meets the sky: as the lattice launch left them (lattice_angles - also for rays whose
+        // record is black, whose texture coordinates say nothing: a frame with thin black features interpolated where the reference
+        // refined and refined where it interpolated, up to a tenth of its pixels; found by the adaptive soak), or, without that
+        // buffer, back out of the texture coordinates (tex_to_angle gives (phi, theta))
+        auto sky = [&](const render_data& r, int x, int y) -> float2 {
+            if (lattice_angles) return lattice_angles[(y / 2) * hw + x / 2];
+            const float2 a = tex_to_angle(r.tex_coord);
+            return make_float2(a.y, a.x);
+        };
+        const float2 la = sky(left, lsx - 2, lsy), ra = sky(right, lsx + 2, lsy), ua = sky(up, lsx, lsy - 2), da = sky(down, lsx, lsy + 2);
+        const float x_error = __builtin_fabsf(angle_between_angles(la, ra));
+        const float y_error = __builtin_fabsf(angle_between_angles(da, ua));
         const float relative_angular_error = (float)((double)(((x_error + x_error + y_error + y_error) / 4.f) / 2) * GR_PI);
         const float fov = GET_FEATURE(field_of_view, dfg);
         const float per_pixel = (float)((double)(fov * 2) * GR_PI / (double)360.f) / width;

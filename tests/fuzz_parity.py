@@ -45,10 +45,15 @@ def quat_mul(a, b):
             aw * bw - ax * bx - ay * by - az * bz]
 
 
+ADAPTIVE = os.environ.get("FUZZ_ADAPTIVE", "0") not in ("", "0")   # every case with adaptive sampling on (the reference GUI's default)
+
+
 def draw_cases(cases, seed):
     """the soak's cases, drawn from one random stream: (index, metric name, metric, cfg, camera position, orientation, observer speed,
-    feature keywords, camera distance)"""
+    feature keywords, camera distance).  FUZZ_ADAPTIVE=1: the same cases with adaptive sampling on, the threshold from a stream of its
+    own (so that a seed names the same cameras either way)"""
     rng = np.random.default_rng(seed)
+    thresholds = np.random.default_rng(seed + 1000003)
     names = sorted(METRICS)
     for case in range(cases):
         name = names[case % len(names)]
@@ -65,6 +70,8 @@ def draw_cases(cases, seed):
         fkw = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change, redshift=int(rng.random() < 0.4),
                    reparameterisation=int(rng.random() < 0.25), field_of_view=float(rng.choice([60.0, 90.0, 110.0])),
                    universe_size=float(rng.choice([20.0, 30.0])), max_precision_radius=float(rng.choice([10.0, 14.0])))
+        if ADAPTIVE:
+            fkw.update(adaptive_sampling=1, adaptive_sampling_threshold=float(thresholds.choice([16.0, 32.0, 64.0])))
         yield case, name, metric, cfg, pos, quat, speed, fkw, r
 
 
@@ -126,7 +133,9 @@ def main():
         line = f"{case:3d} {name:26s} r={r:5.2f} speed={int(any(speed))} redshift={fkw['redshift']} reparam={fkw['reparameterisation']}"
         for label, prog in (("dyn", gra.Program(key, 0)),
                             ("sub", gra.Program(metric.argument_string(features=feats, static=True, cfg_values=cfg), 0))):
-            o = gra.frame_options(mode=gra.MODE_FUSED, use_prepass=0, count_attempts=1)
+            # FUZZ_MODE=reference: the reference-shaped kernel sequence instead of the fused kernels
+            o = gra.frame_options(mode=gra.MODE_REFERENCE if os.environ.get("FUZZ_MODE") == "reference" else gra.MODE_FUSED, use_prepass=0,
+                                  count_attempts=1)
             state.render(prog, metric, cam, out.ptr, (bg.ptr, bg_np.shape[2], bg_np.shape[1], levels), feats, cfg, o)
             state.synchronize()
             px = out.to_numpy(np.float32, (h, w, 4))
@@ -152,6 +161,7 @@ def main():
                     scatter = int((np.abs(theirs["pixels"][..., :3] - ref["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
                     against = int((np.abs(px[..., :3] - theirs["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
                     # ... and the reference build's rays against a float64 evaluation of the same algorithm: sky angles off by > 1e-3
+                    # (with adaptive sampling the traced rays are the lattice's and the refined pixels': a quarter to all of the frame's)
                     p64, t64 = oracles[key].trace_f64(theirs["rays_init"], cfg, pack_features(**fkw), nthreads=os.cpu_count() or 4)
                     both = (t64 == 1) & (theirs["rays"]["terminated"] == 1)
                     d64 = np.abs(np.asarray(theirs["rays"]["position"], dtype=np.float64)[both][:, 2:] - p64[both][:, 2:]).max(axis=1)

@@ -57,6 +57,13 @@ CASES = {
     "kerr_superextremal": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.9)),
     "kerr_prepass": dict(metric="kerr_boyer", size=(96, 64), cfg=dict(a=0.45), prepass=True),
     "kerr_adaptive_sampling": dict(metric="kerr_boyer", size=(48, 28), cfg=dict(a=0.45), features=dict(adaptive_sampling=1, adaptive_sampling_threshold=32.0)),
+    # case 117 of the adaptive soak (FUZZ_ADAPTIVE=1, seed 51), inputs as drawn: a Schwarzschild camera at r = 3.1 whose frame is full
+    # of thin black features (rays that end inside r = 1) - the reference's refinement decision reads those rays' sky angles like any
+    # other's, and a decision taken on the records' texture coordinates (0, 0 for a black record) got a tenth of the pixels wrong
+    "schwarzschild_adaptive_black_features": dict(metric="schwarzschild", scripts=True, size=(64, 36),
+                                                  camera_pos=[-0.6174562416563434, 2.205167715438048, -2.168047126936828, 0.36762825366897056],
+                                                  camera_quat=[-0.6049168524805493, -0.42006472218706736, -0.14871616353429276, 0.6599278244342851],
+                                                  features=dict(adaptive_sampling=1, adaptive_sampling_threshold=16.0, redshift=1)),
     "alcubierre": dict(metric="alcubierre", size=(48, 27), features=dict(redshift=1), camera_pos=[0.0, 0.0, -6.0, 0.5]),
     "double_unequal_kerr": dict(metric="double_unequal_kerr", scripts=True, size=(48, 27), camera_pos=[0.0, 0.0, -6.0, 0.5]),
     # a HYPER-EXTREME constituent (fa2 = a2 / m2 > 1: complex rod half-length, the principal complex roots stay complex; a naked
