@@ -5,6 +5,8 @@ reference's own x86-64 build (oracle/_ref, built by the `precompile` mode where 
 from a float64 evaluation of the same algorithm, in as many places (an ill-conditioned frame - the rule of
 tests/test_gpu_parity.py::test_polar_axis_cases_of_the_soak; reported, not failed).
 Test infrastructure (it runs the oracle).  usage: PYTHONPATH=. python tests/fuzz_parity.py [cases] [seed] [only_case]
+FUZZ_ADAPTIVE=1: adaptive sampling on in every case; FUZZ_PREPASS=1: the prepass on, 128 x 72 frames; FUZZ_MODE=reference: the
+reference-shaped kernel sequence instead of the fused kernels.
 With only_case the one case is replayed (the random stream is advanced through the earlier ones) and its inputs, the oracle's
 and the GPU's pixels and render-data go to gpurun_out/fuzz_case_<seed>_<case>.npz for a closer look."""
 import ctypes
@@ -46,6 +48,7 @@ def quat_mul(a, b):
 
 
 ADAPTIVE = os.environ.get("FUZZ_ADAPTIVE", "0") not in ("", "0")   # every case with adaptive sampling on (the reference GUI's default)
+PREPASS = os.environ.get("FUZZ_PREPASS", "0") not in ("", "0")     # every case with the low-resolution prepass on, frames of 128 x 72
 
 
 def draw_cases(cases, seed):
@@ -111,8 +114,10 @@ def main():
     if len(sys.argv) > 3 and sys.argv[3] == "precompile":
         precompile(cases, seed)
         return 0
-    w, h = 64, 36
-    bg_np, levels = gra.pack_background(gra.synthetic_background(256, 128))
+    w, h = (128, 72) if PREPASS else (64, 36)   # (a prepass grid of 8 x 4 cells)
+    # (four sky texels to a pixel either way: with two, a frame that looks down the chart's axis - grid lines converging on the pole all
+    # over it - turns sky coordinates that agree to 2e-6 into pixels 5e-4 apart on every line, masked RMSE 1.4e-4)
+    bg_np, levels = gra.pack_background(gra.synthetic_background(*((512, 256) if PREPASS else (256, 128))))
     bg = DeviceBuffer.from_numpy(0, bg_np)
     out = DeviceBuffer(0, w * h * 16)
     state = gra.RenderState(w, h, 0)
@@ -126,7 +131,7 @@ def main():
         if key not in oracles:
             oracles[key] = OraclePipeline(build_restate.build(key))
         ref = oracles[key].frame(w, h, cfg, pack_features(**fkw), camera_pos=pos, camera_quat=quat, basis_speed=speed,
-                                 background=(bg_np, levels), nthreads=os.cpu_count() or 4)
+                                 background=(bg_np, levels), nthreads=os.cpu_count() or 4, use_prepass=PREPASS)
         oracles[key].lib.ref_last_attempts.restype = ctypes.c_uint64
         cam = gra.default_camera(pos, quat)
         cam.basis_speed = (gra.c_float * 3)(*speed)
@@ -134,8 +139,8 @@ def main():
         for label, prog in (("dyn", gra.Program(key, 0)),
                             ("sub", gra.Program(metric.argument_string(features=feats, static=True, cfg_values=cfg), 0))):
             # FUZZ_MODE=reference: the reference-shaped kernel sequence instead of the fused kernels
-            o = gra.frame_options(mode=gra.MODE_REFERENCE if os.environ.get("FUZZ_MODE") == "reference" else gra.MODE_FUSED, use_prepass=0,
-                                  count_attempts=1)
+            o = gra.frame_options(mode=gra.MODE_REFERENCE if os.environ.get("FUZZ_MODE") == "reference" else gra.MODE_FUSED,
+                                  use_prepass=1 if PREPASS else 0, count_attempts=1)
             state.render(prog, metric, cam, out.ptr, (bg.ptr, bg_np.shape[2], bg_np.shape[1], levels), feats, cfg, o)
             state.synchronize()
             px = out.to_numpy(np.float32, (h, w, 4))
@@ -148,7 +153,7 @@ def main():
             chaotic = name == "double_unequal_kerr" and max(abs(cfg[2]), abs(cfg[3])) > 1.0
             ok = bad.mean() <= (0.10 if chaotic else 0.01) and rmse <= (3e-4 if chaotic else 1e-4) and np.isfinite(px).all()
             verdict = "" if ok else "  <-- FAIL"
-            if not ok and np.isfinite(px).all() and rmse <= 3e-4:
+            if not ok and np.isfinite(px).all() and rmse <= 3e-4 and bad.mean() > (0.10 if chaotic else 0.01):   # (too many pixels off; a bad RMSE alone stays a failure)
                 # Too many pixels off: is it the case or the kernel?  The reference's own source compiled for x86-64 against the CPU
                 # restatement (same algorithm, same operation order, another compiler): where those two differ in as many pixels, the
                 # frame is ill-conditioned (rays grazing a chart axis: tests/test_gpu_parity.py::test_polar_axis_cases_of_the_soak,
@@ -157,7 +162,7 @@ def main():
                 so = build_ref.prebuilt("fuzz_" + name, key)
                 if so:
                     theirs = OraclePipeline(so).frame(w, h, cfg, pack_features(**fkw), camera_pos=pos, camera_quat=quat, basis_speed=speed,
-                                                      background=(bg_np, levels), nthreads=os.cpu_count() or 4)
+                                                      background=(bg_np, levels), nthreads=os.cpu_count() or 4, use_prepass=PREPASS)
                     scatter = int((np.abs(theirs["pixels"][..., :3] - ref["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
                     against = int((np.abs(px[..., :3] - theirs["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
                     # ... and the reference build's rays against a float64 evaluation of the same algorithm: sky angles off by > 1e-3
