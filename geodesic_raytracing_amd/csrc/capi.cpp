@@ -89,11 +89,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_prepass", "gr_order_tiles", "gr_adaptive_refine", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_prepass", "gr_order_tiles", "gr_adaptive_refine", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_PREPASS, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_PREPASS, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -243,7 +243,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
             if (gr::compile_to_assembly(source, options, assembly, log)) {
                 if (run_limit <= 0 && gr::assemble_code_object(assembly, out, log)) return GR_OK;
                 // the kernels that hold a Verlet loop; the others (set-up, shading, tile order ...) are left as compiled
-                static const std::vector<std::string> integrators = {"gr_trace_fused", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused",
+                static const std::vector<std::string> integrators = {"gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused",
                                                                      "gr_camera_prepass", "gr_do_generic_rays", "gr_get_geodesic_path"};
                 std::string patched = assembly;
                 const gr::vector_run_stats st = gr::break_vector_runs(patched, run_limit, integrators);
@@ -972,7 +972,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
                         int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
                         const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0, const void* tile_order = nullptr,
                         int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr, int inline_prepass = 0, void* tile_cost = nullptr,
-                        int tile_order_by_history = 0, void* lattice_angles = nullptr) {
+                        int tile_order_by_history = 0, void* lattice_rays = nullptr) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
     // the prepass inside the launch: its cell waves are the first tickets (gr_trace_fused's prepass_tickets)
@@ -1020,7 +1020,8 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     // dispatcher then has to retire before the next launch's workgroups get the freed slots
     // experiment hook: GR_TRACE_WAVES_PER_SIMD=k launches k persistent waves per SIMD whatever fits (occupancy studies)
     static const int forced_waves_per_simd = [] { const char* e = getenv("GR_TRACE_WAVES_PER_SIMD"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 0; }();
-    const int kernel_index = rays_per_lane == 2 ? K_TRACE_PAIR : K_TRACE_FUSED;
+    // (the lattice launch of adaptive sampling that leaves its rays behind is a kernel of its own: gr_trace_fused is not touched by it)
+    const int kernel_index = rays_per_lane == 2 ? K_TRACE_PAIR : (lattice == 2 && lattice_rays) ? K_TRACE_FUSED_LATTICE : K_TRACE_FUSED;
     long long resident_groups = resident_trace_groups(p, kernel_index, wg);
     if (resident_groups < 0) return (int)-resident_groups;
     // a caller that keeps several frames in flight may take fewer slots per launch: two smaller launches then share the device
@@ -1067,31 +1068,32 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
                     &lattice, &pending_only, &tile_order, &shading, &prepass_tickets, &ticket_tiles, &tile_cost,
-                    &last_class_is_skipped, &lattice_angles};   // the last nine: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
+                    &last_class_is_skipped, &lattice_rays};   // the last nine: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
     return launch(p, kernel_index, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
 int gr_trace_fused_adaptive(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
                             int height, const void* term, int prepass_width, int prepass_height, const void* e0, const void* e1,
                             const void* e2, const void* e3, const void* cfg, const void* dfg, void* attempt_counter, int lattice,
-                            int pending_only, void* lattice_angles) {
+                            int pending_only, void* lattice_rays) {
     return trace_launch(p, 1, stream, camera_generic, camera_quat, rdata, width, height, 0, 0, 1, term, prepass_width, prepass_height, e0, e1,
                         e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, nullptr, 0, nullptr, 0, nullptr, 0,
-                        lattice == 2 ? lattice_angles : nullptr);
+                        lattice == 2 ? lattice_rays : nullptr);
 }
 
 int gr_adaptive_refine_strips(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg,
-                              int block_rows, int strip_rank, int strip_count, const void* lattice_angles) {
+                              int block_rows, int strip_rank, int strip_count, const void* lattice_rays, const void* cfg) {
     if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + 7) / 8) * 8; }
     if (block_rows <= 0 || block_rows % 8 != 0 || strip_rank < 0 || strip_rank >= strip_count)
         return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
-    void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_angles};
+    if (lattice_rays && !cfg) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_adaptive_refine: lattice_rays needs the metric's cfg");
+    void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_rays, &cfg};
     return launch(p, K_ADAPTIVE_REFINE, stream, (unsigned)((width / 2 + 15) / 16), (unsigned)((height / 2 + 15) / 16), 16, 16, args);
 }
 
 int gr_adaptive_refine(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg,
-                       const void* lattice_angles) {
-    return gr_adaptive_refine_strips(p, stream, rdata, pending_count, width, height, dfg, 0, 0, 1, lattice_angles);
+                       const void* lattice_rays, const void* cfg) {
+    return gr_adaptive_refine_strips(p, stream, rdata, pending_count, width, height, dfg, 0, 0, 1, lattice_rays, cfg);
 }
 
 int gr_trace_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
@@ -1107,7 +1109,7 @@ int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args
     return trace_launch(p, 1, stream, a->camera_generic, a->camera_quat, a->render_data, a->width, a->height, a->block_rows, a->strip_rank,
                         a->strip_count, a->termination_buffer, a->prepass_width, a->prepass_height, a->e0, a->e1, a->e2, a->e3, a->cfg, a->dfg,
                         a->attempt_counter, a->lattice == 2 ? 2 : 1, a->pending_only ? 1 : 0, a->tile_order, a->waves_per_simd, &a->shading,
-                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0, a->lattice == 2 ? a->lattice_angles : nullptr);
+                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0, a->lattice == 2 ? a->lattice_rays : nullptr);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

@@ -59,7 +59,7 @@ struct gr_render_state {
     size_t tile_order_bytes = 0;
     // what each tile of the last fused frame cost (gr_trace_fused_args.tile_cost) and the frame shape that goes with it: the next
     // frame's tiles are handed out dearest first by it (gr_frame_options.tile_history)
-    void* lattice_angles = nullptr;   // adaptive sampling on the fused path: float2 per lattice pixel (allocated on first use)
+    void* lattice_rays = nullptr;   // adaptive sampling on the fused path: 3 float4 per lattice pixel (allocated on first use)
     void* tile_cost = nullptr;
     int tile_cost_shape[3] = {0, 0, 0};   // block_rows, strip_rank, strip_count
     bool tile_cost_valid = false;
@@ -455,7 +455,7 @@ void gr_render_state_destroy(gr_render_state* s) {
     std::vector<void*> ptrs = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
                                s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
                                s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->tile_order,
-                               s->tile_cost, s->lattice_angles};
+                               s->tile_cost, s->lattice_rays};
     for (auto& slot : s->pre) {
         if (slot.stream) { (void)hipStreamSynchronize(slot.stream); (void)hipStreamDestroy(slot.stream); }
         if (slot.ready) (void)hipEventDestroy(slot.ready);
@@ -1011,14 +1011,14 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.attempt_counter = attempts;
                 a.waves_per_simd = opt.trace_waves_per_simd;
                 a.lattice = 2;
-                if (!s->lattice_angles) HIP_CHECK(hipMalloc(&s->lattice_angles, (size_t)(width / 2) * (height / 2) * 2 * sizeof(float)));
-                a.lattice_angles = s->lattice_angles;
+                if (!s->lattice_rays) HIP_CHECK(hipMalloc(&s->lattice_rays, (size_t)(width / 2) * (height / 2) * 12 * sizeof(float)));
+                a.lattice_rays = s->lattice_rays;
                 GR_CHECK(gr_trace_fused_launch(p, stream, &a));
                 GR_CHECK(end(GR_STAGE_TRACE));
                 GR_CHECK(begin(GR_STAGE_ADAPTIVE));
                 HIP_CHECK(hipMemsetAsync(s->rays_adaptive_count, 0, 4, stream));
                 GR_CHECK(gr_adaptive_refine_strips(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows,
-                                                   strip_rank, strip_count, s->lattice_angles));
+                                                   strip_rank, strip_count, s->lattice_rays, s->cfg));
                 a.lattice = 1;
                 a.pending_only = 1;
                 GR_CHECK(gr_trace_fused_launch(p, stream, &a));

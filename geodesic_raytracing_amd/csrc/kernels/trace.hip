@@ -68,11 +68,9 @@ __device__ __forceinline__ float2 tex_to_angle(float2 tex) {
 }
 
 // render_data of one finished ray (body of calculate_render_data, cl.cl:5146-5212)
-// sky_angles (optional): where the ray meets the sky, (theta, phi) as get_intersection_position gives them - also for a ray whose
-// record stays black (it ended inside r = 1), which is what handle_adaptive_sampling decides on (cl.cl:5260-5268)
 __device__ __forceinline__ render_data make_render_data(float4 position, float4 velocity, float4 initial_quat, float ku_uobsu,
                                                         float running, int terminated, int sx, int sy, cfg_t cfg, dfg_t dfg,
-                                                        bool need_redshift, float2* sky_angles = nullptr) {
+                                                        bool need_redshift) {
     render_data dat;
     dat.terminated = terminated;
     dat.sx = sx;
@@ -83,7 +81,6 @@ __device__ __forceinline__ render_data make_render_data(float4 position, float4 
     if (terminated != 1) return dat;
 
     float4 ipos = intersection_position(position, velocity, initial_quat, cfg, dfg);
-    if (sky_angles) *sky_angles = make_float2(ipos.z, ipos.w);
     float4 generic_velocity = velocity / running;
     dat.side = gm::generic_to_spherical(position, cfg).y < 0 ? 0 : 1;
 #if !defined(TRAVERSABLE_EVENT_HORIZON)
@@ -289,6 +286,10 @@ struct trace_shading {
 };
 __device__ __attribute__((noinline)) float4 shade_pixel_in_tile(const render_data& self, float2 beside, float2 below, const trace_shading& shading, dfg_t dfg);
 
+// LATTICE_RAYS: the instantiation of gr_trace_fused_lattice, which also leaves its rays' end states behind (below).  A kernel of its
+// own so that gr_trace_fused stays exactly the code it was: as a run-time option the three stores cost the headline kernel its
+// seventh wave per SIMD (72 VGPRs + 48 B -> 80 + 36 B at six).
+template <bool LATTICE_RAYS>
 __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __restrict__ camera, const float4* __restrict__ camera_quat,
                                            render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank,
                                            int strip_count, const int* __restrict__ termination_buffer, int prepass_width,
@@ -296,7 +297,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
                                            unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
                                            const trace_shading& shading, bool known_skipped, int cell_wave, bool cells_in_flight,
-                                           unsigned int* __restrict__ tile_cost, float2* __restrict__ lattice_angles) {
+                                           unsigned int* __restrict__ tile_cost, float4* __restrict__ lattice_rays) {
     // cell_wave >= 0: this "tile" is 64 cells of the low-resolution prepass (prepass_cell, below) traced by the launch itself:
     // the ray of cell (cx, cy) of the prepass grid, and its verdict goes to the termination buffer instead of a record.
     // cells_in_flight: the launch has such waves, so a tile waits for the cells its pixels look at.
@@ -359,7 +360,6 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     }
     render_data dat;
     unsigned int tries = 0;
-    float2 sky_angles = make_float2(0, 0);
     if (terminated == 2) {
         dat.tex_coord = make_float2(0, 0);
         dat.z_shift = 0;
@@ -387,12 +387,20 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         if (res == RAY_TERMINATED) terminated = 1;
         else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
         dat = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated, cx, cy, cfg,
-                               dfg, GET_FEATURE(redshift, dfg) != 0, &sky_angles);
+                               dfg, GET_FEATURE(redshift, dfg) != 0);
+        // The lattice launch of adaptive sampling leaves where its rays ended - position, velocity, the quaternion of the rotated frame -
+        // for gr_adaptive_refine, which needs what the reference reads off its ray records (get_intersection_position of every
+        // neighbour, also of rays whose record stays black: cl.cl:5260-5268).  Three stores of values that are live anyway: working the
+        // sky angles out here gave the intersection's products a second use, the compiler then formed other fmas, and the records of
+        // every launch came out rounded differently (Schwarzschild 1000 x 500 against gr_trace_compact, pixels apart by > 1e-4:
+        // 3e-5 of the frame -> 1.3e-3); doing it on laundered copies cost the headline kernel a wave per SIMD.
+        if (LATTICE_RAYS && lattice_rays && lattice == 2) {
+            float4* record = lattice_rays + 3 * ((size_t)(cy / 2) * (image_width / 2) + cx / 2);
+            record[0] = s.position;
+            record[1] = s.velocity;
+            record[2] = ray.initial_quat;
+        }
     }
-    // the lattice launch of adaptive sampling leaves the angles gr_adaptive_refine decides on (a ray that was skipped or did not reach
-    // the sky keeps 0, 0: its flag differs from its neighbours' or, where they are all alike, any equal angles give the reference's
-    // verdict - its rays' untouched initial directions are as smooth as a constant)
-    if (lattice_angles && lattice == 2) lattice_angles[(cy / 2) * (image_width / 2) + cx / 2] = sky_angles;
     rdata[cy * width + cx] = dat;
 #ifdef GR_TILE_SHADING   // programs built with -DGR_TILE_SHADING only: carried along unused, the call's spills add 0.12 GB of scratch traffic per 4K launch
     if (shading.out && lattice == 1 && !pending_only && within < tiles_x * tile_rows) {
@@ -429,15 +437,15 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
 // persistent waves - the launch only fills the machine and every wave keeps drawing the next tile from the device-side
 // counter until total_waves are handed out, so a SIMD slot never idles between the end of a short tile (prepass-skipped
 // tiles finish in a few hundred cycles) and the dispatcher's next workgroup.
-extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
-gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+template <bool LATTICE_RAYS>
+__device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
                const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
                int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
                int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped,
-               float2* __restrict__ lattice_angles) {
+               float4* __restrict__ lattice_rays) {
     // prepass_tickets > 0 (persistent launches in image order only): the first prepass_tickets tickets are the waves of the
     // low-resolution prepass, then come the tiles, which wait for the cells they look at (trace_tile).  A frame whose camera was not
     // known in advance then pays the prepass's single-ray latency once per cell wave alongside the first tiles instead of as a
@@ -496,9 +504,9 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
         // 5 instead of 8 waves per SIMD).  Re-reading 96 bytes through the scalar cache per tile is free by comparison.
         asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
         GR_PROBE_TILE_BEGAN
-        trace_tile(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
+        trace_tile<LATTICE_RAYS>(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
                    termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
-                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost, lattice_angles);
+                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost, lattice_rays);
         GR_PROBE_TILE_ENDED
         if (!tile_counter) break;
     }
@@ -508,6 +516,31 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
         atomicAdd(attempt_counter + 3, 1ull);
         GR_PROBE_WAVE_ENDED
     }
+}
+
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
+gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+               render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
+               const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+               const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+               cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
+               int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
+               int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped,
+               float4* __restrict__ lattice_rays) {
+    trace_fused_body<false>(g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg_in, dfg_in, attempt_counter, tile_counter, total_waves, lattice, pending_only, tile_order, shading, prepass_tickets, ticket_tiles, tile_cost, last_class_is_skipped, lattice_rays);
+}
+
+// the lattice launch of adaptive sampling (lattice = 2 with lattice_rays): the same tiles, tickets and integrator
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
+gr_trace_fused_lattice(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+               render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
+               const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+               const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+               cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
+               int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
+               int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped,
+               float4* __restrict__ lattice_rays) {
+    trace_fused_body<true>(g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg_in, dfg_in, attempt_counter, tile_counter, total_waves, lattice, pending_only, tile_order, shading, prepass_tickets, ticket_tiles, tile_cost, last_class_is_skipped, lattice_rays);
 }
 
 // ---- ray compaction ------------------------------------------------------------------------------
@@ -937,7 +970,7 @@ __device__ __forceinline__ render_data interpolate_render_data(render_data r1, r
 // refine, otherwise the angular error across the block against the per-pixel angle times the threshold.
 extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, int* __restrict__ pending_count, int width, int height,
                                               dfg_t dfg, int block_rows, int strip_rank, int strip_count,
-                                              const float2* __restrict__ lattice_angles) {
+                                              const float4* __restrict__ lattice_rays, cfg_t cfg) {
     const int sx = blockIdx.x * blockDim.x + threadIdx.x;
     const int sy = blockIdx.y * blockDim.y + threadIdx.y;
     const int hw = width / 2, hh = height / 2;
@@ -950,12 +983,19 @@ extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, in
     if (sx != 0 && sx != hw - 1 && sy != 0 && sy != hh - 1) {
         const render_data centre = at(lsx, lsy), left = at(lsx - 2, lsy), right = at(lsx + 2, lsy), up = at(lsx, lsy - 2), down = at(lsx, lsy + 2);
         const int down_right_flag = at(lsx + 2, lsy + 2).terminated;
-        // (theta, phi) where each neighbour's ray meets the sky: as the lattice launch left them (lattice_angles - also for rays whose
-        // record is black, whose texture coordinates say nothing: a frame with thin black features interpolated where the reference
-        // refined and refined where it interpolated, up to a tenth of its pixels; found by the adaptive soak), or, without that
-        // buffer, back out of the texture coordinates (tex_to_angle gives (phi, theta))
+        // (theta, phi) where each neighbour's ray meets the sky: the reference's get_intersection_position of the ray as the lattice
+        // launch left it (lattice_rays) - also for rays whose record is black, whose texture coordinates say nothing: decided on
+        // those, a frame with thin black features interpolated where the reference refines and refined where it interpolates, up
+        // to a tenth of its pixels (found by the adaptive soak).  Only neighbours that reached the sky are asked: any other flag
+        // differs from the centre's or - where all six are alike - the rays' untouched initial directions are as smooth as the
+        // constant used here.  Without the buffer: back out of the texture coordinates (tex_to_angle gives (phi, theta)).
         auto sky = [&](const render_data& r, int x, int y) -> float2 {
-            if (lattice_angles) return lattice_angles[(y / 2) * hw + x / 2];
+            if (lattice_rays) {
+                if (r.terminated != 1) return make_float2(0, 0);
+                const float4* record = lattice_rays + 3 * ((size_t)(y / 2) * hw + x / 2);
+                const float4 meets = intersection_position(record[0], record[1], record[2], cfg, dfg);
+                return make_float2(meets.z, meets.w);
+            }
             const float2 a = tex_to_angle(r.tex_coord);
             return make_float2(a.y, a.x);
         };

@@ -362,7 +362,7 @@ typedef struct gr_trace_fused_args {
     void* tile_cost;    /* not NULL: unsigned[number of the device's tiles = (gr_tile_order_bytes - 128) / 8]; the launch leaves what
                          * each tile cost there (the attempts of its longest ray) for gr_order_tiles_by_history.  Every pixel, one ray per lane. */
     int tile_order_by_history;   /* 1: tile_order is gr_order_tiles_by_history's list (its last class is looked up like any tile) */
-    void* lattice_angles;        /* lattice = 2: where the launch leaves the sky angles gr_adaptive_refine decides on (see there); may be NULL */
+    void* lattice_rays;          /* lattice = 2: where the launch leaves its rays' end states for gr_adaptive_refine (see there); may be NULL */
 } gr_trace_fused_args;
 int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args* args);
 /* waves of gr_trace_fused the program's device holds at once (what a persistent launch fills it with): a frame of many more tiles than
@@ -384,20 +384,21 @@ int gr_render_seams(gr_program* p, void* stream, const void* render_data, void* 
 int gr_trace_fused_adaptive(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* render_data,
                             int width, int height, const void* termination_buffer, int prepass_width, int prepass_height,
                             const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg,
-                            void* attempt_counter, int lattice, int pending_only, void* lattice_angles);
+                            void* attempt_counter, int lattice, int pending_only, void* lattice_rays);
 int gr_adaptive_refine(gr_program* p, void* stream, void* render_data, void* pending_count, int width, int height, const void* dfg,
-                       const void* lattice_angles);
-/* lattice_angles: float2[(width / 2) * (height / 2)], written by the lattice launch (lattice = 2) and read by gr_adaptive_refine: where
- * every lattice ray meets the sky, (theta, phi) as the reference's get_intersection_position gives them - also for rays whose record is
- * black (they ended inside r = 1; their texture coordinates are 0, 0), which the reference's decision reads like any other
- * (cl.cl:5260-5268).  NULL on both: the decision falls back on the records' texture coordinates, which differs from the reference's
- * around black features. */
+                       const void* lattice_rays, const void* cfg);
+/* lattice_rays: 3 x float4 per lattice pixel ((width / 2) * (height / 2) * 48 bytes), written by the lattice launch (lattice = 2) and
+ * read by gr_adaptive_refine: where every lattice ray ended (position, velocity, the quaternion of its rotated frame) - what the
+ * reference's decision reads off its ray records through get_intersection_position, also for rays whose render-data record is black
+ * (they ended inside r = 1; their texture coordinates are 0, 0; cl.cl:5260-5268).  NULL on both: the decision falls back on the
+ * records' texture coordinates, which differs from the reference's around black features.  cfg: the metric's dynamic variables
+ * (needed with lattice_rays). */
 /* the same on a device's share of a split frame: only the 2x2 pixel blocks whose rows the device shades or reads as a halo row are
  * decided.  The lattice launch before it (gr_trace_fused_launch with lattice = 2 and the strip description) traces the lattice
  * rows those decisions read - two rows of halo either side of a block - and the launch after it (pending_only = 1, same strip
  * description) the marked pixels of the device's rows; the rows equal those of the whole frame sampled adaptively. */
 int gr_adaptive_refine_strips(gr_program* p, void* stream, void* render_data, void* pending_count, int width, int height,
-                              const void* dfg, int block_rows, int strip_rank, int strip_count, const void* lattice_angles);
+                              const void* dfg, int block_rows, int strip_rank, int strip_count, const void* lattice_rays, const void* cfg);
 
 /* gr_trace_fused with two rays per lane: a wave takes two neighbouring 8x8 tiles and every lane integrates one pixel of each,
  * all per-ray arithmetic in packed fp32 (v_pk_fma/mul/add_f32: one instruction, two rays).  Same arguments, same records;

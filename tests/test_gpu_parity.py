@@ -182,7 +182,7 @@ def test_adaptive_sampling_matches_reference(name):
 @pytest.mark.parametrize("name", ADAPTIVE)
 def test_adaptive_sampling_on_the_fused_path_matches_reference(name):
     """the golden frames through the fused kernels: half-resolution lattice (gr_trace_fused_launch, lattice = 2), gr_adaptive_refine,
-    second fused launch over the marked pixels.  The decision is taken on the sky angles the lattice launch leaves in lattice_angles -
+    second fused launch over the marked pixels.  The decision is taken on the ray end states the lattice launch leaves in lattice_rays -
     the reference's get_intersection_position of every lattice ray, also of those whose record is black.  (Until the adaptive soak -
     tests/fuzz_parity.py with FUZZ_ADAPTIVE=1 - it read them back out of the records' texture coordinates, which are 0, 0 for a black
     record: in schwarzschild_adaptive_black_features, a frame full of thin black features, 223 of 2 304 pixels came out wrong.)"""
