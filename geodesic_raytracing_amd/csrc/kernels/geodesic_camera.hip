@@ -167,6 +167,17 @@ extern "C" __global__ void gr_get_geodesic_path(const lightray* __restrict__ gen
             last_pos_generic = next_pos_generic;
             generic_position_out = next_pos_generic;
             generic_velocity_out = next_vel_generic;
+            // The rotation turns angles; the first two coordinates of such a chart (X, Y, theta, phi with a metric that does not
+            // depend on the angles) go through to-spherical and back unchanged - up to rounding, and that is the catch: ingoing
+            // Eddington-Finkelstein time is t + r*, so the round trip of dX/dlambda adds and subtracts (dr/dlambda) / (1 - rs / r), which at
+            // r = 1.0002 rs is 6 000 against a result of 2.  With exact division (the reference's x86 build) that costs four digits
+            // of seven; with v_rcp_f32 it cost all of them for the step that lands there (tests/fuzz_paths.py: dX/dlambda = -0.67 for
+            // 2.05).  They are taken as they are.
+            generic_velocity_out.x = velocity.x / old_dlambda;
+            generic_velocity_out.y = velocity.y / old_dlambda;
+            // (the position's too: the same chart's time is t + r + rs ln(r / rs - 1), whose round trip is as ill-conditioned there)
+            generic_position_out.x = position.x;
+            generic_position_out.y = position.y;
         }
 #endif
         if (degenerate4(next_position) || degenerate4(next_velocity) || degenerate4(next_acceleration)) break;

@@ -6,7 +6,7 @@ from a float64 evaluation of the same algorithm, in as many places (an ill-condi
 tests/test_gpu_parity.py::test_polar_axis_cases_of_the_soak; reported, not failed).
 Test infrastructure (it runs the oracle).  usage: PYTHONPATH=. python tests/fuzz_parity.py [cases] [seed] [only_case]
 FUZZ_ADAPTIVE=1: adaptive sampling on in every case; FUZZ_PREPASS=1: the prepass on, 128 x 72 frames; FUZZ_MODE=reference: the
-reference-shaped kernel sequence instead of the fused kernels.
+reference-shaped kernel sequence instead of the fused kernels; FUZZ_SIZE=WxH: another frame size.
 With only_case the one case is replayed (the random stream is advanced through the earlier ones) and its inputs, the oracle's
 and the GPU's pixels and render-data go to gpurun_out/fuzz_case_<seed>_<case>.npz for a closer look."""
 import ctypes
@@ -115,6 +115,8 @@ def main():
         precompile(cases, seed)
         return 0
     w, h = (128, 72) if PREPASS else (64, 36)   # (a prepass grid of 8 x 4 cells)
+    if os.environ.get("FUZZ_SIZE"):              # e.g. 100x60: partial 8 x 8 tiles on the right and at the bottom, a 6 x 3 prepass grid
+        w, h = (int(v) for v in os.environ["FUZZ_SIZE"].split("x"))
     # (four sky texels to a pixel either way: with two, a frame that looks down the chart's axis - grid lines converging on the pole all
     # over it - turns sky coordinates that agree to 2e-6 into pixels 5e-4 apart on every line, masked RMSE 1.4e-4)
     bg_np, levels = gra.pack_background(gra.synthetic_background(*((512, 256) if PREPASS else (256, 128))))
