@@ -510,8 +510,9 @@ typedef struct gr_frame_options {
                             * picture since; the first frame, one of another strip description, one whose camera has moved the picture
                             * by more than 48 px or rides a geodesic goes in image order); every such frame records its tiles' costs.
                             * Scheduling only: the pixels do not depend on it.  0 = no; -1 = library default: whole frames of at most
-                            * 32 tiles per wave slot that find the device idle when they are submitted (frames in flight fill each
-                            * other's tails, and the order measured slower there) */
+                            * 32 tiles per wave slot that find no frame of ANOTHER stream still running on the device when they are
+                            * submitted (frames in flight on several streams fill each other's tails, and the order measured slower
+                            * there; frames queued on one stream run one after the other and do follow it) */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 /* What tile_history did with this render state's frames so far: how many recorded their tiles' costs, how many of those followed
