@@ -325,8 +325,14 @@ __device__ __forceinline__ void correct_lightray(float4& position, float4& veloc
     float3 next_pos = cartesian_to_polar(pos_cart);
     float3 next_vel = cartesian_velocity_to_polar_velocity(pos_cart, vel_cart);
     if (sgn < 0) next_pos.x = -next_pos.x;
+    // The rotation turns angles: the chart's first two coordinates and their rates come back from the round trip through spherical
+    // coordinates as they went in, up to rounding - which in a chart whose time mixes in r* (ingoing Eddington-Finkelstein) is the
+    // difference of two terms ~ 1 / (1 - rs / r) near the horizon (geodesic_camera.hip has the measured case).  They are kept.
+    const float first = position.x, second = position.y, first_rate = velocity.x, second_rate = velocity.y;
     position = gm::spherical_to_generic(f4(pos_sph.x, next_pos), cfg);
     velocity = gm::spherical_velocity_to_generic_velocity(f4(pos_sph.x, next_pos), f4(vel_sph.x, next_vel), cfg);
+    position.x = first; position.y = second;
+    velocity.x = first_rate; velocity.y = second_rate;
 #endif
 }
 
