@@ -87,6 +87,7 @@ _SIGNATURES = {
     "gr_features_default": (None, [ctypes.POINTER(Features)]),
     "gr_metric_builtin": (c_int, [c_char_p, ctypes.POINTER(c_void_p)]),
     "gr_metric_load_script": (c_int, [c_char_p, c_char_p, ctypes.POINTER(c_void_p)]),
+    "gr_metric_from_info": (c_int, [ctypes.POINTER(MetricInfo), ctypes.POINTER(c_char_p), ctypes.POINTER(c_float), ctypes.POINTER(c_void_p)]),
     "gr_metric_destroy": (None, [c_void_p]),
     "gr_metric_get_info": (c_int, [c_void_p, ctypes.POINTER(MetricInfo)]),
     "gr_metric_dynamic_var_name": (c_char_p, [c_void_p, c_int]),

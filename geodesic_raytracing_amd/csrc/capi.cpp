@@ -89,13 +89,19 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_prepass", "gr_order_tiles", "gr_adaptive_refine", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_setup", "gr_order_tiles", "gr_adaptive_refine", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_PREPASS, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_SETUP, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
+
+// the kernels of the set-up module (kernels/camera.hip, geodesic_camera.hip): once per frame, one lane, IEEE arithmetic
+bool is_setup_kernel(int k) {
+    return k == K_CART_TO_GENERIC || k == K_INIT_BASIS || k == K_CAMERA_SETUP || k == K_BOOST_TETRAD || k == K_INIT_INERTIAL ||
+           k == K_GEODESIC_PATH || k == K_PARALLEL_TRANSPORT || k == K_INTERPOLATE_GEODESIC;
+}
 
 std::vector<std::string> split_arguments(const std::string& s) {
     std::vector<std::string> out;
@@ -162,6 +168,8 @@ bool kernel_resources(const std::string& code, const char* kernel, int& vgprs, i
 }
 
 // Compiles (or fetches from the on-disk cache) the code object for one macro string.
+int compile_setup_module(const std::string& argument_string, std::string& code);
+
 int compile_code_object(const std::string& argument_string, std::string& code, std::string* key_out = nullptr) {
     // the kernel source: the parts under csrc/kernels/ in this order, as one translation unit (GR_KERNEL_SOURCE: one file instead)
     static const char* const KERNEL_PARTS[] = {"program.hip",       // structs of the boundary, build switches
@@ -170,8 +178,8 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
                                                "setup.hip",         // tetrads, ray set-up
                                                "integrator.hip",    // the Verlet loop, one and two rays per lane
                                                "trace.hip",         // render-data, the reference-shaped and the fused kernels, prepass, tile order, adaptive sampling
-                                               "shading.hip",       // texture sampling, gr_render
-                                               "geodesic_camera.hip"};
+                                               "shading.hip"};      // texture sampling, gr_render
+    // (camera.hip and geodesic_camera.hip - what runs once per frame on one lane - are the set-up module: compile_setup_module)
     std::string source;
     if (const char* env = getenv("GR_KERNEL_SOURCE")) {
         if (!read_file(env, source)) return fail(GR_ERROR_COMPILE, std::string("cannot read kernel source ") + env);
@@ -203,6 +211,16 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
         "-fno-slp-vectorize"};
     for (auto& tok : split_arguments(argument_string)) {
         if (tok.rfind("-D", 0) == 0) opts.push_back(tok);
+        else if (tok == "-cl-fp32-correctly-rounded-divide-sqrt") {
+            // OpenCL's own switch for IEEE divide and square root (the reference does not pass it, metric_manager.hpp:70; a caller who
+            // appends it to the argument string gets what it means): the ray kernels without v_rcp_f32 / v_sqrt_f32 arithmetic.
+            // Measured on the frame that shows the difference most (near-extreme double Kerr, tests/golden/soak/): masked pixel RMSE
+            // 1.30e-4 -> 6.4e-5, pixels off 93 -> 9 of 9 216 - the reference's own distance from itself under a one-ulp change of the
+            // camera position; the Verlet loop pays ~10 instructions per division.
+            for (const char* drop : {"-freciprocal-math", "-fapprox-func", "-fno-hip-fp32-correctly-rounded-divide-sqrt"})
+                opts.erase(std::remove(opts.begin(), opts.end(), std::string(drop)), opts.end());
+            opts.push_back("-fhip-fp32-correctly-rounded-divide-sqrt");
+        }
         else if (tok.rfind("-cl-", 0) == 0 || tok == "-I" || tok == "./") continue;   // OpenCL-only prefix flags
         else return fail(GR_ERROR_INVALID_ARGUMENT, "unsupported token in argument string: " + tok);
     }
@@ -244,7 +262,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
                 if (run_limit <= 0 && gr::assemble_code_object(assembly, out, log)) return GR_OK;
                 // the kernels that hold a Verlet loop; the others (set-up, shading, tile order ...) are left as compiled
                 static const std::vector<std::string> integrators = {"gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused",
-                                                                     "gr_camera_prepass", "gr_do_generic_rays", "gr_get_geodesic_path"};
+                                                                     "gr_do_generic_rays"};
                 std::string patched = assembly;
                 const gr::vector_run_stats st = gr::break_vector_runs(patched, run_limit, integrators);
                 if (gr::assemble_code_object(patched, out, log)) {
@@ -336,6 +354,55 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     return GR_OK;
 }
 
+// The set-up module of a program: the kernels that run once per frame on one lane - camera coordinates, tetrad, the camera's own
+// geodesic - from program + probes + metric + setup + camera + geodesic_camera, built with IEEE arithmetic (kernels/camera.hip says
+// why).  Same macro string, a cache file of its own; no pass over the code, no occupancy rule: nothing here is issue-bound.
+int compile_setup_module(const std::string& argument_string, std::string& code) {
+    static const char* const PARTS[] = {"program.hip", "probes.inc", "metric.hip", "setup.hip", "camera.hip", "geodesic_camera.hip"};
+    std::string source;
+    for (const char* part : PARTS) {
+        std::string text;
+        const std::string path = library_dir() + "/csrc/kernels/" + part;
+        if (!read_file(path, text)) return fail(GR_ERROR_COMPILE, "cannot read kernel source " + path);
+        source += text;
+        if (!text.empty() && text.back() != '\n') source += '\n';
+    }
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno", "-fno-slp-vectorize",
+                                     "-fhip-fp32-correctly-rounded-divide-sqrt", "-DGR_SETUP_MODULE", "-DGR_LIBM_TRIG", "-DGR_LIBM_TANH"};
+    for (auto& tok : split_arguments(argument_string)) {
+        if (tok.rfind("-D", 0) == 0) opts.push_back(tok);
+        else if (tok.rfind("-cl-", 0) == 0 || tok == "-I" || tok == "./") continue;
+        else return fail(GR_ERROR_INVALID_ARGUMENT, "unsupported token in argument string: " + tok);
+    }
+    if (const char* extra = getenv("GR_SETUP_EXTRA_FLAGS"))
+        for (auto& tok : split_arguments(extra)) opts.push_back(tok);
+    int rtc_major = 0, rtc_minor = 0;
+    hiprtcVersion(&rtc_major, &rtc_minor);
+    uint64_t h = fnv1a(source);
+    for (auto& o : opts) h = fnv1a(o + "\n", h);
+    h = fnv1a("set-up module, hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor), h);
+    char name[64];
+    snprintf(name, sizeof(name), "%016llx.setup.hsaco", (unsigned long long)h);
+    std::string cache_dir;
+    if (const char* env = getenv("GR_CACHE_DIR")) cache_dir = env;
+    else cache_dir = library_dir() + "/_cache";
+    const std::string cache_path = cache_dir + "/" + name;
+    if (read_file(cache_path, code) && !code.empty()) return GR_OK;
+    std::string assembly, log;
+    if (!gr::compile_to_assembly(source, opts, assembly, log) || !gr::assemble_code_object(assembly, code, log))
+        return fail(GR_ERROR_COMPILE, "set-up module: " + log);
+    mkdir(cache_dir.c_str(), 0755);
+    static std::atomic<unsigned long> writer{0};
+    const std::string tmp = cache_path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(writer.fetch_add(1));
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        f.write(code.data(), (std::streamsize)code.size());
+        if (!f) { f.close(); remove(tmp.c_str()); return GR_OK; }
+    }
+    if (rename(tmp.c_str(), cache_path.c_str()) != 0) remove(tmp.c_str());
+    return GR_OK;
+}
+
 }  // namespace
 
 struct gr_metric {
@@ -344,11 +411,14 @@ struct gr_metric {
     gr::DynamicVars vars;
     gr::MetricDescriptor desc;
     std::shared_ptr<void> keepalive;   // script interpreter state owning the closures
+    bool settings_only = false;        // gr_metric_from_info: no symbolic content, only what the frame driver reads
+    gr_metric_info stored_info = {};
 };
 
 struct gr_program {
     int device = 0;
     hipModule_t module = nullptr;
+    hipModule_t setup_module = nullptr;   // camera / tetrad / geodesic-camera kernels, IEEE arithmetic (compile_setup_module)
     hipFunction_t fn[K_COUNT] = {};
     void* huge_count = nullptr;   // device int = INT_MAX: "no device-side count" for range launches
     // tile tickets of the persistent fused trace: one counter per launch, taken round robin from a small ring so that
@@ -368,6 +438,7 @@ struct gr_program {
         if (tickets) (void)hipFree(tickets);
         if (huge_count) (void)hipFree(huge_count);
         if (module) (void)hipModuleUnload(module);
+        if (setup_module) (void)hipModuleUnload(setup_module);
     }
 };
 
@@ -435,10 +506,27 @@ int gr_metric_load_script(const char* scripts_dir, const char* name, gr_metric**
     GR_TRY_END
 }
 
+int gr_metric_from_info(const gr_metric_info* info, const char* const* var_names, const float* var_defaults, gr_metric** out) {
+    if (!info || !out || info->num_dynamic_vars < 0 || (info->num_dynamic_vars > 0 && !var_defaults))
+        return fail(GR_ERROR_INVALID_ARGUMENT, "gr_metric_from_info: null argument");
+    GR_TRY_BEGIN
+    auto m = std::make_unique<gr_metric>();
+    m->settings_only = true;
+    m->stored_info = *info;
+    for (int i = 0; i < info->num_dynamic_vars; i++) {
+        m->vars.names.push_back(var_names && var_names[i] ? var_names[i] : "v" + std::to_string(i));
+        m->vars.defaults.push_back(var_defaults[i]);
+    }
+    *out = m.release();
+    return GR_OK;
+    GR_TRY_END
+}
+
 void gr_metric_destroy(gr_metric* m) { delete m; }
 
 int gr_metric_get_info(const gr_metric* m, gr_metric_info* out) {
     if (!m || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (m->settings_only) { *out = m->stored_info; return GR_OK; }
     out->is_big = m->desc.is_big;
     out->is_constant_theta = m->desc.is_spherical && m->cfg.system == gr::CoordinateSystem::X_Y_THETA_PHI;
     out->use_prepass = m->cfg.use_prepass;
@@ -464,6 +552,7 @@ float gr_metric_dynamic_var_default(const gr_metric* m, int i) {
 int gr_metric_argument_string(const gr_metric* m, const gr_features* features, int is_static, const float* cfg_values,
                               int num_cfg_values, char* buffer, size_t capacity, size_t* needed) {
     if (!m) return fail(GR_ERROR_INVALID_ARGUMENT, "null metric");
+    if (m->settings_only) return fail(GR_ERROR_INVALID_ARGUMENT, "a metric made by gr_metric_from_info has no expressions to generate from");
     GR_TRY_BEGIN
     gr::FeatureConfig fc = to_feature_config(features);
     std::string s;
@@ -485,6 +574,7 @@ int gr_metric_argument_string(const gr_metric* m, const gr_features* features, i
 int gr_metric_substituted_op_counts(const gr_metric* m, const float* cfg_values, int num_cfg_values, int* accel_ops,
                                     int* accel_transcendentals, int* coord_ops) {
     if (!m) return fail(GR_ERROR_INVALID_ARGUMENT, "null metric");
+    if (m->settings_only) return fail(GR_ERROR_INVALID_ARGUMENT, "a metric made by gr_metric_from_info has no expressions to count");
     GR_TRY_BEGIN
     std::vector<float> vals(cfg_values, cfg_values + (cfg_values ? num_cfg_values : 0));
     const gr::MetricImpl concrete = m->desc.concrete(m->vars.substitution(vals));
@@ -500,14 +590,19 @@ int gr_metric_substituted_op_counts(const gr_metric* m, const float* cfg_values,
 
 int gr_program_precompile(const char* argument_string) {
     if (!argument_string) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument string");
-    std::string code;
-    return compile_code_object(argument_string, code);
+    std::string code, setup;
+    int rc = compile_code_object(argument_string, code);
+    if (rc != GR_OK) return rc;
+    return compile_setup_module(argument_string, setup);
 }
 
 int gr_program_create(const char* argument_string, int device, gr_program** out) {
     if (!argument_string || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
     std::string code, key;
     int rc = compile_code_object(argument_string, code, &key);
+    if (rc != GR_OK) return rc;
+    std::string setup_code;
+    rc = compile_setup_module(argument_string, setup_code);
     if (rc != GR_OK) return rc;
     HIP_CHECK(hipSetDevice(device));
     auto p = std::make_unique<gr_program>();
@@ -529,7 +624,12 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
     static std::atomic<unsigned long long> next_serial{1};
     p->serial = next_serial.fetch_add(1);
     HIP_CHECK(hipModuleLoadData(&p->module, code.data()));
+    HIP_CHECK(hipModuleLoadData(&p->setup_module, setup_code.data()));
     for (int k = 0; k < K_COUNT; k++) {
+        if (is_setup_kernel(k)) {
+            HIP_CHECK(hipModuleGetFunction(&p->fn[k], p->setup_module, KERNEL_NAMES[k]));
+            continue;
+        }
         if (k == K_TRACE_PAIR) {   // built for some metrics only (pair_kernel_applies)
             if (hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]) != hipSuccess) { p->fn[k] = nullptr; (void)hipGetLastError(); }
             continue;
@@ -880,12 +980,19 @@ int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, fl
     if (block_rows <= 0 || strip_rank < 0 || strip_rank >= strip_count) return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
     if (image_height <= 0) image_height = prepass_height > 0 ? prepass_height * 16 : 16;
     float sx = basis_speed[0], sy = basis_speed[1], sz = basis_speed[2];
-    void* args[] = {&position_cart, &flip, &sx, &sy, &sz, &position_generic_out, &e0_out, &e1_out, &e2_out, &e3_out, &camera_quat, &term,
-                    &prepass_width, &prepass_height, &cfg, &dfg, &image_height, &block_rows, &strip_rank, &strip_count, &cell_attempts,
-                    &row_margin};
     if (row_margin < 0) return fail(GR_ERROR_INVALID_ARGUMENT, "negative row margin");
-    long long cells = (long long)prepass_width * prepass_height;
-    return launch(p, K_CAMERA_PREPASS, stream, blocks(cells > 0 ? cells : 1, 64), 1, 64, 1, args);
+    // the camera's coordinates and tetrad: one lane of the set-up module (IEEE arithmetic, kernels/camera.hip) ...
+    void* setup_args[] = {&position_cart, &flip, &sx, &sy, &sz, &position_generic_out, &e0_out, &e1_out, &e2_out, &e3_out, &cfg};
+    int rc = launch(p, K_CAMERA_SETUP, stream, 1, 1, 64, 1, setup_args);
+    if (rc != GR_OK) return rc;
+    // ... then the prepass grid reads them back (same stream)
+    const long long cells = (long long)prepass_width * prepass_height;
+    if (cells <= 0) return GR_OK;
+    const void* camera_generic = position_generic_out;
+    const void *e0 = e0_out, *e1 = e1_out, *e2 = e2_out, *e3 = e3_out;
+    void* args[] = {&camera_generic, &camera_quat, &term, &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg,
+                    &image_height, &block_rows, &strip_rank, &strip_count, &cell_attempts, &row_margin};
+    return launch(p, K_PREPASS_FUSED, stream, blocks(cells, 64), 1, 64, 1, args);
 }
 
 int gr_prepass_fused(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* term,

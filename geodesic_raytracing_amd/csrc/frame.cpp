@@ -856,7 +856,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         GR_CHECK(gr_cart_to_generic(p, st, cart, generic, 1, cam->flip, s->cfg));
         return gr_init_basis_vectors(p, st, generic, 1, cam->basis_speed, tetrad[0], tetrad[1], tetrad[2], tetrad[3], s->cfg);
     };
-    // fused mode with a Cartesian camera: camera set-up and prepass are one launch (gr_camera_prepass), issued below
+    // fused mode with a Cartesian camera: camera set-up and prepass are one call (gr_camera_prepass), issued below
     const bool one_launch_setup = opt.mode == GR_MODE_FUSED && !gc;
     if (!prefetched && !one_launch_setup) {
         GR_CHECK(begin(GR_STAGE_CAMERA));

@@ -83,6 +83,45 @@ __device__ __forceinline__ float fmin(float x, float y) { return __builtin_fminf
 __device__ __forceinline__ float fmax(float x, float y) { return __builtin_fmaxf(x, y); }
 __device__ __forceinline__ float sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
+// --- $cfg-only temporaries in double precision ------------------------------------------------------
+// GR_CFG_TEMPORARIES (an extension of the macro set, metric_codegen.cpp): the named sub-expressions that depend on nothing but the
+// $cfg parameters, every leaf wrapped into cfgf - a double behind float's interface - so that the generated text, written for
+// float, evaluates them in double; GR_POS_TEMPORARIES is TEMPORARIES0 with those entries replaced by cfg_value(cpvN).  The build's
+// relaxed fp32 arithmetic (v_rcp_f32, v_sqrt_f32, approximate functions) is right for the Verlet loop and wrong for a parameter
+// expression that cancels (the cubic root of the double-Kerr solution as its spins go to 0: a tenth of the dynamic program's frame).
+// These values are wave-uniform and loop-invariant; a string without the extension (the reference's own generator) falls back on
+// TEMPORARIES0.  float -> cfgf is explicit and cfgf -> float implicit, so that "c ? cfgf : float" has one common type (float).
+struct cfgf {
+    double v;
+    __device__ __forceinline__ cfgf() {}
+    __device__ __forceinline__ explicit cfgf(double x) : v(x) {}
+    __device__ __forceinline__ operator float() const { return (float)v; }
+};
+__device__ __forceinline__ float cfg_value(cfgf a) { return (float)a.v; }
+#define GR_CFGF_BINARY(op)                                                                        \
+    __device__ __forceinline__ cfgf operator op(cfgf a, cfgf b) { return cfgf(a.v op b.v); }      \
+    __device__ __forceinline__ cfgf operator op(cfgf a, float b) { return cfgf(a.v op (double)b); } \
+    __device__ __forceinline__ cfgf operator op(float a, cfgf b) { return cfgf((double)a op b.v); }
+GR_CFGF_BINARY(+) GR_CFGF_BINARY(-) GR_CFGF_BINARY(*) GR_CFGF_BINARY(/)
+#undef GR_CFGF_BINARY
+__device__ __forceinline__ cfgf operator-(cfgf a) { return cfgf(-a.v); }
+#define GR_CFGF_FN1(name) __device__ __forceinline__ cfgf name(cfgf a) { return cfgf(::name(a.v)); }
+GR_CFGF_FN1(sin) GR_CFGF_FN1(cos) GR_CFGF_FN1(tan) GR_CFGF_FN1(asin) GR_CFGF_FN1(acos) GR_CFGF_FN1(atan) GR_CFGF_FN1(exp) GR_CFGF_FN1(log)
+GR_CFGF_FN1(sqrt) GR_CFGF_FN1(fabs) GR_CFGF_FN1(sinh) GR_CFGF_FN1(cosh) GR_CFGF_FN1(tanh)
+#undef GR_CFGF_FN1
+#define GR_CFGF_FN2(name)                                                                              \
+    __device__ __forceinline__ cfgf name(cfgf a, cfgf b) { return cfgf(::name(a.v, b.v)); }            \
+    __device__ __forceinline__ cfgf name(cfgf a, float b) { return cfgf(::name(a.v, (double)b)); }     \
+    __device__ __forceinline__ cfgf name(float a, cfgf b) { return cfgf(::name((double)a, b.v)); }
+GR_CFGF_FN2(atan2) GR_CFGF_FN2(pow) GR_CFGF_FN2(fmod) GR_CFGF_FN2(fmin) GR_CFGF_FN2(fmax)
+#undef GR_CFGF_FN2
+__device__ __forceinline__ cfgf sign(cfgf x) { return cfgf(x.v > 0. ? 1. : (x.v < 0. ? -1. : 0.)); }
+#if defined(GR_CFG_TEMPORARIES) && defined(GR_POS_TEMPORARIES) && !defined(GR_NO_CFG_TEMPORARIES)
+#define GR_DECLARE_TEMPORARIES(T) gm::cfgf GR_CFG_TEMPORARIES; T GR_POS_TEMPORARIES;
+#else
+#define GR_DECLARE_TEMPORARIES(T) T TEMPORARIES0;
+#endif
+
 // --- generated-expression hosts (cl.cl:969-1355, 3377-3387) ---------------------------------------
 
 #define GR_POSITION_VARS(p) \
@@ -92,7 +131,7 @@ __device__ __forceinline__ float sign(float x) { return x > 0.f ? 1.f : (x < 0.f
 // g_metric_out has 4 (diagonal) or 16 entries
 __device__ __forceinline__ void metric_at(float4 pos, float* g, cfg_t cfg) {
     GR_POSITION_VARS(pos)
-    float TEMPORARIES0;
+    GR_DECLARE_TEMPORARIES(float)
 #ifndef GENERIC_BIG_METRIC
     g[0] = F1_I; g[1] = F2_I; g[2] = F3_I; g[3] = F4_I;
 #else
@@ -119,7 +158,7 @@ __device__ __forceinline__ void metric_big_at(float4 pos, float* g, cfg_t cfg) {
 // Only the geodesic-camera kernels (parallel transport) use it; the ray kernels never need the partials at run time.
 __device__ void partials_big_at(float4 pos, float* dg, cfg_t cfg) {
     GR_POSITION_VARS(pos)
-    float TEMPORARIES0;
+    GR_DECLARE_TEMPORARIES(float)
     for (int i = 0; i < 64; i++) dg[i] = 0.f;
 #ifndef GENERIC_BIG_METRIC
     const float p[16] = {F1_P, F2_P, F3_P, F4_P, F5_P, F6_P, F7_P, F8_P, F9_P, F10_P, F11_P, F12_P, F13_P, F14_P, F15_P, F16_P};
@@ -175,7 +214,7 @@ __device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 
     const float iv1 = vel.x; const float iv2 = vel.y; const float iv3 = vel.z; const float iv4 = vel.w;
     (void)iv1; (void)iv2; (void)iv3; (void)iv4;
     GR_ACCEL_TRIG(LIBM)
-    float TEMPORARIES0;
+    GR_DECLARE_TEMPORARIES(float)
     float4 a;
     a.x = GEO_ACCEL0;
     a.y = GEO_ACCEL1;
@@ -196,7 +235,7 @@ __device__ __forceinline__ float4 geodesic_acceleration(float4 pos, float4 vel, 
     GR_POSITION_VARS(pos)
     const float iv1 = vel.x; const float iv2 = vel.y; const float iv3 = vel.z; const float iv4 = vel.w;
     (void)iv1; (void)iv2; (void)iv3; (void)iv4;
-    float TEMPORARIES0;
+    GR_DECLARE_TEMPORARIES(float)
     float4 a;
     a.x = GEO_ACCEL0;
     a.y = GEO_ACCEL1;
@@ -336,7 +375,7 @@ __device__ __forceinline__ pair4 geodesic_acceleration(pair4 pos, pair4 vel, cfg
     GR_POSITION_VARS_PAIR(pos)
     const pairf iv1 = vel.x; const pairf iv2 = vel.y; const pairf iv3 = vel.z; const pairf iv4 = vel.w;
     (void)iv1; (void)iv2; (void)iv3; (void)iv4;
-    pairf TEMPORARIES0;
+    GR_DECLARE_TEMPORARIES(pairf)
     pair4 a;
     a.x = GEO_ACCEL0;
     a.y = GEO_ACCEL1;

@@ -102,29 +102,6 @@ __device__ __forceinline__ render_data make_render_data(float4 position, float4 
 // ================================================================================================
 // kernels
 
-extern "C" __global__ void gr_cart_to_generic(const float4* __restrict__ position_cart_in, float4* __restrict__ position_generic_out,
-                                              int count, float flip, cfg_t cfg) {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= count) return;
-    float4 in = position_cart_in[id];
-    float3 polar = cartesian_to_polar(yzw(in));
-    if (flip > 0) polar.x = -polar.x;
-    position_generic_out[id] = gm::spherical_to_generic(f4(in.x, polar), cfg);
-}
-
-extern "C" __global__ void gr_init_basis_vectors(const float4* __restrict__ generic_in, int count, float speed_x, float speed_y, float speed_z,
-                                                 float4* __restrict__ e0_out, float4* __restrict__ e1_out,
-                                                 float4* __restrict__ e2_out, float4* __restrict__ e3_out, cfg_t cfg) {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= count) return;
-    tetrad t;
-    calculate_tetrads(generic_in[id], f3(speed_x, speed_y, speed_z), t, cfg, 1);
-    e0_out[id] = t.e[0];
-    e1_out[id] = t.e[1];
-    e2_out[id] = t.e[2];
-    e3_out[id] = t.e[3];
-}
-
 extern "C" __global__ void gr_clear_termination_buffer(int* __restrict__ termination_buffer, int width, int height) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= width * height) return;
@@ -765,39 +742,6 @@ gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* _
     GR_PARAMETERS_IN_REGISTERS
     prepass_cell(blockIdx.x * blockDim.x + threadIdx.x, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, termination_buffer,
                  prepass_width, prepass_height, cfg, dfg, image_height, block_rows, strip_rank, strip_count, cell_attempts, row_margin);
-}
-
-// cart_to_generic_kernel + init_basis_vectors + the prepass in ONE launch (the reference: three of its launches and the prepass
-// sequence, main.cpp:2311, 2329, 2380-2436).  The camera's metric coordinates and tetrad - one lane's worth of work, ~900
-// instructions - are computed by every lane of the launch for itself (same inputs, same instructions, same values), lane 0 of the
-// launch also stores them for gr_trace_fused.  What this buys is the launch chain of a frame: two single-lane kernels with their
-// queue latencies sat in front of every prepass (1.3 ms on average on the look-ahead stream under load, round-1 profile), which
-// is what a device's share of a frame costs altogether once the frame is split eight ways.  prepass_width * prepass_height may
-// be 0 (metrics without a prepass): the launch is then the camera set-up alone.
-extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
-gr_camera_prepass(const float4* __restrict__ position_cart_in, float flip, float speed_x, float speed_y, float speed_z,
-                  float4* __restrict__ position_generic_out, float4* __restrict__ e0_out, float4* __restrict__ e1_out,
-                  float4* __restrict__ e2_out, float4* __restrict__ e3_out, const float4* __restrict__ g_camera_quat,
-                  int* __restrict__ termination_buffer, int prepass_width, int prepass_height, cfg_t cfg_in, dfg_t dfg_in,
-                  int image_height, int block_rows, int strip_rank, int strip_count, unsigned int* __restrict__ cell_attempts,
-                  int row_margin) {
-    GR_PARAMETERS_IN_REGISTERS
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    const float4 in = *position_cart_in;
-    float3 polar = cartesian_to_polar(yzw(in));
-    if (flip > 0) polar.x = -polar.x;
-    const float4 camera = gm::spherical_to_generic(f4(in.x, polar), cfg);
-    tetrad t;
-    calculate_tetrads(camera, f3(speed_x, speed_y, speed_z), t, cfg, 1);
-    if (id == 0) {
-        *position_generic_out = camera;
-        *e0_out = t.e[0];
-        *e1_out = t.e[1];
-        *e2_out = t.e[2];
-        *e3_out = t.e[3];
-    }
-    prepass_cell(id, camera, *g_camera_quat, t.e[0], t.e[1], t.e[2], t.e[3], termination_buffer, prepass_width, prepass_height, cfg, dfg,
-                 image_height, block_rows, strip_rank, strip_count, cell_attempts, row_margin);
 }
 
 // ---- the order the persistent trace hands its tiles out in -----------------------------------------

@@ -1,4 +1,5 @@
 // metric_codegen.cpp — see metric_codegen.hpp.
+#include <functional>
 #include "metric_codegen.hpp"
 
 #include <cmath>
@@ -517,6 +518,36 @@ std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl
         for (auto& [name, e] : temps.defs) t += name + "=" + to_c(e, names, true) + ",";
         t.pop_back();
         s += "-DTEMPORARIES0=" + t + " ";
+        // The same list once more for the HIP kernels, split (an extension of the macro set; cl.cl and the CPU oracle ignore it):
+        // GR_CFG_TEMPORARIES holds the temporaries that depend on nothing but the $cfg parameters, under the names cpvN, every
+        // leaf wrapped into gm::cfgf - a double behind float's interface - so that the device evaluates them in double precision;
+        // GR_POS_TEMPORARIES is TEMPORARIES0 with those entries replaced by their rounded values.  Why: the kernels are built
+        // with OpenCL's relaxed arithmetic (v_rcp_f32, v_sqrt_f32, approximate library functions), which is what the Verlet loop
+        // needs and what a parameter expression that cancels cannot stand - the cubic root behind the double-Kerr solution as
+        // its spins go to 0 lost every digit and the dynamic program rendered a tenth of the frame wrong (soak 51/189,
+        // tests/golden/soak/).  Parameter-only values are wave-uniform and loop-invariant: their cost does not show.
+        std::unordered_map<E, std::string> cfg_names;
+        std::function<void(E)> wrap_leaves = [&](E e) {
+            if (!e || cfg_names.count(e)) return;
+            if (e->op == VAR) { cfg_names.emplace(e, "gm::cfgf(" + e->name + ")"); return; }
+            wrap_leaves(e->a); wrap_leaves(e->b); wrap_leaves(e->s);
+        };
+        std::string c, p;
+        for (auto& [name, e] : temps.defs) {
+            if (e->deps == sym::DEP_CFG) {
+                wrap_leaves(e);
+                c += "c" + name + "=gm::cfgf(" + to_c(e, &cfg_names, true) + "),";
+                cfg_names[e] = "c" + name;   // (after printing its own body)
+                p += name + "=gm::cfg_value(c" + name + "),";
+            } else {
+                p += name + "=" + to_c(e, names, true) + ",";
+            }
+        }
+        if (!c.empty() && !is_static) {
+            c.pop_back();
+            p.pop_back();
+            s += "-DGR_CFG_TEMPORARIES=" + c + " -DGR_POS_TEMPORARIES=" + p + " ";
+        }
     }
 
     s += is_static ? features.static_argument_string() : features.dynamic_argument_string();

@@ -776,13 +776,36 @@ Temporaries hoist_position_temporaries(const std::vector<E>& roots, const std::s
     };
     for (E r : roots) visit(r);
 
+    // Parameter-only sub-expressions ($cfg values and constants, no coordinate) that divide or call a function are named even when
+    // they are referenced once: the device evaluates the named parameter-only temporaries in double precision (GR_CFG_TEMPORARIES,
+    // metric_codegen.cpp), which it cannot do for an expression buried inside a coordinate-dependent one.  Only the outermost such
+    // node under a parent that depends on something else (or a root) is taken.
+    std::unordered_map<E, bool> delicate_memo;
+    std::function<bool(E)> delicate = [&](E e) -> bool {
+        if (!e || e->op == CONST || e->op == VAR) return false;
+        auto it = delicate_memo.find(e);
+        if (it != delicate_memo.end()) return it->second;
+        bool d = e->op == DIV || e->op == FN1 || (e->op == FN2 && !is_cmp(e->fn)) || delicate(e->a) || delicate(e->b) || delicate(e->s);
+        delicate_memo.emplace(e, d);
+        return d;
+    };
+    std::unordered_set<E> forced;
+    auto parameter_only = [](E e) { return e && e->deps == DEP_CFG; };
+    for (E e : order) {
+        if (parameter_only(e)) continue;
+        for (E c : {e->a, e->b, e->s})
+            if (parameter_only(c) && delicate(c)) forced.insert(c);
+    }
+    for (E r : roots)
+        if (parameter_only(r) && delicate(r)) forced.insert(r);
+
     Temporaries t;
     const uint32_t pos_mask = DEP_V1 | DEP_V2 | DEP_V3 | DEP_V4 | DEP_CFG;
     for (E e : order) {
         if (e->op == CONST || e->op == VAR) continue;
         if (e->deps & ~pos_mask) continue;   // depends on velocity or something else
         if (e->deps == 0) continue;          // pure constant expression (should have folded)
-        if (refs[e] < 2) continue;
+        if (refs[e] < 2 && !forced.count(e)) continue;
         if (e->op == NEG && (e->a->op == VAR || e->a->op == CONST)) continue;
         std::string name = prefix + std::to_string(t.defs.size());
         t.defs.emplace_back(name, e);

@@ -44,10 +44,16 @@ def frame_options(**overrides):
 class Metric:
     """A loaded metric: config + symbolic descriptor (metrics::metric in the reference, metric.hpp:710-715)."""
 
-    def __init__(self, name, scripts_dir=None):
+    def __init__(self, name, scripts_dir=None, _settings=None):
         self.handle = c_void_p()
         self.name = name
-        if scripts_dir is None:
+        self.stored_strings = None
+        if _settings is not None:
+            info, names, defaults = _settings
+            n = len(names)
+            check(lib.gr_metric_from_info(ctypes.byref(info), (ctypes.c_char_p * max(n, 1))(*[v.encode() for v in names]),
+                                          (c_float * max(n, 1))(*defaults), ctypes.byref(self.handle)))
+        elif scripts_dir is None:
             check(lib.gr_metric_builtin(name.encode(), ctypes.byref(self.handle)))
         else:
             check(lib.gr_metric_load_script(str(scripts_dir).encode(), name.encode(), ctypes.byref(self.handle)))
@@ -56,6 +62,18 @@ class Metric:
         n = self.info.num_dynamic_vars
         self.dynamic_vars = [lib.gr_metric_dynamic_var_name(self.handle, i).decode() for i in range(n)]
         self.dynamic_defaults = [lib.gr_metric_dynamic_var_default(self.handle, i) for i in range(n)]
+
+    @classmethod
+    def from_info(cls, name, info, dynamic_vars, dynamic_defaults, argument_strings=None):
+        """gr_metric_from_info: a metric that is only the settings the frame driver reads (info: dict of gr_metric_info's fields).
+        argument_strings = {False: dynamic string, True: substituted string} lets argument_string() hand back stored strings."""
+        mi = MetricInfo()
+        for k, v in info.items():
+            setattr(mi, k, v)
+        mi.num_dynamic_vars = len(dynamic_vars)
+        m = cls(name, _settings=(mi, list(dynamic_vars), [float(v) for v in dynamic_defaults]))
+        m.stored_strings = dict(argument_strings or {})
+        return m
 
     def __del__(self):
         if getattr(self, "handle", None):
@@ -81,6 +99,10 @@ class Metric:
         return default_features(max_acceleration_change=self.info.max_acceleration_change, **overrides)
 
     def argument_string(self, features=None, static=False, cfg_values=None):
+        if self.stored_strings is not None:
+            if bool(static) not in self.stored_strings:
+                raise GeodesicError(f"{self.name}: no stored {'substituted' if static else 'dynamic'} argument string")
+            return self.stored_strings[bool(static)]
         fptr = ctypes.byref(features) if features is not None else None
         arr, n = None, 0
         if cfg_values is not None:

@@ -106,6 +106,11 @@ int gr_metric_builtin(const char* name, gr_metric** out);
  * as content_manager.cpp:9-112 does; the script dialect is the reference's (js_interop.cpp:665-959). */
 int gr_metric_load_script(const char* scripts_dir, const char* name, gr_metric** out);
 
+/* A metric that is only its frame-driver settings - what gr_render_frame reads off a metric: gr_metric_info (prepass, tolerance) and
+ * the $cfg names and defaults - for a caller that already holds the argument strings (a program cache of its own, a fixture):
+ * gr_metric_argument_string fails on it.  var_names may be NULL. */
+int gr_metric_from_info(const gr_metric_info* info, const char* const* var_names, const float* var_defaults, gr_metric** out);
+
 void gr_metric_destroy(gr_metric* m);
 int gr_metric_get_info(const gr_metric* m, gr_metric_info* out);
 const char* gr_metric_dynamic_var_name(const gr_metric* m, int index);

@@ -23,6 +23,12 @@ def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
 
 
+def refscript_golden_names():
+    """the cases of the reference's own scripts/ folder (tests/golden/refscripts/, make_golden.py REFSCRIPT_CASES): names as load_golden takes them"""
+    d = os.path.join(GOLDEN_DIR, "refscripts")
+    return sorted("refscripts/" + f[:-4] for f in os.listdir(d) if f.endswith(".npz"))
+
+
 def path_golden_names():
     d = os.path.join(GOLDEN_DIR, "paths")
     return sorted(f[:-4] for f in os.listdir(d) if f.endswith(".npz"))
@@ -36,12 +42,17 @@ SCRIPTS_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 
 
 def metric_for(meta):
-    """the metric of a golden case: built-in, or loaded from this repository's scripts/ folder"""
+    """the metric of a golden case: built-in, or loaded from this repository's scripts/ folder, or - a case made from one of the
+    reference's own scripts, which the GPU box does not have - the frame-driver settings and the two generated argument strings
+    the fixture carries (dynamic; substituted for the case's parameters and features)"""
+    if meta.get("reference_script"):
+        return gra.Metric.from_info(meta["metric"], meta["info"], meta["dynamic_vars"], meta["dynamic_defaults"],
+                                    {False: meta["argument_string"], True: meta["argument_string_substituted"]})
     return gra.Metric(meta["metric"], SCRIPTS_DIR if meta.get("scripts") else None)
 
 
 def program_for(meta):
-    key = (meta["metric"], bool(meta.get("scripts")))
+    key = (meta["metric"], bool(meta.get("scripts")), bool(meta.get("reference_script")))
     if key not in _programs:
         m = metric_for(meta)
         _programs[key] = (m, gra.Program(m.argument_string(), 0))
@@ -188,6 +199,64 @@ def assert_traced_positions(name, got, want, ordinary, chaotic=False, slack=0.01
         assert (err[sel] > 1e-3).sum() <= max(2, int(slack * sel.sum())), (name, int((err[sel] > 1e-3).sum()), float(err[sel].max()))
     if both.any():
         assert np.percentile(err[both], 90) <= 1e-3, name
+
+
+# Fixtures on which the REFERENCE ITSELF is ill-conditioned (its own fp32 run is further from a float64 evaluation of the same
+# discrete algorithm than the tolerance, in more rays than any two fp32 builds differ): held to the rule of the polar-axis soak
+# cases (tests/test_gpu_parity.py::test_polar_axis_cases_of_the_soak) instead of the standard tolerances.  Measured in the build
+# container (reference's x86 build vs float64 rays off by > 1e-3 / CPU restatement vs reference pixels off by > 1e-3):
+ILL_CONDITIONED = {
+    "refscripts/de_sitter": "rays crossing the cosmological horizon r = sqrt(3 / Lambda) of the static chart: 86 of 1 145 rays / 26 px",
+    "refscripts/godel_cylinder": "Goedel orbits of 700-2 200 attempts that return to the axis of the chart: 105 of 505 rays / 17 px",
+    "refscripts/double_kerr": "the shadow's edge of two holes held apart by a strut: 4 rays, 13 px (1.0 % of the frame, limit 0.5 %)",
+}
+_budgets = {}
+
+
+def ill_conditioned_budget(name, meta, z):
+    """(rays of the reference's own run that are > 1e-3 from the float64 evaluation, pixels of the CPU restatement's frame that are
+    > 1e-3 from the reference's, float64 positions, float64 flags) of a fixture, cached"""
+    if name not in _budgets:
+        from oracle import build_restate
+        from oracle.refpipe import OraclePipeline, pack_features
+        pipe = OraclePipeline(build_restate.build(metric_for(meta).argument_string()))
+        feats = pack_features(**meta["features"])
+        p64, t64 = pipe.trace_f64(z["rays_init"], meta["cfg"], feats, nthreads=8)
+        want = z["rays"]
+        both = (t64 == 1) & (want["terminated"] == 1)
+        reference_off = int((position_err(want["position"][both], p64[both]).max(axis=1) > 1e-3).sum())
+        bg, levels = gra.pack_background(gra.synthetic_background(*meta["bg_size"], seed=meta["bg_seed"]))
+        cpu = pipe.frame(meta["width"], meta["height"], meta["cfg"], feats, camera_pos=meta["camera_pos"], camera_quat=meta["camera_quat"],
+                         basis_speed=meta["basis_speed"], background=(bg, levels), nthreads=8, flip=float(meta.get("flip", 0.0)),
+                         use_prepass=meta["prepass"])
+        cpu_bad = int((np.abs(cpu["pixels"][..., :3] - z["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
+        _budgets[name] = (reference_off, cpu_bad, p64, t64)
+    return _budgets[name]
+
+
+def assert_ill_conditioned_trace(name, meta, z, got):
+    """trace stage of an ILL_CONDITIONED fixture: flags as usual; the rays are not further from the float64 evaluation than the
+    reference's own are (count of rays off by > 1e-3: at most 1.5 x the reference's + 4)"""
+    reference_off, _, p64, t64 = ill_conditioned_budget(name, meta, z)
+    want = z["rays"]
+    assert (got["terminated"] != want["terminated"]).mean() <= 0.005
+    both = (t64 == 1) & (want["terminated"] == 1) & (got["terminated"] == 1)
+    off = int((position_err(got["position"][both], p64[both]).max(axis=1) > 1e-3).sum())
+    assert off <= 1.5 * reference_off + 4, (name, off, reference_off)
+
+
+def assert_pixels(name, meta, z, px, limit=0.005):
+    """end-to-end rule on a frame: after masking pixels off by > 1e-3, RMSE <= 1e-4 (north_star's tolerance) and the mask covers at
+    most `limit` of the frame - an ILL_CONDITIONED fixture: at most twice the larger of (CPU restatement vs reference pixels) and
+    (reference vs float64 rays) + 4 pixels"""
+    d = px[..., :3] - z["pixels"][..., :3]
+    bad = ~(np.abs(d).max(axis=2) <= 1e-3)   # a pixel that is not finite counts as off
+    if name in ILL_CONDITIONED:
+        reference_off, cpu_bad, _, _ = ill_conditioned_budget(name, meta, z)
+        assert bad.sum() <= 2 * max(cpu_bad, reference_off) + 4, (name, int(bad.sum()), cpu_bad, reference_off)
+    else:
+        assert bad.mean() <= limit, (name, float(bad.mean()))
+    assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4, name
 
 
 class GeodesicCamera:

@@ -81,12 +81,16 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
 def test_precompile_produces_gfx950_code_object(tmp_path, monkeypatch):
     monkeypatch.setenv("GR_CACHE_DIR", str(tmp_path))
     gra.Program.precompile(gra.Metric("schwarzschild").argument_string())
-    files = list(tmp_path.glob("*.hsaco"))
-    assert len(files) == 1
-    blob = files[0].read_bytes()
-    assert blob[:4] == b"\x7fELF" and b"gfx950" in blob
-    for k in (b"gr_do_generic_rays", b"gr_trace_fused", b"gr_render", b"gr_init_rays_generic", b"gr_calculate_render_data"):
+    # two code objects per program: the ray kernels (OpenCL's relaxed arithmetic) and the set-up module (camera, tetrad, the camera's
+    # own geodesic: once per frame on one lane, IEEE arithmetic - kernels/camera.hip)
+    files = sorted(tmp_path.glob("*.hsaco"), key=lambda f: f.name.endswith(".setup.hsaco"))
+    assert len(files) == 2 and files[1].name.endswith(".setup.hsaco") and not files[0].name.endswith(".setup.hsaco")
+    blob, setup = files[0].read_bytes(), files[1].read_bytes()
+    assert blob[:4] == b"\x7fELF" and b"gfx950" in blob and setup[:4] == b"\x7fELF" and b"gfx950" in setup
+    for k in (b"gr_do_generic_rays", b"gr_trace_fused", b"gr_render", b"gr_init_rays_generic", b"gr_calculate_render_data", b"gr_prepass_fused"):
         assert k in blob
+    for k in (b"gr_cart_to_generic", b"gr_init_basis_vectors", b"gr_camera_setup", b"gr_get_geodesic_path", b"gr_handle_interpolating_geodesic"):
+        assert k in setup and k not in blob
 
 
 def test_background_packing_layout():
@@ -169,7 +173,7 @@ def test_pair_kernel_is_built_for_fixed_step_programs_only(tmp_path, monkeypatch
         d.mkdir()
         monkeypatch.setenv("GR_CACHE_DIR", str(d))
         gra.Program.precompile(argument_string)
-        (path,) = glob.glob(os.path.join(str(d), "*.hsaco"))
+        (path,) = [f for f in glob.glob(os.path.join(str(d), "*.hsaco")) if not f.endswith(".setup.hsaco")]
         blob = open(path, "rb").read()
         return b"gr_trace_pair" in blob, b"gr_trace_fused" in blob
 
@@ -205,7 +209,7 @@ def test_assembly_pass_cuts_the_vector_runs_of_the_integrator(tmp_path, monkeypa
         monkeypatch.setenv("GR_CACHE_DIR", str(d))
         monkeypatch.setenv("GR_VECTOR_RUN_LIMIT", str(limit))
         gra.Program.precompile(args)
-        (path,) = glob.glob(os.path.join(str(d), "*.hsaco"))
+        (path,) = [f for f in glob.glob(os.path.join(str(d), "*.hsaco")) if not f.endswith(".setup.hsaco")]
         text = subprocess.run([objdump, "-d", "--no-show-raw-insn", path], capture_output=True, text=True, check=True).stdout
         runs, kernel, run = {}, None, 0
         for line in text.splitlines():
@@ -224,7 +228,7 @@ def test_assembly_pass_cuts_the_vector_runs_of_the_integrator(tmp_path, monkeypa
     plain, passed = longest_runs(0, "plain"), longest_runs(8, "pass")
     assert plain["gr_trace_fused"] > 100
     # (the pass counts inside basic blocks, the disassembly has no labels: two runs that meet at a fall-through read as one)
-    assert passed["gr_trace_fused"] <= 16 and passed["gr_camera_prepass"] <= 16 and passed["gr_do_generic_rays"] <= 16
+    assert passed["gr_trace_fused"] <= 16 and passed["gr_prepass_fused"] <= 16 and passed["gr_do_generic_rays"] <= 16
     assert passed["gr_render"] == plain["gr_render"]          # not an integrator kernel: as compiled
 
 

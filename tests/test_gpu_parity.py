@@ -115,16 +115,16 @@ def test_end_to_end(name):
     assert np.sqrt((d[~bad] ** 2).mean()) <= (3e-4 if name in CHAOTIC else 1e-4)
 
 
-def _frame(meta, mode, tiled=0, options=None, substituted=False):
+def _frame(meta, mode, tiled=0, options=None, substituted=False, extra_arguments=""):
     """whole frame through gr_render_frame; substituted = the program with $cfg values and features baked in (the one
-    bench.py times, metric_manager.hpp:153-166) instead of the dynamic one"""
+    bench.py times, metric_manager.hpp:153-166) instead of the dynamic one; extra_arguments: appended to the argument string"""
     from geodesic_raytracing_amd.pipeline import DeviceBuffer
     metric = metric_for(meta)
     feats = gra.default_features(**meta["features"])
     if substituted:
-        prog = gra.Program(metric.argument_string(features=feats, static=True, cfg_values=meta["cfg"]), 0)
+        prog = gra.Program(metric.argument_string(features=feats, static=True, cfg_values=meta["cfg"]) + extra_arguments, 0)
     else:
-        prog = gra.Program(metric.argument_string(), 0)
+        prog = gra.Program(metric.argument_string() + extra_arguments, 0)
     w, h = meta["width"], meta["height"]
     state = gra.RenderState(w, h, 0)
     bg, levels = background(meta)
