@@ -89,11 +89,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_setup", "gr_order_tiles", "gr_adaptive_refine", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_setup", "gr_order_tiles", "gr_adaptive_refine", "gr_trace_pending", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_SETUP, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_SETUP, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_TRACE_PENDING, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -254,6 +254,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
 
     // one build of the kernel source with `options`: through the assembly pass when it is on and the code-object manager is
     // there, else through hiprtc (a source error shows up there with its diagnostics)
+    bool pass_not_applied = false;   // some build of this call went out as compiled although the pass is on
     auto build = [&](const std::vector<std::string>& options, std::string& out) -> int {
         {   // (GR_VECTOR_RUN_LIMIT=0 goes the same way without the pass: which code-object manager hiprtc would find depends on
             // what else the process has loaded, and the copy bundled with PyTorch aborts on these kernels)
@@ -274,8 +275,10 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
                 // The compiler sized its branches for the code it emitted; in a very large function the added instructions can push
                 // one past the 16-bit branch offset ("branch size exceeds simm16").  Then the code as compiled.
                 if (getenv("GR_VERBOSE_BUILD")) fprintf(stderr, "[gr] assembly pass not applied (%s)\n", log.c_str());
+                pass_not_applied = true;
                 if (gr::assemble_code_object(assembly, out, log)) return GR_OK;
             }
+            if (run_limit > 0) pass_not_applied = true;
             if (getenv("GR_VERBOSE_BUILD")) fprintf(stderr, "[gr] building through hiprtc (%s)\n", log.c_str());
         }
         hiprtcProgram prog;
@@ -340,6 +343,16 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
         }
     }
 
+    if (pass_not_applied) {
+        // The cache key says "vector runs <= N"; this code object does not have them cut (a branch pushed past its 16-bit offset, or
+        // the code-object manager could not be loaded and hiprtc built it).  It is used but not cached under that key: a later
+        // process in which the pass can run builds it properly instead of being served this one for good.
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true))
+            fprintf(stderr, "[gr] warning: the pass over the compiled code (vector runs <= %d) could not be applied to a program; it runs as "
+                            "compiled (~20 %% slower Verlet loop) and is not cached.  GR_VERBOSE_BUILD=1 says why.\n", run_limit);
+        return GR_OK;
+    }
     mkdir(cache_dir.c_str(), 0755);
     // unique per writer: a background build (gr_program_create_async) and a foreground build of the same key may run in one
     // process, and several processes share the cache directory; rename() publishes a complete file atomically
@@ -664,8 +677,9 @@ int gr_program_create_async(const char* argument_string, int device, gr_program_
     f->arguments = argument_string;
     f->device = device;
     f->worker = std::thread([f]() {
-        std::string code;
-        int rc = compile_code_object(f->arguments, code);   // hiprtc only: no device work on this thread
+        std::string code, setup;
+        int rc = compile_code_object(f->arguments, code);   // compiler only: no device work on this thread
+        if (rc == GR_OK) rc = compile_setup_module(f->arguments, setup);
         std::lock_guard<std::mutex> lock(f->mu);
         f->rc = rc;
         if (rc != GR_OK) f->error = g_error;
@@ -707,6 +721,7 @@ struct gr_program_manager {
     gr_program* substituted = nullptr;       // swapped in (using_swapped)
     gr_program_future* pending = nullptr;    // substituted_program_opt
     std::vector<gr_program*> retired;
+    std::vector<gr_program_future*> abandoned;   // builds a parameter change overtook: reaped once their worker has finished
     gr_features features{};
     std::vector<float> cfg;
     unsigned long long swaps = 0, updates = 0;
@@ -720,6 +735,26 @@ static int manager_start_build(gr_program_manager* pm) {
     rc = gr_metric_argument_string(pm->metric, &pm->features, 1, pm->cfg.data(), (int)pm->cfg.size(), &arguments[0], need, &need);
     if (rc != GR_OK) return rc;
     return gr_program_create_async(arguments.c_str(), pm->device, &pm->pending);
+}
+
+// A build that a parameter change has overtaken is not waited for (its worker cannot be interrupted inside the compiler, and joining
+// it would stall the caller's frame loop for the rest of the compile - seconds - every time a slider moves): it is set aside and
+// deleted by a later call that finds its worker finished; gr_program_manager_destroy joins what is left.
+static void manager_reap(gr_program_manager* pm, bool wait) {
+    for (size_t i = 0; i < pm->abandoned.size();) {
+        gr_program_future* f = pm->abandoned[i];
+        bool done;
+        {
+            std::lock_guard<std::mutex> lock(f->mu);
+            done = f->done;
+        }
+        if (done || wait) {
+            gr_program_future_destroy(f);   // joins a worker that has already left its last statement (or, at destruction, waits)
+            pm->abandoned.erase(pm->abandoned.begin() + (long)i);
+        } else {
+            i++;
+        }
+    }
 }
 
 static void manager_retire(gr_program_manager* pm, gr_program* p) {
@@ -771,12 +806,14 @@ int gr_program_manager_update(gr_program_manager* pm, const gr_features* feature
     pm->updates++;
     manager_retire(pm, pm->substituted);   // the substituted program is invalid for the new values: the dynamic one again
     pm->substituted = nullptr;
-    if (pm->pending) { gr_program_future_destroy(pm->pending); pm->pending = nullptr; }   // joins the abandoned build
+    if (pm->pending) { pm->abandoned.push_back(pm->pending); pm->pending = nullptr; }   // not joined here: manager_reap
+    manager_reap(pm, false);
     return manager_start_build(pm);
 }
 
 int gr_program_manager_current(gr_program_manager* pm, int wait, gr_program** program, int* is_substituted) {
     if (!pm || !program) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    manager_reap(pm, false);
     while (pm->pending) {
         gr_program* ready = nullptr;
         const int rc = gr_program_future_poll(pm->pending, &ready);
@@ -805,6 +842,7 @@ gr_program* gr_program_manager_dynamic(gr_program_manager* pm) { return pm ? pm-
 void gr_program_manager_destroy(gr_program_manager* pm) {
     if (!pm) return;
     if (pm->pending) gr_program_future_destroy(pm->pending);
+    manager_reap(pm, true);
     for (gr_program* p : pm->retired) gr_program_destroy(p);
     gr_program_destroy(pm->substituted);
     gr_program_destroy(pm->dynamic);
@@ -1085,9 +1123,9 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     // the prepass inside the launch: its cell waves are the first tickets (gr_trace_fused's prepass_tickets)
     int prepass_tickets = 0;
     if (inline_prepass) {
-        if (rays_per_lane != 1 || lattice != 1 || pending_only || (tile_order && !tile_order_by_history) || !term || prepass_width <= 0 ||
+        if (rays_per_lane != 1 || pending_only || (tile_order && !tile_order_by_history) || !term || prepass_width <= 0 ||
             prepass_height <= 0 || prepass_width == width || prepass_height == height)
-            return fail(GR_ERROR_INVALID_ARGUMENT, "inline_prepass: gr_trace_fused on every pixel of its rows, in image order or the order of "
+            return fail(GR_ERROR_INVALID_ARGUMENT, "inline_prepass: gr_trace_fused on every pixel of its rows (or the lattice launch of adaptive sampling), in image order or the order of "
                                                    "gr_order_tiles_by_history (gr_order_tiles' needs the prepass first), with a prepass grid");
         prepass_tickets = (int)(((long long)prepass_width * prepass_height + 63) / 64);
     }
@@ -1151,8 +1189,6 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         ticket_tiles = (int)std::min<long long>(8, std::max<long long>(1, (per_wave + 31) / 32));
         if (const char* e = getenv("GR_TICKET_TILES")) { const int v = atoi(e); if (v >= 1 && v <= 64) ticket_tiles = v; }
     }
-    if (prepass_tickets)   // every cell unknown (GR_CELL_UNKNOWN = -1) until its ray has been traced
-        HIP_CHECK(hipMemsetAsync(const_cast<void*>(term), 0xff, (size_t)prepass_width * prepass_height * sizeof(int), (hipStream_t)stream));
     // the kernel's trace_shading, by value (same layout)
     struct { void* out; const void* bg1; const void* bg2; int bg_width, bg_height, bg_levels, most_probes, compact_out; } shading = {};
     if (shading_in && shading_in->out) {
@@ -1164,14 +1200,20 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         shading.bg_width = shading_in->bg_width; shading.bg_height = shading_in->bg_height; shading.bg_levels = shading_in->bg_levels;
         shading.most_probes = shading_in->max_probes; shading.compact_out = strip_count > 1 ? shading_in->compact_out : 0;
     }
+    if (tile_cost && (rays_per_lane != 1 || lattice != 1 || pending_only))
+        return fail(GR_ERROR_INVALID_ARGUMENT, "tile_cost: gr_trace_fused on every pixel of its rows");
+    // (every argument has been checked by now: nothing below fails for a reason of the caller's, and nothing above has touched a buffer)
+    if (prepass_tickets)   // every cell unknown (GR_CELL_UNKNOWN = -1) until its ray has been traced
+        HIP_CHECK(hipMemsetAsync(const_cast<void*>(term), 0xff, (size_t)prepass_width * prepass_height * sizeof(int), (hipStream_t)stream));
     if (tile_cost) {
-        if (rays_per_lane != 1 || lattice != 1 || pending_only)
-            return fail(GR_ERROR_INVALID_ARGUMENT, "tile_cost: gr_trace_fused on every pixel of its rows");
         HIP_CHECK(hipSetDevice(p->device));
         HIP_CHECK(hipMemsetAsync(tile_cost, 0, (size_t)total_waves * sizeof(unsigned int), (hipStream_t)stream));
     }
-    // gr_order_tiles' last class is a promise (nothing to trace, nothing to look up); gr_order_tiles_by_history's a guess
-    int last_class_is_skipped = (tile_order && !tile_order_by_history) ? 1 : 0;
+    // Whether the list's last class is a promise (gr_order_tiles: nothing to trace, nothing to look up) or a guess
+    // (gr_order_tiles_by_history) is written into the list by the launch that made it, and the kernel reads it there; the caller's
+    // flag only says which he thinks it is, for the checks above.
+    int last_class_is_skipped = 0;   // (kept in the kernel's parameter list: 1 would force the promise, nothing passes it)
+    (void)tile_order_by_history;
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
                     &lattice, &pending_only, &tile_order, &shading, &prepass_tickets, &ticket_tiles, &tile_cost,
@@ -1194,8 +1236,57 @@ int gr_adaptive_refine_strips(gr_program* p, void* stream, void* rdata, void* pe
     if (block_rows <= 0 || block_rows % 8 != 0 || strip_rank < 0 || strip_rank >= strip_count)
         return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
     if (lattice_rays && !cfg) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_adaptive_refine: lattice_rays needs the metric's cfg");
-    void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_rays, &cfg};
+    void* pending_list = nullptr;
+    int phase = 0;
+    void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_rays, &cfg, &pending_list, &phase};
     return launch(p, K_ADAPTIVE_REFINE, stream, (unsigned)((width / 2 + 15) / 16), (unsigned)((height / 2 + 15) / 16), 16, 16, args);
+}
+
+size_t gr_pending_list_bytes(int width, int height) {
+    if (width < 2 || height < 2) return 0;
+    return (32 + 3 * (size_t)(width / 2) * (height / 2)) * sizeof(unsigned int);
+}
+
+size_t gr_lattice_rays_bytes(int width, int height) {
+    if (width < 2 || height < 2) return 0;
+    return (size_t)(width / 2) * (height / 2) * (3 * 16 + 4);   // three float4 of end state + the ray's attempts per lattice pixel
+}
+
+int gr_adaptive_refine_list(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg, int block_rows,
+                            int strip_rank, int strip_count, const void* lattice_rays, const void* cfg, void* pending_list) {
+    if (!p || !rdata || !pending_list) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_adaptive_refine_list: null argument");
+    if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + 7) / 8) * 8; }
+    if (block_rows <= 0 || block_rows % 8 != 0 || strip_rank < 0 || strip_rank >= strip_count)
+        return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
+    if (lattice_rays && !cfg) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_adaptive_refine_list: lattice_rays needs the metric's cfg");
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipMemsetAsync(pending_list, 0, 128, (hipStream_t)stream));
+    for (int phase = 0; phase < 2; phase++) {   // decide, mark and count by cost class; then deal every marked pixel its place
+        void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_rays, &cfg, &pending_list, &phase};
+        int rc = launch(p, K_ADAPTIVE_REFINE, stream, (unsigned)((width / 2 + 15) / 16), (unsigned)((height / 2 + 15) / 16), 16, 16, args);
+        if (rc != GR_OK) return rc;
+    }
+    return GR_OK;
+}
+
+int gr_trace_pending(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width, int height,
+                     const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg, void* attempt_counter,
+                     const void* pending_list, int waves_per_simd) {
+    if (!p || !rdata || !pending_list) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_trace_pending: null argument");
+    if (width < 2 || height < 2) return GR_OK;
+    const int wg = 256;
+    long long groups = resident_trace_groups(p, K_TRACE_PENDING, wg);
+    if (groups < 0) return (int)-groups;
+    if (waves_per_simd >= 1 && waves_per_simd <= 8) groups = std::min(groups, (long long)p->compute_units * 4 * waves_per_simd * 64 / wg);
+    // (how many entries the list holds is only known on the device: the launch fills the machine and its waves draw tickets until
+    // the list is used up - no more workgroups than the worst case needs, though)
+    const long long worst = (3LL * (width / 2) * (height / 2) + wg - 1) / wg;
+    groups = std::max(1LL, std::min(groups, worst));
+    unsigned int* tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
+    void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &pending_list};
+    return launch(p, K_TRACE_PENDING, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
 int gr_adaptive_refine(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg,

@@ -59,7 +59,8 @@ struct gr_render_state {
     size_t tile_order_bytes = 0;
     // what each tile of the last fused frame cost (gr_trace_fused_args.tile_cost) and the frame shape that goes with it: the next
     // frame's tiles are handed out dearest first by it (gr_frame_options.tile_history)
-    void* lattice_rays = nullptr;   // adaptive sampling on the fused path: 3 float4 per lattice pixel (allocated on first use)
+    void* lattice_rays = nullptr;   // adaptive sampling on the fused path: gr_lattice_rays_bytes (allocated on first use)
+    void* pending_list = nullptr;   // ... the pixels of its second launch, dearest first: gr_pending_list_bytes
     void* tile_cost = nullptr;
     int tile_cost_shape[3] = {0, 0, 0};   // block_rows, strip_rank, strip_count
     bool tile_cost_valid = false;
@@ -455,7 +456,7 @@ void gr_render_state_destroy(gr_render_state* s) {
     std::vector<void*> ptrs = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
                                s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
                                s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->tile_order,
-                               s->tile_cost, s->lattice_rays};
+                               s->tile_cost, s->lattice_rays, s->pending_list};
     for (auto& slot : s->pre) {
         if (slot.stream) { (void)hipStreamSynchronize(slot.stream); (void)hipStreamDestroy(slot.stream); }
         if (slot.ready) (void)hipEventDestroy(slot.ready);
@@ -923,8 +924,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // prepass in front and the tiles ordered by its costs (tools/strip_probe.py, STRIP_PROBE_DEPTH=0): a share is few tiles, and
         // which of them start first matters more than the prepass's latency.
         const bool inline_wanted = opt.inline_prepass < 0 ? (inline_default != 0 && strip_count == 1 && !order_capable) : opt.inline_prepass != 0;
-        const bool inline_prepass = inline_wanted && !prefetched && one_launch_setup && use_prepass && !adaptive && keep_lanes == 0 && rays_per_lane == 1 &&
-                                    prepass_width != width && prepass_height != height;
+        // (an adaptively sampled whole frame: the cells ride in front of the lattice launch's tiles)
+        const bool inline_prepass = inline_wanted && !prefetched && one_launch_setup && use_prepass && (!adaptive || strip_count == 1) && keep_lanes == 0 &&
+                                    rays_per_lane == 1 && prepass_width != width && prepass_height != height;
         const bool order_tiles = order_capable && !inline_prepass;
         // (the kernels that record and follow the history are gr_trace_fused's: one ray per lane, no compaction)
         const bool record_history = history_wanted && !device_busy && keep_lanes == 0 && rays_per_lane == 1;
@@ -1011,17 +1013,31 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.attempt_counter = attempts;
                 a.waves_per_simd = opt.trace_waves_per_simd;
                 a.lattice = 2;
-                if (!s->lattice_rays) HIP_CHECK(hipMalloc(&s->lattice_rays, (size_t)(width / 2) * (height / 2) * 12 * sizeof(float)));
+                a.inline_prepass = inline_prepass ? 1 : 0;
+                if (!s->lattice_rays) HIP_CHECK(hipMalloc(&s->lattice_rays, gr_lattice_rays_bytes(width, height)));
+                if (!s->pending_list) HIP_CHECK(hipMalloc(&s->pending_list, gr_pending_list_bytes(width, height)));
                 a.lattice_rays = s->lattice_rays;
                 GR_CHECK(gr_trace_fused_launch(p, stream, &a));
                 GR_CHECK(end(GR_STAGE_TRACE));
                 GR_CHECK(begin(GR_STAGE_ADAPTIVE));
                 HIP_CHECK(hipMemsetAsync(s->rays_adaptive_count, 0, 4, stream));
-                GR_CHECK(gr_adaptive_refine_strips(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows,
-                                                   strip_rank, strip_count, s->lattice_rays, s->cfg));
-                a.lattice = 1;
-                a.pending_only = 1;
-                GR_CHECK(gr_trace_fused_launch(p, stream, &a));
+                // the decisions, the marked pixels as a list ordered dearest first, and the second launch over that list: every lane
+                // of every wave has a ray (GR_ADAPTIVE_PENDING_LIST=0: the marked pixels found by walking the image's tiles again)
+                static const bool as_list = [] { const char* e = getenv("GR_ADAPTIVE_PENDING_LIST"); return !(e && e[0] == '0'); }();
+                if (as_list) {
+                    GR_CHECK(gr_adaptive_refine_list(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows, strip_rank,
+                                                     strip_count, s->lattice_rays, s->cfg, s->pending_list));
+                    GR_CHECK(gr_trace_pending(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, s->tetrad[0],
+                                              s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, s->pending_list,
+                                              opt.trace_waves_per_simd));
+                } else {
+                    GR_CHECK(gr_adaptive_refine_strips(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows,
+                                                       strip_rank, strip_count, s->lattice_rays, s->cfg));
+                    a.lattice = 1;
+                    a.pending_only = 1;
+                    a.inline_prepass = 0;
+                    GR_CHECK(gr_trace_fused_launch(p, stream, &a));
+                }
                 GR_CHECK(end(GR_STAGE_ADAPTIVE));
             } else {
             if (rays_per_lane == 2)

@@ -437,7 +437,7 @@ __device__ __forceinline__ void integrate_pair(pair4& position_io, pair4& veloci
 #ifdef IS_CONSTANT_THETA
         polar.z = splat(GR_PIf / 2);
 #endif
-        pairf r_value = gm::distance_to_object(polar, cfg);
+        pairf r_value = gm::distance_to_object_from(position, polar, cfg);
         pairf ar;
         ar.x = __builtin_fabsf(r_value.x); ar.y = __builtin_fabsf(r_value.y);
         pairf ds;

@@ -70,8 +70,12 @@ __device__ __forceinline__ float cosh(float x) { return ::coshf(x); }
 // polynomial, selects) compiles to ~40 - the Alcubierre acceleration calls it twice per attempt, a quarter of its loop.  Absolute
 // error <= 1.2e-7 everywhere (the subtraction from 1 costs relative accuracy near 0, where the warp-drive shape function only
 // uses differences of tanh of O(1) arguments); saturates to +-1, NaN stays NaN.  -DGR_LIBM_TANH: the library routine.
+// Its RELATIVE error is unbounded next to 0 (tanh x for |x| < 1e-7 comes out 0 or one quantum), so it is used only where the code
+// generator has seen that nothing depends on that: -DGR_TANH_IN_SUMS_ONLY, emitted (metric_codegen.cpp) when every tanh of the
+// metric meets only sums, differences and products with other tanh values, constants and $cfg-only factors - the shape functions
+// of the warp drives.  A script that writes tanh(x) / x or scales a tanh by a coordinate gets the library routine.
 __device__ __forceinline__ float tanh(float x) {
-#ifdef GR_LIBM_TANH
+#if defined(GR_LIBM_TANH) || !defined(GR_TANH_IN_SUMS_ONLY)
     return ::tanhf(x);
 #else
     return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.88539008177792681472f) + 1.f);
@@ -397,6 +401,18 @@ __device__ __forceinline__ pairf distance_to_object(pair4 polar, cfg_t cfg) {
     GR_POSITION_VARS_PAIR(polar)
     pairf d = DISTANCE_FUNC;
     return d;
+}
+// as distance_to_object_from above: every integrator takes its step-size distance from the same expression
+__device__ __forceinline__ pairf distance_to_object_from(pair4 position, pair4 polar, cfg_t cfg) {
+#ifdef GR_DISTANCE_OF_GENERIC
+    GR_POSITION_VARS_PAIR(position)
+    (void)polar;
+    pairf d = GR_DISTANCE_OF_GENERIC;
+    return d;
+#else
+    (void)position;
+    return distance_to_object(polar, cfg);
+#endif
 }
 #endif  // GR_TWO_RAYS_PER_LANE
 

@@ -110,6 +110,11 @@ struct dynamic_feature_config {
 #define GR_PENDING (-1)
 #define GR_TILE_CLASSES 16
 #define GR_TILE_ORDER_HEADER (2 * GR_TILE_CLASSES)   // words in front of gr_order_tiles' list: class counts, class cursors
+// what kind of list it is, left by the launch that made it in the first word behind the list (the classes' scratch area, free once
+// the list is dealt): gr_order_tiles' last class is a PROMISE that no pixel of its tiles needs a ray - the trace writes their records
+// without looking anything up - gr_order_tiles_by_history's a guess that is looked up like any other tile
+#define GR_LIST_BY_PREPASS 0x50524550u
+#define GR_LIST_BY_HISTORY 0x48495354u
 #ifndef GR_TILE_COST_REACH
 #define GR_TILE_COST_REACH 1      // cells either side of the tile centre's whose rays' costs count for the tile's class
 #endif

@@ -378,6 +378,12 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
             record[2] = ray.initial_quat;
         }
     }
+    // ... and, behind the end states, what every lattice ray cost (its attempts; 0 for a pixel the prepass skipped): the estimate
+    // gr_adaptive_refine orders the pixels of the second launch by
+    if (LATTICE_RAYS && lattice_rays && lattice == 2 && cell_wave < 0) {
+        const size_t lattice_pixels = (size_t)(image_width / 2) * (image_height / 2);
+        reinterpret_cast<unsigned int*>(lattice_rays + 3 * lattice_pixels)[(size_t)(cy / 2) * (image_width / 2) + cx / 2] = tries;
+    }
     rdata[cy * width + cx] = dat;
 #ifdef GR_TILE_SHADING   // programs built with -DGR_TILE_SHADING only: carried along unused, the call's spills add 0.12 GB of scratch traffic per 4K launch
     if (shading.out && lattice == 1 && !pending_only && within < tiles_x * tile_rows) {
@@ -446,6 +452,8 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
     const int cell_tickets = prepass_tickets > 0 ? prepass_tickets : 0;
     const int tickets_total = total_waves + cell_tickets;
     const int singles = (tile_counter && tile_order) ? tickets_total - (int)tile_order[GR_TILE_CLASSES - 1] : tickets_total;
+    // the list says itself whether its last class is a promise (program.hip GR_LIST_BY_PREPASS)
+    const bool list_promises = tile_order && (last_class_is_skipped || tile_order[GR_TILE_ORDER_HEADER + total_waves] == GR_LIST_BY_PREPASS);
     for (;;) {
         if (tile_counter) {
             if (held == 0) {
@@ -456,7 +464,7 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
                 // waves: the one counter serves ~10^8 tickets a second, and the 518 400 short tiles of an 8K Alcubierre frame
                 // were waiting for it more than they traced), then GR_SKIP_CHUNK entries of the last class
                 const int single_tickets = (singles + ticket_tiles - 1) / ticket_tiles;
-                known_skipped = tile_order && last_class_is_skipped && drawn >= single_tickets;
+                known_skipped = list_promises && drawn >= single_tickets;
                 if (drawn < single_tickets) {
                     cursor = drawn * ticket_tiles;
                     held = singles - cursor < ticket_tiles ? singles - cursor : ticket_tiles;
@@ -878,6 +886,7 @@ gr_order_tiles(const int* __restrict__ termination_buffer, const unsigned int* _
         for (int c = 0; c < cls; c++) first += list[c];
         list[GR_TILE_ORDER_HEADER + first + group_base[cls] + place] = (unsigned int)tile;
     }
+    if (phase == 1 && tile == 0) classes[0] = tile_history ? GR_LIST_BY_HISTORY : GR_LIST_BY_PREPASS;   // (tile 0's own class was read above)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -912,19 +921,36 @@ __device__ __forceinline__ render_data interpolate_render_data(render_data r1, r
 // of appending rays to a list: the second launch then walks the same 8x8 tiles, neighbouring rays stay in one wave, no atomics
 // order the work.  Same tests as the reference (cl.cl:5242-5282): boundary blocks always refine, differing termination flags
 // refine, otherwise the angular error across the block against the per-pixel angle times the threshold.
+// The pixels of the second launch as a LIST (pending_list != NULL; gr_adaptive_refine_list runs the kernel twice): phase 0 decides,
+// marks and counts the marked pixels by what their rays are expected to cost - the dearest of the four lattice rays around the block,
+// an octave of attempts per class (the lattice launch leaves the attempts behind its rays' end states) - phase 1 deals every marked
+// pixel a place in its class's range, dearest class first.  gr_trace_pending then traces the list 64 entries to a wave: every lane has
+// a ray (a tile of the image has 48 at best and most have a handful), the rays of a wave are neighbours of one cost class, and the
+// longest rays of the frame - the refined pixels are the long ones: 12 % of a 4K Kerr frame's pixels, 59 % of what the adaptive
+// frame traces - start first instead of wherever the image has them.  list[0..15] entries per class, [16..31] cursors, [32..] pixels
+// (y * width + x).
+#define GR_PENDING_CLASSES 16
+#define GR_PENDING_HEADER (2 * GR_PENDING_CLASSES)
 extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, int* __restrict__ pending_count, int width, int height,
                                               dfg_t dfg, int block_rows, int strip_rank, int strip_count,
-                                              const float4* __restrict__ lattice_rays, cfg_t cfg) {
+                                              const float4* __restrict__ lattice_rays, cfg_t cfg, unsigned int* __restrict__ pending_list, int phase) {
+    __shared__ unsigned int group_count[GR_PENDING_CLASSES], group_base[GR_PENDING_CLASSES];
+    const int thread = threadIdx.y * blockDim.x + threadIdx.x;
+    if (pending_list) {
+        if (thread < GR_PENDING_CLASSES) group_count[thread] = 0;
+        __syncthreads();
+    }
     const int sx = blockIdx.x * blockDim.x + threadIdx.x;
     const int sy = blockIdx.y * blockDim.y + threadIdx.y;
     const int hw = width / 2, hh = height / 2;
-    if (sx >= hw || sy >= hh) return;
     const int lsx = 2 * sx, lsy = 2 * sy;
     // split frame: only the pixel blocks whose rows this device shades or reads as a halo row (their lattice neighbours were traced)
-    if (strip_count > 1 && !own_block_within(lsy, 0, height, block_rows, strip_rank, strip_count)) return;
+    bool mine = sx < hw && sy < hh && !(strip_count > 1 && !own_block_within(lsy, 0, height, block_rows, strip_rank, strip_count));
     auto at = [&](int x, int y) -> render_data& { return rdat[y * width + x]; };
-    bool refine = true;
-    if (sx != 0 && sx != hw - 1 && sy != 0 && sy != hh - 1) {
+    bool refine = mine;
+    if (pending_list && phase == 1) refine = mine && at(lsx + 1, lsy).terminated == GR_PENDING;
+    if (!pending_list && !mine) return;
+    if (mine && !(pending_list && phase == 1) && sx != 0 && sx != hw - 1 && sy != 0 && sy != hh - 1) {
         const render_data centre = at(lsx, lsy), left = at(lsx - 2, lsy), right = at(lsx + 2, lsy), up = at(lsx, lsy - 2), down = at(lsx, lsy + 2);
         const int down_right_flag = at(lsx + 2, lsy + 2).terminated;
         // (theta, phi) where each neighbour's ray meets the sky: the reference's get_intersection_position of the ray as the lattice
@@ -953,16 +979,96 @@ extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, in
         const int ct = centre.terminated;
         if (ct != left.terminated || ct != right.terminated || ct != up.terminated || ct != down.terminated || ct != down_right_flag) refine = true;
     }
+    if (!(pending_list && phase == 1) && mine) {
+        if (refine) {
+            at(lsx + 1, lsy).terminated = GR_PENDING;
+            at(lsx, lsy + 1).terminated = GR_PENDING;
+            at(lsx + 1, lsy + 1).terminated = GR_PENDING;
+            if (pending_count) atomicAdd(pending_count, 3);
+        } else {
+            const render_data c = at(lsx, lsy);
+            at(lsx + 1, lsy) = interpolate_render_data(c, at(lsx + 2, lsy));
+            at(lsx, lsy + 1) = interpolate_render_data(c, at(lsx, lsy + 2));
+            at(lsx + 1, lsy + 1) = interpolate_render_data(c, at(lsx + 2, lsy + 2));
+        }
+    }
+    if (!pending_list) return;
+    // the block's cost class: the dearest lattice ray at its four corners, an octave per class, dearest first
+    int cls = -1;
     if (refine) {
-        at(lsx + 1, lsy).terminated = GR_PENDING;
-        at(lsx, lsy + 1).terminated = GR_PENDING;
-        at(lsx + 1, lsy + 1).terminated = GR_PENDING;
-        if (pending_count) atomicAdd(pending_count, 3);
-    } else {
-        const render_data c = at(lsx, lsy);
-        at(lsx + 1, lsy) = interpolate_render_data(c, at(lsx + 2, lsy));
-        at(lsx, lsy + 1) = interpolate_render_data(c, at(lsx, lsy + 2));
-        at(lsx + 1, lsy + 1) = interpolate_render_data(c, at(lsx + 2, lsy + 2));
+        unsigned int dearest = 1;
+        if (lattice_rays) {
+            const unsigned int* cost = reinterpret_cast<const unsigned int*>(lattice_rays + 3 * (size_t)hw * hh);
+            for (int dy = 0; dy < 2; dy++)
+                for (int dx = 0; dx < 2; dx++)
+                    if (sx + dx < hw && sy + dy < hh) { const unsigned int c = cost[(size_t)(sy + dy) * hw + sx + dx]; dearest = c > dearest ? c : dearest; }
+        }
+        const int octave = 31 - __builtin_clz(dearest);
+        cls = GR_PENDING_CLASSES - 1 - (octave > GR_PENDING_CLASSES - 1 ? GR_PENDING_CLASSES - 1 : octave);
+    }
+    // one atomic per class and workgroup on the list's counters (as gr_order_tiles): a block's place among its workgroup's blocks
+    const int lane = thread % 64;
+    unsigned int place = 0;
+    for (int c = 0; c < GR_PENDING_CLASSES; c++) {
+        const unsigned long long members = __builtin_amdgcn_ballot_w64(cls == c);
+        if (members) {
+            const int leader = __builtin_ctzll(members);
+            unsigned int wave_base = 0;
+            if (lane == leader) wave_base = atomicAdd(&group_count[c], 3u * (unsigned int)__builtin_popcountll(members));
+            wave_base = __builtin_amdgcn_readlane(wave_base, leader);
+            if (cls == c) place = wave_base + 3u * (unsigned int)__builtin_popcountll(members & ((1ull << lane) - 1ull));
+        }
+    }
+    __syncthreads();
+    if (thread < GR_PENDING_CLASSES && group_count[thread])
+        group_base[thread] = atomicAdd(pending_list + (phase == 0 ? 0 : GR_PENDING_CLASSES) + thread, group_count[thread]);
+    __syncthreads();
+    if (phase == 1 && cls >= 0) {
+        unsigned int first = 0;
+        for (int c = 0; c < cls; c++) first += pending_list[c];
+        unsigned int* entry = pending_list + GR_PENDING_HEADER + first + group_base[cls] + place;
+        entry[0] = (unsigned int)(lsy * width + lsx + 1);
+        entry[1] = (unsigned int)((lsy + 1) * width + lsx);
+        entry[2] = (unsigned int)((lsy + 1) * width + lsx + 1);
+    }
+}
+
+// The second launch of adaptive sampling over gr_adaptive_refine's list: persistent waves, a ticket is 64 consecutive entries, every
+// lane traces the pixel of its entry exactly as a tile-wave of gr_trace_fused would (make_pixel_ray, integrate_ray, make_render_data)
+// and writes its record.  No prepass look-ups: a marked pixel is traced whatever the prepass said about its cell, as in the reference,
+// whose second do_generic_rays runs over the rays handle_adaptive_sampling appended.
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
+gr_trace_pending(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat, render_data* __restrict__ rdata,
+                 int width, int height, const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2,
+                 const float4* __restrict__ e3, cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter,
+                 unsigned int* __restrict__ ticket_counter, const unsigned int* __restrict__ pending_list) {
+    GR_PARAMETERS_IN_REGISTERS
+    const int lane = threadIdx.x % 64;
+    unsigned int total = 0;
+    for (int c = 0; c < GR_PENDING_CLASSES; c++) total += pending_list[c];
+    for (;;) {
+        unsigned int ticket = 0;
+        if (lane == 0) ticket = atomicAdd(ticket_counter, 1u);
+        const unsigned int first = (unsigned int)__builtin_amdgcn_readfirstlane(ticket) * 64u;
+        if (first >= total) break;
+        asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));   // (as gr_trace_fused: nothing of the set-up hoisted over the loop)
+        unsigned int tries = 0;
+        if (first + lane < total) {
+            const unsigned int pixel = pending_list[GR_PENDING_HEADER + first + lane];
+            const int cx = (int)(pixel % (unsigned int)width), cy = (int)(pixel / (unsigned int)width);
+            lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+            ray_state s;
+            s.position = ray.position;
+            s.velocity = ray.velocity;
+            s.acceleration = ray.acceleration;
+            s.running_dlambda_dnew = 1;
+            int terminated = 0;
+            if (integrate_ray(s, cfg, dfg, &tries) == RAY_TERMINATED) terminated = 1;
+            else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
+            rdata[cy * width + cx] = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated,
+                                                      cx, cy, cfg, dfg, GET_FEATURE(redshift, dfg) != 0);
+        }
+        if (attempt_counter) atomicAdd(attempt_counter + GR_ATTEMPT_COUNTERS_AT + (blockIdx.x % GR_ATTEMPT_COUNTERS), (unsigned long long)tries);
     }
 }
 

@@ -1,5 +1,6 @@
 // metric_codegen.cpp — see metric_codegen.hpp.
 #include <functional>
+#include <unordered_set>
 #include "metric_codegen.hpp"
 
 #include <cmath>
@@ -483,6 +484,44 @@ std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl
         for (int i = 0; i < 4; i++) polar["v" + std::to_string(i + 1)] = impl.to_polar[i];
         const E composed = sym::cancel_round_trip(sym::subst(impl.distance_function, polar));
         if (!sym::contains_division_or_angle(composed)) s += "-DGR_DISTANCE_OF_GENERIC=" + to_c(composed) + " ";
+    }
+
+    {
+        // -DGR_TANH_IN_SUMS_ONLY (kernels/metric.hip gm::tanh): every tanh that depends on a coordinate is used only in sums, differences
+        // and products whose other operand is again such a combination, a constant or a $cfg-only value.  Then an absolute error of
+        // 1e-7 in tanh is an absolute error of that order in everything built from it, and the five-instruction form may stand in
+        // for the library's (which keeps RELATIVE accuracy next to 0 - what tanh(x) / x or r tanh(x) would need).
+        std::vector<E> everything = scoped;
+        everything.insert(everything.end(), impl.to_polar.begin(), impl.to_polar.end());
+        everything.push_back(impl.distance_function);
+        std::unordered_map<E, int> klass;   // 1: constant / $cfg-only / tanh / sum, difference, product of class-1 nodes
+        std::function<bool(E)> in_class = [&](E e) -> bool {
+            if (!e) return false;
+            auto it = klass.find(e);
+            if (it != klass.end()) return it->second == 1;
+            bool ok = e->op == sym::CONST || (e->deps & ~sym::DEP_CFG) == 0 || (e->op == sym::FN1 && e->fn == sym::F_TANH);
+            if (!ok && (e->op == sym::ADD || e->op == sym::SUB || e->op == sym::MUL)) ok = in_class(e->a) && in_class(e->b);
+            if (!ok && e->op == sym::NEG) ok = in_class(e->a);
+            klass[e] = ok ? 1 : 0;
+            return ok;
+        };
+        bool any_tanh = false, sums_only = true;
+        std::unordered_set<E> seen;
+        std::function<void(E)> walk = [&](E e) {
+            if (!e || !seen.insert(e).second) return;
+            for (E c : {e->a, e->b, e->s}) {
+                if (!c) continue;
+                if (c->op == sym::FN1 && c->fn == sym::F_TANH && (c->deps & ~sym::DEP_CFG) != 0) {
+                    any_tanh = true;
+                    const bool combines = (e->op == sym::ADD || e->op == sym::SUB || e->op == sym::MUL) ? in_class(e->a) && in_class(e->b)
+                                                                                                       : e->op == sym::NEG;
+                    if (!combines) sums_only = false;
+                }
+                walk(c);
+            }
+        };
+        for (E r : everything) walk(r);
+        if (any_tanh && sums_only) s += "-DGR_TANH_IN_SUMS_ONLY ";
     }
 
     if (!vars.names.empty()) {

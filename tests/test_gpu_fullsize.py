@@ -166,6 +166,23 @@ def test_kerr_4k_literal_spin_frame_against_the_oracle():
     assert np.percentile(err, 50) <= 5e-6 and np.percentile(err, 90) <= 5e-4 and np.percentile(err, 99) <= 2e-2
 
 
+@pytest.mark.parametrize("name", ["schwarzschild", "schwarzschild_adaptive"])
+def test_schwarzschild_1080p_frame_against_the_oracle(name):
+    """BASELINE.json configs[1] (scripts/schwarzschild.js, 1920x1080, one GPU) at full size, both readings of SURVEY.md 8d item 2:
+    2a as the reference ships the metric - fixed step, the program bench.py times at 4 000 Mrays/s through the two-rays-per-lane
+    kernel - and 2b with the adaptive controller forced (scripts/schwarzschild_adaptive.js); every 4th pixel of the frame against
+    the oracle's 480x270 frame, assertions as for the 4K Kerr frame"""
+    rd, ref = strided_frame_against_oracle(name, 1920, 1080, 4)
+    hit_gpu, hit_ref = rd["terminated"] == 1, ref["terminated"] == 1
+    assert (hit_gpu != hit_ref).mean() <= 0.002
+    both = hit_gpu & hit_ref
+    # (scripts/schwarzschild.js is SINGULAR: a ray that reaches r = 1.05 has terminated too, its record black; the adaptive variant loses those rays)
+    assert both.mean() >= (0.9 if name == "schwarzschild" else 0.3)
+    err = circ_diff(rd["tex_coord"][both], ref["tex_coord"][both]).max(axis=1)
+    assert np.percentile(err, 99) <= 1e-4 and np.percentile(err, 50) <= 2e-6
+    assert (rd["side"][both] == ref["side"][both]).all()
+
+
 def test_double_unequal_kerr_4k_frame_against_the_oracle():
     """BASELINE.json configs[3] on one GPU (scripts/double_unequal_kerr.js, 3840x2160, camera (0,0,-6,0.5)): every 8th pixel of
     the full frame against the oracle's 480x270 frame (measured: flags differ 1e-4, sky coordinates p50 6e-8, p99 2e-6)"""

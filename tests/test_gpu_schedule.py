@@ -48,8 +48,12 @@ def test_tile_order_is_a_permutation_of_the_device_tiles(strip, block_rows):
     rows = block_rows or ((H + 7) // 8) * 8
     _, words = order_list(prog, state, strip, rows, pw, ph)
     n = (words.size - 32) // 2
-    counts, cursors, tiles, classes = words[:16], words[16:32], words[32:32 + n], words[32 + n:]
+    counts, cursors, tiles, classes = words[:16], words[16:32], words[32:32 + n], words[32 + n:].copy()
     assert counts.sum() == tiles.size and (cursors == counts).all()
+    # the first word behind the list says what kind of list it is (its last class a promise: gr_order_tiles; a guess:
+    # gr_order_tiles_by_history) - the trace kernel reads it there; it took the place of tile 0's class, which the list itself still shows
+    assert classes[0] == 0x50524550
+    classes[0] = np.searchsorted(np.cumsum(counts), int(np.flatnonzero(tiles == 0)[0]), side="right")
     assert np.array_equal(np.bincount(classes, minlength=16), counts)
     assert (np.diff(classes[tiles].astype(np.int64)) >= 0).all()   # the list runs through the classes in order
     assert np.array_equal(np.sort(tiles), np.arange(tiles.size, dtype=np.uint32))
@@ -126,8 +130,10 @@ def test_tile_costs_and_the_order_made_from_them():
     check(lib.gr_order_tiles_by_history(prog.handle, None, cost.ptr, W, H, rows, 0, 1, order.ptr, 0, 0))
     check(lib.gr_device_synchronize(0))
     words = order.to_numpy(np.uint32, (nbytes // 4,))
-    counts, listed, classes = words[:16], words[32:32 + tiles], words[32 + tiles:]
+    counts, listed, classes = words[:16], words[32:32 + tiles], words[32 + tiles:].copy()
     assert counts.sum() == tiles and np.array_equal(np.sort(listed), np.arange(tiles, dtype=np.uint32))
+    assert classes[0] == 0x48495354     # the list's kind ("its last class is a guess"), where tile 0's class was; the list still shows that
+    classes[0] = np.searchsorted(np.cumsum(counts), int(np.flatnonzero(listed == 0)[0]), side="right")
     assert (np.diff(classes[listed].astype(np.int64)) >= 0).all()
     grid = costs.reshape(rows // 8, W // 8)
     padded = np.pad(grid, 2, mode="edge")
@@ -469,3 +475,91 @@ def test_program_manager_swaps_and_falls_back():
     assert same_picture(frame(manager.dynamic, a30), frame(other, a30))
     frame(substituted, a45)                        # a retired program stays usable (frames launched with it may be in flight)
     manager.close()
+
+
+def test_program_manager_update_does_not_wait_for_an_overtaken_build(tmp_path, monkeypatch):
+    """a parameter change while a substituted build is running starts the next build at once and leaves the overtaken one to finish on
+    its worker (it used to be joined: every move of a slider stalled the frame loop for the rest of a compile); an empty cache
+    directory makes every build a real one"""
+    import time
+    monkeypatch.setenv("GR_CACHE_DIR", str(tmp_path))
+    metric = gra.Metric("schwarzschild_adaptive", SCRIPTS)
+    feats = metric.features(adaptive_sampling=0)
+    manager = gra.pipeline.ProgramManager(metric, 0, feats, metric.cfg_values(rs=1.0))   # waits for the dynamic program only
+    t0 = time.time()
+    for rs in (1.1, 1.2, 1.3):
+        manager.update(feats, metric.cfg_values(rs=rs))
+        prog = manager.current()                   # never blocks; the dynamic program while the builds run
+        assert prog.handle.value == manager.dynamic.handle.value or manager.is_substituted
+    assert time.time() - t0 < 2.0, "gr_program_manager_update waited for a build"
+    last = manager.current(wait=True)
+    assert manager.is_substituted and last.build_key != manager.dynamic.build_key
+    manager.close()                                # joins whatever is still compiling
+
+
+def test_pending_list_of_adaptive_sampling_holds_the_marked_pixels_dearest_first():
+    """gr_adaptive_refine_list + gr_trace_pending (the second launch of adaptive sampling as a list, 64 entries to a wave, what gr_render_frame
+    runs) against gr_adaptive_refine + the pending_only launch that walks the image's tiles again: the same pixels are marked, the list
+    holds each of them once, class by class with the dearest class first (the lattice rays' attempts around a block say which), and the
+    records of the two second launches agree - flags exactly, sky coordinates to rounding (two kernels around the same device functions)"""
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    feats, cfgv = metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0), metric.cfg_values(a=0.45)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    w, h = 640, 360
+    state = gra.RenderState(w, h, 0)
+    state.render(prog, metric, gra.default_camera(), None, None, feats, cfgv, gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1))
+    state.synchronize()   # camera, tetrad, cfg, features and the prepass flags are on the device now
+    buf = lambda which: state.buffer(which)
+    hw, hh = w // 2, h // 2
+    lattice_rays = DeviceBuffer(0, lib.gr_lattice_rays_bytes(w, h))
+    records = DeviceBuffer(0, w * h * 32)
+    a = gra.TraceFusedArgs(camera_generic=buf(gra.BUF_CAMERA_GENERIC), camera_quat=buf(gra.BUF_CAMERA_QUAT), render_data=records.ptr, width=w, height=h,
+                           termination_buffer=buf(gra.BUF_TERMINATION), prepass_width=w // 16, prepass_height=h // 16, e0=buf(gra.BUF_TETRAD0),
+                           e1=buf(gra.BUF_TETRAD1), e2=buf(gra.BUF_TETRAD2), e3=buf(gra.BUF_TETRAD3), cfg=buf(gra.BUF_CFG), dfg=buf(gra.BUF_DFG),
+                           lattice=2, lattice_rays=lattice_rays.ptr)
+    check(lib.gr_trace_fused_launch(prog.handle, None, ctypes.byref(a)))
+    lattice = records.to_numpy(RENDER_DATA_DTYPE, w * h).copy()
+    cost = download(0, lattice_rays.ptr.value + hw * hh * 48, np.uint32, hw * hh).reshape(hh, hw)
+    traced = lattice.reshape(h, w)[::2, ::2]["terminated"] != 2
+    assert (cost[traced] > 0).all() and (cost[~traced] == 0).all()      # a lattice ray's attempts; 0 where the prepass let it be skipped
+    # (A) the decisions in place + the tiles walked again
+    count_a = DeviceBuffer.from_numpy(0, np.zeros(1, dtype=np.int32))
+    check(lib.gr_adaptive_refine(prog.handle, None, records.ptr, count_a.ptr, w, h, buf(gra.BUF_DFG), lattice_rays.ptr, buf(gra.BUF_CFG)))
+    marked_a = records.to_numpy(RENDER_DATA_DTYPE, w * h)["terminated"] == -1
+    a.lattice, a.pending_only, a.lattice_rays = 1, 1, None
+    check(lib.gr_trace_fused_launch(prog.handle, None, ctypes.byref(a)))
+    frame_a = records.to_numpy(RENDER_DATA_DTYPE, w * h).copy()
+    # (B) the list
+    records_b = DeviceBuffer.from_numpy(0, lattice)
+    count_b = DeviceBuffer.from_numpy(0, np.zeros(1, dtype=np.int32))
+    pending = DeviceBuffer(0, lib.gr_pending_list_bytes(w, h))
+    check(lib.gr_adaptive_refine_list(prog.handle, None, records_b.ptr, count_b.ptr, w, h, buf(gra.BUF_DFG), 0, 0, 1, lattice_rays.ptr, buf(gra.BUF_CFG),
+                                      pending.ptr))
+    marked_b = records_b.to_numpy(RENDER_DATA_DTYPE, w * h)["terminated"] == -1
+    words = pending.to_numpy(np.uint32, lib.gr_pending_list_bytes(w, h) // 4)
+    counts, cursors = words[:16].astype(np.int64), words[16:32].astype(np.int64)
+    total = int(counts.sum())
+    entries = words[32:32 + total].astype(np.int64)
+    assert np.array_equal(marked_a, marked_b) and total == int(marked_b.sum()) == int(count_b.to_numpy(np.int32, 1)[0]) == int(count_a.to_numpy(np.int32, 1)[0])
+    assert np.array_equal(counts, cursors) and 0.02 < total / (w * h) < 0.6
+    assert len(np.unique(entries)) == total and marked_b[entries].all()
+    # class by class, dearest first: the dearest lattice ray at the corners of an entry's 2x2 block falls into its class's octave
+    ey, ex = entries // w, entries % w
+    by, bx = ey // 2, ex // 2
+    corner = np.zeros(total, dtype=np.int64)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            corner = np.maximum(corner, cost[np.minimum(by + dy, hh - 1), np.minimum(bx + dx, hw - 1)])
+    klass = 15 - np.minimum(15, np.floor(np.log2(np.maximum(corner, 1))).astype(np.int64))
+    assert (np.diff(klass) >= 0).all() and np.array_equal(np.bincount(klass, minlength=16), counts)
+    check(lib.gr_trace_pending(prog.handle, None, buf(gra.BUF_CAMERA_GENERIC), buf(gra.BUF_CAMERA_QUAT), records_b.ptr, w, h, buf(gra.BUF_TETRAD0),
+                               buf(gra.BUF_TETRAD1), buf(gra.BUF_TETRAD2), buf(gra.BUF_TETRAD3), buf(gra.BUF_CFG), buf(gra.BUF_DFG), None, pending.ptr, 0))
+    frame_b = records_b.to_numpy(RENDER_DATA_DTYPE, w * h)
+    assert (frame_b["terminated"] >= 0).all() and (frame_a["terminated"] >= 0).all()
+    differ = frame_a["terminated"] != frame_b["terminated"]
+    assert differ.mean() <= 1e-4
+    both = (frame_a["terminated"] == 1) & (frame_b["terminated"] == 1)
+    d = np.abs(frame_a["tex_coord"][both] - frame_b["tex_coord"][both])
+    d = np.minimum(d, 1 - d)
+    assert np.percentile(d, 99) <= 2e-6
+    assert np.array_equal(frame_a[~marked_b], frame_b[~marked_b])   # what the second launch does not trace is the first launch's and the interpolation's

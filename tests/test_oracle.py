@@ -67,7 +67,12 @@ SYMPY_CASES = [("schwarzschild", "schwarzschild"), ("schwarzschild", "schwarzsch
                # a Cartesian-base metric with a dense 4x4 (inverse by adjugate) and the complex-valued double Kerr in Weyl coordinates
                # (complex arithmetic as pairs, csqrt / psqrt / conjugate / self_conjugate_multiply per js_interop.cpp:506-616, 690-732;
                # cylindrical base, its periodicity and weights) - fixtures made from this repository's scripts/*.js
-               ("kerr_schild", "kerr_schild"), ("double_unequal_kerr", "double_unequal_kerr")]
+               ("kerr_schild", "kerr_schild"), ("double_unequal_kerr", "double_unequal_kerr"),
+               # round 4: the charged Kerr family (a third parameter), a spherically symmetric chart that is not Schwarzschild (the
+               # equatorial-plane kernel with a parameter), an off-diagonal chart whose coordinate transforms carry a logarithm of the
+               # parameter (total differentials with sign / fabs), and a cylinder chart with the cylindrical-singularity flags
+               ("kerr_newman_boyer", "kerr_newman"), ("wormhole", "wormhole_through"), ("wormhole", "wormhole_far_side"),
+               ("schwarzschild_ingoing_ef", "ingoing_ef"), ("cosmic_string", "cosmic_string"), ("cosmic_string", "cosmic_string_hit")]
 
 
 def sympy_argument_string(metric):

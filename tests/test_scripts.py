@@ -239,3 +239,26 @@ def test_own_scripts_equal_the_reference_scripts(name):
         pos, vel = sample_point(a, rng), list(rng.uniform(-1, 1, 4))
         assert np.allclose(ma.metric(pos, cfg), mb.metric(pos, cfg), rtol=1e-9, atol=1e-12)
         assert np.allclose(ma.accel(pos, vel, cfg), mb.accel(pos, vel, cfg), rtol=1e-6, atol=1e-9)
+
+
+def test_fast_tanh_only_where_sums_of_tanh_are_all_there_is(tmp_path):
+    """-DGR_TANH_IN_SUMS_ONLY (the five-instruction tanh of kernels/metric.hip, absolute error 1e-7, no relative accuracy next to 0) is
+    emitted for a metric whose tanh values meet only sums, differences and products with each other, constants and $cfg-only factors
+    (a warp-drive shape function), and not for one that divides a tanh by a coordinate or scales it by one"""
+    for sub, n in (("coordinates", "polar_to_polar"), ("origins", "at_origin")):
+        (tmp_path / sub).mkdir(exist_ok=True)
+        (tmp_path / sub / (n + ".js")).write_text(open(os.path.join(OWN, sub, n + ".js")).read())
+    cfg = '{"name": "%s", "to_polar": "polar_to_polar", "from_polar": "polar_to_polar", "origin_distance": "at_origin", "coordinate_system": "OTHER"}'
+    bodies = {
+        "wall": "var f = (CMath.tanh($cfg.s * (x + 1)) - CMath.tanh($cfg.s * (x - 1))) / (2 * CMath.tanh($cfg.s)); return [-1 + f * f, 1, 1, 1]",
+        "ratio": "return [-1 - CMath.tanh(x) / x, 1, 1, 1]",
+        "scaled": "return [-1, 1 + y * CMath.tanh(x), 1, 1]",
+        "none": "return [-1, 1 + x * x, 1, 1]",
+    }
+    flagged = {}
+    for name, body in bodies.items():
+        (tmp_path / (name + ".json")).write_text(cfg % name)
+        (tmp_path / (name + ".js")).write_text("function m(t, x, y, z) { $cfg.s.$default = 2; " + body + " }\nm\n")
+        flagged[name] = "-DGR_TANH_IN_SUMS_ONLY" in gra.Metric(name, tmp_path).argument_string()
+    assert flagged == {"wall": True, "ratio": False, "scaled": False, "none": False}
+    assert "-DGR_TANH_IN_SUMS_ONLY" in gra.Metric("alcubierre", OWN).argument_string()

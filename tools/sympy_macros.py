@@ -164,6 +164,53 @@ def kerr_schild(t, x, y, z):                 # scripts/kerr_schild.js (https://a
     return sp.Matrix(4, 4, lambda i, j: eta[i, j] + f * lv[i] * lv[j])
 
 
+def kerr_newman_boyer(t, r, theta, phi):     # Newman et al. 1965 in Boyer-Lindquist form (MTW box 33.2); the reference's scripts/kerr_newman_boyer.js
+    rs, a, rq = cfg_symbol("rs"), cfg_symbol("a"), cfg_symbol("rq")   # is the same line element with r2q for rq^2 (the fixture's parameters are these)
+    sigma = r * r + a * a * sp.cos(theta) ** 2
+    delta = r * r - rs * r + a * a + rq * rq
+    s2 = sp.sin(theta) ** 2
+    g = sp.zeros(4, 4)
+    # -(delta / sigma) (dt - a s2 dphi)^2 + (s2 / sigma) ((r^2 + a^2) dphi - a dt)^2 + (sigma / delta) dr^2 + sigma dtheta^2, multiplied out
+    g[0, 0] = -(delta / sigma) + (s2 / sigma) * a * a
+    g[0, 3] = g[3, 0] = (delta / sigma) * a * s2 - (s2 / sigma) * (r * r + a * a) * a
+    g[3, 3] = -(delta / sigma) * a * a * s2 * s2 + (s2 / sigma) * (r * r + a * a) ** 2
+    g[1, 1] = sigma / delta
+    g[2, 2] = sigma
+    return g
+
+
+def wormhole(t, l, theta, phi):              # scripts/wormhole.js (Morris-Thorne / Ellis throat of radius n)
+    n = cfg_symbol("n")
+    return sp.diag(-1, 1, l * l + n * n, (l * l + n * n) * sp.sin(theta) ** 2)
+
+
+def schwarzschild_ingoing_ef(vv, r, theta, phi):   # scripts/schwarzschild_ingoing_ef.js
+    rs = cfg_symbol("rs")
+    g = sp.zeros(4, 4)
+    g[0, 0] = -(1 - rs / r)
+    g[0, 1] = g[1, 0] = 1
+    g[2, 2] = r * r
+    g[3, 3] = r * r * sp.sin(theta) ** 2
+    return g
+
+
+def tortoise(r):
+    return r + cfg_symbol("rs") * sp.log(sp.Abs(r - cfg_symbol("rs")))
+
+
+def ingoing_ef_to_polar(vv, r, theta, phi):  # scripts/coordinates/ingoing_ef_to_polar.js
+    return [vv - tortoise(r), r, theta, phi]
+
+
+def polar_to_ingoing_ef(t, r, theta, phi):   # scripts/coordinates/polar_to_ingoing_ef.js
+    return [t + tortoise(r), r, theta, phi]
+
+
+def cosmic_string(t, rho, phi, z):           # Vilenkin 1981: flat space with a wedge of 8 pi mu cut out (this repository's scripts/cosmic_string.js;
+    mu = cfg_symbol("mu")                     # the reference's folder has cosmic_string_bh / _spinning only)
+    return sp.diag(-1, 1, (1 - 4 * mu) ** 2 * rho * rho, 1)
+
+
 class Cx:
     """complex numbers as pairs of real sympy expressions (the role of the reference's dual_complex, js_interop.cpp:506-616)"""
 
@@ -302,6 +349,15 @@ METRICS = {
                        dynvars=["velocity", "sigma", "R"], nonsingular=True),
     "kerr_schild": dict(g=kerr_schild, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=radius, system="CARTESIAN",
                         periodicity=None, singular=None, adaptive=True, detect=True, dynvars=["a", "rs"]),
+    "kerr_newman_boyer": dict(g=kerr_newman_boyer, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                              periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=True, dynvars=["rs", "a", "rq"]),
+    "wormhole": dict(g=wormhole, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                     periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=False, detect=False, dynvars=["n"]),
+    "schwarzschild_ingoing_ef": dict(g=schwarzschild_ingoing_ef, to_polar=ingoing_ef_to_polar, from_polar=polar_to_ingoing_ef, distance=radius,
+                                     system="X_Y_THETA_PHI", periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=True,
+                                     dynvars=["rs"]),
+    "cosmic_string": dict(g=cosmic_string, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius, system="CYLINDRICAL",
+                          periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True, dynvars=["mu"], cylindrical_terminator=0.005),
     # parameters baked in as numbers (csqrt of a symbolic value has no closed real form); the kernel is still the dynamic one
     "double_unequal_kerr": dict(g=double_unequal_kerr, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius,
                                 system="CYLINDRICAL", periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True,
@@ -420,6 +476,8 @@ def argument_string(name):
         out += ["-DW_V1=1", "-DW_V2=1", "-DW_V3=8", "-DW_V4=1"]
     else:
         out += ["-DW_V1=1", "-DW_V2=1", "-DW_V3=1", "-DW_V4=1"]
+    if m.get("cylindrical_terminator") is not None:   # metric.hpp:871-877
+        out += ["-DHAS_CYLINDRICAL_SINGULARITY", "-DCYLINDRICAL_TERMINATOR=" + _lit(m["cylindrical_terminator"])]
     if m.get("nonsingular"):
         out.append("-DUNCONDITIONALLY_NONSINGULAR")
     out.append("-DDISTANCE_FUNC=" + c_expr(sp.sympify(m["distance"](*v))))
