@@ -148,14 +148,26 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # GR_BENCH_ONE_DEVICE=1: a dress rehearsal of the N > 1 run on a box with fewer GPUs than ranks - every rank on device 0, the
+    # process group over gloo, and the frame's exchange through the library's inter-process transport (gr_tiled_create_ipc: RCCL's
+    # call pattern - a group per frame, a send per block, the matching receives on rank 0 - across real process boundaries; RCCL
+    # itself refuses two ranks on one device).  Everything else - rotation of the shares, frames in flight, look-ahead, the complete
+    # N > 1 JSON line - is the code the 8-GPU run executes.  The numbers say nothing (N ranks share one GPU): "rehearsal" marks the line.
+    one_device = os.environ.get("GR_BENCH_ONE_DEVICE") == "1" and world > 1
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = torch.device("cpu") if one_device else device   # where the tensors of the process group's collectives live
     # GR_BENCH_FORCE_DISTRIBUTED=1 drives the multi-GPU code path (process group, strip mode, gather) with one rank
     multi = world > 1 or os.environ.get("GR_BENCH_FORCE_DISTRIBUTED") == "1"
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     W, H = args.width, args.height
     # the metric comes from the script front-end (scripts/kerr_boyer.js + .json), as in the reference
@@ -195,16 +207,21 @@ def main():
         gather_path = "torch.distributed.gather + un-permute"
         if os.environ.get("GR_BENCH_GATHER", "rccl") != "torch":
             try:
-                uid = [gra.TiledFrame.unique_id() if rank == 0 else None] if world > 1 else [None]
-                if world > 1:
-                    dist.broadcast_object_list(uid, src=0)
-                tiled = gra.TiledFrame(world, rank, local_rank, uid[0], W, H, args.block_rows)
-                gather_path = "gr_render_frame_tiled: ncclSend/ncclRecv per block into the frame (RCCL called directly)"
+                if one_device:
+                    tiled = gra.TiledFrame.ipc(world, rank, 0, "bench%s" % os.environ["MASTER_PORT"], W, H, args.block_rows)
+                    gather_path = ("gr_render_frame_tiled: send / receive per block into the frame through the inter-process transport "
+                                   "(GR_BENCH_ONE_DEVICE rehearsal: every rank on device 0)")
+                else:
+                    uid = [gra.TiledFrame.unique_id() if rank == 0 else None] if world > 1 else [None]
+                    if world > 1:
+                        dist.broadcast_object_list(uid, src=0)
+                    tiled = gra.TiledFrame(world, rank, local_rank, uid[0], W, H, args.block_rows)
+                    gather_path = "gr_render_frame_tiled: ncclSend/ncclRecv per block into the frame (RCCL called directly)"
             except Exception as e:   # noqa: BLE001
                 print(f"[bench] rank {rank}: gr_tiled_create failed ({e}); using the torch.distributed gather", file=sys.stderr)
                 tiled = None
         if world > 1:   # every rank must take the same path
-            flag = torch.tensor([1 if tiled is not None else 0], device=device)
+            flag = torch.tensor([1 if tiled is not None else 0], device=coll_device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 tiled, gather_path = None, "torch.distributed.gather + un-permute"
@@ -257,7 +274,7 @@ def main():
             print(f"[bench] rank {rank}: gr_render_frame_tiled failed on its first frame ({e})", file=sys.stderr)
             ok = 0
         done.set()
-        flag = torch.tensor([ok], device=device)
+        flag = torch.tensor([ok], device=coll_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             if rank == 0:
@@ -271,6 +288,7 @@ def main():
         else:
             gather_path += "; first frame checked against rank 0's own frame"
     frame_index = [0]
+    globals_features = [features]
 
     # a batch renderer knows the next frames' cameras: their tetrad + prepass (1.2 ms of pure latency, 507 waves) run on
     # high-priority side streams while the current frame traces (gr_frame_options.next_camera / next_camera2).  Here every
@@ -278,9 +296,10 @@ def main():
     lookahead = ctypes.pointer(camera) if (fused and not args.no_lookahead) else None
     depth = 0 if lookahead is None else (args.lookahead_depth if args.lookahead_depth in (1, 2) else (2 if world > 1 else 1))
 
-    def frame(prog=None, cfgv=None, transfer=True):
+    def frame(prog=None, cfgv=None, transfer=True, feats=None):
         prog = program if prog is None else prog
         cfgv = cfg_values if cfgv is None else cfgv
+        features = feats if feats is not None else globals_features[0]
         slot = ring[frame_index[0] % in_flight]
         frame_index[0] += 1
         with torch.cuda.stream(slot.stream):
@@ -347,7 +366,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     overlapped_clock = [round(slot.state.shader_clock_mhz(), 1) for slot in ring] if args.measure_clock else None
@@ -368,7 +387,7 @@ def main():
             frame(transfer=False)
         torch.cuda.synchronize()
         mine = time.perf_counter() - t1
-        t = torch.tensor([mine], dtype=torch.float64, device=device)
+        t = torch.tensor([mine], dtype=torch.float64, device=coll_device)
         everyone = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(everyone, t)
         per_rank_without = [float(x.item()) / args.steps * 1e3 for x in everyone]
@@ -487,7 +506,7 @@ def main():
     tag = tag or f"{args.metric}_{W}x{H}"
     roofline, valu, stages = roofline_blocks(program, cfg_values, tag, elapsed / args.steps, avg_launch_s, launches)
     if world > 1:   # every rank's trace launch: as timed in the overlapped region, and on its own
-        mine = torch.tensor([avg_launch_s * 1e3, stages.get("trace", 0.0), stages.get("prepass", 0.0)], dtype=torch.float64, device=device)
+        mine = torch.tensor([avg_launch_s * 1e3, stages.get("trace", 0.0), stages.get("prepass", 0.0)], dtype=torch.float64, device=coll_device)
         everyone = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine)
         extra["per_rank_trace_launch_ms"] = {"overlapped": [round(float(t[0]), 4) for t in everyone],
@@ -555,6 +574,34 @@ def main():
             pa = gra.Program(metric.argument_string(features=fa, static=True, cfg_values=cfg_values), local_rank)
             t = timed(camera, fa, cfg_values, pa, gra.MODE_FUSED)
             secondary["adaptive_sampling_on_threshold32_fused_substituted_fps"] = round(1 / t, 1)
+            # ... its stages (one frame at a time: lattice launch with the prepass cells in front of its tiles, decisions + the list of
+            # marked pixels + the launch over that list, texture pass), what it traces, and the same frames the way the headline is
+            # measured (frames in flight, prepass look-ahead): the throughput adaptive sampling exists for
+            stage_acc, traced = {}, 0
+            for _ in range(4):
+                state.render(pa, metric, camera, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), fa, cfg_values,
+                             gra.frame_options(mode=gra.MODE_FUSED, time_kernels=1, count_attempts=1), stream)
+                torch.cuda.synchronize()
+                for k, v in state.stage_ms().items():
+                    stage_acc.setdefault(k, []).append(v)
+            marked = np.empty(1, dtype=np.int32)
+            gra.check(gra.lib.gr_device_download(local_rank, marked.ctypes.data_as(ctypes.c_void_p), state.buffer(gra.BUF_RAYS_ADAPTIVE_COUNT), 4))
+            for _ in range(in_flight + 1):
+                frame(pa, cfg_values, feats=fa)
+            barrier()
+            tp = time.perf_counter()
+            for _ in range(12):
+                frame(pa, cfg_values, feats=fa)
+            barrier()
+            tp = (time.perf_counter() - tp) / 12
+            secondary["adaptive_sampling_on_threshold32_fused_substituted"] = {
+                "one_frame_at_a_time_ms": round(t * 1e3, 3), "pipelined_ms_per_frame": round(tp * 1e3, 3), "pipelined_Mpixels_per_s": round(W * H / tp / 1e6, 1),
+                "speed_up_over_every_pixel_pipelined": round(ms_per_step / (tp * 1e3), 3),
+                "stage_ms": {k: round(float(np.mean(v[1:])), 4) for k, v in stage_acc.items()},
+                "stage_note": "trace = the lattice launch (a quarter of the pixels; the prepass cells are its first tickets), adaptive = gr_adaptive_refine_list + gr_trace_pending",
+                "step_attempts_per_frame": int(state.attempts()), "marked_pixels": int(marked[0]), "marked_fraction": round(float(marked[0]) / (W * H), 4)}
+            for slot in ring:
+                slot.state.trace_log(reset=True)
             del pa
             # the other BASELINE.json configurations, one frame at a time on this one GPU (substituted programs, fused kernel)
             scripts_dir = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
@@ -608,6 +655,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)
+        if one_device:
+            line["rehearsal"] = f"GR_BENCH_ONE_DEVICE=1: {world} ranks on ONE GPU through the inter-process transport - a run of the N > 1 code path, not a measurement"
     if multi:
         if tiled is not None:
             tiled.close()

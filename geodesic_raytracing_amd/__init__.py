@@ -194,6 +194,7 @@ _SIGNATURES = {
     "gr_tiled_unique_id": (c_int, [c_void_p]),
     "gr_tiled_create": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "gr_tiled_create_local": (c_int, [c_int, ctypes.POINTER(c_int), c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_tiled_create_ipc": (c_int, [c_int, c_int, c_int, c_char_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "gr_tiled_destroy": (None, [c_void_p]),
     "gr_render_frame_tiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Camera), ctypes.POINTER(Features),
                                       ctypes.POINTER(c_float), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,

@@ -36,9 +36,43 @@ extern "C" int gr_internal_fail(int code, const char* msg);   // capi.cpp
         if (_rc != GR_OK) return _rc; \
     } while (0)
 
+// Small host -> device uploads (camera, $cfg values, features) go through PINNED memory of the library's own: hipMemcpyAsync from
+// pageable memory may read its source when the stream gets there, not when it is called - and the sources here are locals of
+// gr_render_frame and the caller's structs.  With the device to itself a frame's uploads ran at once and nothing showed; eight
+// processes sharing one GPU (the inter-process rehearsal of a split frame, tests/test_gpu_two_ranks.py) delayed the streams, and
+// a state's first frame read its features off a dead stack frame - one share of one frame rendered with garbage parameters.
+// A ring of 256-byte chunks; a chunk is reused 64 uploads later at the earliest, after the event that covers its last use.
+struct upload_ring {
+    static const int CHUNK = 256, CHUNKS = 64, SEGMENT = 16;
+    char* base = nullptr;
+    hipEvent_t used[CHUNKS / SEGMENT] = {};
+    bool recorded[CHUNKS / SEGMENT] = {};
+    unsigned long long next = 0;
+    int copy(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+        if (bytes > (size_t)CHUNK) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "upload_ring: too large");
+        if (!base) {
+            HIP_CHECK(hipHostMalloc((void**)&base, (size_t)CHUNK * CHUNKS, hipHostMallocDefault));
+            for (auto& e : used) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const int chunk = (int)(next % CHUNKS), segment = chunk / SEGMENT;
+        if (chunk % SEGMENT == 0 && recorded[segment]) HIP_CHECK(hipEventSynchronize(used[segment]));   // (64 uploads ago: long done)
+        memcpy(base + (size_t)chunk * CHUNK, src, bytes);
+        HIP_CHECK(hipMemcpyAsync(dst, base + (size_t)chunk * CHUNK, bytes, hipMemcpyHostToDevice, stream));
+        next++;
+        if (next % SEGMENT == 0) { HIP_CHECK(hipEventRecord(used[segment], stream)); recorded[segment] = true; }
+        return GR_OK;
+    }
+    void release() {
+        if (base) (void)hipHostFree(base);
+        for (auto& e : used) if (e) (void)hipEventDestroy(e);
+        base = nullptr;
+    }
+};
+
 struct gr_render_state {
     int device = 0;
     int width = 0, height = 0;
+    upload_ring uploads;
     // small buffers (render_state.hpp:150-170)
     void* camera_pos_cart = nullptr;
     void* camera_quat = nullptr;
@@ -158,6 +192,7 @@ static const int CFG_MAX = 64;
 // proper-time step per sample, the four tetrad legs parallel transported along it, all resident on the device.
 struct gr_geodesic_camera {
     int device = 0;
+    upload_ring uploads;
     int max_path_length = 0;
     void* path = nullptr;        // float4[max]
     void* velocity = nullptr;    // float4[max]
@@ -437,6 +472,10 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
             if (e == hipSuccess) e = hipEventCreateWithFlags(&slot.ready, hipEventDisableTiming);
         }
     }
+    // hipMemset returns before the device has done it, and the null stream it is ordered on does not hold back the non-blocking
+    // streams frames are submitted on: a state's first frame could be overtaken by its own zeroing (seen with eight processes
+    // sharing one GPU: a share of a state's first frame rendered from a zeroed camera and features)
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->main_mark, hipEventDisableTiming);
     for (int i = 0; i < GR_STAGE_COUNT && e == hipSuccess; i++) {
         e = hipEventCreate(&s->ev_start[i]);
@@ -453,6 +492,8 @@ int gr_render_state_create(int device, int width, int height, gr_render_state** 
 void gr_render_state_destroy(gr_render_state* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();   // (uploads from the pinned ring may still be queued)
+    s->uploads.release();
     std::vector<void*> ptrs = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
                                s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
                                s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->tile_order,
@@ -592,6 +633,7 @@ int gr_geodesic_camera_create(int device, int max_path_length, gr_geodesic_camer
     for (auto& t : g->tetrad) A(&t, 16);
     A(&g->interpolated_velocity, 16);
     A(&g->cfg, CFG_MAX * sizeof(float)); A(&g->dfg, sizeof(gr_features));
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // (the zeroing above must not overtake the first snapshot: see gr_render_state_create)
     if (e != hipSuccess) {
         gr_geodesic_camera_destroy(g);
         return gr_internal_fail(GR_ERROR_DEVICE, (std::string("geodesic camera allocation: ") + hipGetErrorString(e)).c_str());
@@ -603,6 +645,8 @@ int gr_geodesic_camera_create(int device, int max_path_length, gr_geodesic_camer
 void gr_geodesic_camera_destroy(gr_geodesic_camera* g) {
     if (!g) return;
     (void)hipSetDevice(g->device);
+    (void)hipDeviceSynchronize();
+    g->uploads.release();
     void* ptrs[] = {g->path, g->velocity, g->ds, g->count, g->transported[0], g->transported[1], g->transported[2], g->transported[3],
                     g->ray, g->ray_count, g->basis_speed, g->camera_generic, g->tetrad[0], g->tetrad[1], g->tetrad[2], g->tetrad[3],
                     g->interpolated_velocity, g->cfg, g->dfg};
@@ -631,10 +675,10 @@ int gr_geodesic_camera_snapshot(gr_geodesic_camera* g, gr_program* p, const gr_m
     if (speed4[0] * speed4[0] + speed4[1] * speed4[1] + speed4[2] * speed4[2] >= 1.f)
         return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "geodesic basis speed must be below c");
     void* cart = g->interpolated_velocity;   // scratch until the first interpolation
-    HIP_CHECK(hipMemcpyAsync(g->cfg, cfg.data(), cfg.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(g->dfg, &features, sizeof(features), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(g->basis_speed, speed4, 16, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(cart, camera->position, 16, hipMemcpyHostToDevice, stream));
+    GR_CHECK(g->uploads.copy(g->cfg, cfg.data(), cfg.size() * sizeof(float), stream));
+    GR_CHECK(g->uploads.copy(g->dfg, &features, sizeof(features), stream));
+    GR_CHECK(g->uploads.copy(g->basis_speed, speed4, 16, stream));
+    GR_CHECK(g->uploads.copy(cart, camera->position, 16, stream));
     HIP_CHECK(hipMemsetAsync(g->count, 0, 4, stream));
     HIP_CHECK(hipMemsetAsync(g->ray_count, 0, 4, stream));
     // main.cpp:2311-2329 (this frame's camera), then :2689-2758
@@ -774,11 +818,11 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         }
     }
     if (cfg_changed) {
-        HIP_CHECK(hipMemcpyAsync(s->cfg, cfg.data(), cfg.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        GR_CHECK(s->uploads.copy(s->cfg, cfg.data(), cfg.size() * sizeof(float), stream));
         s->host_cfg = cfg;
     }
     if (features_changed) {
-        HIP_CHECK(hipMemcpyAsync(s->dfg, &features, sizeof(features), hipMemcpyHostToDevice, stream));
+        GR_CHECK(s->uploads.copy(s->dfg, &features, sizeof(features), stream));
         s->host_features = features;
         s->features_valid = true;
     }
@@ -815,8 +859,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         }
     }
     if (!prefetched) {
-        HIP_CHECK(hipMemcpyAsync(s->camera_pos_cart, camera->position, 16, hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipMemcpyAsync(s->camera_quat, camera->quat, 16, hipMemcpyHostToDevice, stream));
+        GR_CHECK(s->uploads.copy(s->camera_pos_cart, camera->position, 16, stream));
+        GR_CHECK(s->uploads.copy(s->camera_quat, camera->quat, 16, stream));
     }
 
     for (int i = 0; i < GR_STAGE_COUNT; i++) s->stage_timed[i] = false;
@@ -1111,8 +1155,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             // have belonged to the previous frame (swapped out above): the stream first waits for everything the caller's
             // stream had queued before this frame's trace.
             HIP_CHECK(hipStreamWaitEvent(slot->stream, s->main_mark, 0));
-            HIP_CHECK(hipMemcpyAsync(slot->set.camera_pos_cart, r.camera->position, 16, hipMemcpyHostToDevice, slot->stream));
-            HIP_CHECK(hipMemcpyAsync(slot->set.camera_quat, r.camera->quat, 16, hipMemcpyHostToDevice, slot->stream));
+            GR_CHECK(s->uploads.copy(slot->set.camera_pos_cart, r.camera->position, 16, slot->stream));
+            GR_CHECK(s->uploads.copy(slot->set.camera_quat, r.camera->quat, 16, slot->stream));
             if (one_launch_setup) {
                 GR_CHECK(gr_camera_prepass(p, slot->stream, slot->set.camera_pos_cart, r.camera->flip, r.camera->basis_speed,
                                            slot->set.camera_pos_generic, slot->set.tetrad[0], slot->set.tetrad[1], slot->set.tetrad[2],

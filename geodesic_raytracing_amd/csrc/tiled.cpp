@@ -21,13 +21,21 @@
 // Frames in flight: a participant stages its compact rows in a ring of buffers, one per frame in flight (frame_slot below), so
 // frame k+1 - another stream, another share - never shades into memory frame k's sends still read.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/geodesic_hip.h"
@@ -116,6 +124,7 @@ struct gr_tiled {
     unsigned long long frames = 0;
     std::shared_ptr<peer_group> group;       // GR_TRANSPORT_PEER
     int root_device = 0;
+    std::shared_ptr<void> ipc;               // GR_TRANSPORT_IPC: the ipc_link (defined below; released with the participant)
 
     size_t staging_bytes() const { return (size_t)blocks_per_share * block_rows * width * 16; }
     ~gr_tiled() {
@@ -141,6 +150,119 @@ int rccl_send(void* user, const void* data, size_t floats, int peer, void* strea
 int rccl_recv(void* user, void* data, size_t floats, int peer, void* stream) {
     int rc = rccl()->Recv(data, floats, 7, peer, ((gr_tiled*)user)->comm, (hipStream_t)stream);
     return rc == 0 ? GR_OK : rccl_fail("ncclRecv", rc);
+}
+
+// ---- GR_TRANSPORT_IPC: the point-to-point calls of a split frame between PROCESSES THAT MAY SHARE A DEVICE -------------------------
+// RCCL refuses two ranks on one device, so on a one-GPU box the N-process path of gr_render_frame_tiled - one process per rank, a
+// group per frame, per block a send on the owner and the matching receive on the root, rotation, frames in flight on several
+// streams - could only be exercised with one participant.  This transport keeps the call pattern and the matching rule (the n-th
+// send of rank r to the root meets the root's n-th receive from r) and moves the data itself: a receive publishes where the block
+// goes (the inter-process handle of the allocation + offset) in a mailbox in POSIX shared memory, the send waits for that, maps the
+// handle and copies device to device on its stream; the sender's group end waits for its stream and marks the blocks delivered, the
+// root's group end waits for the marks.  Host-blocking where RCCL is asynchronous - it is a rehearsal stage, not a product path -
+// but every rank issues what it issues under RCCL, in the same order, across real process boundaries.
+struct ipc_slot {
+    std::atomic<unsigned long long> posted;   // sequence number + 1 of the receive this slot describes
+    hipIpcMemHandle_t handle;
+    unsigned long long allocation;            // which of the root's allocations the handle is of (it is exported once; senders map it once)
+    unsigned long long offset, bytes;
+    std::atomic<unsigned long long> done;     // sequence number + 1 once the block has arrived
+};
+const int IPC_DEPTH = 256;                    // receives of one peer that can be outstanding (a frame has blocks_per_share of them)
+struct ipc_shared {
+    std::atomic<unsigned int> magic;          // 0x47524950 once rank 0 has initialised the region
+    std::atomic<unsigned int> arrived;        // ranks that have opened it
+    unsigned int world, pad;
+    ipc_slot box[1];                          // [world][IPC_DEPTH]
+};
+struct ipc_link {
+    std::string name;
+    ipc_shared* shared = nullptr;
+    size_t bytes = 0;
+    int world = 0, rank = 0;
+    bool owner = false;
+    std::vector<unsigned long long> next;                       // per peer: how many sends (on a peer) / receives (on the root) were issued
+    std::vector<std::pair<int, unsigned long long>> in_group;   // (peer, sequence) of this group's calls
+    hipStream_t last_stream = nullptr;
+    std::map<unsigned long long, void*> mapped;                 // a sender: the root's allocations opened so far, by their number
+    std::map<void*, std::pair<hipIpcMemHandle_t, unsigned long long>> exported;   // the root: its allocations exported so far, by base address
+    ipc_slot& slot(int peer, unsigned long long seq) { return shared->box[(size_t)peer * IPC_DEPTH + seq % IPC_DEPTH]; }
+    ~ipc_link() {
+        for (auto& kv : mapped) (void)hipIpcCloseMemHandle(kv.second);
+        if (shared) munmap(shared, bytes);
+        if (owner) shm_unlink(name.c_str());
+    }
+};
+double ipc_timeout_seconds() { const char* e = getenv("GR_TILED_IPC_TIMEOUT"); double v = e ? atof(e) : 60.0; return v > 0 ? v : 60.0; }
+template <class F>
+bool ipc_wait(F ready) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = ipc_timeout_seconds();
+    for (int spins = 0; !ready(); spins++) {
+        if (spins > 1000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return false;
+    }
+    return true;
+}
+int ipc_group_begin(void* user) { ((ipc_link*)user)->in_group.clear(); return GR_OK; }
+int ipc_recv(void* user, void* data, size_t floats, int peer, void*) {
+    ipc_link* l = (ipc_link*)user;
+    if (peer < 0 || peer >= l->world) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "ipc transport: peer");
+    void* base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)data) != hipSuccess) {
+        (void)hipGetLastError();
+        return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: the receive buffer is not device memory of this process");
+    }
+    const unsigned long long seq = l->next[(size_t)peer]++;
+    ipc_slot& sl = l->slot(peer, seq);
+    if (seq >= (unsigned long long)IPC_DEPTH && !ipc_wait([&] { return sl.done.load() >= seq - IPC_DEPTH + 1; }))
+        return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: mailbox full (a peer stopped sending)");
+    auto ex = l->exported.find(base);
+    if (ex == l->exported.end()) {
+        hipIpcMemHandle_t h;
+        HIP_CHECK(hipIpcGetMemHandle(&h, base));
+        ex = l->exported.emplace(base, std::make_pair(h, (unsigned long long)l->exported.size() + 1)).first;
+    }
+    sl.handle = ex->second.first;
+    sl.allocation = ex->second.second;
+    sl.offset = (unsigned long long)((char*)data - (char*)base);
+    sl.bytes = (unsigned long long)floats * 4;
+    sl.posted.store(seq + 1);
+    l->in_group.emplace_back(peer, seq);
+    return GR_OK;
+}
+int ipc_send(void* user, const void* data, size_t floats, int peer, void* stream) {
+    ipc_link* l = (ipc_link*)user;
+    (void)peer;   // every send of a split frame goes to the root; the mailbox is the sender's own
+    const unsigned long long seq = l->next[(size_t)l->rank]++;
+    ipc_slot& sl = l->slot(l->rank, seq);
+    if (!ipc_wait([&] { return sl.posted.load() >= seq + 1; }))
+        return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: the root did not post the matching receive in time");
+    if (sl.bytes != (unsigned long long)floats * 4) return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: send and receive sizes differ");
+    auto it = l->mapped.find(sl.allocation);
+    if (it == l->mapped.end()) {
+        void* ptr = nullptr;
+        HIP_CHECK(hipIpcOpenMemHandle(&ptr, sl.handle, hipIpcMemLazyEnablePeerAccess));
+        it = l->mapped.emplace(sl.allocation, ptr).first;
+    }
+    HIP_CHECK(hipMemcpyAsync((char*)it->second + sl.offset, data, (size_t)sl.bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    l->last_stream = (hipStream_t)stream;
+    l->in_group.emplace_back(l->rank, seq);
+    return GR_OK;
+}
+int ipc_group_end(void* user) {
+    ipc_link* l = (ipc_link*)user;
+    if (l->rank != 0) {   // the copies of this group have left: tell the root
+        if (!l->in_group.empty()) HIP_CHECK(hipStreamSynchronize(l->last_stream));
+        for (auto& c : l->in_group) l->slot(c.first, c.second).done.store(c.second + 1);
+    } else {
+        for (auto& c : l->in_group)
+            if (!ipc_wait([&] { return l->slot(c.first, c.second).done.load() >= c.second + 1; }))
+                return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: a block did not arrive in time");
+    }
+    l->in_group.clear();
+    return GR_OK;
 }
 
 int ring_size() {
@@ -213,6 +335,51 @@ int gr_tiled_create_custom(int world, int rank, int device, const gr_transport* 
     int rc = tiled_common(t.get(), world, rank, device, width, height, block_rows);
     if (rc != GR_OK) return rc;
     t->link = *transport;
+    *out = t.release();
+    return GR_OK;
+}
+
+int gr_tiled_create_ipc(int world, int rank, int device, const char* session, int width, int height, int block_rows, gr_tiled** out) {
+    if (!out || !session || !session[0]) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    if (device < 0) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "device");
+    auto t = std::make_unique<gr_tiled>();
+    t->transport = GR_TRANSPORT_IPC;
+    int rc = tiled_common(t.get(), world, rank, device, width, height, block_rows);
+    if (rc != GR_OK) return rc;
+    if (world > 1) {
+        auto l = std::make_shared<ipc_link>();
+        l->name = std::string("/grtiled_") + session;
+        l->world = world; l->rank = rank;
+        l->next.assign((size_t)world, 0);
+        l->bytes = sizeof(ipc_shared) + sizeof(ipc_slot) * ((size_t)world * IPC_DEPTH);
+        int fd = -1;
+        if (rank == 0) {
+            shm_unlink(l->name.c_str());   // a stale region of an earlier run of the same session
+            fd = shm_open(l->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)l->bytes) != 0) { if (fd >= 0) close(fd); return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: cannot create the shared region"); }
+            l->owner = true;
+        } else if (!ipc_wait([&] { fd = shm_open(l->name.c_str(), O_RDWR, 0600); if (fd < 0) return false;
+                                   struct stat st; if (fstat(fd, &st) == 0 && (size_t)st.st_size >= l->bytes) return true; close(fd); fd = -1; return false; })) {
+            return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: rank 0's shared region did not appear in time");
+        }
+        void* mem = mmap(nullptr, l->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (mem == MAP_FAILED) return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: mmap failed");
+        l->shared = (ipc_shared*)mem;
+        if (rank == 0) {
+            memset(mem, 0, l->bytes);
+            l->shared->world = (unsigned int)world;
+            l->shared->magic.store(0x47524950u);
+        } else if (!ipc_wait([&] { return l->shared->magic.load() == 0x47524950u; }) || l->shared->world != (unsigned int)world) {
+            return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: the shared region is not rank 0's for this world");
+        }
+        // collective, like ncclCommInitRank: returns when every rank has arrived
+        l->shared->arrived.fetch_add(1);
+        if (!ipc_wait([&] { return l->shared->arrived.load() >= (unsigned int)world; }))
+            return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: not every rank arrived in time");
+        t->link = gr_transport{l.get(), ipc_group_begin, ipc_group_end, ipc_send, ipc_recv};
+        t->ipc = l;
+    }
     *out = t.release();
     return GR_OK;
 }

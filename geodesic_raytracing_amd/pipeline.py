@@ -170,6 +170,14 @@ class TiledFrame:
         return bytes(buf)
 
     @staticmethod
+    def ipc(world, rank, device, session, width, height, block_rows=48):
+        """one process per participant, participants may share a device (gr_tiled_create_ipc: RCCL's call pattern over inter-process
+        memory handles; collective)"""
+        handle = c_void_p()
+        check(lib.gr_tiled_create_ipc(world, rank, device, str(session).encode(), width, height, block_rows, ctypes.byref(handle)))
+        return TiledFrame(world, rank, device, None, width, height, block_rows, _handle=handle)
+
+    @staticmethod
     def local(devices, width, height, block_rows=48):
         n = len(devices)
         handles = (c_void_p * n)()

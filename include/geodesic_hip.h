@@ -641,8 +641,12 @@ int gr_device_count(int* count);
  * `rotation`: participant r renders share (r + rotation) % world - rotate with the frame number to even out shares of different
  * cost.  frame_on_root: float4[height * width] on participant 0's device; NULL elsewhere with RCCL, the same pointer for every
  * participant with peer copies. */
+/*   GR_TRANSPORT_IPC: one process per participant like RCCL, but the participants may share a device (RCCL refuses that): the same
+ *     group / send / receive calls in the same order, the blocks copied device to device through inter-process memory handles, the
+ *     matching done in a POSIX shared-memory mailbox named after `session`.  Host-blocking at the end of a group: a rehearsal stage
+ *     for boxes with fewer GPUs than ranks (tests, bench.py's dry run), not a product path.  gr_tiled_create_ipc is collective. */
 typedef struct gr_tiled gr_tiled;
-enum { GR_TRANSPORT_RCCL = 0, GR_TRANSPORT_PEER = 1, GR_TRANSPORT_CUSTOM = 2 };
+enum { GR_TRANSPORT_RCCL = 0, GR_TRANSPORT_PEER = 1, GR_TRANSPORT_CUSTOM = 2, GR_TRANSPORT_IPC = 3 };
 /* the point-to-point calls a split frame needs (the subset of RCCL it uses); every function returns GR_OK or an error code that
  * gr_render_frame_tiled / gr_tiled_exchange hand back.  group_begin / group_end may be NULL. */
 typedef struct gr_transport {
@@ -656,6 +660,7 @@ int gr_tiled_unique_id(void* id_out_128_bytes);
 int gr_tiled_create(int world, int rank, int device, const void* unique_id_128_bytes, int width, int height, int block_rows, gr_tiled** out);
 int gr_tiled_create_custom(int world, int rank, int device, const gr_transport* transport, int width, int height, int block_rows, gr_tiled** out);
 int gr_tiled_create_local(int count, const int* devices, int width, int height, int block_rows, gr_tiled** out_array);
+int gr_tiled_create_ipc(int world, int rank, int device, const char* session, int width, int height, int block_rows, gr_tiled** out);
 void gr_tiled_destroy(gr_tiled* t);
 int gr_render_frame_tiled(gr_tiled* t, gr_render_state* s, gr_program* p, const gr_metric* m, void* stream, const gr_camera* camera,
                           const gr_features* features, const float* cfg_values, int num_cfg_values,

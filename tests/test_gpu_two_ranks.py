@@ -126,8 +126,9 @@ def test_c_abi_tiled_frame_rccl_single_participant():
     assert len(uid) == 128 and any(uid)
 
 
+@pytest.mark.parametrize("world,block", [(3, 24), (8, 16)])
 @pytest.mark.parametrize("staging", [4, 1])
-def test_c_abi_tiled_frames_in_flight_on_several_streams(staging, monkeypatch):
+def test_c_abi_tiled_frames_in_flight_on_several_streams(staging, world, block, monkeypatch):
     """Six frames issued back to back - no synchronisation in between - by three participants, every frame on the next of three
     streams with the share rotating and a frame buffer of its own, as bench.py's ring of render states does.  Each participant
     stages a frame in its own ring slot (csrc/tiled.cpp frame_slot); with more frames than slots (and with a ring of one) a frame
@@ -136,7 +137,7 @@ def test_c_abi_tiled_frames_in_flight_on_several_streams(staging, monkeypatch):
     import geodesic_raytracing_amd as gra
     from geodesic_raytracing_amd.pipeline import DeviceBuffer
     monkeypatch.setenv("GR_TILED_STAGING", str(staging))
-    w, h, world, block, in_flight = 640, 360, 3, 24, 3
+    w, h, in_flight = 640, 360, 3
     metric = gra.Metric("kerr_boyer")
     prog = gra.Program(metric.argument_string(), 0)
     feats = metric.features(adaptive_sampling=0)
@@ -177,3 +178,69 @@ def test_c_abi_tiled_frames_in_flight_on_several_streams(staging, monkeypatch):
     for row in streams:
         for s in row:
             gra.check(gra.lib.gr_stream_destroy(s))
+
+
+def _ipc_worker(rank, world, block, session, out_dir):
+    """one rank of a frame split over `world` PROCESSES that share the test box's one GPU (gr_tiled_create_ipc)"""
+    import geodesic_raytracing_amd as gra
+    from geodesic_raytracing_amd import check, lib
+    from geodesic_raytracing_amd.pipeline import DeviceBuffer
+    w, h, frames, in_flight = 640, 360, 6, 3
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    feats = metric.features(adaptive_sampling=0)
+    cfg = metric.cfg_values(a=0.45)
+    packed, levels = gra.pack_background(gra.synthetic_background(512, 256))
+    bg = DeviceBuffer.from_numpy(0, packed)
+    cams = [gra.default_camera([0, 0.1 * k, -4 - 0.3 * k, 0.05 * k]) for k in range(frames)]
+    part = gra.TiledFrame.ipc(world, rank, 0, session, w, h, block)          # collective: returns when every rank has arrived
+    states = [gra.RenderState(w, h, 0) for _ in range(in_flight)]
+    streams = []
+    for _ in range(in_flight):
+        sp = ctypes.c_void_p()
+        check(lib.gr_stream_create(0, 0, ctypes.byref(sp)))
+        streams.append(sp)
+    outs = [DeviceBuffer(0, w * h * 16) for _ in range(in_flight)] if rank == 0 else [None] * in_flight
+    got = []
+    for k in range(frames):                                                  # the ring of bench.py: frame k on stream k % 3, share rotating
+        j = k % in_flight
+        if rank == 0 and k >= in_flight:                                     # the frame this buffer held has to be read before it is reused
+            check(lib.gr_stream_synchronize(streams[j]))
+            got.append(outs[j].to_numpy(np.float32, (h, w, 4)))
+        o = gra.frame_options(mode=gra.MODE_FUSED)
+        if k + in_flight < frames:
+            o.next_camera, o.next_strip_rank = ctypes.pointer(cams[k + in_flight]), part.share(k + in_flight)
+        part.render(states[j], prog, metric, cams[k], outs[j].ptr if rank == 0 else None, (bg.ptr, 512, 256, levels), feats, cfg, o, streams[j], rotation=k)
+    for sp in streams:
+        check(lib.gr_stream_synchronize(sp))
+    if rank == 0:
+        for k in range(max(0, frames - in_flight), frames):
+            got.append(outs[k % in_flight].to_numpy(np.float32, (h, w, 4)))
+        single, full = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+        for k in range(frames):
+            single.render(prog, metric, cams[k], full.ptr, (bg.ptr, 512, 256, levels), feats, cfg, gra.frame_options(mode=gra.MODE_FUSED))
+            single.synchronize()
+            want = full.to_numpy(np.float32, (h, w, 4))
+            if not np.array_equal(got[k], want):
+                rows = np.flatnonzero((got[k] != want).any(axis=(1, 2)))
+                blocks = sorted(set((rows // block).tolist()))
+                # whose blocks they were in this frame: share s = (rank + k) % world renders the blocks b with b % world == s
+                raise AssertionError(f"world {world} frame {k}: {len(rows)} rows differ, blocks {blocks}, rendered by ranks "
+                                     f"{sorted(set((b % world - k) % world for b in blocks))}")
+        np.save(os.path.join(out_dir, f"ipc_ok_{world}.npy"), np.array([frames]))
+    part.close()
+
+
+@pytest.mark.parametrize("world,block", [(2, 16), (3, 24), (8, 16)])
+def test_c_abi_tiled_frames_across_processes_that_share_the_gpu(world, block, tmp_path):
+    """gr_render_frame_tiled with one PROCESS per rank, as under RCCL - which refuses two ranks on one device, so its transport had run
+    with one participant only.  The inter-process transport (gr_tiled_create_ipc) keeps RCCL's call pattern - a group per frame, a
+    send per block on the owner, the matching receives on rank 0 in issue order - and moves the blocks through inter-process memory
+    handles: worlds of 2, 3 and 8 processes on the test box's one GPU, six frames on three streams with rotating shares and the
+    look-ahead bench.py uses, rank 0's frames bit for bit the single-GPU frames.  (Its first runs found a race that one process alone
+    never showed: gr_render_state_create zeroed its buffers with hipMemset, which returns before the device has done it and is not
+    ordered with the non-blocking streams frames run on - with eight processes on the GPU a state's first frame was overtaken by its
+    own zeroing and one share of it came out rendered from a zeroed camera.)"""
+    session = f"t{os.getpid()}w{world}"
+    mp.spawn(_ipc_worker, args=(world, block, session, str(tmp_path)), nprocs=world, join=True)
+    assert os.path.exists(tmp_path / f"ipc_ok_{world}.npy")
