@@ -43,14 +43,47 @@ class Camera(ctypes.Structure):
     _fields_ = [("position", c_float * 4), ("quat", c_float * 4), ("basis_speed", c_float * 3), ("flip", c_float)]
 
 
+class FrameTuning(ctypes.Structure):
+    """gr_frame_tuning (include/geodesic_hip_internal.h): which fused kernel, schedule and launch size gr_render_frame takes"""
+    _fields_ = [("ray_compaction", c_int), ("rays_per_lane", c_int), ("fused_shading", c_int), ("inline_prepass", c_int),
+                ("trace_waves_per_simd", c_int), ("tile_history", c_int)]
+
+
 class FrameOptions(ctypes.Structure):
+    """gr_frame_options.  The tuning knobs (gr_frame_tuning, behind the `tuning` pointer in C) read and write like fields of this
+    object: setting one attaches a FrameTuning of the library's defaults, owned by the options object."""
     _fields_ = [("mode", c_int), ("tiled", c_int), ("use_prepass", c_int), ("max_probes", c_int), ("strip_rank", c_int),
                 ("strip_count", c_int), ("block_rows", c_int), ("compact_out", c_int), ("time_kernels", c_int),
-                ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera)), ("geodesic", c_void_p),
-                ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("parallel_transport_observer", c_int),
-                ("ray_compaction", c_int), ("next_camera2", ctypes.POINTER(Camera)), ("next_geodesic_time2", c_float),
-                ("next_strip_rank", c_int), ("next_strip_rank2", c_int), ("rays_per_lane", c_int), ("fused_shading", c_int),
-                ("inline_prepass", c_int), ("trace_waves_per_simd", c_int), ("tile_history", c_int)]
+                ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera)), ("next_camera2", ctypes.POINTER(Camera)),
+                ("next_strip_rank", c_int), ("next_strip_rank2", c_int), ("geodesic", c_void_p),
+                ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float),
+                ("parallel_transport_observer", c_int), ("tuning", ctypes.POINTER(FrameTuning))]
+
+    def _tuning(self):
+        t = self.__dict__.get("_owned_tuning")
+        if t is None:
+            t = FrameTuning()
+            lib.gr_frame_tuning_default(ctypes.byref(t))
+            self.__dict__["_owned_tuning"] = t
+            self.tuning = ctypes.pointer(t)
+        return t
+
+
+def _tuning_property(name):
+    def get(self):
+        t = self.__dict__.get("_owned_tuning")
+        if t is None:
+            t = FrameTuning()
+            lib.gr_frame_tuning_default(ctypes.byref(t))
+        return getattr(t, name)
+
+    def put(self, value):
+        setattr(self._tuning(), name, value)
+    return property(get, put)
+
+
+for _name, _ in FrameTuning._fields_:
+    setattr(FrameOptions, _name, _tuning_property(_name))
 
 
 class TraceShading(ctypes.Structure):
@@ -81,7 +114,7 @@ STAGE_NAMES = ["camera", "prepass", "init", "trace", "render_data", "adaptive", 
 (BUF_RAYS_IN, BUF_RAYS_COUNT, BUF_RENDER_DATA, BUF_TERMINATION, BUF_CAMERA_GENERIC, BUF_TETRAD0, BUF_TETRAD1, BUF_TETRAD2,
  BUF_TETRAD3, BUF_RAYS_ADAPTIVE, BUF_RAYS_ADAPTIVE_COUNT, BUF_CFG, BUF_DFG, BUF_CAMERA_QUAT) = range(14)
 
-# every symbol include/geodesic_hip.h declares, with its signature
+# every symbol include/geodesic_hip.h and include/geodesic_hip_internal.h declare, with its signature
 _SIGNATURES = {
     "gr_last_error": (c_char_p, []),
     "gr_features_default": (None, [ctypes.POINTER(Features)]),
@@ -171,6 +204,7 @@ _SIGNATURES = {
     "gr_handle_interpolating_geodesic": (c_int, [c_void_p] * 14 + [c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gr_camera_default": (None, [ctypes.POINTER(Camera)]),
     "gr_frame_options_default": (None, [ctypes.POINTER(FrameOptions)]),
+    "gr_frame_tuning_default": (None, [ctypes.POINTER(FrameTuning)]),
     "gr_render_state_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "gr_render_state_destroy": (None, [c_void_p]),
     "gr_render_frame": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Camera), ctypes.POINTER(Features),

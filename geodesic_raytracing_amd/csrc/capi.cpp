@@ -4,7 +4,7 @@
 // Reference counterparts: metric_manager.hpp:19-219 (program build + cache), main.cpp:139-205 and
 // 2244-2526 (the launches).  HIP is used directly (module API); there is no fallback of any kind:
 // without libamdhip64/hiprtc or without a device the calls fail with GR_ERROR_DEVICE/COMPILE.
-#include "../../include/geodesic_hip.h"
+#include "../../include/geodesic_hip_internal.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>

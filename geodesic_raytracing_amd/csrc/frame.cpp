@@ -20,7 +20,7 @@
 #include <vector>
 #include <mutex>
 
-#include "../../include/geodesic_hip.h"
+#include "../../include/geodesic_hip_internal.h"
 
 extern "C" int gr_internal_fail(int code, const char* msg);   // capi.cpp
 
@@ -349,21 +349,26 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->compact_out = 0;
     o->time_kernels = 0;
     o->count_attempts = 0;
-    o->trace_waves_per_simd = 0;
-    o->fused_shading = -1;
-    o->inline_prepass = -1;
-    o->tile_history = -1;
     o->next_camera = nullptr;
+    o->next_camera2 = nullptr;
+    o->next_strip_rank = -1;
+    o->next_strip_rank2 = -1;
     o->geodesic = nullptr;
     o->geodesic_time = 0;
     o->next_geodesic_time = 0;
-    o->parallel_transport_observer = 1;   // main.cpp:1259
-    o->ray_compaction = -1;
-    o->next_strip_rank = -1;
-    o->next_strip_rank2 = -1;
-    o->next_camera2 = nullptr;
     o->next_geodesic_time2 = 0;
-    o->rays_per_lane = 0;
+    o->parallel_transport_observer = 1;   // main.cpp:1259
+    o->tuning = nullptr;
+}
+
+void gr_frame_tuning_default(gr_frame_tuning* t) {
+    if (!t) return;
+    t->ray_compaction = -1;
+    t->rays_per_lane = 0;
+    t->fused_shading = -1;
+    t->inline_prepass = -1;
+    t->trace_waves_per_simd = 0;
+    t->tile_history = -1;
 }
 
 int gr_device_count(int* count) {
@@ -748,6 +753,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
     gr_frame_options opt;
     gr_frame_options_default(&opt);
     if (opt_in) opt = *opt_in;
+    gr_frame_tuning tune;   // which fused kernel, schedule and launch size (geodesic_hip_internal.h; NULL = the defaults)
+    gr_frame_tuning_default(&tune);
+    if (opt.tuning) tune = *opt.tuning;
     gr_metric_info info;
     GR_CHECK(gr_metric_get_info(m, &info));
 
@@ -926,10 +934,10 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // Not frames of more than 32 tiles per wave slot (8K Alcubierre: 72 short tiles of much the same cost; recording and sorting
         // them measured +3 % on the frame, with nothing to gain).
         const long long tile_words = gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) / 8;
-        const bool history_wanted = (opt.tile_history < 0 ? history_default != 0 && strip_count == 1 && tile_words <= 32 * gr_trace_fused_wave_slots(p)
-                                                          : opt.tile_history != 0) && !adaptive &&
+        const bool history_wanted = (tune.tile_history < 0 ? history_default != 0 && strip_count == 1 && tile_words <= 32 * gr_trace_fused_wave_slots(p)
+                                                          : tune.tile_history != 0) && !adaptive &&
                                     (size_t)gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
-        const bool device_busy = history_wanted && opt.tile_history < 0 && earlier_frame_still_running(s->device, stream);
+        const bool device_busy = history_wanted && tune.tile_history < 0 && earlier_frame_still_running(s->device, stream);
         const bool tile_order_enabled = !history_wanted && (tile_order_mode == 1 || (tile_order_mode == -1 && strip_count > 1));
         const size_t cells = use_prepass ? (size_t)prepass_width * prepass_height : 0;
         // (a frame whose prepass rides in its trace launch - below - has no costs to order by; the frames it announces still do)
@@ -941,21 +949,21 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // library default: no compaction (the benchmark workloads keep > 95 % of their lanes busy without it); experiments can
         // switch it on for every frame with GR_TRACE_COMPACT=<keep_lanes>
         static const int default_compaction = [] { const char* e = getenv("GR_TRACE_COMPACT"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
-        int keep_lanes = opt.ray_compaction < 0 ? default_compaction : opt.ray_compaction;
+        int keep_lanes = tune.ray_compaction < 0 ? default_compaction : tune.ray_compaction;
         // What does not combine is refused, not silently dropped: ray compaction and the two-rays-per-lane kernel trace every
         // pixel (no lattice / pending-only form), in-tile shading needs every pixel's record in its own tile's wave.
-        if (adaptive && opt.ray_compaction > 0)
+        if (adaptive && tune.ray_compaction > 0)
             return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "ray_compaction > 0 with adaptive sampling: gr_trace_compact traces every pixel (switch one of them off)");
-        if (adaptive && opt.rays_per_lane == 2)
+        if (adaptive && tune.rays_per_lane == 2)
             return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2 with adaptive sampling: gr_trace_pair traces every pixel (switch one of them off)");
-        if (opt.fused_shading == 1 && (adaptive || keep_lanes > 0 || opt.rays_per_lane == 2))
+        if (tune.fused_shading == 1 && (adaptive || keep_lanes > 0 || tune.rays_per_lane == 2))
             return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "fused_shading = 1 needs one ray per lane, no compaction and no adaptive sampling");
         if (adaptive) keep_lanes = 0;   // GR_TRACE_COMPACT (an experiment switch for every frame) does not apply to adaptive frames
         // two rays per lane (gr_trace_pair) where the program has that kernel, unless told otherwise
         static const int default_rays_per_lane = [] { const char* e = getenv("GR_TRACE_RAYS_PER_LANE"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2) ? v : GR_DEFAULT_RAYS_PER_LANE; }();
-        int rays_per_lane = opt.rays_per_lane == 1 || opt.rays_per_lane == 2 ? opt.rays_per_lane : default_rays_per_lane;
+        int rays_per_lane = tune.rays_per_lane == 1 || tune.rays_per_lane == 2 ? tune.rays_per_lane : default_rays_per_lane;
         if (rays_per_lane == 2 && !gr_program_has_trace_pair(p)) {
-            if (opt.rays_per_lane == 2) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2: this program has no gr_trace_pair kernel");
+            if (tune.rays_per_lane == 2) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "rays_per_lane = 2: this program has no gr_trace_pair kernel");
             rays_per_lane = 1;
         }
         // The prepass inside the trace launch (gr_trace_fused_args.inline_prepass): for a frame whose prepass was not computed
@@ -967,7 +975,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // measurement - one rank of 8 / of 4, one frame at a time, 2 wave slots per SIMD: 2.41 / 3.42 ms against 2.20 / 2.80 with the
         // prepass in front and the tiles ordered by its costs (tools/strip_probe.py, STRIP_PROBE_DEPTH=0): a share is few tiles, and
         // which of them start first matters more than the prepass's latency.
-        const bool inline_wanted = opt.inline_prepass < 0 ? (inline_default != 0 && strip_count == 1 && !order_capable) : opt.inline_prepass != 0;
+        const bool inline_wanted = tune.inline_prepass < 0 ? (inline_default != 0 && strip_count == 1 && !order_capable) : tune.inline_prepass != 0;
         // (an adaptively sampled whole frame: the cells ride in front of the lattice launch's tiles)
         const bool inline_prepass = inline_wanted && !prefetched && one_launch_setup && use_prepass && (!adaptive || strip_count == 1) && keep_lanes == 0 &&
                                     rays_per_lane == 1 && prepass_width != width && prepass_height != height;
@@ -1055,7 +1063,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.termination_buffer = term; a.prepass_width = pw; a.prepass_height = ph;
                 a.e0 = s->tetrad[0]; a.e1 = s->tetrad[1]; a.e2 = s->tetrad[2]; a.e3 = s->tetrad[3]; a.cfg = s->cfg; a.dfg = s->dfg;
                 a.attempt_counter = attempts;
-                a.waves_per_simd = opt.trace_waves_per_simd;
+                a.waves_per_simd = tune.trace_waves_per_simd;
                 a.lattice = 2;
                 a.inline_prepass = inline_prepass ? 1 : 0;
                 if (!s->lattice_rays) HIP_CHECK(hipMalloc(&s->lattice_rays, gr_lattice_rays_bytes(width, height)));
@@ -1073,7 +1081,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                                      strip_count, s->lattice_rays, s->cfg, s->pending_list));
                     GR_CHECK(gr_trace_pending(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, s->tetrad[0],
                                               s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, s->pending_list,
-                                              opt.trace_waves_per_simd));
+                                              tune.trace_waves_per_simd));
                 } else {
                     GR_CHECK(gr_adaptive_refine_strips(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows,
                                                        strip_rank, strip_count, s->lattice_rays, s->cfg));
@@ -1123,11 +1131,11 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                     s->tile_cost_anchor[0] = anchor[0]; s->tile_cost_anchor[1] = anchor[1];
                     s->tile_cost_camera = *camera;
                 }
-                a.waves_per_simd = opt.trace_waves_per_simd;
+                a.waves_per_simd = tune.trace_waves_per_simd;
                 a.inline_prepass = inline_prepass ? 1 : 0;
                 // the trace shades the pixels whose filter neighbours are in their own tile; gr_render_seams below does the rest
-                shade_in_trace = out && opt.fused_shading == 1 && width % 8 == 0 && height % 8 == 0 && gr_program_has_tile_shading(p);
-                if (opt.fused_shading == 1 && !shade_in_trace && out)   // default: off, on measurement
+                shade_in_trace = out && tune.fused_shading == 1 && width % 8 == 0 && height % 8 == 0 && gr_program_has_tile_shading(p);
+                if (tune.fused_shading == 1 && !shade_in_trace && out)   // default: off, on measurement
                     return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT,
                                             "fused_shading = 1: needs a program built with -DGR_TILE_SHADING and width, height multiples of 8");
                 if (shade_in_trace) {

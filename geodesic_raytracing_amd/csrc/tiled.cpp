@@ -38,7 +38,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/geodesic_hip.h"
+#include "../../include/geodesic_hip_internal.h"
 
 extern "C" int gr_internal_fail(int code, const char* msg);
 struct gr_tiled;
