@@ -35,12 +35,14 @@ struct sky_sampler {
     // between the two mips around `lod`
     __device__ float4 trilinear(float2 uv, float lod) const {
         lod = __builtin_fmaxf(lod, 0.f);
-        uv.x = fmodf(uv.x, 1.f);
-        uv.y = fmodf(uv.y, 1.f);
+        // fmod(x, 1) is x - trunc(x), and a quotient by 2^n a product with 2^-n: the same values as the reference's fmod / exp2 /
+        // divide without the library routines (two probes a pixel at the least, eight at the most, each through here)
+        uv.x = uv.x - __builtin_truncf(uv.x);
+        uv.y = uv.y - __builtin_truncf(uv.y);
         const float fine = floorf(lod), coarse = ceilf(lod);
-        const float fine_scale = exp2f(fine), coarse_scale = exp2f(coarse);
-        const float4 a = bilinear(uv.x / fine_scale, uv.y / fine_scale, fine);
-        const float4 b = bilinear(uv.x / coarse_scale, uv.y / coarse_scale, coarse);
+        const float fine_scale = __builtin_ldexpf(1.f, -(int)fine), coarse_scale = __builtin_ldexpf(1.f, -(int)coarse);
+        const float4 a = bilinear(uv.x * fine_scale, uv.y * fine_scale, fine);
+        const float4 b = bilinear(uv.x * coarse_scale, uv.y * coarse_scale, coarse);
         return a + (b - a) * (lod - fine);
     }
 };
@@ -48,7 +50,8 @@ struct sky_sampler {
 // Footprint of a pixel in texels: the ellipse  A u^2 + B u v + C v^2 = 1  spanned by the texture-space images of the pixel's two
 // edges, each padded by one texel (the "+ 1" that keeps a vanishing footprint from collapsing), reduced to its axes.
 struct sky_footprint {
-    float long_radius, short_radius, angle;
+    float long_radius, short_radius;
+    float cos_angle, sin_angle;   // of the reference's angle = atan2(b, (a - c) / 2): the direction the probes are spaced along
 };
 __device__ __forceinline__ sky_footprint pixel_footprint(float2 along_x, float2 along_y) {
     const float raw_a = along_x.y * along_x.y + along_y.y * along_y.y + 1;
@@ -60,7 +63,12 @@ __device__ __forceinline__ sky_footprint pixel_footprint(float2 along_x, float2 
     sky_footprint f;
     f.long_radius = 1.f / __builtin_sqrtf((a + c - spread) / 2);
     f.short_radius = 1.f / __builtin_sqrtf((a + c + spread) / 2);
-    f.angle = atan2f(b, (a - c) / 2);
+    {   // cos and sin of atan2(y, x) are x / hypot and y / hypot: no angle is ever needed (atan2f + cosf + sinf were a tenth of the pass)
+        const float x = (a - c) / 2, y = b;
+        const float hyp = __builtin_sqrtf(x * x + y * y);
+        f.cos_angle = hyp > 0.f ? x / hyp : 1.f;   // atan2(0, 0) = 0
+        f.sin_angle = hyp > 0.f ? y / hyp : 0.f;
+    }
     f.long_radius = __builtin_fmaxf(f.long_radius, 1.f);
     f.short_radius = __builtin_fmaxf(f.short_radius, 1.f);
     f.long_radius = __builtin_fmaxf(f.long_radius, f.short_radius);
@@ -75,7 +83,7 @@ __device__ float4 integrate_footprint(const sky_sampler& sky, float2 centre, sky
     int probes = (int)floorf(wanted + 0.5f);
     probes = probes < most_probes ? probes : most_probes;
     if (probes < wanted) f.short_radius = 2 * f.long_radius / (probes + 1);
-    float lod = log2f(f.short_radius);
+    float lod = __builtin_amdgcn_logf(f.short_radius);   // v_log_f32 is log2; short_radius >= 1
     const int coarsest = sky.levels - 1;
     if (lod > coarsest) { lod = coarsest; probes = 1; }
     if (probes <= 1) {
@@ -83,7 +91,7 @@ __device__ float4 integrate_footprint(const sky_sampler& sky, float2 centre, sky
         return sky.trilinear(centre, lod);
     }
     const float span = 2 * (f.long_radius - f.short_radius);
-    const float step_u = cosf(f.angle) * span / (probes - 1), step_v = sinf(f.angle) * span / (probes - 1);
+    const float step_u = f.cos_angle * span / (probes - 1), step_v = f.sin_angle * span / (probes - 1);
     const float step_u_norm = step_u / sky.width, step_v_norm = step_v / sky.height;
     const float step2 = (step_u * step_u + step_v * step_v) / (f.long_radius * f.long_radius);
     // probe k sits at (2k - (probes - 1)) half steps from the centre; an even count starts one half step further out on the
@@ -92,7 +100,7 @@ __device__ float4 integrate_footprint(const sky_sampler& sky, float2 centre, sky
     float4 sum = f4(0, 0, 0, 0);
     float weight_sum = 0;
     for (int k = 0; k < probes; k++, half_steps += 2) {
-        const float weight = expf(-2.f * ((half_steps * half_steps / 4.f) * step2));
+        const float weight = __builtin_amdgcn_exp2f(-2.88539008177792681472f * ((half_steps * half_steps / 4.f) * step2));   // exp(-2 d^2) on v_exp_f32
         const float offset = half_steps / 2.f;
         sum = sum + weight * sky.trilinear(make_float2(centre.x + offset * step_u_norm, centre.y + offset * step_v_norm), lod);
         weight_sum += weight;
@@ -101,8 +109,11 @@ __device__ float4 integrate_footprint(const sky_sampler& sky, float2 centre, sky
 }
 
 // colour (cl.cl:326-350, 5366-5413)
-__device__ __forceinline__ float srgb_to_linear(float v) { return v < 0.04045f ? v / 12.92f : powf((v + 0.055f) / 1.055f, 2.4f); }
-__device__ __forceinline__ float linear_to_srgb(float v) { return v <= 0.0031308f ? v * 12.92f : 1.055f * powf(v, 1.0f / 2.4f) - 0.055f; }
+// x^y for x > 0 on v_log_f32 / v_exp_f32: the colour curves take powers of values in (0, 1] with |log2 x| < 9, where the error of this
+// form is below 2e-7 of the result (the library's pow: ~100 instructions, three to six of them a pixel)
+__device__ __forceinline__ float colour_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+__device__ __forceinline__ float srgb_to_linear(float v) { return v < 0.04045f ? v / 12.92f : colour_pow((v + 0.055f) / 1.055f, 2.4f); }
+__device__ __forceinline__ float linear_to_srgb(float v) { return v <= 0.0031308f ? v * 12.92f : 1.055f * colour_pow(v, 1.0f / 2.4f) - 0.055f; }
 __device__ __forceinline__ float3 srgb_to_linear(float3 c) { return f3(srgb_to_linear(c.x), srgb_to_linear(c.y), srgb_to_linear(c.z)); }
 __device__ __forceinline__ float3 linear_to_srgb(float3 c) { return f3(linear_to_srgb(c.x), linear_to_srgb(c.y), linear_to_srgb(c.z)); }
 __device__ __forceinline__ float luminous_energy(float3 v) { return v.x * 0.2125f + v.y * 0.7154f + v.z * 0.0721f; }
@@ -116,7 +127,9 @@ __device__ float3 apply_redshift(float3 linear, float z, dfg_t dfg) {
     const float reference_wavelength = 555 / light_speed;
     const float seen_wavelength = reference_wavelength / (z + 1);
     const float luminance = 0.2126f * linear.x + 0.7152f * linear.y + 0.0722f * linear.z;
-    const float shifted_luminance = clampf(powf(seen_wavelength, 3.f) * luminance / powf(reference_wavelength, 3.f), 0.f, 1.f);
+    // (seen / reference)^3 as the reference writes it, pow(seen, 3) * luminance / pow(reference, 3), with the cubes multiplied out
+    const float shifted_luminance = clampf((seen_wavelength * seen_wavelength * seen_wavelength) * luminance /
+                                           (reference_wavelength * reference_wavelength * reference_wavelength), 0.f, 1.f);
     if ((double)luminance > 0.00001) linear = saturate3((shifted_luminance / luminance) * linear);
     const float energy = luminous_energy(linear);
     const float3 pure_red = f3(1 / 0.2125f, 0.f, 0.f), pure_green = f3(0, (float)(1 / 0.7154), 0.f), pure_blue = f3(0.f, 0.f, (float)(1 / 0.0721));
@@ -140,7 +153,12 @@ __device__ __forceinline__ float wrapped_difference(float a, float b) {
     const float angle_a = (float)((double)a * (2 * GR_PI / (double)1.f));
     const float angle_b = (float)((double)b * (2 * GR_PI / (double)1.f));
     const float d = angle_b - angle_a;
-    return (float)((double)(1.f * atan2f(sinf(d), cosf(d))) / (2 * GR_PI));
+    // atan2(sin d, cos d) is d brought into (-pi, pi]: for the differences between neighbouring pixels that is d itself, across the
+    // texture's seam one turn is taken off.  (The library's sin, cos and atan2 here - four differences a pixel - were 400 of the
+    // pass's ~1 000 vector instructions per pixel.)
+    const float two_pi = 6.283185307179586f;
+    const float wrapped = __builtin_fabsf(d) <= 3.14159274101257324f ? d : d - two_pi * __builtin_rintf(d / two_pi);
+    return (float)((double)(1.f * wrapped) / (2 * GR_PI));
 }
 
 // One pixel: `self` is its record, `beside` / `below` the texture coordinates of its horizontal / vertical neighbour - the next
