@@ -178,9 +178,10 @@ _SIGNATURES = {
     "gr_adaptive_refine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gr_pending_list_bytes": (c_size_t, [c_int, c_int]),
     "gr_lattice_rays_bytes": (c_size_t, [c_int, c_int]),
-    "gr_adaptive_refine_list": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gr_adaptive_refine_list": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "gr_trace_pending": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_int]),
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gr_adaptive_refine_strips": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gr_camera_prepass": (c_int, [c_void_p, c_void_p, c_void_p, c_float, ctypes.POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),

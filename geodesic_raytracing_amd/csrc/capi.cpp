@@ -1238,13 +1238,15 @@ int gr_adaptive_refine_strips(gr_program* p, void* stream, void* rdata, void* pe
     if (lattice_rays && !cfg) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_adaptive_refine: lattice_rays needs the metric's cfg");
     void* pending_list = nullptr;
     int phase = 0;
-    void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_rays, &cfg, &pending_list, &phase};
+    const void* block_cost_before = nullptr;
+    void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_rays, &cfg, &pending_list, &phase,
+                    &block_cost_before};
     return launch(p, K_ADAPTIVE_REFINE, stream, (unsigned)((width / 2 + 15) / 16), (unsigned)((height / 2 + 15) / 16), 16, 16, args);
 }
 
 size_t gr_pending_list_bytes(int width, int height) {
     if (width < 2 || height < 2) return 0;
-    return (32 + 3 * (size_t)(width / 2) * (height / 2)) * sizeof(unsigned int);
+    return (128 + 3 * (size_t)(width / 2) * (height / 2)) * sizeof(unsigned int);   // 64 class counts, 64 cursors, the pixels
 }
 
 size_t gr_lattice_rays_bytes(int width, int height) {
@@ -1253,16 +1255,18 @@ size_t gr_lattice_rays_bytes(int width, int height) {
 }
 
 int gr_adaptive_refine_list(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg, int block_rows,
-                            int strip_rank, int strip_count, const void* lattice_rays, const void* cfg, void* pending_list) {
+                            int strip_rank, int strip_count, const void* lattice_rays, const void* cfg, void* pending_list,
+                            const void* block_cost_before) {
     if (!p || !rdata || !pending_list) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_adaptive_refine_list: null argument");
     if (strip_count <= 1) { strip_count = 1; strip_rank = 0; block_rows = ((height + 7) / 8) * 8; }
     if (block_rows <= 0 || block_rows % 8 != 0 || strip_rank < 0 || strip_rank >= strip_count)
         return fail(GR_ERROR_INVALID_ARGUMENT, "bad strip description");
     if (lattice_rays && !cfg) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_adaptive_refine_list: lattice_rays needs the metric's cfg");
     HIP_CHECK(hipSetDevice(p->device));
-    HIP_CHECK(hipMemsetAsync(pending_list, 0, 128, (hipStream_t)stream));
+    HIP_CHECK(hipMemsetAsync(pending_list, 0, 128 * sizeof(unsigned int), (hipStream_t)stream));
     for (int phase = 0; phase < 2; phase++) {   // decide, mark and count by cost class; then deal every marked pixel its place
-        void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_rays, &cfg, &pending_list, &phase};
+        void* args[] = {&rdata, &pending_count, &width, &height, &dfg, &block_rows, &strip_rank, &strip_count, &lattice_rays, &cfg, &pending_list, &phase,
+                        &block_cost_before};
         int rc = launch(p, K_ADAPTIVE_REFINE, stream, (unsigned)((width / 2 + 15) / 16), (unsigned)((height / 2 + 15) / 16), 16, 16, args);
         if (rc != GR_OK) return rc;
     }
@@ -1271,7 +1275,7 @@ int gr_adaptive_refine_list(gr_program* p, void* stream, void* rdata, void* pend
 
 int gr_trace_pending(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width, int height,
                      const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg, void* attempt_counter,
-                     const void* pending_list, int waves_per_simd) {
+                     const void* pending_list, int waves_per_simd, void* block_cost) {
     if (!p || !rdata || !pending_list) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_trace_pending: null argument");
     if (width < 2 || height < 2) return GR_OK;
     const int wg = 256;
@@ -1285,7 +1289,8 @@ int gr_trace_pending(gr_program* p, void* stream, const void* camera_generic, co
     unsigned int* tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
     HIP_CHECK(hipSetDevice(p->device));
     HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
-    void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &pending_list};
+    void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &pending_list,
+                    &block_cost};
     return launch(p, K_TRACE_PENDING, stream, (unsigned)groups, 1, wg, 1, args);
 }
 

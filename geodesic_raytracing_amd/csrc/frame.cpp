@@ -95,6 +95,13 @@ struct gr_render_state {
     // frame's tiles are handed out dearest first by it (gr_frame_options.tile_history)
     void* lattice_rays = nullptr;   // adaptive sampling on the fused path: gr_lattice_rays_bytes (allocated on first use)
     void* pending_list = nullptr;   // ... the pixels of its second launch, dearest first: gr_pending_list_bytes
+    // ... and what the rays of each 2x2 block cost in this frame / in the frame before (the two alternate): the order of the next
+    // frame's list while the picture moves little
+    void* block_cost = nullptr;
+    void* block_cost_before = nullptr;
+    bool block_cost_valid = false;
+    unsigned long long block_cost_program = 0;
+    gr_camera block_cost_camera{};
     void* tile_cost = nullptr;
     int tile_cost_shape[3] = {0, 0, 0};   // block_rows, strip_rank, strip_count
     bool tile_cost_valid = false;
@@ -502,7 +509,7 @@ void gr_render_state_destroy(gr_render_state* s) {
     std::vector<void*> ptrs = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
                                s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
                                s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->tile_order,
-                               s->tile_cost, s->lattice_rays, s->pending_list};
+                               s->tile_cost, s->lattice_rays, s->pending_list, s->block_cost, s->block_cost_before};
     for (auto& slot : s->pre) {
         if (slot.stream) { (void)hipStreamSynchronize(slot.stream); (void)hipStreamDestroy(slot.stream); }
         if (slot.ready) (void)hipEventDestroy(slot.ready);
@@ -1077,12 +1084,26 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 // of every wave has a ray (GR_ADAPTIVE_PENDING_LIST=0: the marked pixels found by walking the image's tiles again)
                 static const bool as_list = [] { const char* e = getenv("GR_ADAPTIVE_PENDING_LIST"); return !(e && e[0] == '0'); }();
                 if (as_list) {
+                    // the list's order: what the lattice rays around a block cost, and - while the picture has moved little since - what
+                    // the block's own rays cost in this state's frame before (the long rays are filaments a pixel or two wide)
+                    static const float history_max_motion = [] { const char* e = getenv("GR_ADAPTIVE_HISTORY_MAX_MOTION"); return e ? (float)atof(e) : 48.f; }();
+                    const size_t image_blocks = (size_t)(width / 2) * (height / 2);
+                    std::swap(s->block_cost, s->block_cost_before);
+                    if (!s->block_cost) HIP_CHECK(hipMalloc(&s->block_cost, image_blocks * sizeof(unsigned int)));
+                    const bool by_history = strip_count == 1 && s->block_cost_valid && s->block_cost_before && !cfg_changed && !features_changed &&
+                                            s->block_cost_program == gr_program_serial(p) && !gc &&
+                                            picture_motion(s->block_cost_camera, *camera, features.field_of_view, width) <= history_max_motion;
+                    HIP_CHECK(hipMemsetAsync(s->block_cost, 0, image_blocks * sizeof(unsigned int), stream));
                     GR_CHECK(gr_adaptive_refine_list(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows, strip_rank,
-                                                     strip_count, s->lattice_rays, s->cfg, s->pending_list));
+                                                     strip_count, s->lattice_rays, s->cfg, s->pending_list, by_history ? s->block_cost_before : nullptr));
                     GR_CHECK(gr_trace_pending(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, s->tetrad[0],
                                               s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, s->pending_list,
-                                              tune.trace_waves_per_simd));
+                                              tune.trace_waves_per_simd, s->block_cost));
+                    s->block_cost_valid = strip_count == 1;
+                    s->block_cost_program = gr_program_serial(p);
+                    s->block_cost_camera = *camera;
                 } else {
+                    s->block_cost_valid = false;
                     GR_CHECK(gr_adaptive_refine_strips(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows,
                                                        strip_rank, strip_count, s->lattice_rays, s->cfg));
                     a.lattice = 1;

@@ -927,13 +927,24 @@ __device__ __forceinline__ render_data interpolate_render_data(render_data r1, r
 // pixel a place in its class's range, dearest class first.  gr_trace_pending then traces the list 64 entries to a wave: every lane has
 // a ray (a tile of the image has 48 at best and most have a handful), the rays of a wave are neighbours of one cost class, and the
 // longest rays of the frame - the refined pixels are the long ones: 12 % of a 4K Kerr frame's pixels, 59 % of what the adaptive
-// frame traces - start first instead of wherever the image has them.  list[0..15] entries per class, [16..31] cursors, [32..] pixels
-// (y * width + x).
-#define GR_PENDING_CLASSES 16
+// frame traces - start first instead of wherever the image has them.  A quarter of an octave per class: the 64 rays of a wave run
+// in lock step until the longest is done, and with whole octaves a wave's rays differed by up to 2x (the launch traced 191 M
+// attempts a millisecond where a launch over 8x8 tiles of neighbours traces 270).  list[0..63] entries per class, [64..127] cursors,
+// [128..] pixels (y * width + x).
+#define GR_PENDING_CLASSES 64
 #define GR_PENDING_HEADER (2 * GR_PENDING_CLASSES)
+// class of a cost in attempts: dearest first, four to the octave (the two bits below the leading one)
+__device__ __forceinline__ int pending_class(unsigned int cost) {
+    if (cost < 4u) return GR_PENDING_CLASSES - 1;
+    const int octave = 31 - __builtin_clz(cost);
+    int fine = 4 * octave + (int)((cost >> (octave - 2)) & 3u);   // 8 .. 127
+    if (fine > 4 * 15 + 3) fine = 4 * 15 + 3;                      // (the step cap is 16 384 = octave 14)
+    return GR_PENDING_CLASSES - 1 - fine;
+}
 extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, int* __restrict__ pending_count, int width, int height,
                                               dfg_t dfg, int block_rows, int strip_rank, int strip_count,
-                                              const float4* __restrict__ lattice_rays, cfg_t cfg, unsigned int* __restrict__ pending_list, int phase) {
+                                              const float4* __restrict__ lattice_rays, cfg_t cfg, unsigned int* __restrict__ pending_list, int phase,
+                                              const unsigned int* __restrict__ block_cost_before) {
     __shared__ unsigned int group_count[GR_PENDING_CLASSES], group_base[GR_PENDING_CLASSES];
     const int thread = threadIdx.y * blockDim.x + threadIdx.x;
     if (pending_list) {
@@ -1003,21 +1014,25 @@ extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, in
                 for (int dx = 0; dx < 2; dx++)
                     if (sx + dx < hw && sy + dy < hh) { const unsigned int c = cost[(size_t)(sy + dy) * hw + sx + dx]; dearest = c > dearest ? c : dearest; }
         }
-        const int octave = 31 - __builtin_clz(dearest);
-        cls = GR_PENDING_CLASSES - 1 - (octave > GR_PENDING_CLASSES - 1 ? GR_PENDING_CLASSES - 1 : octave);
+        // ... or what the block's own rays cost in the frame before (gr_trace_pending leaves the dearest of the three; the caller
+        // passes it while the picture has moved little): the long rays of the shadow's edge are filaments a pixel or two wide, and the
+        // lattice rays either side of one say nothing about it
+        if (block_cost_before) { const unsigned int c = block_cost_before[(size_t)sy * hw + sx]; dearest = c > dearest ? c : dearest; }
+        cls = pending_class(dearest);
     }
     // one atomic per class and workgroup on the list's counters (as gr_order_tiles): a block's place among its workgroup's blocks
     const int lane = thread % 64;
     unsigned int place = 0;
-    for (int c = 0; c < GR_PENDING_CLASSES; c++) {
+    // (the classes present in the wave, one after the other: a wave of neighbouring blocks holds a handful of the 64)
+    for (unsigned long long todo = __builtin_amdgcn_ballot_w64(cls >= 0); todo;) {
+        const int c = __builtin_amdgcn_readlane(cls, __builtin_ctzll(todo));
         const unsigned long long members = __builtin_amdgcn_ballot_w64(cls == c);
-        if (members) {
-            const int leader = __builtin_ctzll(members);
-            unsigned int wave_base = 0;
-            if (lane == leader) wave_base = atomicAdd(&group_count[c], 3u * (unsigned int)__builtin_popcountll(members));
-            wave_base = __builtin_amdgcn_readlane(wave_base, leader);
-            if (cls == c) place = wave_base + 3u * (unsigned int)__builtin_popcountll(members & ((1ull << lane) - 1ull));
-        }
+        const int leader = __builtin_ctzll(members);
+        unsigned int wave_base = 0;
+        if (lane == leader) wave_base = atomicAdd(&group_count[c], 3u * (unsigned int)__builtin_popcountll(members));
+        wave_base = __builtin_amdgcn_readlane(wave_base, leader);
+        if (cls == c) place = wave_base + 3u * (unsigned int)__builtin_popcountll(members & ((1ull << lane) - 1ull));
+        todo &= ~members;
     }
     __syncthreads();
     if (thread < GR_PENDING_CLASSES && group_count[thread])
@@ -1041,7 +1056,9 @@ extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
 gr_trace_pending(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat, render_data* __restrict__ rdata,
                  int width, int height, const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2,
                  const float4* __restrict__ e3, cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter,
-                 unsigned int* __restrict__ ticket_counter, const unsigned int* __restrict__ pending_list) {
+                 unsigned int* __restrict__ ticket_counter, const unsigned int* __restrict__ pending_list, unsigned int* __restrict__ block_cost) {
+    // block_cost (may be NULL; zeroed by the caller): one word per 2x2 block of the image, left holding what the dearest of the block's
+    // rays cost - the order of the next frame's list (gr_adaptive_refine's block_cost_before)
     GR_PARAMETERS_IN_REGISTERS
     const int lane = threadIdx.x % 64;
     unsigned int total = 0;
@@ -1067,6 +1084,7 @@ gr_trace_pending(const float4* __restrict__ g_generic_camera_in, const float4* _
             else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
             rdata[cy * width + cx] = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated,
                                                       cx, cy, cfg, dfg, GET_FEATURE(redshift, dfg) != 0);
+            if (block_cost) atomicMax(block_cost + (size_t)(cy / 2) * (width / 2) + cx / 2, tries);
         }
         if (attempt_counter) atomicAdd(attempt_counter + GR_ATTEMPT_COUNTERS_AT + (blockIdx.x % GR_ATTEMPT_COUNTERS), (unsigned long long)tries);
     }

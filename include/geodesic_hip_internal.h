@@ -198,17 +198,21 @@ int gr_adaptive_refine(gr_program* p, void* stream, void* render_data, void* pen
                        const void* lattice_rays, const void* cfg);
 /* The second launch as a list (what gr_render_frame does): gr_adaptive_refine_list decides and marks as gr_adaptive_refine_strips does
  * and leaves the marked pixels in pending_list (gr_pending_list_bytes), ordered by what their rays are expected to cost - the dearest of
- * the four lattice rays around the block, an octave of attempts per class, dearest first; gr_trace_pending traces the list 64 entries to
- * a wave (waves_per_simd as in gr_trace_fused_args; 0 = as many as fit).  Every lane of every wave has a ray, the rays of a wave are
- * neighbours of one cost class, and the longest rays of the frame start first.  Records equal those of the pending_only launch to
- * rounding (another kernel around the same device functions). */
+ * the four lattice rays around the block, a quarter of an octave of attempts per class, dearest first; gr_trace_pending traces the list 64
+ * entries to a wave (waves_per_simd as in gr_trace_fused_args; 0 = as many as fit).  Every lane of every wave has a ray, the rays of a wave
+ * are neighbours of one cost class, and the longest rays of the frame start first.  Records equal those of the pending_only launch to
+ * rounding (another kernel around the same device functions).  block_cost (unsigned per 2x2 block, (width / 2) * (height / 2), zeroed by the
+ * caller; may be NULL): gr_trace_pending leaves what the dearest ray of each block cost; given to the NEXT frame's gr_adaptive_refine_list
+ * as block_cost_before (while the picture has moved little) it orders that list by the blocks' own rays - the lattice rays either side of
+ * a filament of long rays say nothing about it. */
 size_t gr_pending_list_bytes(int width, int height);
 size_t gr_lattice_rays_bytes(int width, int height);
 int gr_adaptive_refine_list(gr_program* p, void* stream, void* render_data, void* pending_count, int width, int height, const void* dfg,
-                            int block_rows, int strip_rank, int strip_count, const void* lattice_rays, const void* cfg, void* pending_list);
+                            int block_rows, int strip_rank, int strip_count, const void* lattice_rays, const void* cfg, void* pending_list,
+                            const void* block_cost_before);
 int gr_trace_pending(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* render_data, int width, int height,
                      const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg, void* attempt_counter,
-                     const void* pending_list, int waves_per_simd);
+                     const void* pending_list, int waves_per_simd, void* block_cost);
 /* lattice_rays: gr_lattice_rays_bytes(width, height) bytes - 3 x float4 per lattice pixel, and behind those one unsigned per lattice
  * pixel: the attempts its ray took (the cost estimate of gr_adaptive_refine_list) - written by the lattice launch (lattice = 2) and
  * read by gr_adaptive_refine: where every lattice ray ended (position, velocity, the quaternion of its rotated frame) - what the

@@ -510,7 +510,7 @@ def test_program_manager_update_does_not_wait_for_an_overtaken_build(tmp_path, m
 def test_pending_list_of_adaptive_sampling_holds_the_marked_pixels_dearest_first():
     """gr_adaptive_refine_list + gr_trace_pending (the second launch of adaptive sampling as a list, 64 entries to a wave, what gr_render_frame
     runs) against gr_adaptive_refine + the pending_only launch that walks the image's tiles again: the same pixels are marked, the list
-    holds each of them once, class by class with the dearest class first (the lattice rays' attempts around a block say which), and the
+    holds each of them once, class by class - a quarter of an octave of attempts each - with the dearest class first (the lattice rays' attempts around a block say which), and the
     records of the two second launches agree - flags exactly, sky coordinates to rounding (two kernels around the same device functions)"""
     metric = gra.Metric("kerr_boyer", SCRIPTS)
     feats, cfgv = metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0), metric.cfg_values(a=0.45)
@@ -544,12 +544,12 @@ def test_pending_list_of_adaptive_sampling_holds_the_marked_pixels_dearest_first
     count_b = DeviceBuffer.from_numpy(0, np.zeros(1, dtype=np.int32))
     pending = DeviceBuffer(0, lib.gr_pending_list_bytes(w, h))
     check(lib.gr_adaptive_refine_list(prog.handle, None, records_b.ptr, count_b.ptr, w, h, buf(gra.BUF_DFG), 0, 0, 1, lattice_rays.ptr, buf(gra.BUF_CFG),
-                                      pending.ptr))
+                                      pending.ptr, None))
     marked_b = records_b.to_numpy(RENDER_DATA_DTYPE, w * h)["terminated"] == -1
     words = pending.to_numpy(np.uint32, lib.gr_pending_list_bytes(w, h) // 4)
-    counts, cursors = words[:16].astype(np.int64), words[16:32].astype(np.int64)
+    counts, cursors = words[:64].astype(np.int64), words[64:128].astype(np.int64)
     total = int(counts.sum())
-    entries = words[32:32 + total].astype(np.int64)
+    entries = words[128:128 + total].astype(np.int64)
     assert np.array_equal(marked_a, marked_b) and total == int(marked_b.sum()) == int(count_b.to_numpy(np.int32, 1)[0]) == int(count_a.to_numpy(np.int32, 1)[0])
     assert np.array_equal(counts, cursors) and 0.02 < total / (w * h) < 0.6
     assert len(np.unique(entries)) == total and marked_b[entries].all()
@@ -560,10 +560,13 @@ def test_pending_list_of_adaptive_sampling_holds_the_marked_pixels_dearest_first
     for dy in (0, 1):
         for dx in (0, 1):
             corner = np.maximum(corner, cost[np.minimum(by + dy, hh - 1), np.minimum(bx + dx, hw - 1)])
-    klass = 15 - np.minimum(15, np.floor(np.log2(np.maximum(corner, 1))).astype(np.int64))
-    assert (np.diff(klass) >= 0).all() and np.array_equal(np.bincount(klass, minlength=16), counts)
+    # a quarter of an octave per class: 4 * floor(log2 cost) + the two bits below the leading one, counted down from 63
+    octave = np.floor(np.log2(np.maximum(corner, 1))).astype(np.int64)
+    fine = np.where(corner < 4, 0, 4 * octave + ((corner >> np.maximum(octave - 2, 0)) & 3))
+    klass = 63 - np.minimum(fine, 63)
+    assert (np.diff(klass) >= 0).all() and np.array_equal(np.bincount(klass, minlength=64), counts)
     check(lib.gr_trace_pending(prog.handle, None, buf(gra.BUF_CAMERA_GENERIC), buf(gra.BUF_CAMERA_QUAT), records_b.ptr, w, h, buf(gra.BUF_TETRAD0),
-                               buf(gra.BUF_TETRAD1), buf(gra.BUF_TETRAD2), buf(gra.BUF_TETRAD3), buf(gra.BUF_CFG), buf(gra.BUF_DFG), None, pending.ptr, 0))
+                               buf(gra.BUF_TETRAD1), buf(gra.BUF_TETRAD2), buf(gra.BUF_TETRAD3), buf(gra.BUF_CFG), buf(gra.BUF_DFG), None, pending.ptr, 0, None))
     frame_b = records_b.to_numpy(RENDER_DATA_DTYPE, w * h)
     assert (frame_b["terminated"] >= 0).all() and (frame_a["terminated"] >= 0).all()
     differ = frame_a["terminated"] != frame_b["terminated"]
@@ -573,3 +576,27 @@ def test_pending_list_of_adaptive_sampling_holds_the_marked_pixels_dearest_first
     d = np.minimum(d, 1 - d)
     assert np.percentile(d, 99) <= 2e-6
     assert np.array_equal(frame_a[~marked_b], frame_b[~marked_b])   # what the second launch does not trace is the first launch's and the interpolation's
+
+
+def test_adaptive_list_ordered_by_the_frame_before_changes_no_pixel():
+    """the second frame of a render state orders its list of marked pixels by what the blocks' own rays cost in the first
+    (gr_trace_pending's block_cost -> gr_adaptive_refine_list's block_cost_before): scheduling only - the frames of a camera that
+    stands still, moves a little and jumps are those of fresh render states, bit for bit"""
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    feats, cfgv = metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0), metric.cfg_values(a=0.45)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    w, h = 1280, 720
+    dbg, levels = background()
+
+    def frame(state, cam):
+        out = DeviceBuffer(0, w * h * 16)
+        state.render(prog, metric, cam, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv, gra.frame_options(mode=gra.MODE_FUSED))
+        state.synchronize()
+        return out.to_numpy(np.float32, (h, w, 4)), download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h)
+
+    warm = gra.RenderState(w, h, 0)
+    for k, cam in enumerate([gra.default_camera(), gra.default_camera(), gra.default_camera([0, 0.01, -4.0, 0.005]), gra.default_camera([0, 0.5, -7.0, 2.0])]):
+        got, rd = frame(warm, cam)
+        want, rd_fresh = frame(gra.RenderState(w, h, 0), cam)
+        assert (rd["terminated"] >= 0).all()
+        assert rd.tobytes() == rd_fresh.tobytes() and got.tobytes() == want.tobytes(), k
