@@ -254,9 +254,26 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
     float exit_ds = 0, exit_running = 1;
     {
         const trig_flavour<false> polynomial;
+#if GR_PRIORITY_TRIPS > 0
+        unsigned trips = 0, next_level = GR_PRIORITY_TRIPS;
+#endif
         for (;;) {
             float4 p1, v1, a1;
             float ds_used, running_before;
+#if GR_PRIORITY_TRIPS > 0
+            // A wave whose rays are still going after GR_PRIORITY_TRIPS trips (two attempts each) is on the launch's critical path -
+            // a launch lasts at least as long as its longest ray, and a ray's attempts are a dependent chain that gets one issue
+            // slot in (waves per SIMD) while the SIMD is full.  The hardware's issue arbiter takes the highest-priority ready wave
+            // first: raising the priority of the long waves (again at twice and four times the count) shortens their chain towards
+            // what a wave alone on its SIMD achieves and costs the others exactly the slots it takes - the same work, a shorter tail.
+            // Wave-uniform: the trip count is the same for every lane still in the loop.  Arithmetic untouched.
+            if (__builtin_expect(++trips == next_level, 0)) {
+                if (next_level == GR_PRIORITY_TRIPS) __builtin_amdgcn_s_setprio(1);
+                else if (next_level == 2 * GR_PRIORITY_TRIPS) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+                next_level = next_level < 4 * GR_PRIORITY_TRIPS ? 2 * next_level : 0xffffffffu;
+            }
+#endif
             // A ray that leaves is left in set 0: lanes that have left are masked off for the rest of the loop, so set 0 keeps their
             // state with no registers of its own; a ray that leaves from set 1 is copied over first (opaque copies, once per ray).
             if (attempt(polynomial, p0, v0, a0, p1, v1, a1, ds_used, running_before)) {
@@ -271,6 +288,9 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
             }
         }
     }
+#if GR_PRIORITY_TRIPS > 0
+    __builtin_amdgcn_s_setprio(0);
+#endif
     float4 position = p0, velocity = v0, acceleration = a0;
 #ifdef IS_CONSTANT_THETA
     position.z = GR_PIf / 2; velocity.z = 0; acceleration.z = 0;

@@ -132,6 +132,12 @@ struct dynamic_feature_config {
 // in the persistent fused kernel -> 5 waves/SIMD, which already saturates the VALU; the complex-valued double-Kerr
 // metric: 186-370 VGPRs -> 1-2 waves/SIMD but no spills).  Measured on MI355X: forcing 6-8 waves on Kerr does not make it
 // faster; capping double Kerr at 128 VGPRs costs 5.3x.
+// trips of the fast Verlet loop (two attempts each) after which a wave raises its issue priority, again at twice and four times
+// the count (integrator.hip); 0 = never.  Measured (tools/priority_probe.py, 4K Kerr): a = 0.9 one frame at a time 17.8 -> 16.3 ms
+// with 64 ... 256 alike, 16.6 with 512; a = 0.45, frames in flight, adaptive sampling, shares of a split frame: unchanged.
+#ifndef GR_PRIORITY_TRIPS
+#define GR_PRIORITY_TRIPS 128
+#endif
 #ifndef GR_TRACE_WAVES
 #define GR_TRACE_WAVES 1
 #endif
