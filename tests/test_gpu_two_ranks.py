@@ -105,6 +105,59 @@ def test_c_abi_tiled_frame_with_peer_copies_equals_the_single_gpu_frame():
             p.close()
 
 
+def test_a_participant_whose_render_fails_does_not_stall_the_others_and_the_host_falls_back_to_fewer():
+    """SURVEY.md 5, "per-GPU failure -> fall back to fewer strips": participant 1 of 3 is handed an option its program cannot serve
+    (in-tile shading without a program built for it): its call returns the render's error, but it has still taken part in the frame's
+    transfers, so the other two complete and their rows of the frame are the single-GPU frame's.  The host then does what the design
+    leaves to it - a share is a pure function of (rank, world, rotation), nothing migrates: a group of the two survivors - and the
+    next frame is the single-GPU frame again, bit for bit."""
+    import geodesic_raytracing_amd as gra
+    from geodesic_raytracing_amd.distributed import StripPlan
+    from geodesic_raytracing_amd.pipeline import DeviceBuffer
+    w, h, block = 640, 360, 24
+    metric = gra.Metric("kerr_boyer")
+    prog = gra.Program(metric.argument_string(), 0)
+    feats = metric.features(adaptive_sampling=0)
+    cfg = metric.cfg_values(a=0.45)
+    packed, levels = gra.pack_background(gra.synthetic_background(512, 256))
+    bg = DeviceBuffer.from_numpy(0, packed)
+    cams = [gra.default_camera([0, 0.1 * k, -4 - 0.3 * k, 0.05 * k]) for k in range(2)]
+    full, single, want = DeviceBuffer(0, w * h * 16), gra.RenderState(w, h, 0), []
+    for cam in cams:
+        single.render(prog, metric, cam, full.ptr, (bg.ptr, 512, 256, levels), feats, cfg, gra.frame_options(mode=gra.MODE_FUSED))
+        single.synchronize()
+        want.append(full.to_numpy(np.float32, (h, w, 4)))
+    frame = DeviceBuffer(0, w * h * 16)
+    parts = gra.TiledFrame.local([0] * 3, w, h, block)
+    states = [gra.RenderState(w, h, 0) for _ in range(3)]
+    failed = []
+    for r in range(3):
+        o = gra.frame_options(mode=gra.MODE_FUSED, fused_shading=1 if r == 1 else -1)
+        try:
+            parts[r].render(states[r], prog, metric, cams[0], frame.ptr, (bg.ptr, 512, 256, levels), feats, cfg, o, rotation=0)
+        except gra.GeodesicError as e:
+            failed.append(r)
+            assert "fused_shading" in str(e)
+    assert failed == [1]
+    parts[0].join()
+    gra.check(gra.lib.gr_device_synchronize(0))
+    got = frame.to_numpy(np.float32, (h, w, 4))
+    plan = StripPlan(h, 3, block)
+    for r in (0, 2):
+        for a, b in plan.blocks_of(parts[r].share(0)):
+            assert np.array_equal(got[a:b], want[0][a:b]), (r, a)
+    for p_ in parts:
+        p_.close()
+    parts = gra.TiledFrame.local([0] * 2, w, h, block)      # the survivors, renumbered
+    for r in range(2):
+        parts[r].render(states[r], prog, metric, cams[1], frame.ptr, (bg.ptr, 512, 256, levels), feats, cfg, gra.frame_options(mode=gra.MODE_FUSED), rotation=1)
+    parts[0].join()
+    gra.check(gra.lib.gr_device_synchronize(0))
+    assert np.array_equal(frame.to_numpy(np.float32, (h, w, 4)), want[1])
+    for p_ in parts:
+        p_.close()
+
+
 def test_c_abi_tiled_frame_rccl_single_participant():
     """the RCCL entry points with world = 1 (no communicator needed, the frame is rendered in place), and - when librccl loads -
     the unique id call"""
