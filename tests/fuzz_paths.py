@@ -69,6 +69,14 @@ def main():
             for i in sorted(set([0, max(first - 1, 0), max(first, 0), min(first + 1, n - 1), min(first + 2, n - 1), n // 2, n - 2, n - 1])):
                 print("  step", i, "position", want["path"][i], "gpu", got["path"][i], "ds", want["ds"][i], got["ds"][i])
                 print("       velocity", want["velocity"][i], "gpu", got["velocity"][i])
+            if got["count"] == want["count"]:
+                d = np.abs(got["transported"] - want["transported"])
+                print("transported tetrads: shape", d.shape, "largest difference", float(d.max()), "at", np.unravel_index(int(d.argmax()), d.shape),
+                      "scale", float(np.abs(want["transported"]).max()))
+                worst_vector = np.unravel_index(int(d.argmax()), d.shape)[0]
+                for i in sorted(set([0, 1, n // 2, n - 2, n - 1, int(np.unravel_index(int(d.argmax()), d.shape)[1]) if d.ndim == 3 else 0])):
+                    print("  sample", i, "reference", want["transported"][worst_vector][i] if d.ndim == 3 else want["transported"][i],
+                          "gpu", got["transported"][worst_vector][i] if d.ndim == 3 else got["transported"][i])
         if np.abs(got["tetrad_boosted"] - want["tetrad_boosted"]).max() > 2e-6 * max(1.0, np.abs(want["tetrad_boosted"]).max()):
             problems.append("boosted tetrad")
         if got["count"] != want["count"]:
