@@ -153,8 +153,16 @@ def main():
     # call pattern - a group per frame, a send per block, the matching receives on rank 0 - across real process boundaries; RCCL
     # itself refuses two ranks on one device).  Everything else - rotation of the shares, frames in flight, look-ahead, the complete
     # N > 1 JSON line - is the code the 8-GPU run executes.  The numbers say nothing (N ranks share one GPU): "rehearsal" marks the line.
-    one_device = os.environ.get("GR_BENCH_ONE_DEVICE") == "1" and world > 1
-    if one_device:
+    # GR_BENCH_ONE_DEVICE=rccl: the same rehearsal through RCCL itself - the process group over "nccl" and the frame's exchange through
+    # gr_tiled_create, i.e. EXACTLY the code of the 8-GPU run.  RCCL's "Duplicate GPU detected" check compares (host, bus id): every
+    # rank claims a host of its own (NCCL_HOSTID), RCCL takes the ranks for nodes of a cluster and moves the data through its socket
+    # transport over the loopback interface.
+    rehearsal = os.environ.get("GR_BENCH_ONE_DEVICE", "") if world > 1 else ""
+    rccl_rehearsal = rehearsal == "rccl"
+    one_device = rehearsal == "1"
+    if rccl_rehearsal:
+        os.environ.update(NCCL_HOSTID="bench-rank%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET_GDR_LEVEL="0")
+    if one_device or rccl_rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -657,6 +665,9 @@ def main():
         line.update(extra)
         if one_device:
             line["rehearsal"] = f"GR_BENCH_ONE_DEVICE=1: {world} ranks on ONE GPU through the inter-process transport - a run of the N > 1 code path, not a measurement"
+        if rccl_rehearsal:
+            line["rehearsal"] = (f"GR_BENCH_ONE_DEVICE=rccl: {world} ranks on ONE GPU, process group and frame exchange through RCCL (every rank claims a host "
+                                 "of its own, RCCL's socket transport over loopback) - the code of the N-GPU run, not a measurement")
     if multi:
         if tiled is not None:
             tiled.close()

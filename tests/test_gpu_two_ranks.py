@@ -1,9 +1,10 @@
 """GPU test (-m gpu): two processes sharing the one GPU of the test box play ranks 0 and 1 of a row-split frame: each renders
 its (rotating) strips with the look-ahead options bench.py uses, the strips are gathered with the library's FrameGather over gloo
-(RCCL refuses two ranks on one device, so the strips are staged through host memory here), and rank 0's assembled frames must be
-bit-identical to the single-process frame."""
+(staged through host memory), and rank 0's assembled frames must be bit-identical to the single-process frame.  Further down: the C ABI's
+tiled frame with peer copies, across processes through the inter-process transport, and through RCCL itself with 2, 3 and 8 ranks."""
 import ctypes
 import os
+import time
 
 import numpy as np
 import pytest
@@ -233,8 +234,12 @@ def test_c_abi_tiled_frames_in_flight_on_several_streams(staging, world, block, 
             gra.check(gra.lib.gr_stream_destroy(s))
 
 
-def _ipc_worker(rank, world, block, session, out_dir):
-    """one rank of a frame split over `world` PROCESSES that share the test box's one GPU (gr_tiled_create_ipc)"""
+def _ipc_worker(rank, world, block, session, out_dir, transport="ipc"):
+    """one rank of a frame split over `world` PROCESSES that share the test box's one GPU (gr_tiled_create_ipc; transport "rccl":
+    gr_tiled_create itself, every rank claiming a host of its own - see the RCCL test below)"""
+    if transport == "rccl":
+        os.environ.update(NCCL_HOSTID=f"{session}-rank{rank}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET_GDR_LEVEL="0",
+                          NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
     import geodesic_raytracing_amd as gra
     from geodesic_raytracing_amd import check, lib
     from geodesic_raytracing_amd.pipeline import DeviceBuffer
@@ -246,7 +251,19 @@ def _ipc_worker(rank, world, block, session, out_dir):
     packed, levels = gra.pack_background(gra.synthetic_background(512, 256))
     bg = DeviceBuffer.from_numpy(0, packed)
     cams = [gra.default_camera([0, 0.1 * k, -4 - 0.3 * k, 0.05 * k]) for k in range(frames)]
-    part = gra.TiledFrame.ipc(world, rank, 0, session, w, h, block)          # collective: returns when every rank has arrived
+    if transport == "rccl":
+        id_file = os.path.join(out_dir, "rccl_id")
+        if rank == 0:
+            with open(id_file + ".tmp", "wb") as f:
+                f.write(bytes(gra.TiledFrame.unique_id()))
+            os.rename(id_file + ".tmp", id_file)
+        deadline = time.time() + 60
+        while not os.path.exists(id_file):
+            assert time.time() < deadline, "no communicator id from rank 0"
+            time.sleep(0.05)
+        part = gra.TiledFrame(world, rank, 0, open(id_file, "rb").read(), w, h, block)      # ncclCommInitRank: collective
+    else:
+        part = gra.TiledFrame.ipc(world, rank, 0, session, w, h, block)      # collective: returns when every rank has arrived
     states = [gra.RenderState(w, h, 0) for _ in range(in_flight)]
     streams = []
     for _ in range(in_flight):
@@ -280,7 +297,7 @@ def _ipc_worker(rank, world, block, session, out_dir):
                 # whose blocks they were in this frame: share s = (rank + k) % world renders the blocks b with b % world == s
                 raise AssertionError(f"world {world} frame {k}: {len(rows)} rows differ, blocks {blocks}, rendered by ranks "
                                      f"{sorted(set((b % world - k) % world for b in blocks))}")
-        np.save(os.path.join(out_dir, f"ipc_ok_{world}.npy"), np.array([frames]))
+        np.save(os.path.join(out_dir, f"{transport}_ok_{world}.npy"), np.array([frames]))
     part.close()
 
 
@@ -297,3 +314,15 @@ def test_c_abi_tiled_frames_across_processes_that_share_the_gpu(world, block, tm
     session = f"t{os.getpid()}w{world}"
     mp.spawn(_ipc_worker, args=(world, block, session, str(tmp_path)), nprocs=world, join=True)
     assert os.path.exists(tmp_path / f"ipc_ok_{world}.npy")
+
+
+@pytest.mark.parametrize("world,block", [(2, 16), (3, 24), (8, 16)])
+def test_c_abi_tiled_frames_over_rccl_with_several_ranks_on_one_gpu(world, block, tmp_path):
+    """The RCCL transport itself (gr_tiled_create: ncclCommInitRank, a group of ncclSend / ncclRecv per frame) with more than one rank.
+    RCCL refuses two ranks of one host on one device ("Duplicate GPU detected"), so every rank claims a host of its own (NCCL_HOSTID):
+    RCCL then takes the ranks for nodes of a cluster and moves the blocks through its socket transport over the loopback interface -
+    slow, and exactly the calls, groups, streams and matching an 8-GPU node runs through xGMI.  Same schedule and same check as the
+    inter-process test above: six frames on three streams, shares rotating, rank 0's frames the single-GPU frames bit for bit."""
+    session = f"r{os.getpid()}w{world}"
+    mp.spawn(_ipc_worker, args=(world, block, session, str(tmp_path), "rccl"), nprocs=world, join=True)
+    assert os.path.exists(tmp_path / f"rccl_ok_{world}.npy")
