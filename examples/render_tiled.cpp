@@ -5,6 +5,7 @@
 //   examples/render_tiled --spawn 8 geodesic_raytracing_amd/scripts kerr_boyer 3840 2160 frame.png [frames] [name=value ...]
 //       forks one worker per GPU (rank r -> device r) and waits for them; or, started by any launcher of your own, one process each:
 //   examples/render_tiled --rank R --world N --device D --id-file /tmp/id geodesic_raytracing_amd/scripts kerr_boyer 3840 2160 frame.png
+//   examples/render_tiled --spawn 3 --one-device 1 ...   rehearsal on a box with one GPU: every rank on device 0, RCCL through sockets
 //
 // Every rank renders its (rotating) share of the image rows with frames in flight on streams of their own, rank 0 receives
 // every block at its place in the frame (gr_render_frame_tiled), writes the last frame as a PNG and prints frames per second
@@ -189,7 +190,7 @@ static int worker(int world, int rank, int device, const std::string& id_file, i
 }
 
 int main(int argc, char** argv) {
-    int world = 1, rank = 0, device = -1, spawn = 0;
+    int world = 1, rank = 0, device = -1, spawn = 0, one_device = 0;
     std::string id_file;
     int a = 1;
     for (; a < argc && std::strncmp(argv[a], "--", 2) == 0; a += 2) {
@@ -199,10 +200,11 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[a], "--rank")) rank = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--device")) device = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--id-file")) id_file = argv[a + 1];
+        else if (!std::strcmp(argv[a], "--one-device")) one_device = std::atoi(argv[a + 1]);
         else { std::fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
     }
     if (argc - a < 5) {
-        std::fprintf(stderr, "usage: %s (--spawn N | --world N --rank R [--device D] --id-file PATH) <scripts dir> <metric> <width> <height> <out.png> "
+        std::fprintf(stderr, "usage: %s (--spawn N [--one-device 1] | --world N --rank R [--device D] --id-file PATH) <scripts dir> <metric> <width> <height> <out.png> "
                              "[frames] [name=value ...]\n", argv[0]);
         return 2;
     }
@@ -214,7 +216,15 @@ int main(int argc, char** argv) {
         for (int r = 0; r < spawn; r++) {
             const pid_t pid = fork();
             if (pid == 0) {
-                const int rc = worker(spawn, r, r, id_file, argc - a, argv + a);
+                if (one_device) {
+                    // rehearsal on a box with fewer GPUs than ranks: RCCL refuses two ranks of one host on one device, so every
+                    // rank claims a host of its own and RCCL talks through its socket transport over the loopback interface
+                    setenv("NCCL_HOSTID", ("render-tiled-" + std::to_string((long)getppid()) + "-rank" + std::to_string(r)).c_str(), 1);
+                    setenv("NCCL_SOCKET_IFNAME", "lo", 1);
+                    setenv("NCCL_IB_DISABLE", "1", 1);
+                    setenv("NCCL_NET_GDR_LEVEL", "0", 1);
+                }
+                const int rc = worker(spawn, r, one_device ? 0 : r, id_file, argc - a, argv + a);
                 std::fflush(nullptr);   // _exit does not flush stdio
                 _exit(rc);
             }

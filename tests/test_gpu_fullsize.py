@@ -468,7 +468,9 @@ def test_cpp_tiled_example_renders_a_png(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "examples")], stdout=subprocess.DEVNULL)
     want, _, _ = render("kerr_boyer", 640, 360, cfg=dict(a=0.45), options=dict(mode=gra.MODE_FUSED), scripts=SCRIPTS)
-    for tag, launch in (("rank", ["--world", "1", "--rank", "0"]), ("spawn", ["--spawn", "1"])):
+    # --spawn 3 --one-device 1: three processes on the one GPU through RCCL itself (every rank claims a host of its own, RCCL's socket
+    # transport over loopback: tests/test_gpu_two_ranks.py) - the torch-free N-process host end to end
+    for tag, launch in (("rank", ["--world", "1", "--rank", "0"]), ("spawn", ["--spawn", "1"]), ("spawn3", ["--spawn", "3", "--one-device", "1"])):
         out = str(tmp_path / f"tiled_{tag}.png")
         r = subprocess.run([os.path.join(root, "examples", "render_tiled")] + launch + [SCRIPTS, "kerr_boyer", "640", "360", out, "5", "a=0.45"],
                            capture_output=True, text=True)
@@ -477,6 +479,10 @@ def test_cpp_tiled_example_renders_a_png(tmp_path):
         img = cli.read_png(out)
         assert img.shape == (360, 640, 4)
         assert ((want[..., :3].max(axis=2) == 0) == (img[..., :3].max(axis=2) == 0)).mean() > 0.999
+        if tag == "rank":
+            alone = img
+        else:
+            assert np.array_equal(img, alone), tag       # the same frame whoever rendered which rows
 
 
 @pytest.mark.parametrize("name,size", [("schwarzschild", (1920, 1080)), ("minkowski", (1000, 500)), ("wormhole", (1280, 720))])
