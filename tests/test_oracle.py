@@ -72,7 +72,19 @@ SYMPY_CASES = [("schwarzschild", "schwarzschild"), ("schwarzschild", "schwarzsch
                # equatorial-plane kernel with a parameter), an off-diagonal chart whose coordinate transforms carry a logarithm of the
                # parameter (total differentials with sign / fabs), and a cylinder chart with the cylindrical-singularity flags
                ("kerr_newman_boyer", "kerr_newman"), ("wormhole", "wormhole_through"), ("wormhole", "wormhole_far_side"),
-               ("schwarzschild_ingoing_ef", "ingoing_ef"), ("cosmic_string", "cosmic_string"), ("cosmic_string", "cosmic_string_hit")]
+               ("schwarzschild_ingoing_ef", "ingoing_ef"), ("cosmic_string", "cosmic_string"), ("cosmic_string", "cosmic_string_hit"),
+               # round 4, late: five metrics of the reference's own folder, against the fixtures made from its unmodified scripts
+               # (tests/golden/refscripts): real powers with a parameter in the exponent, an off-diagonal t-r chart with atan2 / exp / sqrt
+               # of parameters, a deficit angle in a hole's chart, Kerr in ingoing coordinates (three off-diagonal pairs, the
+               # Eddington-Finkelstein coordinate transforms; also with the prepass its JSON asks for)
+               ("schwarzschild_accurate", "refscripts/schwarzschild_accurate"), ("cosmic_string_bh", "refscripts/cosmic_string_bh"),
+               ("janis_newman_winicour", "refscripts/janis_newman_winicour"), ("ellis_drainhole", "refscripts/ellis_drainhole"),
+               ("kerr_ingoing_ef", "refscripts/kerr_ingoing_ef"), ("kerr_ingoing_ef", "refscripts/kerr_ingoing_ef_prepass"),
+               # ... charged Kerr in Kerr-Schild coordinates (with the prepass, a horizon and a naked singularity), a spinning string
+               # in a cylinder chart, a time-dependent Cartesian chart built of tanh steps
+               ("kerr_newman_schild", "refscripts/kerr_newman_schild"), ("kerr_newman_schild", "refscripts/kerr_newman_schild_prepass"),
+               ("kerr_newman_schild", "refscripts/kerr_newman_schild_hole_prepass"),
+               ("cosmic_string_spinning", "refscripts/cosmic_string_spinning"), ("krasnikov_cartesian", "refscripts/krasnikov_cartesian")]
 
 
 def sympy_argument_string(metric):
@@ -83,6 +95,12 @@ def sympy_argument_string(metric):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tool = os.path.join(root, "tools", "sympy_macros.py")
     key = hashlib.sha1(open(tool, "rb").read()).hexdigest()[:16]
+    # the tool's own output, committed next to the fixtures with the tool's hash (python tools/sympy_macros.py --golden): used while the
+    # hash matches, so that a fresh clone does not spend ten minutes in sympy
+    golden = os.path.join(root, "tests", "golden", "sympy")
+    if os.path.exists(os.path.join(golden, "TOOL_HASH")) and open(os.path.join(golden, "TOOL_HASH")).read().strip() == key \
+            and os.path.exists(os.path.join(golden, metric + ".args")):
+        return open(os.path.join(golden, metric + ".args")).read()
     cached = os.path.join(root, "oracle", "_build", f"sympy_{metric}_{key}.args")
     if os.path.exists(cached):
         return open(cached).read()

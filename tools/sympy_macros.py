@@ -23,6 +23,7 @@ commented out (cl.cl:3315), so its value is never evaluated.
 
     python tools/sympy_macros.py kerr_boyer        # prints the argument string
 """
+import os
 import sys
 
 import sympy as sp
@@ -85,7 +86,7 @@ def c_expr(e):
             root = "sqrt(" + c_expr(b) + ")"
             body = "(" + "*".join([root] * abs(n)) + ")"
             return body if n > 0 else "(1.0f/" + body + ")"
-        raise ValueError("unsupported power " + str(e))
+        return "pow(" + c_expr(b) + "," + c_expr(x) + ")"      # (a real power of a parameter-dependent base: janis_newman_winicour)
     if isinstance(e, sp.Function):
         name = {"Abs": "fabs"}.get(type(e).__name__, type(e).__name__)
         return name + "(" + ",".join(c_expr(a) for a in e.args) + ")"
@@ -209,6 +210,96 @@ def polar_to_ingoing_ef(t, r, theta, phi):   # scripts/coordinates/polar_to_ingo
 def cosmic_string(t, rho, phi, z):           # Vilenkin 1981: flat space with a wedge of 8 pi mu cut out (this repository's scripts/cosmic_string.js;
     mu = cfg_symbol("mu")                     # the reference's folder has cosmic_string_bh / _spinning only)
     return sp.diag(-1, 1, (1 - 4 * mu) ** 2 * rho * rho, 1)
+
+
+# ---- round 4: metrics of the reference's own folder (the fixtures under tests/golden/refscripts come from its unmodified scripts) ----
+
+def schwarzschild_accurate(t, r, theta, phi):   # scripts/schwarzschild_accurate.js: Schwarzschild with rs a parameter, settings of polar_base.json
+    rs = cfg_symbol("rs")
+    return sp.diag(-(1 - rs / r), 1 / (1 - rs / r), r * r, r * r * sp.sin(theta) ** 2)
+
+
+def cosmic_string_bh(t, r, theta, phi):      # scripts/cosmic_string_bh.js (Aryal, Ford & Vilenkin 1986: a string through a Schwarzschild hole)
+    rs, B = cfg_symbol("rs"), cfg_symbol("B")
+    return sp.diag(-(1 - rs / r), 1 / (1 - rs / r), r * r, r * r * B * B * sp.sin(theta) ** 2)
+
+
+def janis_newman_winicour(t, r, theta, phi):   # scripts/janis_newman_winicour.js (arXiv:1408.6041)
+    r0, mu = cfg_symbol("r0"), cfg_symbol("mu")
+    A = ((2 * r - r0 * (mu - 1)) / (2 * r + r0 * (mu + 1))) ** (1 / mu)
+    Bq = sp.Rational(1, 4) * (2 * r + r0 * (mu + 1)) ** (1 / mu + 1) / (2 * r - r0 * (mu - 1)) ** (1 / mu - 1)
+    return sp.diag(-A, 1 / A, Bq, Bq * sp.sin(theta) ** 2)
+
+
+def ellis_drainhole(t, r, theta, phi):       # scripts/ellis_drainhole.js (Ellis 1973 in the proper-radius form with the ether flow F)
+    m, n = cfg_symbol("m"), cfg_symbol("n")
+    alpha = sp.sqrt(n * n - m * m)
+    pseudophi = (n / alpha) * (sp.pi / 2 - sp.atan2(r - m, alpha))
+    F = -sp.sqrt(1 - sp.exp(-(2 * m / n) * pseudophi))
+    R2 = ((r - m) ** 2 + alpha * alpha) / (1 - F * F)
+    g = sp.zeros(4, 4)
+    # -(1 - F^2) dt^2 + dr^2 - 2 F dt dr + R^2 dOmega^2 with the script's signs
+    g[0, 0] = -(1 - F * F)
+    g[1, 1] = 1
+    g[0, 1] = g[1, 0] = -F
+    g[2, 2] = R2
+    g[3, 3] = R2 * sp.sin(theta) ** 2
+    return g
+
+
+def kerr_ingoing_ef(vv, r, theta, phi):      # scripts/kerr_ingoing_ef.js (Kerr in ingoing Kerr coordinates, scholarpedia Kerr-Newman (47), signature flipped)
+    rs, a = cfg_symbol("rs"), cfg_symbol("a")
+    ct, st = sp.cos(theta), sp.sin(theta)
+    R2 = r * r + a * a * ct * ct
+    D = r * r + a * a - rs * r
+    g = sp.zeros(4, 4)
+    g[0, 0] = -(1 - rs * r / R2)
+    g[0, 1] = g[1, 0] = 1
+    g[0, 3] = g[3, 0] = -(a * st * st / R2) * (rs * r)
+    g[1, 3] = g[3, 1] = -a * st * st
+    g[2, 2] = R2
+    g[3, 3] = -(st * st / R2) * (D * a * a * st * st - (a * a + r * r) ** 2)
+    return g
+
+
+def kerr_newman_schild(t, x, y, z):          # scripts/kerr_newman_schild.js (Kerr-Newman in Kerr-Schild coordinates; parameters a, rs, Q in that order)
+    a, rs, Q = cfg_symbol("a"), cfg_symbol("rs"), cfg_symbol("Q")
+    R2 = x * x + y * y + z * z
+    Rm2 = x * x + y * y - z * z
+    r2 = (-a * a + sp.sqrt(a ** 4 - 2 * a * a * Rm2 + R2 * R2) + R2) / 2
+    r = sp.sqrt(r2)
+    lv = [1, (r * x + a * y) / (r2 + a * a), (r * y - a * x) / (r2 + a * a), z / r]
+    f = (rs * r - Q * Q) * r2 / (r2 * r2 + a * a * z * z)
+    eta = sp.diag(-1, 1, 1, 1)
+    return sp.Matrix(4, 4, lambda i, j: eta[i, j] + f * lv[i] * lv[j])
+
+
+def cosmic_string_spinning(t, p, phi, z):    # scripts/cosmic_string_spinning.js, entry for entry (its cross term sits at [t][p])
+    a, k = cfg_symbol("a"), cfg_symbol("k")
+    g = sp.zeros(4, 4)
+    g[0, 0] = -1
+    g[1, 1] = 1
+    g[2, 2] = a * a + k * k * p * p
+    g[3, 3] = 1
+    g[0, 1] = g[1, 0] = a
+    return g
+
+
+def krasnikov_theta(x, e):                   # Everett & Roman's smoothed step, as the script has it
+    return sp.Rational(1, 2) * (sp.tanh(2 * ((2 * x / e) - 1)) + 1)
+
+
+def krasnikov_cartesian(t, x, y, z):         # scripts/krasnikov_cartesian.js (Krasnikov tube along x, Everett & Roman 1997)
+    e, D, pmax, little_d = cfg_symbol("e"), cfg_symbol("D"), cfg_symbol("pmax"), cfg_symbol("littled")
+    p = sp.sqrt(y * y + z * z)
+    k = 1 - (2 - little_d) * krasnikov_theta(pmax - p, e) * krasnikov_theta(t - x - p, e) * (krasnikov_theta(x, e) - krasnikov_theta(x + e - D, e))
+    g = sp.zeros(4, 4)
+    g[0, 0] = -1
+    g[1, 1] = k
+    g[2, 2] = 1
+    g[3, 3] = 1
+    g[0, 1] = g[1, 0] = sp.Rational(1, 2) * (1 - k)
+    return g
 
 
 class Cx:
@@ -358,6 +449,24 @@ METRICS = {
                                      dynvars=["rs"]),
     "cosmic_string": dict(g=cosmic_string, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius, system="CYLINDRICAL",
                           periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True, dynvars=["mu"], cylindrical_terminator=0.005),
+    # the reference's own folder (settings: <name>.json over polar_base.json / ingoing_ef_base.json)
+    "schwarzschild_accurate": dict(g=schwarzschild_accurate, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                                   periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=True, dynvars=["rs"]),
+    "cosmic_string_bh": dict(g=cosmic_string_bh, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                             periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=True, dynvars=["rs", "B"]),
+    "janis_newman_winicour": dict(g=janis_newman_winicour, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                                  periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=False, dynvars=["r0", "mu"]),
+    "ellis_drainhole": dict(g=ellis_drainhole, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                            periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=False, detect=False, dynvars=["m", "n"]),
+    "kerr_ingoing_ef": dict(g=kerr_ingoing_ef, to_polar=ingoing_ef_to_polar, from_polar=polar_to_ingoing_ef, distance=radius,
+                            system="X_Y_THETA_PHI", periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=True,
+                            dynvars=["rs", "a"]),
+    "kerr_newman_schild": dict(g=kerr_newman_schild, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=radius, system="CARTESIAN",
+                               periodicity=None, singular=None, adaptive=True, detect=True, dynvars=["a", "rs", "Q"]),
+    "cosmic_string_spinning": dict(g=cosmic_string_spinning, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius,
+                                   system="CYLINDRICAL", periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=False, dynvars=["a", "k"]),
+    "krasnikov_cartesian": dict(g=krasnikov_cartesian, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=radius, system="CARTESIAN",
+                                periodicity=None, singular=None, adaptive=True, detect=False, dynvars=["e", "D", "pmax", "littled"]),
     # parameters baked in as numbers (csqrt of a symbolic value has no closed real form); the kernel is still the dynamic one
     "double_unequal_kerr": dict(g=double_unequal_kerr, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius,
                                 system="CYLINDRICAL", periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True,
@@ -501,5 +610,22 @@ def argument_string(name):
     return "-DLINEAR_FRAMEBUFFER " + text
 
 
+def tool_hash():
+    import hashlib
+    return hashlib.sha1(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16]
+
+
 if __name__ == "__main__":
-    print(argument_string(sys.argv[1] if len(sys.argv) > 1 else "kerr_boyer"))
+    if len(sys.argv) > 1 and sys.argv[1] == "--golden":
+        # every metric's string into tests/golden/sympy/ with the hash of this file: what tests/test_oracle.py uses while the hash
+        # matches (the derivations of the two dense charts take sympy minutes each); python tools/sympy_macros.py --golden after an edit
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sympy")
+        os.makedirs(out, exist_ok=True)
+        for name in (sys.argv[2:] or sorted(METRICS)):
+            with open(os.path.join(out, name + ".args"), "w") as f:
+                f.write(argument_string(name))
+            print("wrote", name, flush=True)
+        with open(os.path.join(out, "TOOL_HASH"), "w") as f:
+            f.write(tool_hash())
+    else:
+        print(argument_string(sys.argv[1] if len(sys.argv) > 1 else "kerr_boyer"))
