@@ -84,7 +84,10 @@ SYMPY_CASES = [("schwarzschild", "schwarzschild"), ("schwarzschild", "schwarzsch
                # in a cylinder chart, a time-dependent Cartesian chart built of tanh steps
                ("kerr_newman_schild", "refscripts/kerr_newman_schild"), ("kerr_newman_schild", "refscripts/kerr_newman_schild_prepass"),
                ("kerr_newman_schild", "refscripts/kerr_newman_schild_hole_prepass"),
-               ("cosmic_string_spinning", "refscripts/cosmic_string_spinning"), ("krasnikov_cartesian", "refscripts/krasnikov_cartesian")]
+               ("cosmic_string_spinning", "refscripts/cosmic_string_spinning"), ("krasnikov_cartesian", "refscripts/krasnikov_cartesian"),
+               # ... charts whose time coordinate is not the first (flat and Schwarzschild), a chart of coordinate system "OTHER"
+               ("minkowski_skew", "refscripts/minkowski_skew"), ("skewed_schwarzschild", "refscripts/skewed_schwarzschild"),
+               ("krasnikov_cylindrical", "refscripts/krasnikov_cylindrical")]
 
 
 def sympy_argument_string(metric):

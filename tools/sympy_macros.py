@@ -302,6 +302,38 @@ def krasnikov_cartesian(t, x, y, z):         # scripts/krasnikov_cartesian.js (K
     return g
 
 
+def minkowski_skew(x, t, y, z):               # scripts/minkowski_skew.js: flat space with the time coordinate second
+    return sp.diag(1, -1, 1, 1)
+
+
+def cartesian_skew_to_polar(x, t, y, z):      # scripts/coordinates/cartesian_skew_to_polar.js
+    return [t, sp.sqrt(x * x + y * y + z * z), sp.atan2(sp.sqrt(x * x + y * y), z), sp.atan2(y, x)]
+
+
+def polar_to_cartesian_skew(t, r, theta, phi):   # scripts/coordinates/polar_to_cartesian_skew.js
+    return [r * sp.sin(theta) * sp.cos(phi), t, r * sp.sin(theta) * sp.sin(phi), r * sp.cos(theta)]
+
+
+def skewed_schwarzschild(r, t, theta, phi):   # scripts/skewed_schwarzschild.js: Schwarzschild (rs = 1) with the radius first
+    return sp.diag(1 / (1 - 1 / r), -(1 - 1 / r), r * r, r * r * sp.sin(theta) ** 2)
+
+
+def swap_first_two(a, b, c, d):               # scripts/coordinates/skewed_polar_to_polar.js and polar_to_skewed_polar.js
+    return [b, a, c, d]
+
+
+def krasnikov_cylindrical(t, p, phi, x):      # scripts/krasnikov_cylindrical.js: the tube along the cylinder's axis; e, D, pmax are numbers in it
+    e, D, pmax, little_d = sp.Rational(1, 10), 2, 1, sp.Rational(1, 100)
+    k = 1 - (2 - little_d) * krasnikov_theta(pmax - p, e) * krasnikov_theta(t - x - p, e) * (krasnikov_theta(x, e) - krasnikov_theta(x + e - D, e))
+    g = sp.zeros(4, 4)
+    g[0, 0] = -1
+    g[1, 1] = 1
+    g[2, 2] = p * p
+    g[3, 3] = k
+    g[0, 3] = g[3, 0] = sp.Rational(1, 2) * (1 - k)
+    return g
+
+
 class Cx:
     """complex numbers as pairs of real sympy expressions (the role of the reference's dual_complex, js_interop.cpp:506-616)"""
 
@@ -467,6 +499,12 @@ METRICS = {
                                    system="CYLINDRICAL", periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=False, dynvars=["a", "k"]),
     "krasnikov_cartesian": dict(g=krasnikov_cartesian, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=radius, system="CARTESIAN",
                                 periodicity=None, singular=None, adaptive=True, detect=False, dynvars=["e", "D", "pmax", "littled"]),
+    "minkowski_skew": dict(g=minkowski_skew, to_polar=cartesian_skew_to_polar, from_polar=polar_to_cartesian_skew, distance=radius, system="CARTESIAN",
+                           periodicity=None, singular=None, adaptive=False, detect=False, dynvars=[]),
+    "skewed_schwarzschild": dict(g=skewed_schwarzschild, to_polar=swap_first_two, from_polar=swap_first_two, distance=radius, system="X_Y_THETA_PHI",
+                                 periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=True, dynvars=[]),
+    "krasnikov_cylindrical": dict(g=krasnikov_cylindrical, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius, system="OTHER",
+                                  periodicity=None, singular=None, adaptive=True, detect=False, dynvars=["e", "D", "pmax"]),
     # parameters baked in as numbers (csqrt of a symbolic value has no closed real form); the kernel is still the dynamic one
     "double_unequal_kerr": dict(g=double_unequal_kerr, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius,
                                 system="CYLINDRICAL", periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True,
