@@ -87,7 +87,17 @@ SYMPY_CASES = [("schwarzschild", "schwarzschild"), ("schwarzschild", "schwarzsch
                ("cosmic_string_spinning", "refscripts/cosmic_string_spinning"), ("krasnikov_cartesian", "refscripts/krasnikov_cartesian"),
                # ... charts whose time coordinate is not the first (flat and Schwarzschild), a chart of coordinate system "OTHER"
                ("minkowski_skew", "refscripts/minkowski_skew"), ("skewed_schwarzschild", "refscripts/skewed_schwarzschild"),
-               ("krasnikov_cylindrical", "refscripts/krasnikov_cylindrical")]
+               ("krasnikov_cylindrical", "refscripts/krasnikov_cylindrical"),
+               ("de_sitter", "refscripts/de_sitter"), ("godel_cylinder", "refscripts/godel_cylinder"),
+               # ... Kerr with cos theta as a coordinate (coordinate transforms with acos / cos), Misner space (a chart of its own with
+               # exponential transforms and a periodicity that is a parameter), an evaporating hole and Thorne's wormhole (CMath.select)
+               ("kerr_rational_polynomial", "refscripts/kerr_rational_polynomial"), ("misner_4d", "refscripts/misner_4d"),
+               ("schwarzschild_ingoing_ef_hawking", "refscripts/schwarzschild_ingoing_ef_hawking"),
+               ("configurable_wormhole", "refscripts/configurable_wormhole"),
+               # ... a hole in a magnetic universe, two Schwarzschild holes on the axis of a Weyl chart (eight square roots, the
+               # cylindrical-singularity flags with the terminator from the script's JSON)
+               ("ernst", "refscripts/ernst"), ("double_schwarzschild", "refscripts/double_schwarzschild"),
+               ("double_kerr", "refscripts/double_kerr")]
 
 
 def sympy_argument_string(metric):
@@ -138,6 +148,13 @@ def test_reference_with_independent_sympy_macros_agrees_with_the_fixtures(metric
     for f in ("position", "velocity", "acceleration", "initial_quat"):
         assert np.abs(ri[f] - gi[f]).max() <= 2e-5, f
     assert (ri["terminated"] == gi["terminated"]).all()
+    if name in ILL_CONDITIONED:
+        # the reference's own fp32 run of this frame is further from a float64 evaluation than the tolerance in more rays than two fp32
+        # builds differ (gpu_stages.ILL_CONDITIONED): the rule the GPU is held to there - not further from float64 than the fixture
+        # is, pixels off within the budget - and the set-up stages above, which are what a misread macro would break, as tightly as ever
+        assert_ill_conditioned_trace(name, meta, z, r["rays"])
+        assert_pixels(name, meta, z, r["pixels"])
+        return
     assert (r["rays"]["terminated"] != z["rays"]["terminated"]).mean() <= 0.005
     assert_traced_positions(name, r["rays"], z["rays"], ordinary_rays(meta, z), slack=0.002)
     if "termination" in z:

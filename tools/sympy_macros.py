@@ -87,6 +87,13 @@ def c_expr(e):
             body = "(" + "*".join([root] * abs(n)) + ")"
             return body if n > 0 else "(1.0f/" + body + ")"
         return "pow(" + c_expr(b) + "," + c_expr(x) + ")"      # (a real power of a parameter-dependent base: janis_newman_winicour)
+    if isinstance(e, sp.core.relational.Relational):   # (a condition that sympy's cse has made a temporary of: 1.0f / 0.0f once assigned)
+        rel = {sp.Le: "<=", sp.Lt: "<", sp.Ge: ">=", sp.Gt: ">"}[type(e)]
+        return "(" + c_expr(e.lhs) + rel + c_expr(e.rhs) + ")"
+    if isinstance(e, sp.Piecewise):             # CMath.select(condition, a, b)
+        (a, cond), (b, _) = e.args
+        test = "(" + cond.name + "!=0.0f)" if cond.is_Symbol else c_expr(cond)
+        return "(" + test + "?" + c_expr(a) + ":" + c_expr(b) + ")"
     if isinstance(e, sp.Function):
         name = {"Abs": "fabs"}.get(type(e).__name__, type(e).__name__)
         return name + "(" + ",".join(c_expr(a) for a in e.args) + ")"
@@ -302,6 +309,109 @@ def krasnikov_cartesian(t, x, y, z):         # scripts/krasnikov_cartesian.js (K
     return g
 
 
+def de_sitter(t, r, theta, phi):             # scripts/de_sitter.js: the static chart
+    lam = cfg_symbol("cosmological_constant")
+    return sp.diag(-(1 - lam * r * r / 3), 1 / (1 - lam * r * r / 3), r * r, r * r * sp.sin(theta) ** 2)
+
+
+def godel_cylinder(t, r, phi, z):            # scripts/godel_cylinder.js, entry for entry
+    a = cfg_symbol("a")
+    g = sp.zeros(4, 4)
+    g[0, 0] = -1
+    g[1, 1] = 1 / (1 + (r / (2 * a)) ** 2)
+    g[2, 2] = r * r * (1 - (r / (2 * a)) ** 2)
+    g[3, 3] = 1
+    g[0, 2] = g[2, 0] = -r * r / (sp.sqrt(2) * a)
+    return g
+
+
+def kerr_rational_polynomial(t, r, X, phi):   # scripts/kerr_rational_polynomial.js (Kerr with X = cos theta as the third coordinate)
+    m, a = cfg_symbol("m"), cfg_symbol("a")
+    S = r * r + a * a * X * X
+    g = sp.zeros(4, 4)
+    g[0, 0] = -(1 - 2 * m * r / S)
+    g[1, 1] = S / (r * r - 2 * m * r + a * a)
+    g[2, 2] = S / (1 - X * X)
+    g[3, 3] = (1 - X * X) * (r * r + a * a + (2 * m * a * a * r * (1 - X * X)) / S)
+    g[0, 3] = g[3, 0] = -(2 * a * m * r * (1 - X * X)) / S
+    return g
+
+
+def rational_to_polar(t, r, X, phi):          # scripts/coordinates/rational_to_polar.js
+    return [t, r, sp.acos(X), phi]
+
+
+def polar_to_rational(t, r, theta, phi):      # scripts/coordinates/polar_to_rational.js
+    return [t, r, sp.cos(theta), phi]
+
+
+def misner_4d(T, psi, y, z):                  # scripts/misner_4d.js (arXiv:1102.0907 (25)): -2 dT dpsi - T dpsi^2 + dy^2 + dz^2
+    g = sp.zeros(4, 4)
+    g[0, 1] = g[1, 0] = -1
+    g[1, 1] = -T
+    g[2, 2] = 1
+    g[3, 3] = 1
+    return g
+
+
+def misner_4d_to_polar(T, psi, y, z):         # scripts/coordinates/misner_4d_to_polar.js
+    t = T * sp.exp(psi / 2) - sp.exp(-psi / 2)
+    x = T * sp.exp(psi / 2) + sp.exp(-psi / 2)
+    return [t, sp.sqrt(x * x + y * y + z * z), sp.atan2(sp.sqrt(x * x + y * y), z), sp.atan2(y, x)]
+
+
+def polar_to_misner_4d(t, r, theta, phi):     # scripts/coordinates/polar_to_misner_4d.js
+    x = r * sp.sin(theta) * sp.cos(phi)
+    y = r * sp.sin(theta) * sp.sin(phi)
+    z = r * sp.cos(theta)
+    return [(x * x - t * t) / 4, -2 * sp.log((x - t) / 2), y, z]
+
+
+def hawking(vv, r, theta, phi):               # scripts/schwarzschild_ingoing_ef_hawking.js (arXiv:2103.08340: an evaporating hole in ingoing coordinates)
+    rs_base, lifetime = cfg_symbol("rs_base"), cfg_symbol("lifetime")
+    M0 = rs_base / 2
+    k = 2 * (M0 ** 3 / lifetime) ** sp.Rational(1, 3)
+    rs_v = sp.Piecewise((k * (lifetime - vv) ** sp.Rational(1, 3), vv <= lifetime), (0, True))
+    g = sp.zeros(4, 4)
+    g[0, 0] = -(1 - rs_v / r)
+    g[0, 1] = g[1, 0] = 1
+    g[2, 2] = r * r
+    g[3, 3] = r * r * sp.sin(theta) ** 2
+    return g
+
+
+def configurable_wormhole(t, l, theta, phi):  # scripts/configurable_wormhole.js (James, von Tunzelmann, Franklin & Thorne 2015, eq. 5)
+    M, p, a = cfg_symbol("M"), cfg_symbol("p"), cfg_symbol("a")
+    x = 2 * (sp.Abs(l) - a) / (sp.pi * M)
+    r = sp.Piecewise((p, sp.Abs(l) <= a), (p + M * (x * sp.atan(x) - sp.Rational(1, 2) * sp.log(1 + x * x)), True))
+    return sp.diag(-1, 1, r * r, r * r * sp.sin(theta) ** 2)
+
+
+def ernst(t, r, theta, phi):                 # scripts/ernst.js (Ernst 1976: a Schwarzschild hole in Melvin's magnetic universe)
+    B, rs = cfg_symbol("B"), cfg_symbol("rs")
+    lam2 = (1 + B * B * r * r * sp.sin(theta) ** 2) ** 2
+    return sp.diag(-lam2 * (1 - rs / r), lam2 / (1 - rs / r), lam2 * r * r, r * r * sp.sin(theta) ** 2 / lam2)
+
+
+def double_schwarzschild(t, p, phi, z):      # scripts/double_schwarzschild.js (two rods on the axis of a Weyl chart; Israel & Khan 1964)
+    M1, M2, z0 = cfg_symbol("M1"), cfg_symbol("M2"), cfg_symbol("z")
+    e, M = M2 - M1, M1 + M2
+    half = sp.Rational(1, 2)
+    ak = {1: -half * (M - e) - z0, 2: half * (M - e) - z0, 3: -half * (M + e) + z0, 4: half * (M + e) + z0}
+
+    def R(k):
+        return sp.sqrt(p * p + (z - ak[k]) ** 2)
+
+    def Y(k):
+        return R(k) + ak[k] - z
+
+    def Yij(i, j):
+        return R(i) * R(j) + (z - ak[i]) * (z - ak[j]) + p * p
+    e2k = (Yij(4, 3) * Yij(2, 1) * Yij(4, 1) * Yij(3, 2)) / (4 * Yij(4, 2) * Yij(3, 1) * R(1) * R(2) * R(3) * R(4))
+    e2U = (Y(1) * Y(3)) / (Y(2) * Y(4))
+    return sp.diag(-e2U, e2k / e2U, p * p / e2U, e2k / e2U)
+
+
 def minkowski_skew(x, t, y, z):               # scripts/minkowski_skew.js: flat space with the time coordinate second
     return sp.diag(1, -1, 1, 1)
 
@@ -461,6 +571,49 @@ def double_unequal_kerr(t, p, phi, z):       # scripts/double_unequal_kerr.js (M
     return g
 
 
+def double_kerr(t, p, phi, z):               # scripts/double_kerr.js (two equal Kerr holes on a strut), parameters as numbers: its defaults
+    import numpy as np
+    q = {k: sp.Float(float(np.float32(val)), 30) for k, val in dict(R=3.0, M=0.3, a=0.27).items()}   # the values the device holds
+    R, M, a = q["R"], q["M"], q["a"]
+    i = Cx(0, 1)
+    d = 2 * M * a * (R * R - 4 * M * M + 4 * a * a) / (R * R + 2 * M * R + 4 * a * a)
+    sigma_sq = M * M - a * a + (4 * M * M * a * a * (R * R - 4 * M * M + 4 * a * a)) / (R * R + 2 * M * R + 4 * a * a) ** 2
+    sp_ = sp.sqrt(sigma_sq)                  # real for these parameters
+    sn_ = -sp_
+    ia, id_ = i * a, i * d
+
+    def num(c):                              # constants to numbers: keeps the expressions small
+        c = Cx.of(c)
+        return Cx(sp.N(c.re, 30), sp.N(c.im, 30))
+
+    def upper(sg):
+        return num((Cx(-M * (2 * sg + R)) + id_) / (Cx(2 * M * M) + (Cx(R) + 2 * ia) * (Cx(sg) + ia))) * sp.sqrt(p * p + (z + R / 2 + sg) ** 2)
+
+    def lower(sg):
+        return num((Cx(-M * (2 * sg - R)) + id_) / (Cx(2 * M * M) - (Cx(R) - 2 * ia) * (Cx(sg) + ia))) * sp.sqrt(p * p + (z - R / 2 + sg) ** 2)
+    Rp, Rn, rp, rn = upper(sp_), upper(sn_), lower(sp_), lower(sn_)
+    K0 = sp.N(4 * sigma_sq * ((R * R + 2 * M * R + 4 * a * a) ** 2 - 16 * M * M * a * a) / (M * M * ((R + 2 * M) ** 2 + 4 * a * a)), 30)
+    s2 = sp.N(sigma_sq, 30)
+    s1 = sp.N(sp_, 30)
+    A = (R * R) * (Rp - Rn) * (rp - rn) - 4 * s2 * (Rp - rp) * (Rn - rn)
+    B = 2 * R * s1 * ((R + 2 * s1) * (Rn - rp) - (R - 2 * s1) * (Rp - rn))
+    G = (-z) * B + (R * s1) * (2 * R * (Rn * rn - Rp * rp) + 4 * s1 * (Rp * Rn - rp * rn) - (R * R - 4 * s2) * (Rp - Rn - rp + rn))
+    AB = A.conj() + B.conj()
+    norm = A.abs2() - B.abs2()
+    w = 4 * a - 2 * (G * AB).im / norm
+    denom = ((A + B) * AB).re
+    f = norm / denom
+    i_f = denom / norm
+    i_f_e2g = denom / (K0 * K0 * (Rp * Rn * rp * rn).re)
+    g = sp.zeros(4, 4)
+    g[0, 0] = -f
+    g[2, 2] = i_f * p * p - w * w * f
+    g[0, 2] = g[2, 0] = f * w
+    g[1, 1] = i_f_e2g
+    g[3, 3] = i_f_e2g
+    return g
+
+
 # settings resolved from scripts/<name>.json + the base it inherits (polar_base.json / cartesian_base.json)
 METRICS = {
     "schwarzschild": dict(g=schwarzschild, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
@@ -499,6 +652,26 @@ METRICS = {
                                    system="CYLINDRICAL", periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=False, dynvars=["a", "k"]),
     "krasnikov_cartesian": dict(g=krasnikov_cartesian, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=radius, system="CARTESIAN",
                                 periodicity=None, singular=None, adaptive=True, detect=False, dynvars=["e", "D", "pmax", "littled"]),
+    "de_sitter": dict(g=de_sitter, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                      periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=False, detect=False, dynvars=["cosmological_constant"]),
+    "godel_cylinder": dict(g=godel_cylinder, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius, system="CYLINDRICAL",
+                           periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True, dynvars=["a"], cylindrical_terminator=0.005),
+    "kerr_rational_polynomial": dict(g=kerr_rational_polynomial, to_polar=rational_to_polar, from_polar=polar_to_rational, distance=radius,
+                                     system="X_Y_THETA_PHI", periodicity=None, singular=None, adaptive=True, detect=True, dynvars=["m", "a"]),
+    "misner_4d": dict(g=misner_4d, to_polar=misner_4d_to_polar, from_polar=polar_to_misner_4d, distance=radius, system="OTHER",
+                      periodicity=[0, cfg_symbol("phi0"), 0, 0], singular=None, adaptive=True, detect=True, dynvars=["phi0"]),
+    "schwarzschild_ingoing_ef_hawking": dict(g=hawking, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                                             periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=True,
+                                             dynvars=["rs_base", "lifetime"]),
+    "configurable_wormhole": dict(g=configurable_wormhole, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                                  periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=False, dynvars=["M", "p", "a"]),
+    "ernst": dict(g=ernst, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                  periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=None, adaptive=True, detect=True, dynvars=["B", "rs"]),
+    "double_schwarzschild": dict(g=double_schwarzschild, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius,
+                                 system="CYLINDRICAL", periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True,
+                                 dynvars=["M1", "M2", "z"], cylindrical_terminator=0.005),
+    "double_kerr": dict(g=double_kerr, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius, system="CYLINDRICAL",
+                        periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True, dynvars=["R", "M", "a"]),
     "minkowski_skew": dict(g=minkowski_skew, to_polar=cartesian_skew_to_polar, from_polar=polar_to_cartesian_skew, distance=radius, system="CARTESIAN",
                            periodicity=None, singular=None, adaptive=False, detect=False, dynvars=[]),
     "skewed_schwarzschild": dict(g=skewed_schwarzschild, to_polar=swap_first_two, from_polar=swap_first_two, distance=radius, system="X_Y_THETA_PHI",
