@@ -97,7 +97,7 @@ SYMPY_CASES = [("schwarzschild", "schwarzschild"), ("schwarzschild", "schwarzsch
                # ... a hole in a magnetic universe, two Schwarzschild holes on the axis of a Weyl chart (eight square roots, the
                # cylindrical-singularity flags with the terminator from the script's JSON)
                ("ernst", "refscripts/ernst"), ("double_schwarzschild", "refscripts/double_schwarzschild"),
-               ("double_kerr", "refscripts/double_kerr")]
+               ("double_kerr", "refscripts/double_kerr"), ("minkowski", "minkowski"), ("minkowski", "minkowski_tilted")]
 
 
 def sympy_argument_string(metric):

@@ -412,6 +412,10 @@ def double_schwarzschild(t, p, phi, z):      # scripts/double_schwarzschild.js (
     return sp.diag(-e2U, e2k / e2U, p * p / e2U, e2k / e2U)
 
 
+def minkowski(t, x, y, z):                    # scripts/minkowski.js
+    return sp.diag(-1, 1, 1, 1)
+
+
 def minkowski_skew(x, t, y, z):               # scripts/minkowski_skew.js: flat space with the time coordinate second
     return sp.diag(1, -1, 1, 1)
 
@@ -672,6 +676,8 @@ METRICS = {
                                  dynvars=["M1", "M2", "z"], cylindrical_terminator=0.005),
     "double_kerr": dict(g=double_kerr, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius, system="CYLINDRICAL",
                         periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True, dynvars=["R", "M", "a"]),
+    "minkowski": dict(g=minkowski, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=radius, system="CARTESIAN",
+                      periodicity=None, singular=None, adaptive=False, detect=False, dynvars=[]),
     "minkowski_skew": dict(g=minkowski_skew, to_polar=cartesian_skew_to_polar, from_polar=polar_to_cartesian_skew, distance=radius, system="CARTESIAN",
                            periodicity=None, singular=None, adaptive=False, detect=False, dynvars=[]),
     "skewed_schwarzschild": dict(g=skewed_schwarzschild, to_polar=swap_first_two, from_polar=swap_first_two, distance=radius, system="X_Y_THETA_PHI",
