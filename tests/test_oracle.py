@@ -97,7 +97,8 @@ SYMPY_CASES = [("schwarzschild", "schwarzschild"), ("schwarzschild", "schwarzsch
                # ... a hole in a magnetic universe, two Schwarzschild holes on the axis of a Weyl chart (eight square roots, the
                # cylindrical-singularity flags with the terminator from the script's JSON)
                ("ernst", "refscripts/ernst"), ("double_schwarzschild", "refscripts/double_schwarzschild"),
-               ("double_kerr", "refscripts/double_kerr"), ("minkowski", "minkowski"), ("minkowski", "minkowski_tilted")]
+               ("double_kerr", "refscripts/double_kerr"), ("minkowski", "minkowski"), ("minkowski", "minkowski_tilted"),
+               ("double_kerr_alt", "refscripts/double_kerr_alt"), ("symmetric_warp_drive", "refscripts/symmetric_warp_drive")]
 
 
 def sympy_argument_string(metric):
@@ -161,10 +162,12 @@ def test_reference_with_independent_sympy_macros_agrees_with_the_fixtures(metric
         assert (r["termination"] != z["termination"]).mean() <= 0.01
     rd, gd = r["render_data"], z["render_data"]
     same = (rd["terminated"] == 1) & (gd["terminated"] == 1)
-    assert np.percentile(circ_diff(rd["tex_coord"][same], gd["tex_coord"][same]), 99) <= 1e-4
-    if meta["features"].get("redshift"):
-        # end to end (unlike the per-stage GPU tests): rays that wind around the photon sphere amplify last-place differences
-        assert np.percentile(np.abs(rd["z_shift"][same] - gd["z_shift"][same]), 90) <= 1e-4
+    assert same.any() or name == "refscripts/symmetric_warp_drive"      # (that script's metric loses every ray, in the reference too)
+    if same.any():
+        assert np.percentile(circ_diff(rd["tex_coord"][same], gd["tex_coord"][same]), 99) <= 1e-4
+        if meta["features"].get("redshift"):
+            # end to end (unlike the per-stage GPU tests): rays that wind around the photon sphere amplify last-place differences
+            assert np.percentile(np.abs(rd["z_shift"][same] - gd["z_shift"][same]), 90) <= 1e-4
     d = r["pixels"][..., :3] - z["pixels"][..., :3]
     bad = np.abs(d).max(axis=2) > 1e-3
     assert bad.mean() <= 0.005

@@ -618,6 +618,67 @@ def double_kerr(t, p, phi, z):               # scripts/double_kerr.js (two equal
     return g
 
 
+def double_kerr_alt(t, p, phi, z):           # scripts/double_kerr_alt.js (arXiv:1702.02209: two equal counter-rotating... as the script has them), defaults as numbers
+    import numpy as np
+    qn = {k: sp.Float(float(np.float32(val)), 30) for k, val in dict(R=4.0, M=0.3, q=0.2).items()}
+    R, M, q = qn["R"], qn["M"], qn["q"]
+    i = Cx(0, 1)
+
+    def num(c):
+        c = Cx.of(c)
+        return Cx(sp.N(c.re, 30), sp.N(c.im, 30))
+    sigma = sp.N(sp.sqrt(M * M - q * q * (1 - (4 * M * M * (R * R - 4 * M * M + 4 * q * q)) / (R * (R + 2 * M) + 4 * q * q) ** 2)), 30)
+    r1 = sp.sqrt(p * p + (z - R / 2 - sigma) ** 2)
+    r2 = sp.sqrt(p * p + (z - R / 2 + sigma) ** 2)
+    r3 = sp.sqrt(p * p + (z + R / 2 - sigma) ** 2)
+    r4 = sp.sqrt(p * p + (z + R / 2 + sigma) ** 2)
+    d = 2 * M * q * (R * R - 4 * M * M + 4 * q * q) / (R * (R + 2 * M) + 4 * q * q)
+    pp = num(Cx(2 * (M * M - q * q) - (R + 2 * M) * sigma + M * R, q * (R - 2 * sigma) + d))
+    pn = num(Cx(2 * (M * M - q * q) - (R - 2 * M) * sigma - M * R, q * (R - 2 * sigma) - d))
+    sp_ = num(Cx(2 * (M * M - q * q) + (R - 2 * M) * sigma - M * R, q * (R + 2 * sigma) - d))
+    sn = num(Cx(2 * (M * M - q * q) + (R + 2 * M) * sigma + M * R, q * (R + 2 * sigma) + d))
+    k0 = sp.N((R * R - 4 * sigma * sigma) * ((R * R - 4 * M * M) * (M * M - sigma * sigma) + 4 * q ** 4 + 4 * M * q * d), 30)
+    kp = num(Cx(R + 2 * sigma, 4 * q))
+    kn = num(Cx(R - 2 * sigma, -4 * q))
+    c = Cx.conj
+    delta = num(4 * sigma * sigma * (pp * pn * sp_ * sn)) * (r1 * r2) + num(4 * sigma * sigma * (c(pp) * c(pn) * c(sp_) * c(sn))) * (r3 * r4) \
+        - num(R * R * (c(pp) * c(pn) * sp_ * sn)) * (r1 * r3) - num(R * R * (pp * pn * c(sp_) * c(sn))) * (r2 * r4) \
+        + num((R * R - 4 * sigma * sigma) * (c(pp) * pn * c(sp_) * sn)) * (r1 * r4) + num((R * R - 4 * sigma * sigma) * (pp * c(pn) * sp_ * c(sn))) * (r2 * r3)
+    im_p, im_s = (pp * c(pn)).im, (sp_ * c(sn)).im
+    gamma = num(Cx(0, -2 * sigma * R)) * (num((R - 2 * sigma) * im_p * (sp_ * sn)) * r1 - num((R - 2 * sigma) * im_p * (c(sp_) * c(sn))) * r4
+                                        + num((R + 2 * sigma) * im_s * (pp * pn)) * r2 - num((R + 2 * sigma) * im_s * (c(pp) * c(pn))) * r3)
+    G = num(4 * sigma * sigma * (Cx(R, -2 * q) * pp * pn * sp_ * sn)) * (r1 * r2) - num(4 * sigma * sigma * (Cx(R, 2 * q) * c(pp) * c(pn) * c(sp_) * c(sn))) * (r3 * r4) \
+        - num(2 * R * R * (Cx(sigma, -q) * c(pp) * c(pn) * sp_ * sn)) * (r1 * r3) + num(2 * R * R * (Cx(sigma, q) * pp * pn * c(sp_) * c(sn))) * (r2 * r4) \
+        - num(Cx(0, 2 * q * (R * R - 4 * sigma * sigma) * (pp * c(pn) * sp_ * c(sn)).re)) * (r1 * r4 + r2 * r3) \
+        - num(Cx(0, sigma * R)) * (num((R - 2 * sigma) * im_p * (c(kp) * sp_ * sn)) * r1 + num((R - 2 * sigma) * im_p * (kp * c(sp_) * c(sn))) * r4
+                                 + num((R + 2 * sigma) * im_s * (kn * pp * pn)) * r2 + num((R + 2 * sigma) * im_s * (c(kn) * c(pp) * c(pn))) * r3)
+    norm = delta.abs2() - gamma.abs2()
+    dmg = delta - gamma
+    w = 2 * (dmg * (z * c(gamma) + c(G))).im / norm
+    e2y = norm / (256 * sigma ** 4 * R ** 4 * k0 * k0 * r1 * r2 * r3 * r4)
+    f = norm / (dmg * (c(delta) - c(gamma))).re
+    g = sp.zeros(4, 4)
+    g[0, 0] = -f
+    g[1, 1] = e2y / f
+    g[2, 2] = p * p / f - f * w * w
+    g[3, 3] = e2y / f
+    g[0, 2] = g[2, 0] = f * w
+    return g
+
+
+def symmetric_warp_drive(t, r, theta_unused, phi):   # scripts/symmetric_warp_drive.js (arXiv:2010.11031; the script pins theta to pi / 2 inside the metric)
+    theta = sp.pi / 2
+    rg = 1
+    a20 = 1 - sp.Integer(rg) / r
+    a0 = sp.sqrt(a20)
+    yrr0 = 1 / (1 - sp.Integer(rg) / r)
+    gamma_0 = r ** 4 * sp.sin(theta) ** 2 / (1 - sp.Integer(rg) / r)
+    littlea = rg * theta / a0
+    littleb = rg * theta - sp.sqrt(gamma_0)
+    U = (littlea * (a20 + t / theta) ** sp.Rational(3, 2) - littleb) / (littlea * a0 ** 3 - littleb)
+    return sp.diag(-(a20 + t / theta), U * yrr0, U * r * r, U * r * r * sp.sin(theta) ** 2)
+
+
 # settings resolved from scripts/<name>.json + the base it inherits (polar_base.json / cartesian_base.json)
 METRICS = {
     "schwarzschild": dict(g=schwarzschild, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
@@ -676,6 +737,10 @@ METRICS = {
                                  dynvars=["M1", "M2", "z"], cylindrical_terminator=0.005),
     "double_kerr": dict(g=double_kerr, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius, system="CYLINDRICAL",
                         periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True, dynvars=["R", "M", "a"]),
+    "double_kerr_alt": dict(g=double_kerr_alt, to_polar=cylindrical_to_polar, from_polar=polar_to_cylindrical, distance=radius, system="CYLINDRICAL",
+                            periodicity=[0, 0, 2 * sp.pi, 0], singular=None, adaptive=True, detect=True, dynvars=["R", "M", "q"]),
+    "symmetric_warp_drive": dict(g=symmetric_warp_drive, to_polar=identity, from_polar=identity, distance=radius, system="X_Y_THETA_PHI",
+                                 periodicity=[0, 0, sp.pi, 2 * sp.pi], singular=1.001, adaptive=True, detect=True, dynvars=[]),
     "minkowski": dict(g=minkowski, to_polar=cartesian_to_polar, from_polar=polar_to_cartesian, distance=radius, system="CARTESIAN",
                       periodicity=None, singular=None, adaptive=False, detect=False, dynvars=[]),
     "minkowski_skew": dict(g=minkowski_skew, to_polar=cartesian_skew_to_polar, from_polar=polar_to_cartesian_skew, distance=radius, system="CARTESIAN",
