@@ -248,7 +248,8 @@ def main():
     ring = [Slot(i == 0) for i in range(in_flight)]
     state, out, stream = ring[0].state, ring[0].out, ring[0].stream.cuda_stream
 
-    # The RCCL exchange of gr_render_frame_tiled cannot be exercised with two ranks before the first multi-GPU run (RCCL refuses
+    # The RCCL exchange of gr_render_frame_tiled has run with several ranks only over RCCL's socket transport (GR_BENCH_ONE_DEVICE=rccl:
+    # ranks that each claim a host of their own; RCCL refuses
     # two ranks on one device), so the first thing an N > 1 run does is check it: one frame through it, compared on rank 0 with the
     # frame rank 0 renders on its own (a device's share of a split frame equals those rows of the whole frame bit for bit, tests/).
     # A frame that differs sends every rank to the round-1 gather; a frame that does not come back within two minutes ends the run

@@ -153,7 +153,7 @@ int rccl_recv(void* user, void* data, size_t floats, int peer, void* stream) {
 }
 
 // ---- GR_TRANSPORT_IPC: the point-to-point calls of a split frame between PROCESSES THAT MAY SHARE A DEVICE -------------------------
-// RCCL refuses two ranks on one device, so on a one-GPU box the N-process path of gr_render_frame_tiled - one process per rank, a
+// RCCL refuses two ranks of one host on one device (unless each claims a host of its own: NCCL_HOSTID, tests/test_gpu_two_ranks.py), so on a one-GPU box the N-process path of gr_render_frame_tiled - one process per rank, a
 // group per frame, per block a send on the owner and the matching receive on the root, rotation, frames in flight on several
 // streams - could only be exercised with one participant.  This transport keeps the call pattern and the matching rule (the n-th
 // send of rank r to the root meets the root's n-th receive from r) and moves the data itself: a receive publishes where the block

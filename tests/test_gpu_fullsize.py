@@ -460,7 +460,7 @@ def test_cpp_example_renders_a_png(tmp_path):
 
 def test_cpp_tiled_example_renders_a_png(tmp_path):
     """examples/render_tiled.cpp - the N-process host of a split frame written against the C ABI alone - with the one participant
-    a one-GPU box allows (RCCL refuses two ranks on a device): communicator-less gr_tiled_create, frames in flight on three
+    a one-GPU box allows as it is (RCCL refuses two ranks of one host on a device): communicator-less gr_tiled_create, frames in flight on three
     streams through gr_render_frame_tiled, PNG from rank 0; through --spawn (the fork-per-GPU launcher) as well"""
     import os
     import subprocess
