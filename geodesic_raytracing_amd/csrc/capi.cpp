@@ -140,7 +140,7 @@ bool pair_kernel_applies(const std::vector<std::string>& opts) {
 
 // VGPRs and scratch bytes per lane of one kernel, read from the code object's metadata note (msgpack: the kernel's map holds
 // ".name", later ".private_segment_fixed_size" and ".vgpr_count" - keys are sorted).  false when the note is not understood.
-bool kernel_resources(const std::string& code, const char* kernel, int& vgprs, int& scratch_bytes) {
+bool kernel_resources(const std::string& code, const char* kernel, int& vgprs, int& scratch_bytes, int* sgprs = nullptr) {
     auto msgpack_uint = [&](size_t at, long& value) -> bool {
         if (at >= code.size()) return false;
         const unsigned char c = (unsigned char)code[at];
@@ -164,7 +164,24 @@ bool kernel_resources(const std::string& code, const char* kernel, int& vgprs, i
     if (!msgpack_uint(s + scratch_key.size(), sv) || !msgpack_uint(v + vgpr_key.size(), vv)) return false;
     vgprs = (int)vv;
     scratch_bytes = (int)sv;
+    if (sgprs) {
+        const std::string sgpr_key = ".sgpr_count";
+        const size_t g = code.find(sgpr_key, at);
+        long gv = 0;
+        *sgprs = (g != std::string::npos && g < v && msgpack_uint(g + sgpr_key.size(), gv)) ? (int)gv : 0;
+    }
     return vgprs > 0 && vgprs <= 512;
+}
+
+// Waves per SIMD a kernel of 256-thread workgroups is resident with on gfx950, by registers.  Vector registers: 512 per lane in
+// granules of 8.  Scalar registers: 800 per SIMD, a wave takes its count + 6 (VCC, flat scratch, XNACK) rounded up to 16, plus 16 -
+// measured with a timeline of tile begin / end stamps (tools/timeline_probe.py): the Kerr kernel at 72 VGPRs and 94 SGPRs holds 6
+// waves per SIMD, not the 7 its vector registers allow; capped to 90 or 78 SGPRs it holds 7; at 64 VGPRs and <= 74 SGPRs 8.
+int resident_waves_per_simd(int vgprs, int sgprs) {
+    int by_vgprs = 512 / (((vgprs + 7) / 8) * 8);
+    int by_sgprs = sgprs > 0 ? 800 / ((((sgprs + 6) + 15) / 16) * 16 + 16) : 8;
+    int w = by_vgprs < by_sgprs ? by_vgprs : by_sgprs;
+    return w > 8 ? 8 : w;
 }
 
 // Compiles (or fetches from the on-disk cache) the code object for one macro string.
@@ -313,7 +330,10 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     // 1 535 / 6.2; to 72 (7 waves, 84 bytes) 1 530 / 6.2.  With today's loop: 6 waves spill 24 bytes; 7 and 8 waves measure the same.
     // Rule: rebuild with the register budget of five sixths of what the free build took, rounded down to an occupancy step,
     // and keep that build unless it spills more than 96 bytes per lane (the same source compiles to a spill that differs by 20 B
-    // from one hiprtc run to the next, and a limit next to the expected number flipped the decision with it).
+    // from one hiprtc run to the next, and a limit next to the expected number flipped the decision with it) - or unless its waves
+    // would not be resident anyway (round 4): the kernel's ~94 scalar registers admit 6 waves per SIMD, so the "7 waves" build of
+    // rounds 2 and 3 (72 VGPRs, 48 B spilled) ran 6 like the 80-register build that spills 16 B; that one is 3 % faster one frame at
+    // a time (5.46 against 5.65 ms, 4K Kerr) and the same with frames in flight.
     bool tuned_by_caller = false;
     for (auto& o : opts) tuned_by_caller |= o.rfind("-DGR_FUSED_WAVES", 0) == 0 || o.rfind("-DGR_TRACE_WAVES", 0) == 0;
     const char* tuning = getenv("GR_OCCUPANCY_TUNING");
@@ -332,12 +352,13 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
                 std::vector<std::string> capped = opts;
                 capped.push_back("-DGR_FUSED_WAVES=" + std::to_string(waves));
                 std::string code2;
-                int v2 = 0, s2 = 0;
-                const bool built = build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2);
-                const bool keep = built && s2 <= scratch + 96;
+                int v2 = 0, s2 = 0, g2 = 0;
+                const bool built = build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2, &g2);
+                const bool resident = built && resident_waves_per_simd(v2, g2) >= waves;
+                const bool keep = built && s2 <= scratch + 96 && resident;
                 if (getenv("GR_VERBOSE_BUILD"))
-                    fprintf(stderr, "[gr] gr_trace_fused: free build %d VGPRs / %d B scratch; held to %d waves: %d VGPRs / %d B scratch%s\n", vgprs,
-                            scratch, waves, v2, s2, keep ? " (kept)" : " (dropped)");
+                    fprintf(stderr, "[gr] gr_trace_fused: free build %d VGPRs / %d B scratch; held to %d waves: %d VGPRs / %d SGPRs / %d B scratch%s\n", vgprs,
+                            scratch, waves, v2, g2, s2, keep ? " (kept)" : resident ? " (dropped)" : " (dropped: its scalar registers admit fewer waves)");
                 if (keep) { code.swap(code2); break; }
             }
         }
