@@ -103,11 +103,15 @@ class OraclePipeline:
             out["adaptive_count"] = int(count2[0])
         out["render_data"] = rdata.copy()
         if background is not None:
-            bg, levels = background
+            # (sky, levels): the same sky on both sides of a wormhole; (sky1, sky2, levels): mip_background / mip_background2 of
+            # render (cl.cl:5453-5457) - read_mipmap returns the first for side >= 1 and the second otherwise (cl.cl:5445-5448)
+            bg, bg2, levels = background if len(background) == 3 else (background[0], background[0], background[1])
             bg = np.ascontiguousarray(bg, dtype=np.uint8)
+            bg2 = np.ascontiguousarray(bg2, dtype=np.uint8)
+            assert bg.shape == bg2.shape
             bh, bw = bg.shape[1], bg.shape[2]
             pixels = np.zeros((height, width, 4), dtype="<f4")
-            L.ref_render(_p(rdata), _p(rcount), n, _p(pixels), _p(bg), _p(bg), bw, bh, levels, width, height, max_probes, _p(cfg),
+            L.ref_render(_p(rdata), _p(rcount), n, _p(pixels), _p(bg), _p(bg2), bw, bh, levels, width, height, max_probes, _p(cfg),
                          _p(dfg), nthreads)
             out["pixels"] = pixels
         return out

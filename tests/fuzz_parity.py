@@ -53,10 +53,12 @@ PREPASS = os.environ.get("FUZZ_PREPASS", "0") not in ("", "0")     # every case 
 
 def draw_cases(cases, seed):
     """the soak's cases, drawn from one random stream: (index, metric name, metric, cfg, camera position, orientation, observer speed,
-    feature keywords, camera distance).  FUZZ_ADAPTIVE=1: the same cases with adaptive sampling on, the threshold from a stream of its
-    own (so that a seed names the same cameras either way)"""
+    feature keywords, camera distance, max_probes).  FUZZ_ADAPTIVE=1: the same cases with adaptive sampling on, the threshold from a
+    stream of its own (so that a seed names the same cameras either way).  Round 5: use_old_redshift (with redshift on), min_step
+    (values at which calculate_ds_error's bail-out fires, cl.cl:3439-3450) and render's probe cap (cl.cl:5597-5613) from a third stream."""
     rng = np.random.default_rng(seed)
     thresholds = np.random.default_rng(seed + 1000003)
+    knobs = np.random.default_rng(seed + 2000003)
     names = sorted(METRICS)
     for case in range(cases):
         name = names[case % len(names)]
@@ -75,7 +77,11 @@ def draw_cases(cases, seed):
                    universe_size=float(rng.choice([20.0, 30.0])), max_precision_radius=float(rng.choice([10.0, 14.0])))
         if ADAPTIVE:
             fkw.update(adaptive_sampling=1, adaptive_sampling_threshold=float(thresholds.choice([16.0, 32.0, 64.0])))
-        yield case, name, metric, cfg, pos, quat, speed, fkw, r
+        old_redshift, min_step, max_probes = knobs.random() < 0.5, float(knobs.choice([1e-6, 1e-6, 1e-3, 1e-2])), int(knobs.choice([1, 4, 8, 8, 16]))
+        if fkw["redshift"]:
+            fkw["use_old_redshift"] = int(old_redshift)
+        fkw["min_step"] = min_step
+        yield case, name, metric, cfg, pos, quat, speed, fkw, r, max_probes
 
 
 def _precompile(argument_string):
@@ -88,7 +94,7 @@ def precompile(cases, seed):
     the soak on the GPU box spends its time rendering"""
     import multiprocessing
     strings, oracle_keys = [], []
-    for case, name, metric, cfg, pos, quat, speed, fkw, r in draw_cases(cases, seed):
+    for case, name, metric, cfg, pos, quat, speed, fkw, r, max_probes in draw_cases(cases, seed):
         key = metric.argument_string()
         if key not in oracle_keys:
             oracle_keys.append(key)
@@ -119,12 +125,14 @@ def main():
         w, h = (int(v) for v in os.environ["FUZZ_SIZE"].split("x"))
     # (four sky texels to a pixel either way: with two, a frame that looks down the chart's axis - grid lines converging on the pole all
     # over it - turns sky coordinates that agree to 2e-6 into pixels 5e-4 apart on every line, masked RMSE 1.4e-4)
-    bg_np, levels = gra.pack_background(gra.synthetic_background(*((512, 256) if PREPASS else (256, 128))))
-    bg = DeviceBuffer.from_numpy(0, bg_np)
+    sky_size = (512, 256) if PREPASS else (256, 128)
+    bg_np, levels = gra.pack_background(gra.synthetic_background(*sky_size))
+    bg2_np, _ = gra.pack_background(gra.synthetic_background(*sky_size, seed=0x2B5EED))   # what a ray that ends on the far side samples (cl.cl:5445-5448)
+    bg, bg2 = DeviceBuffer.from_numpy(0, bg_np), DeviceBuffer.from_numpy(0, bg2_np)
     out = DeviceBuffer(0, w * h * 16)
     state = gra.RenderState(w, h, 0)
     oracles, worst, failed, explained = {}, 0.0, 0, 0
-    for case, name, metric, cfg, pos, quat, speed, fkw, r in draw_cases(cases, seed):
+    for case, name, metric, cfg, pos, quat, speed, fkw, r, max_probes in draw_cases(cases, seed):
         only = int(sys.argv[3]) if len(sys.argv) > 3 else None
         if only is not None and case != only:
             continue
@@ -133,17 +141,17 @@ def main():
         if key not in oracles:
             oracles[key] = OraclePipeline(build_restate.build(key))
         ref = oracles[key].frame(w, h, cfg, pack_features(**fkw), camera_pos=pos, camera_quat=quat, basis_speed=speed,
-                                 background=(bg_np, levels), nthreads=os.cpu_count() or 4, use_prepass=PREPASS)
+                                 background=(bg_np, bg2_np, levels), nthreads=os.cpu_count() or 4, use_prepass=PREPASS, max_probes=max_probes)
         oracles[key].lib.ref_last_attempts.restype = ctypes.c_uint64
         cam = gra.default_camera(pos, quat)
         cam.basis_speed = (gra.c_float * 3)(*speed)
-        line = f"{case:3d} {name:26s} r={r:5.2f} speed={int(any(speed))} redshift={fkw['redshift']} reparam={fkw['reparameterisation']}"
+        line = f"{case:3d} {name:26s} r={r:5.2f} speed={int(any(speed))} redshift={fkw['redshift']}{'o' if fkw.get('use_old_redshift') else ''} reparam={fkw['reparameterisation']} min_step={fkw['min_step']:.0e} probes={max_probes:2d}"
         for label, prog in (("dyn", gra.Program(key, 0)),
                             ("sub", gra.Program(metric.argument_string(features=feats, static=True, cfg_values=cfg), 0))):
             # FUZZ_MODE=reference: the reference-shaped kernel sequence instead of the fused kernels
             o = gra.frame_options(mode=gra.MODE_REFERENCE if os.environ.get("FUZZ_MODE") == "reference" else gra.MODE_FUSED,
-                                  use_prepass=1 if PREPASS else 0, count_attempts=1)
-            state.render(prog, metric, cam, out.ptr, (bg.ptr, bg_np.shape[2], bg_np.shape[1], levels), feats, cfg, o)
+                                  use_prepass=1 if PREPASS else 0, count_attempts=1, max_probes=max_probes)
+            state.render(prog, metric, cam, out.ptr, ((bg.ptr, bg2.ptr), bg_np.shape[2], bg_np.shape[1], levels), feats, cfg, o)
             state.synchronize()
             px = out.to_numpy(np.float32, (h, w, 4))
             d = px[..., :3] - ref["pixels"][..., :3]
@@ -164,7 +172,7 @@ def main():
                 so = build_ref.prebuilt("fuzz_" + name, key)
                 if so:
                     theirs = OraclePipeline(so).frame(w, h, cfg, pack_features(**fkw), camera_pos=pos, camera_quat=quat, basis_speed=speed,
-                                                      background=(bg_np, levels), nthreads=os.cpu_count() or 4, use_prepass=PREPASS)
+                                                      background=(bg_np, bg2_np, levels), nthreads=os.cpu_count() or 4, use_prepass=PREPASS, max_probes=max_probes)
                     scatter = int((np.abs(theirs["pixels"][..., :3] - ref["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
                     against = int((np.abs(px[..., :3] - theirs["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
                     # ... and the reference build's rays against a float64 evaluation of the same algorithm: sky angles off by > 1e-3

@@ -26,6 +26,7 @@ from oracle.refpipe import OraclePipeline, pack_features  # noqa: E402
 
 BG_SIZE = (256, 128)
 BG_SEED = 0x5EED
+BG_SEED2 = 0x2B5EED   # the second sky (mip_background2 of render, cl.cl:5453-5457: what a ray that ends on the far side of a wormhole samples)
 
 
 def quat_axis_angle(axis, angle):
@@ -91,6 +92,20 @@ CASES = {
     "schwarzschild_adaptive_rs": dict(metric="schwarzschild_adaptive", scripts=True, size=(48, 27), cfg=dict(rs=1.6),
                                       camera_pos=[0.0, 3.0, -6.0, 2.0], camera_quat=TILTED_QUAT),
     "kerr_moving_observer": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.3, 0.0, 0.2], features=dict(redshift=1)),
+    # round 5: branches of render / the step controller no fixture reached.  A Kerr observer flying at the hole (the frame is blue-shifted:
+    # z < 0 nearly everywhere) with the energy-conserving branch of redshift() switched off (use_old_redshift, cl.cl:5397-5405) ...
+    "kerr_blueshift_old_redshift": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.1, 0.45, 0.05],
+                                        features=dict(redshift=1, use_old_redshift=1)),
+    "kerr_blueshift": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.1, 0.45, 0.05], features=dict(redshift=1)),
+    # ... the probe cap of the anisotropic filter (iProbes = min(iProbes, maxProbes), cl.cl:5597-5613) below and above the GUI's 8, on a
+    # wide view of a near hole (strongly stretched pixels next to the shadow) over a sky large enough for the filter to matter ...
+    "kerr_max_probes_1": dict(metric="kerr_boyer", size=(64, 36), bg_size=(1024, 512), cfg=dict(a=0.45), max_probes=1, features=dict(field_of_view=110.0)),
+    "kerr_max_probes_16": dict(metric="kerr_boyer", size=(64, 36), bg_size=(1024, 512), cfg=dict(a=0.45), max_probes=16, features=dict(field_of_view=110.0)),
+    # ... and a min_step at which calculate_ds_error's bail-out (next_ds == min_step && diff > err * 10000 -> DS_RETURN, cl.cl:3439-3450) fires
+    # (measured on the reference's x86 build: 50 of the 1 296 rays of the first and 97 of the second end differently than with 1e-6)
+    "kerr_min_step": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), features=dict(min_step=1e-2)),
+    "kerr_script_min_step_far": dict(metric="kerr_boyer", scripts=True, tag="kerr_boyer_script", size=(48, 27), cfg=dict(a=0.45), camera_pos=[0.0, 0.0, -8.0, 0.0],
+                                     features=dict(min_step=1e-2)),
 }
 
 
@@ -307,16 +322,17 @@ def make_case(name, spec, scripts_dir=None, subdir=None):
     feats.update(spec.get("features", {}))
     w, h = spec["size"]
     bg_size = tuple(spec.get("bg_size", BG_SIZE))
-    bg_rgba = gra.synthetic_background(*bg_size, seed=BG_SEED)
-    bg, levels = gra.pack_background(bg_rgba)
+    bg, levels = gra.pack_background(gra.synthetic_background(*bg_size, seed=BG_SEED))
+    bg2, _ = gra.pack_background(gra.synthetic_background(*bg_size, seed=BG_SEED2))
+    max_probes = int(spec.get("max_probes", 8))
     pipe = OraclePipeline(so)
     prepass = bool(spec.get("prepass", False))
     res = pipe.frame(w, h, cfg, pack_features(**feats), camera_pos=spec.get("camera_pos", (0, 0, -4, 0)),
-                     camera_quat=spec.get("camera_quat", DEFAULT_QUAT), use_prepass=prepass, background=(bg, levels),
-                     basis_speed=spec.get("basis_speed", (0, 0, 0)), flip=float(spec.get("flip", 0.0)))
+                     camera_quat=spec.get("camera_quat", DEFAULT_QUAT), use_prepass=prepass, background=(bg, bg2, levels),
+                     basis_speed=spec.get("basis_speed", (0, 0, 0)), flip=float(spec.get("flip", 0.0)), max_probes=max_probes)
     meta = dict(flip=float(spec.get("flip", 0.0)), metric=spec["metric"], scripts=bool(spec.get("scripts")), width=w, height=h, cfg=cfg, features=feats, camera_pos=list(map(float, spec.get("camera_pos", (0, 0, -4, 0)))),
-                camera_quat=list(map(float, spec.get("camera_quat", DEFAULT_QUAT))), prepass=prepass, bg_size=bg_size, bg_seed=BG_SEED,
-                basis_speed=list(map(float, spec.get("basis_speed", (0, 0, 0)))), max_probes=8,
+                camera_quat=list(map(float, spec.get("camera_quat", DEFAULT_QUAT))), prepass=prepass, bg_size=bg_size, bg_seed=BG_SEED, bg_seed2=BG_SEED2,
+                basis_speed=list(map(float, spec.get("basis_speed", (0, 0, 0)))), max_probes=max_probes,
                 argument_string_fnv=hex(hash(metric.argument_string()) & 0xffffffff))
     if scripts_dir:
         info = metric.info

@@ -59,6 +59,15 @@ def program_for(meta):
     return _programs[key]
 
 
+def backgrounds(meta):
+    """(sky 1, sky 2, levels) of a golden case, packed as render reads them: mip_background is what a ray that ends on the near side
+    samples, mip_background2 the far side (read_mipmap, cl.cl:5421-5449: side >= 1 ? v1 : v2).  Two different skies since round 5 -
+    until then every test passed one buffer twice, and a near/far mix-up in the kernel would have passed all of them."""
+    bg, levels = gra.pack_background(gra.synthetic_background(*meta["bg_size"], seed=meta["bg_seed"]))
+    bg2, _ = gra.pack_background(gra.synthetic_background(*meta["bg_size"], seed=meta["bg_seed2"]))
+    return bg, bg2, levels
+
+
 def features_from(meta):
     f = gra.default_features()
     for k, v in meta["features"].items():
@@ -131,13 +140,13 @@ class Stages:
                                                    self.cfg.ptr, self.dfg.ptr))
         return rdata.to_numpy(RENDER_DATA_DTYPE, self.w * self.h)
 
-    def render(self, rdata, background, levels, max_probes=8):
+    def render(self, rdata, background, background2, levels, max_probes=8):
         d_r = buf(rdata)
         count = buf(np.array([self.w * self.h], dtype=np.int32))
-        bg = buf(background)
+        bg, bg2 = buf(background), buf(background2)
         out = buf(np.zeros((self.h, self.w, 4), dtype=np.float32))
         bh, bw = background.shape[1], background.shape[2]
-        gra.check(gra.lib.gr_render(self.p, None, d_r.ptr, count.ptr, self.w * self.h, out.ptr, bg.ptr, bg.ptr, bw, bh, levels, self.w,
+        gra.check(gra.lib.gr_render(self.p, None, d_r.ptr, count.ptr, self.w * self.h, out.ptr, bg.ptr, bg2.ptr, bw, bh, levels, self.w,
                                     self.h, max_probes, self.cfg.ptr, self.dfg.ptr))
         return out.to_numpy(np.float32, (self.h, self.w, 4))
 
@@ -225,9 +234,9 @@ def ill_conditioned_budget(name, meta, z):
         want = z["rays"]
         both = (t64 == 1) & (want["terminated"] == 1)
         reference_off = int((position_err(want["position"][both], p64[both]).max(axis=1) > 1e-3).sum())
-        bg, levels = gra.pack_background(gra.synthetic_background(*meta["bg_size"], seed=meta["bg_seed"]))
+        bg, bg2, levels = backgrounds(meta)
         cpu = pipe.frame(meta["width"], meta["height"], meta["cfg"], feats, camera_pos=meta["camera_pos"], camera_quat=meta["camera_quat"],
-                         basis_speed=meta["basis_speed"], background=(bg, levels), nthreads=8, flip=float(meta.get("flip", 0.0)),
+                         basis_speed=meta["basis_speed"], background=(bg, bg2, levels), nthreads=8, flip=float(meta.get("flip", 0.0)),
                          use_prepass=meta["prepass"])
         cpu_bad = int((np.abs(cpu["pixels"][..., :3] - z["pixels"][..., :3]).max(axis=2) > 1e-3).sum())
         _budgets[name] = (reference_off, cpu_bad, p64, t64)

@@ -211,6 +211,47 @@ def test_alcubierre_8k_frame_against_the_oracle():
     assert np.percentile(dz, 99) <= 1e-5 and np.abs(ref["z_shift"][both]).max() > 0
 
 
+def test_adaptive_4k_frame_against_the_oracle():
+    """The adaptively sampled frame bench.py reports (`adaptive_sampling_on_threshold32_fused_substituted`: scripts/kerr_boyer.js, a = 0.45,
+    3840x2160, threshold 32, substituted program, fused kernels - lattice launch, gr_adaptive_refine_list, gr_trace_pending -, prepass on)
+    against the CPU oracle's adaptively sampled frame of the SAME size (handle_adaptive_sampling, cl.cl:5223-5345; host sequence main.cpp:
+    2480-2510).  The strided comparison of the other full-size tests does not apply - which pixels are refined depends on the resolution -
+    so the oracle renders all 8.3 M pixels on every host core (about 15 s on the GPU box).  Until round 5 this mode met the oracle only
+    at 48x28 / 64x36 / 128x72.  Rules: refined pixels within 0.5 % of the oracle's count; pixels by the standard end-to-end rule
+    (off by > 1e-3: at most 0.5 % of the frame; RMSE of the rest <= 1e-4); no record left pending."""
+    import os
+    from oracle import build_restate
+    from oracle.refpipe import OraclePipeline, pack_features
+    w, h = 3840, 2160
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfg = metric.cfg_values(a=0.45)
+    fkw = dict(adaptive_sampling=1, adaptive_sampling_threshold=32.0)
+    feats = metric.features(**fkw)
+    prog = gra.Program(metric.argument_string(features=feats, static=True, cfg_values=cfg), 0)
+    sky, levels = gra.pack_background(gra.synthetic_background(1024, 512))
+    sky2, _ = gra.pack_background(gra.synthetic_background(1024, 512, seed=0x2B5EED))
+    dsky, dsky2 = DeviceBuffer.from_numpy(0, sky), DeviceBuffer.from_numpy(0, sky2)
+    out = DeviceBuffer(0, w * h * 16)
+    state = gra.RenderState(w, h, 0)
+    state.render(prog, metric, gra.default_camera(), out.ptr, ((dsky.ptr, dsky2.ptr), 1024, 512, levels), feats, cfg,
+                 gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1))
+    state.synchronize()
+    px = out.to_numpy(np.float32, (h, w, 4))
+    marked = int(download(0, state.buffer(gra.BUF_RAYS_ADAPTIVE_COUNT), np.int32, 1)[0])
+    rd = download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h)
+    assert (rd["terminated"] >= 0).all()
+    del rd
+    pipe = OraclePipeline(build_restate.build(metric.argument_string()))
+    ref = pipe.frame(w, h, cfg, pack_features(max_acceleration_change=metric.info.max_acceleration_change, **fkw), use_prepass=True,
+                     background=(sky, sky2, levels), nthreads=os.cpu_count() or 4)
+    assert 0.02 * w * h < ref["adaptive_count"] < 0.5 * w * h
+    assert abs(marked - ref["adaptive_count"]) <= 0.005 * ref["adaptive_count"], (marked, ref["adaptive_count"])
+    d = px[..., :3] - ref["pixels"][..., :3]
+    bad = ~(np.abs(d).max(axis=2) <= 1e-3)
+    assert bad.mean() <= 0.005, float(bad.mean())
+    assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
+
+
 @pytest.mark.parametrize("world,block", [(2, 16), (8, 16), (3, 24), (8, 48), (4, 48), (2, 64)])   # bench.py deals 48-row blocks
 def test_row_block_decomposition_equals_full_frame(world, block):
     """what rank r of N computes in strip mode is bit-identical to the same rows of the single-GPU frame"""

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 import geodesic_raytracing_amd as gra  # noqa: E402
 from gpu_stages import (ILL_CONDITIONED, Stages, assert_ill_conditioned_trace, assert_pixels, assert_traced_positions, circ_diff, load_golden,  # noqa: E402
                         metric_for, ordinary_rays, refscript_golden_names)
-from test_gpu_parity import _frame, background  # noqa: E402
+from test_gpu_parity import _frame  # noqa: E402
+from gpu_stages import backgrounds  # noqa: E402
 
 ALL = refscript_golden_names()
 PREPASS = [n for n in ALL if n.endswith("_prepass")]
@@ -89,8 +90,8 @@ def test_render_data(name):
 @pytest.mark.parametrize("name", PLAIN)
 def test_render_pixels(name):
     meta, z = load_golden(name)
-    bg, levels = background(meta)
-    got = Stages(meta).render(z["render_data"], bg, levels, meta["max_probes"])
+    bg, bg2, levels = backgrounds(meta)
+    got = Stages(meta).render(z["render_data"], bg, bg2, levels, meta["max_probes"])
     d = got[..., :3] - z["pixels"][..., :3]
     assert np.sqrt((d ** 2).mean()) <= 1e-5
     assert np.abs(d).max() <= 2e-4
@@ -102,8 +103,8 @@ def test_end_to_end(name):
     st = Stages(meta)
     cam, tet = st.camera()
     rays = st.trace(st.init_rays(cam, tet))
-    bg, levels = background(meta)
-    px = st.render(st.render_data(rays), bg, levels, meta["max_probes"])
+    bg, bg2, levels = backgrounds(meta)
+    px = st.render(st.render_data(rays), bg, bg2, levels, meta["max_probes"])
     assert_pixels(name, meta, z, px)
 
 

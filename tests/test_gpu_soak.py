@@ -28,7 +28,8 @@ pytestmark = pytest.mark.gpu
 
 import geodesic_raytracing_amd as gra  # noqa: E402
 from gpu_stages import Stages, assert_pixels, load_golden, metric_for  # noqa: E402
-from test_gpu_parity import _frame, background  # noqa: E402
+from test_gpu_parity import _frame  # noqa: E402
+from gpu_stages import backgrounds  # noqa: E402
 
 SOAK = ["soak/cosmic_string_on_axis_51_45", "soak/double_kerr_near_extreme_61_167", "soak/double_kerr_spins_zero_51_189",
         "soak/minkowski_off_axis_44_171", "soak/minkowski_off_axis_44_171_prepass"]
@@ -56,11 +57,11 @@ def one_ulp_sensitivity(meta, z):
         from oracle import build_restate
         from oracle.refpipe import OraclePipeline, pack_features
         pipe = OraclePipeline(build_restate.build(metric_for(meta).argument_string()))
-        bg, levels = background(meta)
+        bg, bg2, levels = backgrounds(meta)
 
         def frame(pos):
             return pipe.frame(meta["width"], meta["height"], meta["cfg"], pack_features(**meta["features"]), camera_pos=pos,
-                              camera_quat=meta["camera_quat"], use_prepass=meta["prepass"], background=(bg, levels),
+                              camera_quat=meta["camera_quat"], use_prepass=meta["prepass"], background=(bg, bg2, levels),
                               basis_speed=meta["basis_speed"], nthreads=8)["pixels"]
         base = frame(meta["camera_pos"])
         pos32 = np.array(meta["camera_pos"], dtype=np.float32)

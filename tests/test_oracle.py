@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import geodesic_raytracing_amd as gra
-from gpu_stages import ILL_CONDITIONED, assert_ill_conditioned_trace, assert_pixels, assert_traced_positions, circ_diff, golden_names, refscript_golden_names, load_golden, load_path_golden, metric_for, ordinary_rays, path_golden_names, rel_err, vec_err
+from gpu_stages import ILL_CONDITIONED, assert_ill_conditioned_trace, assert_pixels, backgrounds, assert_traced_positions, circ_diff, golden_names, refscript_golden_names, load_golden, load_path_golden, metric_for, ordinary_rays, path_golden_names, rel_err, vec_err
 from oracle import build_ref, build_restate
 from oracle.refpipe import OraclePipeline, pack_features
 
@@ -13,10 +13,11 @@ CHAOTIC = {"kerr_superextremal", "double_unequal_kerr_hyperextreme"}
 
 
 def run_oracle(so, meta):
-    bg, levels = gra.pack_background(gra.synthetic_background(*meta["bg_size"], seed=meta["bg_seed"]))
+    bg, bg2, levels = backgrounds(meta)
     return OraclePipeline(so).frame(meta["width"], meta["height"], meta["cfg"], pack_features(**meta["features"]),
                                     camera_pos=meta["camera_pos"], camera_quat=meta["camera_quat"], use_prepass=meta["prepass"],
-                                    background=(bg, levels), basis_speed=meta["basis_speed"], nthreads=4, flip=float(meta.get("flip", 0.0)))
+                                    background=(bg, bg2, levels), basis_speed=meta["basis_speed"], nthreads=4, flip=float(meta.get("flip", 0.0)),
+                                    max_probes=meta["max_probes"])
 
 
 @pytest.mark.parametrize("name", golden_names() + refscript_golden_names())

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import geodesic_raytracing_amd as gra
-from gpu_stages import Stages, load_golden, golden_names, circ_diff, rel_err
+from gpu_stages import Stages, backgrounds, load_golden, golden_names, circ_diff, rel_err
 
 def pct(x, q): return float(np.percentile(x, q)) if len(x) else 0.0
 
@@ -37,12 +37,12 @@ for name in golden_names():
     rep["rd_tex_p99"], rep["rd_tex_max"] = pct(te,99), pct(te,100)
     rep["rd_z_max"] = float(np.abs(rd["z_shift"][ok] - grd["z_shift"][ok]).max()) if ok.any() else 0
     rep["rd_side_mismatch"] = int((rd["side"][ok] != grd["side"][ok]).sum())
-    bg, levels = gra.pack_background(gra.synthetic_background(*meta["bg_size"], seed=meta["bg_seed"]))
-    px = st.render(grd, bg, levels)
+    bg, bg2, levels = backgrounds(meta)
+    px = st.render(grd, bg, bg2, levels)
     d = px[..., :3] - z["pixels"][..., :3]
     rep["render_rmse"] = float(np.sqrt((d**2).mean())); rep["render_max"] = float(np.abs(d).max())
     # end to end
-    r2 = st.trace(ri); rd2 = st.render_data(r2); px2 = st.render(rd2, bg, levels)
+    r2 = st.trace(ri); rd2 = st.render_data(r2); px2 = st.render(rd2, bg, bg2, levels)
     d2 = px2[..., :3] - z["pixels"][..., :3]
     rep["e2e_rmse"] = float(np.sqrt((d2**2).mean())); rep["e2e_max"] = float(np.abs(d2).max()); rep["e2e_bad_1e-3"] = float((np.abs(d2).max(axis=2) > 1e-3).mean())
     print(json.dumps({k: (round(v, 8) if isinstance(v, float) else v) for k, v in rep.items()}), flush=True)

@@ -19,6 +19,13 @@ OPS = {
     # how many distinct VGPR sources an fp32 op reads
     "fma_same": ("v_fma_f32 {a}, {a}, {a}, {a}", 1), "fma_2src": ("v_fma_f32 {a}, {a}, %8, {a}", 1), "fma_sgpr": ("v_fma_f32 {a}, {a}, %11, %9", 1),
     "fma_sgpr2": ("v_fma_f32 {a}, {a}, %11, {a}", 1), "fma_const": ("v_fma_f32 {a}, {a}, 0.5, 1.0", 1), "fmac_sv": ("v_fmac_f32 {a}, %11, %9", 1),
+    # round 5: candidates for the loop's selects, masks and combined tests (which of them issue at the full rate?)
+    "bitop3": ("v_bitop3_b32 {a}, {a}, %8, %9 bitop3:0xca", 1), "bfe_i": ("v_bfe_i32 {a}, {a}, 0, 1", 1), "bfe_u": ("v_bfe_u32 {a}, {a}, 1, 1", 1),
+    "ashr": ("v_ashrrev_i32 {a}, 31, {a}", 1), "lshl": ("v_lshlrev_b32 {a}, 30, {a}", 1), "max3": ("v_max3_f32 {a}, {a}, %8, %9", 1),
+    "cmp_abs": ("v_cmp_lt_f32_e64 vcc, |{a}|, %8", 1), "cmp_class": ("v_cmp_class_f32 vcc, {a}, %8", 1), "and_or": ("v_and_or_b32 {a}, {a}, %8, %9", 1), "lshl_add": ("v_lshl_add_u32 {a}, {a}, 1, %8", 1), "lshl_or": ("v_lshl_or_b32 {a}, {a}, 1, %8", 1),
+    "sub_co": ("v_subrev_co_u32 {a}, vcc, 1, {a}", 1), "cvt_f_u": ("v_cvt_f32_u32 {a}, {a}", 1), "cvt_ubyte": ("v_cvt_f32_ubyte0 {a}, {a}", 1),
+    "ldexp": ("v_ldexp_f32 {a}, {a}, %8", 1), "cmp_u": ("v_cmp_eq_u32 vcc, {a}, %8", 1),
+    "add3": ("v_add3_u32 {a}, {a}, %8, %9", 1), "perm": ("v_perm_b32 {a}, {a}, %8, %9", 1), "sub_f": ("v_sub_f32 {a}, {a}, %8", 1),
     "mul_sgpr": ("v_mul_f32 {a}, %11, {a}", 1), "mul_const": ("v_mul_f32 {a}, 0.5, {a}", 1), "mul_lit": ("v_mul_f32 {a}, 0x3f8ccccd, {a}", 1),
 }
 # instruction pairs / special sequences (8 lines each)
