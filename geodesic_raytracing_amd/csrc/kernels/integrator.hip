@@ -83,23 +83,31 @@ __device__ __forceinline__ float max_f32_uniform(float uniform, float x) { float
 #ifdef ADAPTIVE_PRECISION
 struct step_controller {
     float floor_q, root, singular_q, min_step;
-    __device__ __forceinline__ step_controller(float max_acceleration, float min_step_in) {
+    float root99, floor_step, ambient;   // 0.99 root; min(min_step, ambient); the largest near step (0.2)
+    __device__ __forceinline__ step_controller(float max_acceleration, float min_step_in, float ambient_in) {
         const float scale = 65536.f;
         const float floor_diff = max_acceleration * scale / 1e10f;
         floor_q = floor_diff * floor_diff;
         root = __builtin_sqrtf(max_acceleration * scale);
+        root99 = 0.99f * root;
         const float singular = max_acceleration * 10000 * scale;
         singular_q = singular * singular;
         min_step = min_step_in;
+        ambient = ambient_in;
+        floor_step = __builtin_fminf(min_step_in, ambient_in);
     }
-    // diff^2 of acceleration_to_precision (cl.cl:3400-3429), floored
-    __device__ __forceinline__ float error_q(float4 acc) const {
+    // diff^2 of acceleration_to_precision (cl.cl:3400-3429) before its floor.  A NaN component makes it NaN, an infinite one infinite.
+    __device__ __forceinline__ float raw_error_q(float4 acc) const {
         const float k = 0.01f * 65536.f / GR_W_MAX;
         const float wx = acc.x * (float)(W_V1), wy = acc.y * (float)(W_V2), wz = acc.z * (float)(W_V3), ww = acc.w * (float)(W_V4);
         const float d2 = __builtin_fmaf(wx, wx, __builtin_fmaf(wy, wy, __builtin_fmaf(wz, wz, ww * ww)));
-        return max_f32_uniform(floor_q, d2 * (k * k));   // a NaN error takes the floor: the step is then accepted and its velocity is caught as degenerate
+        return d2 * (k * k);
     }
+    // ... floored (the ray's first step suggestion, where nothing clamps the result)
+    __device__ __forceinline__ float error_q(float4 acc) const { return max_f32_uniform(floor_q, raw_error_q(acc)); }
     __device__ __forceinline__ float suggestion(float q) const { return root * __builtin_amdgcn_rsqf(__builtin_sqrtf(q)); }
+    // every weight non-zero: a NaN anywhere in an acceleration shows in its error (the loop's degeneracy test rests on it)
+    static constexpr bool error_sees_every_component = (float)(W_V1) != 0 && (float)(W_V2) != 0 && (float)(W_V3) != 0 && (float)(W_V4) != 0;
 };
 #endif
 
@@ -110,9 +118,11 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
     float4 p0 = s.position, v0 = s.velocity, a0 = s.acceleration;
     float4 p1 = p0, v1 = v0, a1 = a0;
     const float f_in_x = RESUMABLE ? s.f_in_x : __builtin_fabsf(v0.x);
+    const float subambient_precision = 0.5f;
+    const float ambient_precision = 0.2f;
     float next_ds = 0.00001f;
 #ifdef ADAPTIVE_PRECISION
-    const step_controller controller(GET_FEATURE(max_acceleration_change, dfg), GET_FEATURE(min_step, dfg));
+    const step_controller controller(GET_FEATURE(max_acceleration_change, dfg), GET_FEATURE(min_step, dfg), ambient_precision);
     if (RESUMABLE) next_ds = s.next_ds;
     else {
         float4 a = a0;
@@ -121,9 +131,10 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
 #endif
         next_ds = controller.suggestion(controller.error_q(a));
     }
+    // The loop carries the step suggestion as the step a ray inside the precision radius would take: min(suggestion, ambient), the only
+    // way the reference ever reads it (cl.cl:4101-4107).  Every update below leaves it clamped the same way.
+    next_ds = min_f32_uniform(ambient_precision, next_ds);
 #endif
-    const float subambient_precision = 0.5f;
-    const float ambient_precision = 0.2f;
     const float new_max = GET_FEATURE(max_precision_radius, dfg);
     const float new_min = 3;
     const float universe = GET_FEATURE(universe_size, dfg);
@@ -143,7 +154,14 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         lost |= pos.y < CYLINDRICAL_TERMINATOR;
 #endif
 #ifndef UNCONDITIONALLY_NONSINGULAR
-        lost |= __builtin_fabsf(vel.x / run) > 1000 + f_in_x && __builtin_fabsf(acc.x / run) > 100;
+        // |dt/dlambda| > 1000 + its initial value AND |d2t/dlambda2| > 100 (cl.cl:4118-4127): the first condition alone in the hot path,
+        // the second only in a wave one of whose rays meets the first (a compare is two issue slots, the wave-uniform branch a scalar one)
+        bool runaway = __builtin_fabsf(vel.x / run) > 1000 + f_in_x;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(runaway) != 0, 0)) {
+            asm volatile("; second condition of the runaway test");
+            runaway = runaway && __builtin_fabsf(acc.x / run) > 100;
+        }
+        lost |= runaway;
 #endif
         (void)pos; (void)vel; (void)acc; (void)run;
         return lost;
@@ -174,8 +192,10 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
 #endif
         const float ar = __builtin_fabsf(gm::distance_to_object_from(position, polar, cfg));
         const bool inside = ar < new_max;
+        const bool wave_inside = __builtin_amdgcn_ballot_w64(inside) != 0;   // (taken here, where the compare is: one scalar instruction)
+        (void)wave_inside;
 #ifdef ADAPTIVE_PRECISION
-        const float near_ds = min_f32_uniform(ambient_precision, next_ds);
+        const float near_ds = next_ds;   // carried clamped (above, and every update below)
 #else
         const float near_ds = min_f32_uniform(ambient_precision, mixf(ambient_precision, subambient_precision, (clampf(ar, new_min, new_max) - new_min) / (new_max - new_min)));
 #endif
@@ -206,38 +226,86 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
             running *= K;   // also on an attempt that is then rejected, as the reference does (cl.cl:4152-4154)
         }
 
-        bool accept = true, dead = false;
-#ifdef ADAPTIVE_PRECISION
-        if (inside) {
-            // calculate_ds_error (cl.cl:3431-3456)
-            const float q = controller.error_q(next_acceleration);
-            // 0.99 * ds * clamp(suggested / ds, 0.3, 2) with ds > 0, without forming the quotient
-            float nds = __builtin_amdgcn_fmed3f(0.99f * controller.suggestion(q), (0.99f * 0.3f) * ds, (0.99f * 2.f) * ds);
-            nds = max_f32_uniform(controller.min_step, nds);
-            next_ds = nds;
-#ifdef SINGULARITY_DETECTION
-            dead = (q > controller.singular_q) & (nds == controller.min_step);   // DS_RETURN: lost
-#endif
-            accept = !(nds < ds * (1 / 1.95f));   // back-step: retry from the same state with the smaller step
-        }
-#endif
-        // IS_DEGENERATE on the accepted velocity: a non-finite sum <=> a non-finite component (finite components cannot
-        // overflow the sum below ~1e38).  A rejected attempt is not tested (the reference `continue`s before its test: an
-        // overshoot into a singularity is retried with the smaller step).
-        const float poison = (next_velocity.x + next_velocity.y) + (next_velocity.z + next_velocity.w);
-        dead |= accept & !(__builtin_fabsf(poison) <= 3.402823466e+38f);
         // The new state is written where the next attempt reads it; a rejection (once in ~35 000 attempts) puts the old state
         // back over it.  The copies are opaque to the compiler on purpose: as plain assignments it turns the two outcomes into
         // twelve selects per attempt.
         po = next_position;
         vo = next_velocity;
         ao = next_acceleration;
-        if (__builtin_expect(!accept, 0)) {
-            overwrite(po, position);
-            overwrite(vo, velocity);
-            overwrite(ao, acceleration);
-            asm volatile("v_add_u32 %0, 1, %0\n\tv_add_u32 %1, 1, %1" : "+v"(rejections), "+v"(budget));   // the step it did not take
+        bool dead = false;
+#ifdef ADAPTIVE_PRECISION
+        // calculate_ds_error (cl.cl:3431-3456), then IS_DEGENERATE on an accepted step (cl.cl:4235-4244) - arranged so that the path every
+        // attempt takes holds TWO compares, everything that happens once in thousands of attempts sits behind one wave-uniform branch,
+        // and no lane mask is ever turned into a register and back (round 5; the loop had eight compares, five selects and four
+        // min / max here and at its top - instructions that issue at half the rate of a multiply):
+        //   * the controller's arithmetic runs on every lane (a wave issues it for all lanes anyway) on the carried near step, which IS
+        //     ds for a ray inside the precision radius; only the update of the carried step is selected by `inside`;
+        //   * 0.99 ds clamp(suggested / ds, 0.3, 2), then max(., min_step), then the min(., ambient) of the next attempt's loop top:
+        //     two v_med3 (the second does both one-sided clamps; floor_step = min(min_step, ambient) keeps it a median);
+        //   * the floor of the error (cl.cl:3414-3419) is gone from the loop: it only bounds the suggestion from above, by 1e5, and the
+        //     clamp to 1.98 ds <= 0.4 follows;
+        //   * a NaN acceleration - a singularity overshot, or a sin / cos argument outside the polynomial's range (metric.hip: the
+        //     poison) - makes the error NaN, and fma(error, 0, step) hands that to the one compare that also finds a rejected step:
+        //     !(step >= ds / 1.95).  (IS_DEGENERATE's test of the velocity for infinities without a NaN finds them one attempt later,
+        //     as NaNs; such a ray is lost either way and writes nothing.)
+        // The rare block then redoes the reference's tests in the reference's own terms and order.
+        // (a wave none of whose rays is inside the radius - the last dozen attempts of every outgoing ray - skips all of it and tests
+        // the velocity, as the fixed-step loop does)
+        float q, nds1;
+        unsigned long long rare_lanes;   // (the ballot taken where the compares are: a lane mask that crosses the branch as a bool comes back through a register)
+        if (wave_inside) {
+            q = controller.raw_error_q(next_acceleration);
+            nds1 = __builtin_amdgcn_fmed3f(controller.root99 * __builtin_amdgcn_rsqf(__builtin_sqrtf(q)), (0.99f * 0.3f) * near_ds, (0.99f * 2.f) * near_ds);
+            const float clamped = __builtin_amdgcn_fmed3f(nds1, controller.floor_step, controller.ambient);
+            const float threshold = near_ds * (1 / 1.95f);
+            // (one ballot per compare, joined as scalars: the ballot of an OR of compares is lowered through a register)
+            rare_lanes = __builtin_amdgcn_ballot_w64(!(__builtin_fmaf(q, 0.f, clamped) >= threshold));
+#ifdef SINGULARITY_DETECTION
+            rare_lanes |= __builtin_amdgcn_ballot_w64(clamped == controller.floor_step);   // (with min_step > ambient - nobody's setting - every attempt takes the rare block: slow, exact)
+#endif
+            if (!step_controller::error_sees_every_component) {   // a metric with a zero weight: the velocity's own test as well
+                const float poison = (next_velocity.x + next_velocity.y) + (next_velocity.z + next_velocity.w);
+                rare_lanes |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(poison) <= 3.402823466e+38f));
+            }
+            next_ds = inside ? clamped : near_ds;   // also on an attempt that is then rejected (cl.cl:3443 comes before the returns)
+        } else {
+            // no ray of the wave inside the radius: nothing of the controller applies; a non-finite velocity (their sum) is handed to
+            // the rare block as a NaN "error"
+            const float poison = (next_velocity.x + next_velocity.y) + (next_velocity.z + next_velocity.w);
+            q = poison * 0.f;
+            nds1 = 0;
+            rare_lanes = __builtin_amdgcn_ballot_w64(!(q == q));
         }
+        if (__builtin_expect(rare_lanes != 0, 0)) {
+            asm volatile("; rejected step, singularity, degenerate state");
+            const float nds = max_f32_uniform(controller.min_step, nds1);
+#ifdef SINGULARITY_DETECTION
+            dead = inside & (q > controller.singular_q) & (nds == controller.min_step);   // DS_RETURN: lost
+#endif
+            const bool reject = inside & (nds < ds * (1 / 1.95f));   // DS_SKIP: retry from the same state with the smaller step
+            // IS_DEGENERATE on the accepted state.  A rejected attempt is not tested (the reference `continue`s before its test: an
+            // overshoot into a singularity is retried with the smaller step).
+            bool degenerate = !(q == q);
+            if (!step_controller::error_sees_every_component) {
+                const float poison = (next_velocity.x + next_velocity.y) + (next_velocity.z + next_velocity.w);
+                degenerate |= !(__builtin_fabsf(poison) <= 3.402823466e+38f);
+            }
+            dead |= !reject & degenerate;
+            if (reject) {
+                overwrite(po, position);
+                overwrite(vo, velocity);
+                overwrite(ao, acceleration);
+                asm volatile("v_add_u32 %0, 1, %0\n\tv_add_u32 %1, 1, %1" : "+v"(rejections), "+v"(budget));   // the step it did not take
+            }
+        }
+#else
+        {
+            // IS_DEGENERATE on the accepted velocity: a non-finite sum <=> a non-finite component (finite components cannot
+            // overflow the sum below ~1e38); a non-finite acceleration makes the velocity computed from it non-finite in the same step
+            const float poison = (next_velocity.x + next_velocity.y) + (next_velocity.z + next_velocity.w);
+            dead = !(__builtin_fabsf(poison) <= 3.402823466e+38f);
+        }
+#endif
         // the rare exit: the state the ray is left in, (p, v, a), has just passed the loop-top tests
         if (__builtin_expect(dead, 0)) return true;
         if (RESUMABLE) {

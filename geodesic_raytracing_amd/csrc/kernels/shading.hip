@@ -156,8 +156,13 @@ __device__ __forceinline__ float wrapped_difference(float a, float b) {
     // atan2(sin d, cos d) is d brought into (-pi, pi]: for the differences between neighbouring pixels that is d itself, across the
     // texture's seam one turn is taken off.  (The library's sin, cos and atan2 here - four differences a pixel - were 400 of the
     // pass's ~1 000 vector instructions per pixel.)
-    const float two_pi = 6.283185307179586f;
-    const float wrapped = __builtin_fabsf(d) <= 3.14159274101257324f ? d : d - two_pi * __builtin_rintf(d / two_pi);
+    // One value takes neither road: |d| = float(pi) exactly - a record in the equatorial plane (v = 0.5) next to a black one (0, 0), i.e.
+    // the shadow's edge on the middle row of a frame with an even number of rows.  float(pi) lies 8.7e-8 beyond pi, so sin d has the
+    // sign opposite to d's and atan2(sin d, cos d) is the float below pi with the OTHER sign: the footprint's long axis is mirrored
+    // (found by the round-5 fixture kerr_max_probes_16, one pixel off by 2e-2; invisible with up to 8 probes on the odd-rowed fixtures).
+    const float two_pi = 6.283185307179586f, pi_f = 3.14159274101257324f, below_pi = 3.14159250259399414f;
+    float wrapped = __builtin_fabsf(d) <= pi_f ? d : d - two_pi * __builtin_rintf(d / two_pi);
+    if (__builtin_fabsf(d) == pi_f) wrapped = d > 0 ? -below_pi : below_pi;
     return (float)((double)(1.f * wrapped) / (2 * GR_PI));
 }
 

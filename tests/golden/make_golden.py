@@ -98,9 +98,9 @@ CASES = {
                                         features=dict(redshift=1, use_old_redshift=1)),
     "kerr_blueshift": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), basis_speed=[0.1, 0.45, 0.05], features=dict(redshift=1)),
     # ... the probe cap of the anisotropic filter (iProbes = min(iProbes, maxProbes), cl.cl:5597-5613) below and above the GUI's 8, on a
-    # wide view of a near hole (strongly stretched pixels next to the shadow) over a sky large enough for the filter to matter ...
-    "kerr_max_probes_1": dict(metric="kerr_boyer", size=(64, 36), bg_size=(1024, 512), cfg=dict(a=0.45), max_probes=1, features=dict(field_of_view=110.0)),
-    "kerr_max_probes_16": dict(metric="kerr_boyer", size=(64, 36), bg_size=(1024, 512), cfg=dict(a=0.45), max_probes=16, features=dict(field_of_view=110.0)),
+    # wide view of a near hole (strongly stretched pixels next to the shadow) over a sky of four texels to a pixel ...
+    "kerr_max_probes_1": dict(metric="kerr_boyer", size=(64, 36), bg_size=(512, 256), cfg=dict(a=0.45), max_probes=1, features=dict(field_of_view=110.0)),
+    "kerr_max_probes_16": dict(metric="kerr_boyer", size=(64, 36), bg_size=(512, 256), cfg=dict(a=0.45), max_probes=16, features=dict(field_of_view=110.0)),
     # ... and a min_step at which calculate_ds_error's bail-out (next_ds == min_step && diff > err * 10000 -> DS_RETURN, cl.cl:3439-3450) fires
     # (measured on the reference's x86 build: 50 of the 1 296 rays of the first and 97 of the second end differently than with 1e-6)
     "kerr_min_step": dict(metric="kerr_boyer", size=(48, 27), cfg=dict(a=0.45), features=dict(min_step=1e-2)),
