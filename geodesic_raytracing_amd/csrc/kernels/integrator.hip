@@ -166,13 +166,30 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         (void)pos; (void)vel; (void)acc; (void)run;
         return lost;
     };
-    auto stop_terminated = [&](float4 polar) {
+    // |r| >= universe_size, and for a SINGULAR metric |r| < its terminator (cl.cl:4086-4095).  Where r is a square root (a Cartesian
+    // chart: GR_POLAR_R_SQUARED) the comparison is made on its argument: sqrt is monotonic, the two forms differ by which side a
+    // radius within an ulp of the bound falls on.
+#ifdef GR_POLAR_R_SQUARED
+    const float universe2 = universe * universe;
+    auto stop_terminated = [&](float4 position, float4 polar) {
+        (void)polar;
+        const float r2 = gm::polar_radius_squared(position, cfg);
+        bool t = r2 >= universe2;
+#ifdef SINGULAR
+        t |= r2 < (float)(SINGULAR_TERMINATOR) * (float)(SINGULAR_TERMINATOR);
+#endif
+        return t;
+    };
+#else
+    auto stop_terminated = [&](float4 position, float4 polar) {
+        (void)position;
         bool t = __builtin_fabsf(polar.y) >= universe;
 #ifdef SINGULAR
         t |= __builtin_fabsf(polar.y) < SINGULAR_TERMINATOR;
 #endif
         return t;
     };
+#endif
     const float far_offset = ambient_precision - 0.1f * new_max;
     // One Verlet attempt from (p, v, a): the state the next attempt starts from goes to (po, vo, ao) - the new state, or the old
     // one again after a rejection.  Returns true when the loop is to be left: the ray is done and (p, v, a) is its final state
@@ -203,7 +220,7 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         const float ds = inside ? near_ds : far_ds;
         ds_used = ds;
         running_before = running;
-        if (stop_lost(position, velocity, acceleration, running) | stop_terminated(polar)) return true;
+        if (stop_lost(position, velocity, acceleration, running) | stop_terminated(position, polar)) return true;
         GR_PROBE_EXTRA_INSTRUCTIONS(ds)
         // velocity Verlet (step_verlet, cl.cl:3273-3346) in the reference's operation order.  (Through the half-kicked velocity
         // h = v + a ds/2 - x' = x + h ds, v~ = h + a ds/2, v' = h + a' ds/2 - it is 16 fmas instead of 20 operations and the same
@@ -374,7 +391,7 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         polar.z = GR_PIf / 2;
 #endif
         lost_at_top = stop_lost(position, velocity, acceleration, running);
-        terminated_at_top = stop_terminated(polar);
+        terminated_at_top = stop_terminated(position, polar);
     };
     classify();
 #if !defined(GR_FAST_TRIG) && !defined(GR_LIBM_TRIG) && !defined(GR_PROBE_NO_SLOW_TRIG)

@@ -81,6 +81,9 @@ __device__ __forceinline__ float tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.88539008177792681472f) + 1.f);
 #endif
 }
+// device-only forms the code generator lowers to (csrc/sym.cpp lower_for_device; GR_DEVICE_ACCEL*): bare v_exp_f32 and v_rsq_f32
+__device__ __forceinline__ float gr_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float gr_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
 __device__ __forceinline__ float fmod(float x, float y) { return ::fmodf(x, y); }
 __device__ __forceinline__ float fmin(float x, float y) { return __builtin_fminf(x, y); }
@@ -218,8 +221,20 @@ __device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 
     const float iv1 = vel.x; const float iv2 = vel.y; const float iv3 = vel.z; const float iv4 = vel.w;
     (void)iv1; (void)iv2; (void)iv3; (void)iv4;
     GR_ACCEL_TRIG(LIBM)
-    GR_DECLARE_TEMPORARIES(float)
     float4 a;
+#if defined(GR_DEVICE_ACCEL0) && !defined(GR_NO_DEVICE_LOWERING)
+    // the Verlet loop's own form of the same expressions (metric_codegen.cpp: GR_DEVICE_ACCEL*)
+    float GR_DEVICE_TEMPORARIES;
+    a.x = GR_DEVICE_ACCEL0;
+    a.y = GR_DEVICE_ACCEL1;
+#ifndef GENERIC_CONSTANT_THETA
+    a.z = GR_DEVICE_ACCEL2;
+#else
+    a.z = 0.f;
+#endif
+    a.w = GR_DEVICE_ACCEL3;
+#else
+    GR_DECLARE_TEMPORARIES(float)
     a.x = GEO_ACCEL0;
     a.y = GEO_ACCEL1;
 #ifndef GENERIC_CONSTANT_THETA
@@ -228,6 +243,7 @@ __device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 
     a.z = 0.f;
 #endif
     a.w = GEO_ACCEL3;
+#endif
     return a;
 }
 // everywhere outside the Verlet loop (ray set-up, geodesic paths): gm::sin / gm::cos with their own large-argument branches
@@ -275,6 +291,14 @@ __device__ __forceinline__ float4 spherical_velocity_to_generic_velocity(float4 
     (void)dv1; (void)dv2; (void)dv3; (void)dv4;
     return make_float4(FROM_DCOORD1, FROM_DCOORD2, FROM_DCOORD3, FROM_DCOORD4);
 }
+
+#ifdef GR_POLAR_R_SQUARED
+// TO_COORD2 squared, straight from the metric's own coordinates (metric_codegen.cpp: emitted when TO_COORD2 is a square root)
+__device__ __forceinline__ float polar_radius_squared(float4 in, cfg_t cfg) {
+    GR_POSITION_VARS(in)
+    return GR_POLAR_R_SQUARED;
+}
+#endif
 
 __device__ __forceinline__ float distance_to_object(float4 polar, cfg_t cfg) {
     GR_POSITION_VARS(polar)

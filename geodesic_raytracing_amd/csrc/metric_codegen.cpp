@@ -476,6 +476,9 @@ std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl
     if (cfg.unconditionally_nonsingular) s += "-DUNCONDITIONALLY_NONSINGULAR ";
 
     s += "-DDISTANCE_FUNC=" + to_c(impl.distance_function) + " ";
+    // GR_POLAR_R_SQUARED: the radius the boundary tests compare (TO_COORD2) is a square root in a Cartesian chart - the fused
+    // integrator compares its argument with the squared bounds instead (one v_sqrt_f32 less per attempt).  An extension, as below.
+    if (impl.to_polar[1]->op == sym::FN1 && impl.to_polar[1]->fn == sym::F_SQRT) s += "-DGR_POLAR_R_SQUARED=" + to_c(impl.to_polar[1]->a) + " ";
     {
         // DISTANCE_FUNC(TO_COORD(x)) as one expression of the metric's own coordinates - where the trip to polar coordinates and back
         // cancels completely (no division, no angle left: the rewrite is not an identity where a hypotenuse vanishes).  An extension
@@ -486,14 +489,22 @@ std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl
         if (!sym::contains_division_or_angle(composed)) s += "-DGR_DISTANCE_OF_GENERIC=" + to_c(composed) + " ";
     }
 
+    bool tanh_in_sums_only = false;
     {
-        // -DGR_TANH_IN_SUMS_ONLY (kernels/metric.hip gm::tanh): every tanh that depends on a coordinate is used only in sums, differences
-        // and products whose other operand is again such a combination, a constant or a $cfg-only value.  Then an absolute error of
-        // 1e-7 in tanh is an absolute error of that order in everything built from it, and the five-instruction form may stand in
-        // for the library's (which keeps RELATIVE accuracy next to 0 - what tanh(x) / x or r tanh(x) would need).
+        // -DGR_TANH_IN_SUMS_ONLY (kernels/metric.hip gm::tanh): the five-instruction tanh has an ABSOLUTE error of 1.2e-7 and no relative
+        // accuracy next to 0 (the library's has).  It may stand in where nothing depends on that:
+        //   * a tanh itself is only negated, added to, subtracted from or multiplied with other tanh values, constants and $cfg-only
+        //     values and combinations of these ("class 1": a warp drive's shape function) - not divided by or scaled with a coordinate;
+        //   * what is built from it further up (round 5: the round-4 analysis looked at the direct parent of each tanh only, so
+        //     (tanh a - tanh b) / r and sqrt(k tanh a) passed) is never the numerator of a quotient by a coordinate-dependent value, never
+        //     the argument of a function, never a select's condition.  A product with a coordinate-dependent factor IS allowed there: the
+        //     chain rule makes one out of every derivative ((1 - tanh^2) x / r), and it scales a sum's absolute error - which the
+        //     library's rounding of tanh values of order 1 has as well - by no more than the coordinates' own size.
+        // A metric that fails either test gets the library routine.
         std::vector<E> everything = scoped;
         everything.insert(everything.end(), impl.to_polar.begin(), impl.to_polar.end());
         everything.push_back(impl.distance_function);
+        auto is_tanh = [](E e) { return e && e->op == sym::FN1 && e->fn == sym::F_TANH && (e->deps & ~sym::DEP_CFG) != 0; };
         std::unordered_map<E, int> klass;   // 1: constant / $cfg-only / tanh / sum, difference, product of class-1 nodes
         std::function<bool(E)> in_class = [&](E e) -> bool {
             if (!e) return false;
@@ -505,23 +516,37 @@ std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl
             klass[e] = ok ? 1 : 0;
             return ok;
         };
+        std::unordered_map<E, bool> taint_memo;
+        std::function<bool(E)> tainted = [&](E e) -> bool {
+            if (!e || e->op == sym::CONST || e->op == sym::VAR) return false;
+            auto it = taint_memo.find(e);
+            if (it != taint_memo.end()) return it->second;
+            const bool t = is_tanh(e) || tainted(e->a) || tainted(e->b) || tainted(e->s);
+            taint_memo.emplace(e, t);
+            return t;
+        };
         bool any_tanh = false, sums_only = true;
         std::unordered_set<E> seen;
         std::function<void(E)> walk = [&](E e) {
             if (!e || !seen.insert(e).second) return;
             for (E c : {e->a, e->b, e->s}) {
-                if (!c) continue;
-                if (c->op == sym::FN1 && c->fn == sym::F_TANH && (c->deps & ~sym::DEP_CFG) != 0) {
-                    any_tanh = true;
-                    const bool combines = (e->op == sym::ADD || e->op == sym::SUB || e->op == sym::MUL) ? in_class(e->a) && in_class(e->b)
-                                                                                                       : e->op == sym::NEG;
-                    if (!combines) sums_only = false;
+                if (!c || !tainted(c)) continue;
+                any_tanh = true;
+                bool ok;
+                if (is_tanh(c)) {
+                    ok = (e->op == sym::ADD || e->op == sym::SUB || e->op == sym::MUL) ? in_class(e->a) && in_class(e->b) : e->op == sym::NEG;
+                } else {
+                    ok = e->op == sym::ADD || e->op == sym::SUB || e->op == sym::MUL || e->op == sym::NEG;
+                    if (e->op == sym::DIV) ok = c == e->b || (e->b->deps & ~sym::DEP_CFG) == 0;   // a denominator, or over a parameter-only value
+                    if (e->op == sym::SELECT) ok = c != e->a;
                 }
-                walk(c);
+                if (!ok) sums_only = false;
             }
+            walk(e->a); walk(e->b); walk(e->s);
         };
         for (E r : everything) walk(r);
-        if (any_tanh && sums_only) s += "-DGR_TANH_IN_SUMS_ONLY ";
+        tanh_in_sums_only = any_tanh && sums_only;
+        if (tanh_in_sums_only) s += "-DGR_TANH_IN_SUMS_ONLY ";
     }
 
     if (!vars.names.empty()) {
@@ -546,6 +571,23 @@ std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl
     }
 
     for (int i = 0; i < 4; i++) s += "-DGEO_ACCEL" + std::to_string(i) + "=" + to_c(impl.accel[i], names) + " ";
+    if (is_static) {
+        // GR_DEVICE_ACCEL0..3 / GR_DEVICE_TEMPORARIES: the accelerations once more, rewritten for the device (sym::lower_for_device: one
+        // exponential for the two tanh of a shape function, v_rsq_f32 for a root and its reciprocal) with temporaries of their own - an
+        // extension of the macro set the HIP kernels' Verlet loop prefers; cl.cl and the CPU oracle never see it.  Substituted programs
+        // only (their parameters are literals: the exponential splits at build time).
+        bool lowered_differs = false;
+        const std::vector<E> lowered = sym::lower_for_device(impl.accel, tanh_in_sums_only, &lowered_differs);
+        if (lowered_differs) {
+            const Temporaries device_temps = hoist_position_temporaries(lowered, "qv");
+            std::string t;
+            for (auto& [name, e] : device_temps.defs) t += name + "=" + to_c(e, &device_temps.names, true) + ",";
+            if (t.empty()) t = "qv_unused=0.0f,";
+            t.pop_back();
+            s += "-DGR_DEVICE_TEMPORARIES=" + t + " ";
+            for (int i = 0; i < 4; i++) s += "-DGR_DEVICE_ACCEL" + std::to_string(i) + "=" + to_c(lowered[i], &device_temps.names) + " ";
+        }
+    }
     for (int i = 0; i < 4; i++) s += "-DFIX_LIGHT" + std::to_string(i) + "=" + to_c(impl.fix_light[i]) + " ";
     s += "-DMETRIC_TIME_G00=" + to_c(impl.real_eq[0], names) + " ";
 

@@ -137,6 +137,8 @@ double apply1(Fn f, double x) {
         case F_COSH: return std::cosh(x);
         case F_TANH: return std::tanh(x);
         case F_SIGN: return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0);
+        case F_EXP2_FAST: return std::exp2(x);
+        case F_RSQRT_FAST: return 1.0 / std::sqrt(x);
         default: throw std::runtime_error("apply1: bad function");
     }
 }
@@ -175,6 +177,8 @@ const char* fn_name(Fn f) {
         case F_COSH: return "cosh";
         case F_TANH: return "tanh";
         case F_SIGN: return "sign";
+        case F_EXP2_FAST: return "gr_exp2";
+        case F_RSQRT_FAST: return "gr_rsqrt";
         case F_ATAN2: return "atan2";
         case F_POW: return "pow";
         case F_FMOD: return "fmod";
@@ -218,6 +222,10 @@ E add(E a, E b) {
     if (b->op == NEG) return sub(a, b->a);
     if (a->op == NEG) return sub(b, a->a);
     if (b->op == CONST && b->c < 0) return sub(a, constant(-b->c));
+    // a term and its opposite one level down cancel: (x - y) + y = x  (round 5, with the rules in sub: the inverse of a warp drive's
+    // t-x block has the determinant (v^2 f^2 - 1) - v^2 f^2, which is -1 and was evaluated - and divided by - every attempt)
+    if (a->op == SUB && a->b == b) return a->a;
+    if (b->op == SUB && b->b == a) return b->a;
     {
         double ca, cb; E ta, tb;
         split_coef(a, ca, ta);
@@ -236,6 +244,12 @@ E sub(E a, E b) {
     if (b->op == NEG) return add(a, b->a);
     if (a->op == NEG) return neg(add(a->a, b));
     if (b->op == CONST && b->c < 0) return add(a, constant(-b->c));
+    if (a->op == SUB && a->a == b) return neg(a->b);            // (x - y) - x = -y
+    if (a->op == ADD && a->a == b) return a->b;                 // (x + y) - x = y
+    if (a->op == ADD && a->b == b) return a->a;                 // (y + x) - x = y
+    if (b->op == ADD && b->a == a) return neg(b->b);            // x - (x + y) = -y
+    if (b->op == ADD && b->b == a) return neg(b->a);            // x - (y + x) = -y
+    if (b->op == SUB && b->a == a) return b->b;                 // x - (x - y) = y
     {
         double ca, cb; E ta, tb;
         split_coef(a, ca, ta);
@@ -637,6 +651,109 @@ double eval_rec(E e, const std::map<std::string, double>& env, std::unordered_ma
 double eval(E e, const std::map<std::string, double>& env) {
     std::unordered_map<E, double> memo;
     return eval_rec(e, env, memo);
+}
+
+// ---- device lowering (sym.hpp) ----------------------------------------------------------------------------------------------
+namespace {
+struct DeviceLowering {
+    bool fast_tanh;
+    bool changed = false;
+    std::unordered_set<E> rooted;            // s of every x / sqrt(s) met in the first pass
+    std::unordered_map<E, E> memo;
+
+    // e = position part + literal part (the literal summed through +, - and a literal factor)
+    static void split_literal(E e, E& rest, double& lit) {
+        if (e->op == CONST) { rest = nullptr; lit = e->c; return; }
+        if (e->op == ADD || e->op == SUB) {
+            E ra, rb; double la, lb;
+            split_literal(e->a, ra, la);
+            split_literal(e->b, rb, lb);
+            const double sgn = e->op == ADD ? 1.0 : -1.0;
+            lit = la + sgn * lb;
+            if (!rb) rest = ra;
+            else if (!ra) rest = e->op == ADD ? rb : neg(rb);
+            else rest = e->op == ADD ? add(ra, rb) : sub(ra, rb);
+            return;
+        }
+        if (e->op == MUL && e->a->op == CONST) {
+            E r; double l;
+            split_literal(e->b, r, l);
+            lit = e->a->c * l;
+            rest = r ? mul(e->a, r) : nullptr;
+            return;
+        }
+        if (e->op == NEG) {
+            E r; double l;
+            split_literal(e->a, r, l);
+            lit = -l;
+            rest = r ? neg(r) : nullptr;
+            return;
+        }
+        rest = e; lit = 0.0;
+    }
+
+    void collect(E e, std::unordered_set<E>& seen) {
+        if (!e || !seen.insert(e).second) return;
+        if (e->op == DIV && e->b->op == FN1 && e->b->fn == F_SQRT) rooted.insert(e->b->a);
+        collect(e->a, seen); collect(e->b, seen); collect(e->s, seen);
+    }
+
+    E run(E e) {
+        if (e->op == CONST || e->op == VAR) return e;
+        auto it = memo.find(e);
+        if (it != memo.end()) return it->second;
+        E r = nullptr;
+        switch (e->op) {
+            case ADD: r = add(run(e->a), run(e->b)); break;
+            case SUB: r = sub(run(e->a), run(e->b)); break;
+            case MUL: r = mul(run(e->a), run(e->b)); break;
+            case NEG: r = neg(run(e->a)); break;
+            case DIV:
+                if (e->b->op == FN1 && e->b->fn == F_SQRT) {
+                    r = mul(run(e->a), fn1(F_RSQRT_FAST, run(e->b->a)));
+                    changed = true;
+                } else {
+                    r = div(run(e->a), run(e->b));
+                }
+                break;
+            case FN1:
+                if (e->fn == F_SQRT && rooted.count(e->a)) {
+                    E s = run(e->a);
+                    r = mul(s, fn1(F_RSQRT_FAST, s));
+                    changed = true;
+                } else if (e->fn == F_TANH && fast_tanh && (e->deps & ~DEP_CFG) != 0) {
+                    const double k = 2.88539008177792681472;   // 2 / ln 2
+                    E u = run(e->a), rest = nullptr;
+                    double lit = 0.0;
+                    split_literal(u, rest, lit);
+                    E power;
+                    if (rest && lit != 0.0 && std::fabs(k * lit) <= 64.0) power = mul(constant(fl(std::exp2(k * lit))), fn1(F_EXP2_FAST, mul(constant(fl(k)), rest)));
+                    else power = fn1(F_EXP2_FAST, mul(constant(fl(k)), u));
+                    r = sub(constant(1.0), div(constant(2.0), add(power, constant(1.0))));
+                    changed = true;
+                } else {
+                    r = fn1(e->fn, run(e->a));
+                }
+                break;
+            case FN2: r = fn2(e->fn, run(e->a), run(e->b)); break;
+            case SELECT: r = select(run(e->a), run(e->b), run(e->s)); break;
+            default: throw std::runtime_error("lower_for_device: bad op");
+        }
+        memo.emplace(e, r);
+        return r;
+    }
+};
+}  // namespace
+
+std::vector<E> lower_for_device(const std::vector<E>& roots, bool fast_tanh, bool* changed) {
+    DeviceLowering l;
+    l.fast_tanh = fast_tanh;
+    std::unordered_set<E> seen;
+    for (E r : roots) l.collect(r, seen);
+    std::vector<E> out;
+    for (E r : roots) out.push_back(l.run(r));
+    if (changed) *changed = l.changed;
+    return out;
 }
 
 std::string const_to_c(double v) {

@@ -24,6 +24,8 @@ enum Fn : uint8_t {
     // unary
     F_SIN, F_COS, F_TAN, F_ASIN, F_ACOS, F_ATAN, F_EXP, F_LOG, F_SQRT, F_FABS, F_SINH, F_COSH,
     F_TANH, F_SIGN,
+    // device-only forms (lower_for_device; never in a string cl.cl or the oracle compiles): 2^x on v_exp_f32, 1 / sqrt(x) on v_rsq_f32
+    F_EXP2_FAST, F_RSQRT_FAST,
     // binary
     F_ATAN2, F_POW, F_FMOD, F_MIN, F_MAX,
     // real / imaginary part of the principal square root of the complex number (a + i b).  Primitive so that its
@@ -90,6 +92,17 @@ bool contains_division_or_angle(E e);
 // issues at a quarter of the v_mul_f32 rate.  `memo` carries the rewritten nodes across calls so that several roots
 // keep sharing sub-expressions.
 E share_reciprocals(E e, std::unordered_map<E, E>& memo);
+
+// The expressions evaluated every Verlet attempt, rewritten for the device's instruction costs (a transcendental issues at a
+// quarter of a multiply's rate); the results go into macros of their own (GR_DEVICE_ACCEL*, metric_codegen.cpp) - the strings the
+// reference's cl.cl and the CPU oracle compile are not touched:
+//   * fast_tanh (the metric's tanh values meet only sums and products, GR_TANH_IN_SUMS_ONLY): tanh u -> 1 - 2 / (2^(k u) + 1),
+//     k = 2 / ln 2, and with u = p + c, c a literal with |k c| <= 64: 2^(k p) 2^(k c) - the two tanh of a warp drive's shape
+//     function, tanh(sigma (r + R)) and tanh(sigma (r - R)), then share ONE exponential;
+//   * x / sqrt(s) -> x rsqrt(s), and where that reciprocal root exists sqrt(s) -> s rsqrt(s): one v_rsq_f32 instead of
+//     v_sqrt_f32 + v_rcp_f32 (not an identity at s = 0, where the quotient it replaces is not a number either).
+// `changed` reports whether any rule fired.
+std::vector<E> lower_for_device(const std::vector<E>& roots, bool fast_tanh, bool* changed);
 
 // fully parenthesised C expression (valid OpenCL C, HIP device C++ and host C++); float literals.
 // `names` maps node -> identifier for nodes that were hoisted into temporaries.

@@ -262,3 +262,51 @@ def test_fast_tanh_only_where_sums_of_tanh_are_all_there_is(tmp_path):
         flagged[name] = "-DGR_TANH_IN_SUMS_ONLY" in gra.Metric(name, tmp_path).argument_string()
     assert flagged == {"wall": True, "ratio": False, "scaled": False, "none": False}
     assert "-DGR_TANH_IN_SUMS_ONLY" in gra.Metric("alcubierre", OWN).argument_string()
+    # round 5: what is built from a sum of tanh further up counts too (the analysis used to look at each tanh's direct parent only) -
+    # a sum divided by a coordinate and a function of one get the library routine; a product with a coordinate-dependent factor passes
+    # (the chain rule makes one out of every derivative of a shape function: it only scales an absolute error)
+    more = {
+        "sum_over_coordinate": "return [-1 - (CMath.tanh(x + 1) - CMath.tanh(x - 1)) / y, 1, 1, 1]",
+        "root_of_tanh": "return [-1 - CMath.sqrt(CMath.tanh(x * x) * $cfg.s), 1, 1, 1]",
+        "sum_times_coordinate": "return [-1, 1 + y * (CMath.tanh(x) + 2), 1, 1]",
+        "sum_over_parameter": "return [-1 - (CMath.tanh(x + 1) - CMath.tanh(x - 1)) / $cfg.s, 1, 1, 1]",
+    }
+    for name, body in more.items():
+        (tmp_path / (name + ".json")).write_text(cfg % name)
+        (tmp_path / (name + ".js")).write_text("function m(t, x, y, z) { $cfg.s.$default = 2; " + body + " }\nm\n")
+        flagged[name] = "-DGR_TANH_IN_SUMS_ONLY" in gra.Metric(name, tmp_path).argument_string()
+    assert (flagged["sum_over_coordinate"], flagged["root_of_tanh"], flagged["sum_times_coordinate"], flagged["sum_over_parameter"]) == (False, False, True, True)
+
+
+def test_device_lowering_of_the_accelerations_is_the_same_function():
+    """GR_DEVICE_ACCEL0..3 / GR_DEVICE_TEMPORARIES (csrc/sym.cpp lower_for_device; substituted programs): the accelerations rewritten for
+    the device - tanh u -> 1 - 2 / (2^(k u) + 1) with ONE exponential for the two tanh of a shape function, x / sqrt(s) -> x rsqrt(s),
+    sqrt(s) -> s rsqrt(s) - against GEO_ACCEL0..3 of the same string in float64 at random states; the strings cl.cl and the oracle
+    compile (GEO_ACCEL*, TEMPORARIES0) hold none of the device-only functions; a dynamic program carries no lowering"""
+    import math
+    import random
+    from macro_eval import _FUNCS
+    _FUNCS.setdefault("gr_exp2", lambda x: 2.0 ** x if x < 1000 else math.inf)
+    _FUNCS.setdefault("gr_rsqrt", lambda x: 1.0 / math.sqrt(x))
+    rng = random.Random(5)
+    for name, expect in (("alcubierre", dict(exp2=1, rsqrt=1)), ("kerr_schild", dict(rsqrt=1)), ("double_unequal_kerr", dict(rsqrt=1))):
+        metric = gra.Metric(name, OWN)
+        assert "GR_DEVICE_ACCEL0" not in metric.argument_string()
+        text = metric.argument_string(features=metric.features(adaptive_sampling=0), static=True, cfg_values=metric.cfg_values())
+        macros = parse_macros(text)
+        assert "GR_DEVICE_ACCEL0" in macros and "GR_DEVICE_TEMPORARIES" in macros
+        for k in ("GEO_ACCEL0", "GEO_ACCEL1", "GEO_ACCEL2", "GEO_ACCEL3", "TEMPORARIES0"):
+            assert "gr_exp2" not in macros[k] and "gr_rsqrt" not in macros[k]
+        device = macros["GR_DEVICE_TEMPORARIES"] + "".join(macros["GR_DEVICE_ACCEL%d" % i] for i in range(4))
+        if "exp2" in expect:
+            assert device.count("gr_exp2(") == expect["exp2"] and "tanh(" not in device
+        assert device.count("gr_rsqrt(") >= expect["rsqrt"]
+        original = MacroSet(text)
+        lowered = MacroSet(text.replace("-DTEMPORARIES0=", "-DUNUSED_TEMPORARIES0=").replace("-DGR_DEVICE_TEMPORARIES=", "-DTEMPORARIES0="))
+        for _ in range(20):
+            pos = [rng.uniform(-1, 1), rng.uniform(1.5, 6), rng.uniform(0.4, 2.6), rng.uniform(-3, 3)]
+            vel = [rng.uniform(-1, 1) for _ in range(4)]
+            e0, e1 = original.env(pos, vel), lowered.env(pos, vel)
+            for i in range(4):
+                a, b = original.value("GEO_ACCEL%d" % i, e0), lowered.value("GR_DEVICE_ACCEL%d" % i, e1)
+                assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (name, i, a, b)
