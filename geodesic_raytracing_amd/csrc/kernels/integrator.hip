@@ -207,6 +207,20 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
 #ifdef IS_CONSTANT_THETA
         polar.z = GR_PIf / 2;
 #endif
+#if defined(GR_DISTANCE_SQUARED_OF_GENERIC) && defined(ADAPTIVE_PRECISION)
+        // the distance is a square root of the position (a Cartesian chart): inside <=> its argument < radius^2, and the root - only
+        // the far step reads it - is taken in a wave that has a ray outside (a v_sqrt_f32 is four multiplies' issue time)
+        const float ar2 = gm::distance_squared_from(position, cfg);
+        const bool inside = ar2 < new_max * new_max;
+        const unsigned long long inside_lanes = __builtin_amdgcn_ballot_w64(inside);
+        const bool wave_inside = inside_lanes != 0;
+        const float near_ds = next_ds;
+        float far_ds = near_ds;
+        if (inside_lanes != __builtin_amdgcn_ballot_w64(true)) {
+            asm volatile("; a ray outside the precision radius: the far step");   // (keeps the root from being hoisted out of the branch)
+            far_ds = __builtin_fmaf(0.1f, __builtin_sqrtf(ar2), far_offset);
+        }
+#else
         const float ar = __builtin_fabsf(gm::distance_to_object_from(position, polar, cfg));
         const bool inside = ar < new_max;
         const bool wave_inside = __builtin_amdgcn_ballot_w64(inside) != 0;   // (taken here, where the compare is: one scalar instruction)
@@ -217,6 +231,7 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         const float near_ds = min_f32_uniform(ambient_precision, mixf(ambient_precision, subambient_precision, (clampf(ar, new_min, new_max) - new_min) / (new_max - new_min)));
 #endif
         const float far_ds = __builtin_fmaf(0.1f, ar, far_offset);   // 0.1 (|r| - max_precision_radius) + ambient
+#endif
         const float ds = inside ? near_ds : far_ds;
         ds_used = ds;
         running_before = running;

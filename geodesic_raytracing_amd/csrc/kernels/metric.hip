@@ -319,6 +319,13 @@ __device__ __forceinline__ float distance_to_object_from(float4 position, float4
 #endif
 }
 
+#ifdef GR_DISTANCE_SQUARED_OF_GENERIC
+__device__ __forceinline__ float distance_squared_from(float4 position, cfg_t cfg) {
+    GR_POSITION_VARS(position)
+    return GR_DISTANCE_SQUARED_OF_GENERIC;
+}
+#endif
+
 #ifdef GR_TWO_RAYS_PER_LANE
 // --- the same hosts for two rays per lane (gr_trace_pair): every variable of the generated expressions is a pair of
 // floats, one per ray, so their multiplies, adds and fmas become v_pk_mul/add/fma_f32 with nothing to shuffle ------------

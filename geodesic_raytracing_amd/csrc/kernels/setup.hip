@@ -140,21 +140,28 @@ __device__ __forceinline__ float4 normalise_metric(float4 v, const float* g) {
 __device__ int frame_basis_with_swap(const float* g, int index_swap, tetrad& out) {
     float4 arr[4] = {f4(1, 0, 0, 0), f4(0, 1, 0, 0), f4(0, 0, 1, 0), f4(0, 0, 0, 1)};
     float lengths[4] = {g[0], g[5], g[10], g[15]};
-    {
-        float4 t = arr[0]; arr[0] = arr[index_swap]; arr[index_swap] = t;
-        float l = lengths[0]; lengths[0] = lengths[index_swap]; lengths[index_swap] = l;
-    }
+    // (every index into these small arrays is a literal after unrolling - "the k that equals the index" instead of the index itself -
+    // so that they live in registers: indexed by a register they were 64 bytes of scratch per lane in every kernel that computes a
+    // tetrad per ray, the fused trace with redshift among them)
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+        if (k == index_swap) {
+            swap4(arr[0], arr[k]);
+            const float l = lengths[0]; lengths[0] = lengths[k]; lengths[k] = l;
+        }
     int indices[4] = {0, 1, 2, 3};
     int first_nonzero = -1;
     const float eps = 0.00001f;
-    for (int i = 0; i < 4; i++) {
-        if (!(__builtin_fabsf(lengths[i]) <= eps)) { first_nonzero = i; break; }
-    }
+#pragma unroll
+    for (int i = 3; i >= 0; i--)
+        if (!(__builtin_fabsf(lengths[i]) <= eps)) first_nonzero = i;   // the first one: the last assignment of a descending scan
     if (first_nonzero == -1) first_nonzero = 0;
-    if (first_nonzero != 0) {
-        float4 t = arr[0]; arr[0] = arr[first_nonzero]; arr[first_nonzero] = t;
-        int q = indices[0]; indices[0] = indices[first_nonzero]; indices[first_nonzero] = q;
-    }
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+        if (k == first_nonzero) {
+            swap4(arr[0], arr[k]);
+            const int q = indices[0]; indices[0] = indices[k]; indices[k] = q;
+        }
     // Gram-Schmidt in the metric (cl.cl:1647-1675)
     float4 u1 = arr[0];
     float4 u2 = arr[1];
@@ -168,8 +175,10 @@ __device__ int frame_basis_with_swap(const float* g, int index_swap, tetrad& out
     u4 = u4 - gram_project(u3, u4, g);
     float4 res[4] = {normalise_metric(u1, g), normalise_metric(u2, g), normalise_metric(u3, g), normalise_metric(u4, g)};
     float4 sorted[4];
+#pragma unroll
     for (int i = 0; i < 4; i++) {
         int old_index = indices[i];
+#pragma unroll
         for (int k = 0; k < 4; k++)
             if (k == old_index) sorted[k] = res[i];
     }

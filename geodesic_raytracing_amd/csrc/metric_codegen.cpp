@@ -486,7 +486,12 @@ std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl
         std::map<std::string, E> polar;
         for (int i = 0; i < 4; i++) polar["v" + std::to_string(i + 1)] = impl.to_polar[i];
         const E composed = sym::cancel_round_trip(sym::subst(impl.distance_function, polar));
-        if (!sym::contains_division_or_angle(composed)) s += "-DGR_DISTANCE_OF_GENERIC=" + to_c(composed) + " ";
+        if (!sym::contains_division_or_angle(composed)) {
+            s += "-DGR_DISTANCE_OF_GENERIC=" + to_c(composed) + " ";
+            // ... and where that is a square root, its argument: "inside the precision radius" is then a comparison of squares, and the
+            // root itself - the far step needs it - is taken only in a wave that has a ray outside
+            if (composed->op == sym::FN1 && composed->fn == sym::F_SQRT) s += "-DGR_DISTANCE_SQUARED_OF_GENERIC=" + to_c(composed->a) + " ";
+        }
     }
 
     bool tanh_in_sums_only = false;
