@@ -106,6 +106,7 @@ static int worker(int world, int rank, int device, const std::string& id_file, i
     }
     gr_tiled* tiled = nullptr;
     CHECK(gr_tiled_create(world, rank, device, world > 1 ? id : nullptr, width, height, block_rows, &tiled));
+    CHECK(gr_tiled_look_ahead(tiled, in_flight));   // a render state's next frame is in_flight rotations on: its look-ahead prepass is for that share
 
     const int bw = 2048, bh = 1024;
     std::vector<unsigned char> sky((size_t)bw * bh * 4);
@@ -145,7 +146,6 @@ static int worker(int world, int rank, int device, const std::string& id_file, i
             gr_frame_options options;
             gr_frame_options_default(&options);
             options.next_camera = &camera;   // a batch renderer knows the next camera: its prepass runs ahead on a side stream
-            options.next_strip_rank = gr_tiled_share(tiled, k + in_flight);
             if (transfer) {
                 CHECK(gr_render_frame_tiled(tiled, states[j], program, metric, streams[j], &camera, &features, cfg.data(), info.num_dynamic_vars,
                                             d_background, d_background, bw, bh, levels, frames_on_root[j], &options, k));

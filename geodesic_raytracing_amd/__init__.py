@@ -46,7 +46,8 @@ class Camera(ctypes.Structure):
 class FrameTuning(ctypes.Structure):
     """gr_frame_tuning (include/geodesic_hip_internal.h): which fused kernel, schedule and launch size gr_render_frame takes"""
     _fields_ = [("ray_compaction", c_int), ("rays_per_lane", c_int), ("fused_shading", c_int), ("inline_prepass", c_int),
-                ("trace_waves_per_simd", c_int), ("tile_history", c_int)]
+                ("trace_waves_per_simd", c_int), ("tile_history", c_int), ("next_strip_rank", c_int), ("next_strip_rank2", c_int),
+                ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float), ("count_attempts", c_int)]
 
 
 class FrameOptions(ctypes.Structure):
@@ -54,10 +55,8 @@ class FrameOptions(ctypes.Structure):
     object: setting one attaches a FrameTuning of the library's defaults, owned by the options object."""
     _fields_ = [("mode", c_int), ("tiled", c_int), ("use_prepass", c_int), ("max_probes", c_int), ("strip_rank", c_int),
                 ("strip_count", c_int), ("block_rows", c_int), ("compact_out", c_int), ("time_kernels", c_int),
-                ("count_attempts", c_int), ("next_camera", ctypes.POINTER(Camera)), ("next_camera2", ctypes.POINTER(Camera)),
-                ("next_strip_rank", c_int), ("next_strip_rank2", c_int), ("geodesic", c_void_p),
-                ("geodesic_time", c_float), ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float),
-                ("parallel_transport_observer", c_int), ("tuning", ctypes.POINTER(FrameTuning))]
+                ("next_camera", ctypes.POINTER(Camera)), ("next_camera2", ctypes.POINTER(Camera)), ("geodesic", c_void_p),
+                ("geodesic_time", c_float), ("parallel_transport_observer", c_int), ("tuning", ctypes.POINTER(FrameTuning))]
 
     def _tuning(self):
         t = self.__dict__.get("_owned_tuning")
@@ -140,6 +139,7 @@ _SIGNATURES = {
     "gr_program_manager_current": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int)]),
     "gr_program_manager_dynamic": (c_void_p, [c_void_p]),
     "gr_program_manager_destroy": (None, [c_void_p]),
+    "gr_program_manager_counters": (None, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gr_program_kernel_info": (c_int, [c_void_p, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gr_cart_to_generic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "gr_init_basis_vectors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_float), c_void_p, c_void_p,
@@ -238,6 +238,7 @@ _SIGNATURES = {
     "gr_tiled_create_custom": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "gr_tiled_exchange": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gr_tiled_staging_bytes": (c_size_t, [c_void_p]),
+    "gr_tiled_look_ahead": (c_int, [c_void_p, c_int]),
     "gr_tiled_share": (c_int, [c_void_p, c_int]),
     "gr_tiled_block_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gr_tiled_block_rows_of": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

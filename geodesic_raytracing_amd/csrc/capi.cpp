@@ -187,6 +187,30 @@ int resident_waves_per_simd(int vgprs, int sgprs) {
 // Compiles (or fetches from the on-disk cache) the code object for one macro string.
 int compile_setup_module(const std::string& argument_string, std::string& code);
 
+// the fallback of both modules' builds: hiprtc itself (no pass over the code; a source error shows up here with its diagnostics)
+int build_through_hiprtc(const std::string& source, const char* name, const std::vector<std::string>& options, std::string& out) {
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, source.c_str(), name, 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(GR_ERROR_COMPILE, "hiprtcCreateProgram failed");
+    std::vector<const char*> copts;
+    for (auto& o : options) copts.push_back(o.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(GR_ERROR_COMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    out.assign(n, '\0');
+    hiprtcGetCode(prog, &out[0]);
+    hiprtcDestroyProgram(&prog);
+    return GR_OK;
+}
+
 int compile_code_object(const std::string& argument_string, std::string& code, std::string* key_out = nullptr) {
     // the kernel source: the parts under csrc/kernels/ in this order, as one translation unit (GR_KERNEL_SOURCE: one file instead)
     static const char* const KERNEL_PARTS[] = {"program.hip",       // structs of the boundary, build switches
@@ -298,26 +322,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
             if (run_limit > 0) pass_not_applied = true;
             if (getenv("GR_VERBOSE_BUILD")) fprintf(stderr, "[gr] building through hiprtc (%s)\n", log.c_str());
         }
-        hiprtcProgram prog;
-        if (hiprtcCreateProgram(&prog, source.c_str(), "geodesic_kernels_all_parts.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-            return fail(GR_ERROR_COMPILE, "hiprtcCreateProgram failed");
-        std::vector<const char*> copts;
-        for (auto& o : options) copts.push_back(o.c_str());
-        hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
-        if (r != HIPRTC_SUCCESS) {
-            size_t n = 0;
-            hiprtcGetProgramLogSize(prog, &n);
-            std::string log(n, '\0');
-            if (n) hiprtcGetProgramLog(prog, &log[0]);
-            hiprtcDestroyProgram(&prog);
-            return fail(GR_ERROR_COMPILE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log);
-        }
-        size_t n = 0;
-        hiprtcGetCodeSize(prog, &n);
-        out.assign(n, '\0');
-        hiprtcGetCode(prog, &out[0]);
-        hiprtcDestroyProgram(&prog);
-        return GR_OK;
+        return build_through_hiprtc(source, "geodesic_kernels_all_parts.hip", options, out);
     };
     int rc = build(opts, code);
     if (rc != GR_OK) return rc;
@@ -394,12 +399,25 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
 int compile_setup_module(const std::string& argument_string, std::string& code) {
     static const char* const PARTS[] = {"program.hip", "probes.inc", "metric.hip", "setup.hip", "camera.hip", "geodesic_camera.hip"};
     std::string source;
-    for (const char* part : PARTS) {
-        std::string text;
-        const std::string path = library_dir() + "/csrc/kernels/" + part;
-        if (!read_file(path, text)) return fail(GR_ERROR_COMPILE, "cannot read kernel source " + path);
-        source += text;
-        if (!text.empty() && text.back() != '\n') source += '\n';
+    // GR_SETUP_KERNEL_SOURCE: one file instead of the parts, as GR_KERNEL_SOURCE is for the ray kernels' module.  (GR_KERNEL_SOURCE
+    // alone replaces the ray kernels only - the tools that use it patch the trace kernel - and this module is then built from the
+    // library's own parts: said once on stderr, so that nobody takes a patched metric.hip to reach the camera kernels.)
+    if (const char* env = getenv("GR_SETUP_KERNEL_SOURCE")) {
+        if (!read_file(env, source)) return fail(GR_ERROR_COMPILE, std::string("cannot read set-up kernel source ") + env);
+    } else {
+        if (getenv("GR_KERNEL_SOURCE")) {
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "[gr] note: GR_KERNEL_SOURCE replaces the ray kernels' source only; the set-up module (camera, tetrad, geodesic camera) is built "
+                                "from the library's csrc/kernels - GR_SETUP_KERNEL_SOURCE replaces that\n");
+        }
+        for (const char* part : PARTS) {
+            std::string text;
+            const std::string path = library_dir() + "/csrc/kernels/" + part;
+            if (!read_file(path, text)) return fail(GR_ERROR_COMPILE, "cannot read kernel source " + path);
+            source += text;
+            if (!text.empty() && text.back() != '\n') source += '\n';
+        }
     }
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno", "-fno-slp-vectorize",
                                      "-fhip-fp32-correctly-rounded-divide-sqrt", "-DGR_SETUP_MODULE", "-DGR_LIBM_TRIG", "-DGR_LIBM_TANH"};
@@ -423,8 +441,13 @@ int compile_setup_module(const std::string& argument_string, std::string& code) 
     const std::string cache_path = cache_dir + "/" + name;
     if (read_file(cache_path, code) && !code.empty()) return GR_OK;
     std::string assembly, log;
-    if (!gr::compile_to_assembly(source, opts, assembly, log) || !gr::assemble_code_object(assembly, code, log))
-        return fail(GR_ERROR_COMPILE, "set-up module: " + log);
+    if (!gr::compile_to_assembly(source, opts, assembly, log) || !gr::assemble_code_object(assembly, code, log)) {
+        // the code-object manager could not be loaded (or is the copy bundled with another library): hiprtc, as for the ray kernels'
+        // module - this module needs no pass over its code, so the result is the same program and is cached like any other
+        if (getenv("GR_VERBOSE_BUILD")) fprintf(stderr, "[gr] set-up module: building through hiprtc (%s)\n", log.c_str());
+        const int rc = build_through_hiprtc(source, "geodesic_setup_kernels.hip", opts, code);
+        if (rc != GR_OK) return rc;
+    }
     mkdir(cache_dir.c_str(), 0755);
     static std::atomic<unsigned long> writer{0};
     const std::string tmp = cache_path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(writer.fetch_add(1));
@@ -690,6 +713,7 @@ struct gr_program_future {
     int rc = GR_OK;
     std::string error;
     std::string code;
+    std::atomic<bool> cancelled{false};   // nobody wants the result any more: the worker stops at its next stage boundary
 };
 
 int gr_program_create_async(const char* argument_string, int device, gr_program_future** out) {
@@ -700,7 +724,7 @@ int gr_program_create_async(const char* argument_string, int device, gr_program_
     f->worker = std::thread([f]() {
         std::string code, setup;
         int rc = compile_code_object(f->arguments, code);   // compiler only: no device work on this thread
-        if (rc == GR_OK) rc = compile_setup_module(f->arguments, setup);
+        if (rc == GR_OK && !f->cancelled.load()) rc = compile_setup_module(f->arguments, setup);
         std::lock_guard<std::mutex> lock(f->mu);
         f->rc = rc;
         if (rc != GR_OK) f->error = g_error;
@@ -741,11 +765,11 @@ struct gr_program_manager {
     gr_program* dynamic = nullptr;
     gr_program* substituted = nullptr;       // swapped in (using_swapped)
     gr_program_future* pending = nullptr;    // substituted_program_opt
+    bool pending_is_stale = false;           // the parameters changed while it was building: its result is discarded, the next build follows it
     std::vector<gr_program*> retired;
-    std::vector<gr_program_future*> abandoned;   // builds a parameter change overtook: reaped once their worker has finished
     gr_features features{};
     std::vector<float> cfg;
-    unsigned long long swaps = 0, updates = 0;
+    unsigned long long swaps = 0, updates = 0, builds_started = 0;
 };
 
 static int manager_start_build(gr_program_manager* pm) {
@@ -755,27 +779,29 @@ static int manager_start_build(gr_program_manager* pm) {
     std::string arguments(need, '\0');
     rc = gr_metric_argument_string(pm->metric, &pm->features, 1, pm->cfg.data(), (int)pm->cfg.size(), &arguments[0], need, &need);
     if (rc != GR_OK) return rc;
+    pm->pending_is_stale = false;
+    pm->builds_started++;
     return gr_program_create_async(arguments.c_str(), pm->device, &pm->pending);
 }
 
-// A build that a parameter change has overtaken is not waited for (its worker cannot be interrupted inside the compiler, and joining
-// it would stall the caller's frame loop for the rest of the compile - seconds - every time a slider moves): it is set aside and
-// deleted by a later call that finds its worker finished; gr_program_manager_destroy joins what is left.
-static void manager_reap(gr_program_manager* pm, bool wait) {
-    for (size_t i = 0; i < pm->abandoned.size();) {
-        gr_program_future* f = pm->abandoned[i];
-        bool done;
-        {
-            std::lock_guard<std::mutex> lock(f->mu);
-            done = f->done;
-        }
-        if (done || wait) {
-            gr_program_future_destroy(f);   // joins a worker that has already left its last statement (or, at destruction, waits)
-            pm->abandoned.erase(pm->abandoned.begin() + (long)i);
-        } else {
-            i++;
-        }
+// AT MOST ONE BUILD IN FLIGHT (round 5).  A build that a parameter change has overtaken is not waited for - its worker cannot be
+// interrupted inside the compiler, and joining it would stall the caller's frame loop for the rest of the compile every time a slider
+// moves - but neither is a second one started next to it: a slider dragged for ten seconds changes the parameters every frame, and a
+// build per change (round 4) meant hundreds of compiler threads and code-object-manager contexts alive at once.  The overtaken build is
+// marked stale and told to stop at its next stage; the manager only remembers the latest parameters; whoever next finds the worker
+// finished (update or current) discards its result and starts the build of the latest parameters.  The reference cancels the pending
+// build the same way (metric_manager.hpp:129-166).  Returns < 0 on an error of the build that was started.
+static int manager_follow_stale_build(gr_program_manager* pm) {
+    if (!pm->pending || !pm->pending_is_stale) return GR_OK;
+    bool done;
+    {
+        std::lock_guard<std::mutex> lock(pm->pending->mu);
+        done = pm->pending->done;
     }
+    if (!done) return GR_OK;
+    gr_program_future_destroy(pm->pending);   // joins a worker that has left its last statement
+    pm->pending = nullptr;
+    return manager_start_build(pm);
 }
 
 static void manager_retire(gr_program_manager* pm, gr_program* p) {
@@ -827,15 +853,26 @@ int gr_program_manager_update(gr_program_manager* pm, const gr_features* feature
     pm->updates++;
     manager_retire(pm, pm->substituted);   // the substituted program is invalid for the new values: the dynamic one again
     pm->substituted = nullptr;
-    if (pm->pending) { pm->abandoned.push_back(pm->pending); pm->pending = nullptr; }   // not joined here: manager_reap
-    manager_reap(pm, false);
+    if (pm->pending) {   // one build in flight: it is overtaken, the next one starts when its worker has finished
+        pm->pending_is_stale = true;
+        pm->pending->cancelled.store(true);
+        return manager_follow_stale_build(pm);
+    }
     return manager_start_build(pm);
 }
 
 int gr_program_manager_current(gr_program_manager* pm, int wait, gr_program** program, int* is_substituted) {
     if (!pm || !program) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
-    manager_reap(pm, false);
     while (pm->pending) {
+        if (pm->pending_is_stale) {   // an overtaken build: nothing of it is wanted; the build of the latest parameters follows it
+            const int rc = manager_follow_stale_build(pm);
+            if (rc != GR_OK) return rc;
+            if (pm->pending && pm->pending_is_stale) {   // its worker is still inside the compiler
+                if (!wait) break;
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            }
+            continue;
+        }
         gr_program* ready = nullptr;
         const int rc = gr_program_future_poll(pm->pending, &ready);
         if (rc < 0) {   // the substituted build failed: the dynamic program goes on serving, the error is reported once
@@ -860,10 +897,14 @@ int gr_program_manager_current(gr_program_manager* pm, int wait, gr_program** pr
 
 gr_program* gr_program_manager_dynamic(gr_program_manager* pm) { return pm ? pm->dynamic : nullptr; }
 
+void gr_program_manager_counters(const gr_program_manager* pm, unsigned long long out[4]) {
+    if (!pm || !out) return;
+    out[0] = pm->updates; out[1] = pm->swaps; out[2] = pm->builds_started; out[3] = pm->pending && pm->pending_is_stale ? 1 : 0;
+}
+
 void gr_program_manager_destroy(gr_program_manager* pm) {
     if (!pm) return;
-    if (pm->pending) gr_program_future_destroy(pm->pending);
-    manager_reap(pm, true);
+    if (pm->pending) { pm->pending->cancelled.store(true); gr_program_future_destroy(pm->pending); }
     for (gr_program* p : pm->retired) gr_program_destroy(p);
     gr_program_destroy(pm->substituted);
     gr_program_destroy(pm->dynamic);

@@ -129,6 +129,8 @@ struct scope {
 }  // namespace
 
 bool compile_to_assembly(const std::string& source, const std::vector<std::string>& options, std::string& assembly, std::string& log) {
+    // GR_NO_CODE_OBJECT_MANAGER=1: behave as where libamd_comgr cannot be loaded (tests of the hiprtc fallback of both modules)
+    if (const char* e = getenv("GR_NO_CODE_OBJECT_MANAGER"); e && e[0] == '1') { log = "code-object manager switched off (GR_NO_CODE_OBJECT_MANAGER)"; return false; }
     const comgr_api& c = comgr();
     if (!c.lib) { log = c.error; return false; }
     scope sc(c);

@@ -355,15 +355,10 @@ void gr_frame_options_default(gr_frame_options* o) {
     o->block_rows = 16;
     o->compact_out = 0;
     o->time_kernels = 0;
-    o->count_attempts = 0;
     o->next_camera = nullptr;
     o->next_camera2 = nullptr;
-    o->next_strip_rank = -1;
-    o->next_strip_rank2 = -1;
     o->geodesic = nullptr;
     o->geodesic_time = 0;
-    o->next_geodesic_time = 0;
-    o->next_geodesic_time2 = 0;
     o->parallel_transport_observer = 1;   // main.cpp:1259
     o->tuning = nullptr;
 }
@@ -376,6 +371,11 @@ void gr_frame_tuning_default(gr_frame_tuning* t) {
     t->inline_prepass = -1;
     t->trace_waves_per_simd = 0;
     t->tile_history = -1;
+    t->next_strip_rank = -1;
+    t->next_strip_rank2 = -1;
+    t->next_geodesic_time = 0;
+    t->next_geodesic_time2 = 0;
+    t->count_attempts = 0;
 }
 
 int gr_device_count(int* count) {
@@ -897,7 +897,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         return GR_OK;
     };
     void* attempts = nullptr;
-    if (opt.count_attempts) {
+    if (tune.count_attempts) {
         HIP_CHECK(hipMemsetAsync(s->attempts, 0, GR_COUNTER_WORDS * 8, stream));
         attempts = s->attempts;
     }
@@ -1019,8 +1019,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         std::vector<request> todo;
         bool claimed[gr_render_state::LOOKAHEAD] = {};   // a slot serves one request (two frames may share one camera)
         if (use_prepass) {
-            request asked[2] = {{opt.next_camera, opt.next_geodesic_time, opt.next_strip_rank},
-                                {opt.next_camera2, opt.next_geodesic_time2, opt.next_strip_rank2}};
+            request asked[2] = {{opt.next_camera, tune.next_geodesic_time, tune.next_strip_rank},
+                                {opt.next_camera2, tune.next_geodesic_time2, tune.next_strip_rank2}};
             for (auto& r : asked) {
                 if (!r.camera) continue;
                 if (r.strip_rank < 0 || r.strip_rank >= strip_count) r.strip_rank = strip_rank;

@@ -122,6 +122,7 @@ struct gr_tiled {
     gr_transport link{};                     // point-to-point calls of GR_TRANSPORT_RCCL / GR_TRANSPORT_CUSTOM
     std::vector<frame_slot> ring;
     unsigned long long frames = 0;
+    int look_ahead = 1;                      // gr_tiled_look_ahead: rotations between a frame and the frame its options->next_camera is for
     std::shared_ptr<peer_group> group;       // GR_TRANSPORT_PEER
     int root_device = 0;
     std::shared_ptr<void> ipc;               // GR_TRANSPORT_IPC: the ipc_link (defined below; released with the participant)
@@ -416,6 +417,12 @@ void gr_tiled_destroy(gr_tiled* t) { delete t; }
 
 int gr_tiled_share(const gr_tiled* t, int rotation) { return t ? ((t->rank + (rotation % t->world + t->world)) % t->world) : 0; }
 
+int gr_tiled_look_ahead(gr_tiled* t, int rotations) {
+    if (!t || rotations < 1) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "gr_tiled_look_ahead: a participant and a distance of at least one rotation");
+    t->look_ahead = rotations;
+    return GR_OK;
+}
+
 int gr_tiled_block_rows(int height, int block_rows, int world, int share, int local_block, int* row_begin, int* row_end) {
     if (!row_begin || !row_end || height < 1 || block_rows < 1 || world < 1 || share < 0 || share >= world || local_block < 0) return -1;
     const long long a = ((long long)local_block * world + share) * block_rows;
@@ -496,6 +503,14 @@ int gr_render_frame_tiled(gr_tiled* t, gr_render_state* s, gr_program* p, const 
     if (options) opt = *options;
     opt.mode = GR_MODE_FUSED;
     const int share = gr_tiled_share(t, rotation);
+    // the shares of the look-ahead frames (options->next_camera, next_camera2): this render state's next two calls, look_ahead rotations
+    // apart - unless the caller's own tuning names them
+    gr_frame_tuning tune;
+    gr_frame_tuning_default(&tune);
+    if (opt.tuning) tune = *opt.tuning;
+    if (t->world > 1 && opt.next_camera && tune.next_strip_rank < 0) tune.next_strip_rank = gr_tiled_share(t, rotation + t->look_ahead);
+    if (t->world > 1 && opt.next_camera2 && tune.next_strip_rank2 < 0) tune.next_strip_rank2 = gr_tiled_share(t, rotation + 2 * t->look_ahead);
+    opt.tuning = &tune;
     if (t->world > 1) {
         opt.strip_count = t->world;
         opt.strip_rank = share;

@@ -268,6 +268,12 @@ class ProgramManager:
         self.is_substituted = bool(swapped.value)
         return self._borrowed(handle)
 
+    def counters(self):
+        """dict: updates taken, substituted programs swapped in, substituted builds started (at most one runs at a time), stale_build_running"""
+        out = (ctypes.c_ulonglong * 4)()
+        lib.gr_program_manager_counters(self.handle, out)
+        return dict(updates=int(out[0]), swaps=int(out[1]), builds_started=int(out[2]), stale_build_running=bool(out[3]))
+
     def close(self):
         if getattr(self, "handle", None):
             lib.gr_program_manager_destroy(self.handle)

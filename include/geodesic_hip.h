@@ -191,11 +191,17 @@ struct gr_camera {
     float basis_speed[3];   /* cartesian_basis_speed, main.cpp:2320-2327 */
     float flip;             /* flip_sign > 0 puts the camera on the far side (negative r) */
 };
-void gr_camera_default(gr_camera* out);   /* pos (0,0,-4,0), axis-angle (1,0,0,-pi/2) */  enum { GR_MODE_REFERENCE = 0,   /* one
-                       launch per reference kernel, 96-byte ray records in HBM */ GR_MODE_FUSED = 1 };     /* gr_prepass_fused +
-                       gr_trace_fused + gr_render */  /* Snapshot of the camera's own timelike geodesic, resident on the device: the
-                       buffers of main.cpp:1232-1242 * (geodesic_trace / vel / ds / count) and the four parallel-transported tetrad
-                       legs. */ typedef struct gr_geodesic_camera gr_geodesic_camera;
+/* pos (0,0,-4,0), axis-angle (1,0,0,-pi/2) */
+void gr_camera_default(gr_camera* out);
+
+enum {
+    GR_MODE_REFERENCE = 0,   /* one launch per reference kernel, 96-byte ray records in HBM */
+    GR_MODE_FUSED = 1        /* gr_prepass_fused + gr_trace_fused + gr_render */
+};
+
+/* Snapshot of the camera's own timelike geodesic, resident on the device: the buffers of main.cpp:1232-1242
+ * (geodesic_trace / vel / ds / count) and the four parallel-transported tetrad legs. */
+typedef struct gr_geodesic_camera gr_geodesic_camera;
 
 typedef struct gr_frame_tuning gr_frame_tuning;   /* geodesic_hip_internal.h: which fused kernel, schedule and launch size (defaults are right) */
 
@@ -210,18 +216,16 @@ typedef struct gr_frame_options {
     int strip_count;       /*   global block b belongs to device b % strip_count (1 = whole image on this device) */
     int block_rows;        /*   multiple of 8                                                                      */
     int compact_out;       /*   1: write this device's blocks back to back into out (gather layout)               */
-    int time_kernels;      /* 1: HIP events around every stage of this frame; 2: one event pair per trace launch (internal header) */
-    int count_attempts;    /* accumulate Verlet step attempts (gr_render_state_attempts, internal header) */
+    int time_kernels;      /* 1: HIP events around every stage of this frame (gr_render_state_stage_ms); 2: one event pair per trace launch (internal header) */
     const struct gr_camera* next_camera;   /* fused mode, optional: the camera of the NEXT gr_render_frame call of this state.  Its tetrad
                             * and prepass are computed on a side stream while this frame traces.  NULL = no look-ahead. */
     const struct gr_camera* next_camera2;  /* optional: the camera of the call after that (two prepasses in flight: split frames) */
-    int next_strip_rank;   /* strip_rank of the next_camera / next_camera2 frames when a device's share rotates from frame to frame; */
-    int next_strip_rank2;  /*   -1 = the same as this frame's */
     const gr_geodesic_camera* geodesic;   /* camera_on_geodesic (main.cpp:2264-2293): position and tetrad come from this snapshot at
                             * proper time geodesic_time instead of camera->position; camera->quat still orients the view */
-    float geodesic_time, next_geodesic_time, next_geodesic_time2;   /* current_geodesic_time of this frame / the look-ahead frames */
+    float geodesic_time;   /* current_geodesic_time of this frame */
     int parallel_transport_observer;   /* 1 (default, main.cpp:1259): interpolate the transported tetrads; 0: rebuild them */
-    const gr_frame_tuning* tuning;     /* NULL = library defaults */
+    const gr_frame_tuning* tuning;     /* NULL = library defaults; also where the look-ahead frames' strip ranks and geodesic times and the
+                                        * measurement switches live (geodesic_hip_internal.h) */
 } gr_frame_options;
 void gr_frame_options_default(gr_frame_options* out);
 
@@ -303,8 +307,12 @@ int gr_render_frame_tiled(gr_tiled* t, gr_render_state* s, gr_program* p, const 
                           void* background2, int bg_width, int bg_height, int bg_levels, void* frame_on_root, const
                           gr_frame_options* options, int rotation);
 int gr_tiled_join(gr_tiled* root, void* stream);
-/* the share participant t renders in a frame with this rotation (what to put into options->next_strip_rank for a look-ahead) */
+/* the share participant t renders in a frame with this rotation */
 int gr_tiled_share(const gr_tiled* t, int rotation);
+/* A caller that cycles through n render states (n frames in flight) and passes options->next_camera says so here: the look-ahead frame of a
+ * call with rotation k is then the frame of rotation k + n (next_camera2: k + 2 n), and gr_render_frame_tiled computes its prepass for the
+ * share the participant will have by then.  Default 1. */
+int gr_tiled_look_ahead(gr_tiled* t, int rotations);
 
 /* ---- host helper: background image ----------------------------------------------------------- */
 /* load_mipped_image (graphics_settings.cpp:152-212): an RGBA8 image and its box-filtered mip chain in `levels` same-size slices (mip i

@@ -30,6 +30,12 @@ struct gr_frame_tuning {
                             * render state's previous frame (gr_order_tiles_by_history, shifted by how far the camera has moved the
                             * picture since); 0 = no; -1 = library default: whole frames of at most 32 tiles per wave slot that find no
                             * frame of ANOTHER stream still running on the device when they are submitted.  Scheduling only. */
+    /* -- what rides with the look-ahead cameras of gr_frame_options (next_camera, next_camera2) -- */
+    int next_strip_rank;   /* strip_rank of the next_camera / next_camera2 frames when a device's share rotates from frame to frame; */
+    int next_strip_rank2;  /*   -1 (default) = the same as this frame's.  gr_render_frame_tiled fills both in (gr_tiled_look_ahead). */
+    float next_geodesic_time, next_geodesic_time2;   /* current_geodesic_time of the look-ahead frames (gr_frame_options.geodesic) */
+    /* -- measurement -- */
+    int count_attempts;    /* 1: accumulate the Verlet step attempts of this frame (gr_render_state_attempts) */
 };
 void gr_frame_tuning_default(gr_frame_tuning* out);
 
@@ -43,6 +49,10 @@ enum { GR_BUF_RAYS_IN = 0, GR_BUF_RAYS_COUNT = 1, GR_BUF_RENDER_DATA = 2, GR_BUF
        GR_BUF_RAYS_ADAPTIVE_COUNT = 10, GR_BUF_CFG = 11, GR_BUF_DFG = 12, GR_BUF_CAMERA_QUAT = 13 };
 /* device pointer of one of the state's buffers (NULL if not allocated) */
 void* gr_render_state_buffer(gr_render_state* s, int which);
+
+/* counters of a program manager: out[0] parameter changes taken (gr_program_manager_update), [1] substituted programs swapped in, [2] substituted
+ * builds started - never more than one of them is running -, [3] 1 while a build is running whose result nobody wants any more */
+void gr_program_manager_counters(const gr_program_manager* pm, unsigned long long out[4]);
 
 /* Background build of the "substituted" program (metric_manager.hpp:153-166, swapped in by check_substitution :172-219): create_async
  * returns at once; poll returns 1 and a loaded program when it is ready, 0 while pending, < 0 on a build error. */

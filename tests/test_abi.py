@@ -39,6 +39,39 @@ def test_library_exports_every_declared_symbol():
     assert set(contract) | set(internal) == set(gra.EXPORTED_SYMBOLS)
 
 
+def test_headers_read_line_by_line():
+    """a formatter once folded a declaration, an enum, their comments and a typedef into one run-on paragraph of geodesic_hip.h; it
+    compiled, nobody could read it.  Both headers, line-wise: every function declaration, typedef, struct and enum starts its line (after
+    at most a closing comment on a line of its own), no line holds two statements of that kind, and no comment opens after code and
+    closes before more code follows on the same line."""
+    for header in ("geodesic_hip.h", "geodesic_hip_internal.h"):
+        inside_comment = False
+        for number, line in enumerate(open(os.path.join(ROOT, "include", header)).read().split("\n"), 1):
+            where = f"include/{header}:{number}: {line.strip()[:100]}"
+            text = line
+            if inside_comment:                                   # a block comment that began on an earlier line
+                if "*/" not in text:
+                    continue
+                text = text[text.index("*/") + 2:]
+                inside_comment = False
+                assert text.strip() == "", "code behind the end of a comment - " + where
+            code = re.sub(r"/\*.*?\*/", "", text)                # comments that open and close on the line
+            if "/*" in code:
+                code, inside_comment = code[:code.index("/*")], True
+            # one statement to a line: nothing but white space between a ';' and the end of the code (for-loops there are none)
+            assert not re.search(r";\s*\S", code), "two statements on one line - " + where
+            # a declaration starts its line (struct members and continuation lines are indented; the rest starts in column 0)
+            if re.search(r"\b(?:typedef|enum)\b|\bgr_\w+\s*\(", code) and not line.startswith((" ", "\t", "*")):
+                assert re.match(r"(?:typedef|enum|struct|int|long|double|void|unsigned|const|float|size_t|gr_\w+\*?)\b", code), "a declaration that does not start its line - " + where
+    # the options struct of the contract keeps to the frame's own description: the look-ahead frames' shares and times and the attempt
+    # counter live in gr_frame_tuning (geodesic_hip_internal.h)
+    public = open(os.path.join(ROOT, "include", "geodesic_hip.h")).read()
+    body = public[public.index("typedef struct gr_frame_options {"):public.index("} gr_frame_options;")]
+    for moved in ("next_strip_rank", "next_geodesic_time", "count_attempts"):
+        assert moved not in body
+    assert len(re.findall(r"^\s{4}[a-z].*?;", body, flags=re.M)) <= 15
+
+
 def test_struct_layouts():
     assert LIGHTRAY_DTYPE.itemsize == 96          # sizeof(struct lightray), cl.cl:813-824
     assert RENDER_DATA_DTYPE.itemsize == 32       # sizeof(struct render_data), cl.cl:5066-5074
@@ -102,6 +135,26 @@ def test_precompile_produces_gfx950_code_object(tmp_path, monkeypatch):
         assert k in blob
     for k in (b"gr_cart_to_generic", b"gr_init_basis_vectors", b"gr_camera_setup", b"gr_get_geodesic_path", b"gr_handle_interpolating_geodesic"):
         assert k in setup and k not in blob
+
+
+def test_both_modules_build_without_the_code_object_manager(tmp_path):
+    """where libamd_comgr cannot be loaded (GR_NO_CODE_OBJECT_MANAGER=1 stands in for that) both code objects of a program come from
+    hiprtc itself: the ray kernels - used but not cached, they lack the pass over their code - and, since round 5, the set-up module,
+    which needs no pass and is cached (until then gr_program_create failed with GR_ERROR_COMPILE where it used to fall back).  In a
+    process of its own: the library looks for the code-object manager once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import geodesic_raytracing_amd as gra\n"
+            "gra.Program.precompile(gra.Metric('minkowski').argument_string())\n")
+    env = dict(os.environ, GR_CACHE_DIR=str(tmp_path), GR_NO_CODE_OBJECT_MANAGER="1", GR_VERBOSE_BUILD="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "set-up module: building through hiprtc" in r.stderr and "could not be applied" in r.stderr
+    files = [f.name for f in tmp_path.glob("*.hsaco")]
+    assert len(files) == 1 and files[0].endswith(".setup.hsaco")
+    blob = (tmp_path / files[0]).read_bytes()
+    assert blob[:4] == b"\x7fELF" and b"gr_camera_setup" in blob
 
 
 def test_background_packing_layout():

@@ -508,8 +508,22 @@ def test_program_manager_update_does_not_wait_for_an_overtaken_build(tmp_path, m
         prog = manager.current()                   # never blocks; the dynamic program while the builds run
         assert prog.handle.value == manager.dynamic.handle.value or manager.is_substituted
     assert time.time() - t0 < 2.0, "gr_program_manager_update waited for a build"
+    # ... and starts no build next to one that is running (round 5; a build per change meant a compiler thread per frame of a slider
+    # drag): a burst of changes is taken in - the dynamic program serves - while at most the overtaken build and, once that has left
+    # the compiler, the build of the LATEST parameters have been started
+    before = manager.counters()["builds_started"]
+    for k in range(40):
+        manager.update(feats, metric.cfg_values(rs=1.3 + 0.001 * (k + 1)))
+        manager.current()
+    burst = manager.counters()
+    assert burst["updates"] >= 43 and burst["builds_started"] - before <= 2, burst
+    assert time.time() - t0 < 4.0, "gr_program_manager_update waited for a build"
     last = manager.current(wait=True)
     assert manager.is_substituted and last.build_key != manager.dynamic.build_key
+    assert manager.counters()["builds_started"] - before <= 3 and not manager.counters()["stale_build_running"]
+    # the program that was swapped in is the one of the last parameters: the same frame as a program built for them directly
+    direct = gra.Program(metric.argument_string(feats, static=True, cfg_values=metric.cfg_values(rs=1.3 + 0.001 * 40)), 0)
+    assert direct.build_key == last.build_key
     manager.close()                                # joins whatever is still compiling
 
 
