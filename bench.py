@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--mode", default="fused", choices=["fused", "reference"])
     ap.add_argument("--program", default="static", choices=["static", "dynamic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="port", choices=["port", "reference"],
+                    help="port (default): this repository's restatement oracle/restate.cpp, built on the spot - what a fresh clone has; reference: the "
+                         "reference's cl.cl compiled for x86-64 (oracle/_ref/*.so, build container only) where that object is present")
+    ap.add_argument("--no-build-timing", action="store_true", help="skip program_build_s (two cold compiles of the substituted program, ~30 s of a host core)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (other poses / modes); used for profiling runs")
     ap.add_argument("--no-lookahead", action="store_true", help="do not overlap the next frame's prepass with this frame's trace")
     ap.add_argument("--lookahead-depth", type=int, default=0, help="frames of prepass look-ahead (1 or 2); default 1 on one GPU, "
@@ -97,16 +101,20 @@ def parse():
     return args
 
 
-def cpu_baseline(metric_name, cfg_values, features_kw, target_seconds):
+def cpu_baseline(metric_name, cfg_values, features_kw, target_seconds, prefer="port"):
     """Times the CPU side on a bounded sample of the same workload: a low-resolution frame with the same camera and field of
     view (same ray distribution), all host cores.  The reference's own cl.cl compiled for x86-64 (oracle/_ref, built in the
     build container for exactly this macro string and shipped as a .so) when it is there - kind "reference" - otherwise this
-    repository's C++ restatement of it (oracle/restate.cpp) - kind "port"."""
+    repository's C++ restatement of it (oracle/restate.cpp) - kind "port".  Round 5: "port" is the default - it is what the tracked tree
+    builds anywhere; the x86 build of cl.cl does not travel to the GPU box any more (.gpurunignore), and how the two
+    compare is measured once in the build container: profiles/r05_cpu_calibration.txt."""
     from oracle import build_restate, build_ref
     from oracle.refpipe import OraclePipeline, pack_features
     import geodesic_raytracing_amd as gra
     m = gra.Metric(metric_name, os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"))
-    so = build_ref.prebuilt(metric_name + "_script", m.argument_string()) or build_ref.prebuilt(metric_name, m.argument_string())
+    so = None
+    if prefer == "reference":
+        so = build_ref.prebuilt(metric_name + "_script", m.argument_string()) or build_ref.prebuilt(metric_name, m.argument_string())
     kind = "reference" if so else "port"
     if not so:
         so = build_restate.build(m.argument_string())
@@ -131,6 +139,35 @@ def cpu_baseline(metric_name, cfg_values, features_kw, target_seconds):
     return {"value": round(w2 * h2 / t2 / 1e6, 6), "unit": "Mrays/s", "cores": cores, "kind": kind,
             "sample": f"{w2}x{h2} frame of the same camera/metric (init + Verlet trace of every pixel, no prepass skip) through {what}, "
                       f"{t2:.1f} s on {cores} threads"}
+
+
+def program_build_seconds(metric_name, spin, redshift):
+    """Cold build times of the substituted program on this host, in a process and a cache directory of their own with the compiler's own
+    result cache off (AMD_COMGR_CACHE=0): (a) the first program of a shape - the free build, the occupancy rule's capped builds, the
+    set-up module; (b) the next parameter set of the same shape (a slider moved: the remembered occupancy decision, one compiler run + the
+    set-up module).  What a maintainer waits for between a parameter change and the swap of the substituted program."""
+    import subprocess
+    import tempfile
+    code = (
+        "import sys, time\n"
+        "import geodesic_raytracing_amd as gra\n"
+        "m = gra.Metric(sys.argv[1], sys.argv[2])\n"
+        "spin, redshift = float(sys.argv[3]), int(sys.argv[4])\n"
+        "out = []\n"
+        "for k in range(2):\n"
+        "    cfg = m.cfg_values(a=spin + 0.01 * k) if 'a' in m.dynamic_vars else [v * (1 + 0.01 * k) for v in m.cfg_values()]\n"
+        "    text = m.argument_string(features=m.features(adaptive_sampling=0, redshift=redshift), static=True, cfg_values=cfg)\n"
+        "    t = time.perf_counter(); gra.Program.precompile(text); out.append(time.perf_counter() - t)\n"
+        "print(out[0], out[1])\n")
+    with tempfile.TemporaryDirectory(prefix="gr_build_timing") as d:
+        env = dict(os.environ, GR_CACHE_DIR=d, AMD_COMGR_CACHE="0", PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", code, metric_name, os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"), str(spin), str(redshift)],
+                           env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": r.stderr[-400:]}
+    first, again = (float(x) for x in r.stdout.split()[-2:])
+    return {"first_of_its_shape": round(first, 2), "next_parameters_same_shape": round(again, 2),
+            "note": "substituted program, both code objects (ray kernels + set-up module), one host core, compiler cache off"}
 
 
 def main():
@@ -184,8 +221,11 @@ def main():
     features = metric.features(adaptive_sampling=0, redshift=args.redshift)
     # metric_manager.hpp:19-219: dynamic program first, substituted program (parameters baked in) built in the
     # background and swapped in; the steady state the reference runs in - and the one timed here - is the substituted one
-    manager = gra.pipeline.ProgramManager(metric, local_rank, features, cfg_values)
+    t_start = time.perf_counter()
+    manager = gra.pipeline.ProgramManager(metric, local_rank, features, cfg_values)   # returns with the dynamic program loaded
+    t_dynamic_ready = time.perf_counter() - t_start
     program = manager.current(wait=(args.program == "static"))
+    t_substituted_ready = time.perf_counter() - t_start
     if args.program == "dynamic":
         program = manager.dynamic
     bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
@@ -359,7 +399,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    t_first = time.perf_counter()
+    frame()
+    torch.cuda.synchronize()
+    first_frame_s = time.perf_counter() - t_first
+    for _ in range(max(0, args.warmup - 1)):
         frame()
     # every render state of the ring must have rendered once before the clock starts (buffers touched, its look-ahead slots
     # filled); with fewer warm-up steps than states the missing ones are rendered here, untimed, and reported as priming_frames
@@ -644,10 +688,29 @@ def main():
                 del st2, out2
             extra["secondary"] = secondary
 
+    startup = None
+    if rank == 0 and world == 1:
+        # what a user waits for, warm cache (the code objects are in geodesic_raytracing_amd/_cache): library + dynamic program loaded,
+        # substituted program swapped in, first frame on the screen (its buffers allocated, its kernels loaded)
+        startup = {"dynamic_program_ready_s": round(t_dynamic_ready, 3), "substituted_program_ready_s": round(t_substituted_ready, 3),
+                   "first_frame_s": round(first_frame_s, 3), "time_to_first_frame_s": round(t_substituted_ready + first_frame_s, 3),
+                   "note": "from gr_program_manager_create to the first complete 4K frame; code objects from the on-disk cache (a cold build: program_build_s)"}
+        if not args.no_build_timing and not args.no_secondary:
+            startup["program_build_s"] = program_build_seconds(args.metric, args.spin, args.redshift)
+        extra["startup"] = startup
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # (two seconds of the headline frame, untimed, right before the host takes over for the CPU baseline: the driver samples the
+        # device's activity from outside, and bursts of 0.1 s between long host phases are easy to miss)
+        t_busy = time.perf_counter()
+        while time.perf_counter() - t_busy < 2.0:
+            for _ in range(8):
+                frame()
+            torch.cuda.synchronize()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         feats_kw = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change)
-        cpu = cpu_baseline(args.metric, cfg_values, feats_kw, args.cpu_seconds)
+        cpu = cpu_baseline(args.metric, cfg_values, feats_kw, args.cpu_seconds, prefer=args.cpu_baseline)
 
     if rank == 0:
         line = {

@@ -324,8 +324,64 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
         }
         return build_through_hiprtc(source, "geodesic_kernels_all_parts.hip", options, out);
     };
-    int rc = build(opts, code);
-    if (rc != GR_OK) return rc;
+    // The occupancy rule below costs up to three more compiler runs.  Its outcome depends on the program's SHAPE - kernel source,
+    // options, the metric's expressions - far more than on the literals a substituted program carries, and a slider move changes only
+    // those: the decision is remembered per shape (the options with every float literal blanked) next to the code objects, and a program
+    // of a known shape is built held to the remembered wave count straight away - one compiler run, the swap of the substituted program
+    // after a parameter change ~20 s -> ~8 s - as long as that build still meets the rule's own conditions.
+    bool tuned_by_caller = false;
+    for (auto& o : opts) tuned_by_caller |= o.rfind("-DGR_FUSED_WAVES", 0) == 0 || o.rfind("-DGR_TRACE_WAVES", 0) == 0;
+    const char* tuning = getenv("GR_OCCUPANCY_TUNING");
+    const bool rule_applies = !tuned_by_caller && !(tuning && tuning[0] == '0');
+    std::string shape_path;
+    {
+        uint64_t sh = fnv1a(source);
+        for (auto& o : opts) {
+            std::string blank;
+            for (size_t i = 0; i < o.size();) {
+                const bool starts_number = isdigit((unsigned char)o[i]) && (i == 0 || !(isalnum((unsigned char)o[i - 1]) || o[i - 1] == '_'));
+                if (!starts_number) { blank += o[i++]; continue; }
+                size_t j = i;
+                while (j < o.size() && (isdigit((unsigned char)o[j]) || o[j] == '.' || ((o[j] == 'e' || o[j] == 'E') && j + 1 < o.size() && (isdigit((unsigned char)o[j + 1]) || o[j + 1] == '-' || o[j + 1] == '+')) ||
+                                        ((o[j] == '-' || o[j] == '+') && j > i && (o[j - 1] == 'e' || o[j - 1] == 'E')))) j++;
+                const bool is_float = j < o.size() && o[j] == 'f' && o.substr(i, j - i).find_first_of(".e") != std::string::npos;
+                if (is_float) { blank += '#'; i = j + 1; } else { blank.append(o, i, j - i); i = j; }
+            }
+            // (the generator orders the operands of sums and products by a hash that takes the literals in, and numbers its temporaries as
+            // it meets them: two parameter sets give the same expressions in another order.  What is left after blanking the literals
+            // is therefore taken as a bag of characters, every digit the same - a hint's key may collide, the conditions above decide.)
+            for (char& ch : blank) if (isdigit((unsigned char)ch)) ch = '9';
+            const size_t eq = blank.find('=');
+            if (eq != std::string::npos) std::sort(blank.begin() + (long)eq + 1, blank.end());
+            sh = fnv1a(blank + "\n", sh);
+        }
+        sh = fnv1a("shape, hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + ", runs " + std::to_string(run_limit), sh);
+        char shape_name[64];
+        snprintf(shape_name, sizeof(shape_name), "%016llx.occupancy", (unsigned long long)sh);
+        shape_path = cache_dir + "/" + shape_name;
+    }
+    bool settled_from_memory = false;
+    if (rule_applies) {
+        std::string note;
+        int waves = 0, free_vgprs = 0, free_scratch = 0;
+        if (read_file(shape_path, note) && sscanf(note.c_str(), "waves=%d free_vgprs=%d free_scratch=%d", &waves, &free_vgprs, &free_scratch) == 3 && waves >= 1 && waves <= 8) {
+            std::vector<std::string> capped = opts;
+            capped.push_back("-DGR_FUSED_WAVES=" + std::to_string(waves));
+            std::string code2;
+            int v2 = 0, s2 = 0, g2 = 0;
+            if (build(capped, code2) == GR_OK && kernel_resources(code2, "gr_trace_fused", v2, s2, &g2) && s2 <= free_scratch + 96 &&
+                resident_waves_per_simd(v2, g2) >= waves) {
+                code.swap(code2);
+                settled_from_memory = true;
+                if (getenv("GR_VERBOSE_BUILD"))
+                    fprintf(stderr, "[gr] gr_trace_fused: held to %d waves as remembered for programs of this shape: %d VGPRs / %d SGPRs / %d B scratch (kept, one compiler run)\n", waves, v2, g2, s2);
+            }
+        }
+    }
+    if (!settled_from_memory) {
+        int rc = build(opts, code);
+        if (rc != GR_OK) return rc;
+    }
 
     // Occupancy of the fused trace kernel.  Left alone, the register allocator takes what the kernel could use at its widest
     // point (Kerr, substituted: 97 VGPRs, 5 waves per SIMD), part of which is cold inside the Verlet loop (set-up and epilogue
@@ -339,10 +395,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     // would not be resident anyway (round 4): the kernel's ~94 scalar registers admit 6 waves per SIMD, so the "7 waves" build of
     // rounds 2 and 3 (72 VGPRs, 48 B spilled) ran 6 like the 80-register build that spills 16 B; that one is 3 % faster one frame at
     // a time (5.46 against 5.65 ms, 4K Kerr) and the same with frames in flight.
-    bool tuned_by_caller = false;
-    for (auto& o : opts) tuned_by_caller |= o.rfind("-DGR_FUSED_WAVES", 0) == 0 || o.rfind("-DGR_TRACE_WAVES", 0) == 0;
-    const char* tuning = getenv("GR_OCCUPANCY_TUNING");
-    if (!tuned_by_caller && !(tuning && tuning[0] == '0')) {
+    if (rule_applies && !settled_from_memory) {
         int vgprs = 0, scratch = 0;
         if (kernel_resources(code, "gr_trace_fused", vgprs, scratch) && vgprs > 64) {
             auto waves_of = [](int regs) { int w = 512 / (((regs + 7) / 8) * 8); return w > 8 ? 8 : w; };
@@ -364,7 +417,17 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
                 if (getenv("GR_VERBOSE_BUILD"))
                     fprintf(stderr, "[gr] gr_trace_fused: free build %d VGPRs / %d B scratch; held to %d waves: %d VGPRs / %d SGPRs / %d B scratch%s\n", vgprs,
                             scratch, waves, v2, g2, s2, keep ? " (kept)" : resident ? " (dropped)" : " (dropped: its scalar registers admit fewer waves)");
-                if (keep) { code.swap(code2); break; }
+                if (keep) {
+                    code.swap(code2);
+                    if (!pass_not_applied) {   // remembered for the next program of this shape
+                        mkdir(cache_dir.c_str(), 0755);
+                        std::ofstream f(shape_path + ".tmp" + std::to_string((long)getpid()));
+                        f << "waves=" << waves << " free_vgprs=" << vgprs << " free_scratch=" << scratch << "\n";
+                        f.close();
+                        if (rename((shape_path + ".tmp" + std::to_string((long)getpid())).c_str(), shape_path.c_str()) != 0) remove((shape_path + ".tmp" + std::to_string((long)getpid())).c_str());
+                    }
+                    break;
+                }
             }
         }
     }

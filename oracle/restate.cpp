@@ -1077,12 +1077,16 @@ void ref_do_generic_rays(void* rays_v, const int* count, int n_items, const void
         std::vector<std::thread> pool;
         for (int t = 0; t < nthreads; t++)
             pool.emplace_back([&, t]() {
+                // (the attempts are counted in a local and stored once: eight-byte counters of neighbouring threads share a cache line,
+                // and an increment per attempt through it made 8 threads barely faster than one - round 5, tools/cpu_calibration.py)
+                uint64_t mine = 0;
                 for (long base = (long)t * 64; base < n; base += (long)nthreads * 64)
                     for (long id = base; id < base + 64 && id < n; id++) {
                         if (ray_write_counts) ray_write_counts[id] = 0;
                         if (rays[id].terminated == 2) continue;
-                        trace_ray(&rays[id], (cfg_t)cfg, (dfg_t)dfg, &per_thread[t]);
+                        trace_ray(&rays[id], (cfg_t)cfg, (dfg_t)dfg, &mine);
                     }
+                per_thread[t] = mine;
             });
         for (auto& th : pool) th.join();
     }
