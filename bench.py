@@ -621,6 +621,32 @@ def main():
             secondary["adaptive_sampling_on_threshold32_fps"] = round(1 / t, 1)
             t = timed(camera, features, cfg_values, manager.dynamic, gra.MODE_REFERENCE)
             secondary["reference_kernel_sequence_dynamic_program_fps"] = round(1 / t, 1)
+            # The drop-in path as a maintainer binds it (one launch per reference kernel, 96-byte ray records in HBM, rays
+            # in 8x8-tile slot order) with the roofline SURVEY.md 8d defines for THAT Verlet kernel: 140 B per ray (96 read + 12 of the
+            # header re-read + 32 written back on termination) over the time of gr_do_generic_rays; counter traffic of the same launches:
+            # profiles/r05_reference_sequence_pmc.txt (tools/final_profiles.sh ... refseq)
+            def reference_sequence(prog, wall_s):
+                acc = {}
+                for _ in range(5):
+                    state.render(prog, metric, camera, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), features, cfg_values,
+                                 gra.frame_options(mode=gra.MODE_REFERENCE, tiled=1, time_kernels=1, count_attempts=1), stream)
+                    torch.cuda.synchronize()
+                    for k, v in state.stage_ms().items():
+                        acc.setdefault(k, []).append(v)
+                stage = {k: round(float(np.mean(v[1:])), 4) for k, v in acc.items()}
+                trace_s = stage["trace"] * 1e-3
+                attempts_ref = int(state.attempts())
+                flops_per_attempt = valu["flops_per_attempt"]
+                hbm = 140 * W * H / trace_s / 1e9
+                return {"fps": round(1 / wall_s, 1), "ms_per_frame": round(wall_s * 1e3, 3), "stage_ms": stage,
+                        "roofline": {"bound": "hbm", "kernel": "gr_do_generic_rays", "achieved": round(hbm, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(hbm / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": 140 * W * H, "launch_ms": stage["trace"],
+                                     "traffic": None, "traffic_source": "profiles/r05_reference_sequence_pmc.txt (FETCH_SIZE / WRITE_SIZE of gr_do_generic_rays)"},
+                        "valu_frac": round(flops_per_attempt * attempts_ref / trace_s / 1e12 / VALU_PEAK_TFLOPS, 4),
+                        "step_attempts_per_frame": attempts_ref, "trace_over_fused_trace": round(stage["trace"] / max(stages.get("trace", 0.0), 1e-9), 3)}
+            secondary["reference_kernel_sequence"] = {"dynamic_program": reference_sequence(manager.dynamic, t)}
+            t = timed(camera, features, cfg_values, program, gra.MODE_REFERENCE)
+            secondary["reference_kernel_sequence"]["substituted_program"] = reference_sequence(program, t)
             # the reference's own speed-up on the fused path with its substituted program: a quarter of the primary rays, the blocks
             # that need it refined (cl.cl:5223-5345), one frame at a time
             fa = metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0)
