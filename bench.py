@@ -178,6 +178,21 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
+    rccl_log = None
+    if world > 1:
+        # RCCL says at start-up which transport every channel takes (P2P/IPC = xGMI between the GPUs of a node, SHM, NET/Socket ...): kept
+        # in a file per rank and summarised in the line (`rccl`), so that the first run on a node says whether xGMI carried the frame.
+        # Before torch is imported: the library settles its log level the first time anything asks it something.
+        import tempfile
+        rccl_log = os.path.join(tempfile.gettempdir(), f"gr_bench_rccl.{os.environ.get('MASTER_PORT', '0')}.rank{rank}")
+        try:
+            os.remove(rccl_log)
+        except OSError:
+            pass
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,NET,SHM")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+
     import torch
     import torch.distributed as dist
     import geodesic_raytracing_amd as gra
@@ -201,6 +216,8 @@ def main():
         os.environ.update(NCCL_HOSTID="bench-rank%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET_GDR_LEVEL="0")
     if one_device or rccl_rehearsal:
         local_rank = 0
+    if one_device:
+        rccl_log = None
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     coll_device = torch.device("cpu") if one_device else device   # where the tensors of the process group's collectives live
@@ -758,6 +775,28 @@ def main():
         if rccl_rehearsal:
             line["rehearsal"] = (f"GR_BENCH_ONE_DEVICE=rccl: {world} ranks on ONE GPU, process group and frame exchange through RCCL (every rank claims a host "
                                  "of its own, RCCL's socket transport over loopback) - the code of the N-GPU run, not a measurement")
+    if multi and rccl_log:
+        # channels by transport, over all ranks: " ... Channel 02/1 : 3[3] -> 0[0] via P2P/IPC" -> {"P2P/IPC": n, ...}
+        mine = {}
+        try:
+            ctypes.CDLL(None).fflush(None)
+            for text in open(os.environ.get("NCCL_DEBUG_FILE", rccl_log), errors="replace"):
+                if "Channel" in text and " via " in text:
+                    kind = text.split(" via ", 1)[1].split()[0]
+                    mine[kind] = mine.get(kind, 0) + 1
+        except OSError as e:
+            print(f"[bench] rank {rank}: no RCCL log to read ({e})", file=sys.stderr)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if rank == 0:
+            total = {}
+            for d in everyone:
+                for k, v in (d or {}).items():
+                    total[k] = total.get(k, 0) + v
+            line["rccl"] = {"ranks": world, "channels_by_transport": total or None, "exchange": gather_path,
+                            "note": "P2P/IPC between two GPUs of one node is xGMI; NET/Socket means the ranks were taken for separate hosts (the one-GPU rehearsal)"}
+            if without_transfer_s:
+                line["rccl"]["per_rank_ms_per_frame_without_transfer"] = [round(x, 4) for x in per_rank_without]
     if multi:
         if tiled is not None:
             tiled.close()

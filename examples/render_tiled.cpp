@@ -6,6 +6,9 @@
 //       forks one worker per GPU (rank r -> device r) and waits for them; or, started by any launcher of your own, one process each:
 //   examples/render_tiled --rank R --world N --device D --id-file /tmp/id geodesic_raytracing_amd/scripts kerr_boyer 3840 2160 frame.png
 //   examples/render_tiled --spawn 3 --one-device 1 ...   rehearsal on a box with one GPU: every rank on device 0, RCCL through sockets
+//   examples/render_tiled --spawn 8 --self-test 1 ...    first contact with a new node: N ranks on whatever GPUs there are (rank r on
+//       device r % count; fewer GPUs than ranks: RCCL through sockets as above), rank 0 compares the gathered frame with the same frame
+//       rendered on its own GPU alone, and the launcher prints which RCCL transport every channel took (P2P/IPC over xGMI, SHM, NET)
 //
 // Every rank renders its (rotating) share of the image rows with frames in flight on streams of their own, rank 0 receives
 // every block at its place in the frame (gr_render_frame_tiled), writes the last frame as a PNG and prints frames per second
@@ -15,6 +18,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +37,7 @@
     } while (0)
 
 static int g_rank = 0;
+static int g_self_test = 0;
 
 // the id of gr_tiled_unique_id from rank 0 to everybody: written to a temporary name and renamed, so a reader sees all of it or nothing
 static bool publish_id(const std::string& path, const unsigned char id[128]) {
@@ -68,6 +73,21 @@ static int worker(int world, int rank, int device, const std::string& id_file, i
     if (argc > 5 && !std::strchr(argv[5], '=')) { frames = std::atoi(argv[5]); first_override = 6; }
     const int block_rows = 48, in_flight = 3;
 
+    if (g_self_test) {
+        // whatever GPUs this node has: rank r on device r % count; with fewer GPUs than ranks every rank claims a host of its own so
+        // that RCCL accepts two of them on one device (socket transport over loopback - the exchange's code, not its speed)
+        int count = 0;
+        CHECK(gr_device_count(&count));
+        if (count < 1) { std::fprintf(stderr, "[rank %d] no GPU\n", rank); return 1; }
+        device = rank % count;
+        if (count < world) {
+            setenv("NCCL_HOSTID", ("render-tiled-" + std::to_string((long)getppid()) + "-rank" + std::to_string(rank)).c_str(), 1);
+            setenv("NCCL_SOCKET_IFNAME", "lo", 1);
+            setenv("NCCL_IB_DISABLE", "1", 1);
+            setenv("NCCL_NET_GDR_LEVEL", "0", 1);
+        }
+        if (rank == 0) std::printf("self-test: %d ranks on %d GPU(s)%s\n", world, count, count < world ? " (several ranks to a device: RCCL over sockets)" : "");
+    }
     gr_metric* metric = nullptr;
     CHECK(gr_metric_load_script(scripts, name, &metric));
     gr_metric_info info;
@@ -176,6 +196,33 @@ static int worker(int world, int rank, int device, const std::string& id_file, i
         CHECK(gr_write_frame_png(out_path, frame.data(), width, height));
         std::printf("%s %dx%d over %d GPU(s), %d frames, %d in flight: %.1f frames/s with the transfer to rank 0, %.1f without; wrote %s\n", name, width,
                     height, world, frames, in_flight, frames / with_transfer, frames / without_transfer, out_path);
+        if (g_self_test) {
+            // the same frame on this GPU alone (the split changes who traces a row, not what is traced: the frames are equal bit for bit)
+            gr_render_state* whole = nullptr;
+            void* d_whole = nullptr;
+            CHECK(gr_render_state_create(device, width, height, &whole));
+            CHECK(gr_device_alloc(device, (size_t)width * height * 16, &d_whole));
+            gr_frame_options options;
+            gr_frame_options_default(&options);
+            options.mode = GR_MODE_FUSED;
+            CHECK(gr_render_frame(whole, program, metric, streams[0], &camera, &features, cfg.data(), info.num_dynamic_vars, d_background, d_background,
+                                  bw, bh, levels, d_whole, &options));
+            CHECK(gr_stream_synchronize(streams[0]));
+            std::vector<float> alone((size_t)width * height * 4);
+            CHECK(gr_device_download(device, alone.data(), d_whole, alone.size() * sizeof(float)));
+            size_t differing = 0;
+            double worst = 0;
+            for (size_t i = 0; i < alone.size(); i++) {
+                const double d = std::fabs((double)alone[i] - (double)frame[i]);
+                if (d > 0) differing++;
+                if (d > worst || d != d) worst = d != d ? 1e30 : d;
+            }
+            std::printf("self-test: gathered frame against the single-GPU frame: %zu of %zu values differ, largest difference %.3g -> %s\n", differing,
+                        alone.size(), worst, differing == 0 ? "IDENTICAL" : worst <= 1e-3 ? "within 1e-3" : "MISMATCH");
+            gr_device_free(device, d_whole);
+            gr_render_state_destroy(whole);
+            if (worst > 1e-3) return 1;
+        }
     }
     gr_tiled_destroy(tiled);
     for (int j = 0; j < in_flight; j++) {
@@ -201,6 +248,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[a], "--device")) device = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--id-file")) id_file = argv[a + 1];
         else if (!std::strcmp(argv[a], "--one-device")) one_device = std::atoi(argv[a + 1]);
+        else if (!std::strcmp(argv[a], "--self-test")) g_self_test = std::atoi(argv[a + 1]);
         else { std::fprintf(stderr, "unknown option %s\n", argv[a]); return 2; }
     }
     if (argc - a < 5) {
@@ -213,9 +261,15 @@ int main(int argc, char** argv) {
         id_file = "/tmp/gr_tiled_id." + std::to_string((long)getpid());
         std::remove(id_file.c_str());
         std::vector<pid_t> children;
+        const std::string rccl_log = "/tmp/gr_tiled_rccl." + std::to_string((long)getpid());
         for (int r = 0; r < spawn; r++) {
             const pid_t pid = fork();
             if (pid == 0) {
+                if (g_self_test) {   // RCCL says which transport every channel took; the launcher reads it back below
+                    setenv("NCCL_DEBUG", "INFO", 1);
+                    setenv("NCCL_DEBUG_SUBSYS", "INIT,P2P,NET,SHM", 1);
+                    setenv("NCCL_DEBUG_FILE", (rccl_log + ".rank" + std::to_string(r)).c_str(), 1);
+                }
                 if (one_device) {
                     // rehearsal on a box with fewer GPUs than ranks: RCCL refuses two ranks of one host on one device, so every
                     // rank claims a host of its own and RCCL talks through its socket transport over the loopback interface
@@ -238,6 +292,31 @@ int main(int argc, char** argv) {
             failed += !(WIFEXITED(status) && WEXITSTATUS(status) == 0);
         }
         std::remove(id_file.c_str());
+        if (g_self_test) {
+            // "... Channel 03/1 : 2[2] -> 0[0] via P2P/IPC" and the like: count the channels by what follows "via"
+            std::vector<std::pair<std::string, int>> transports;
+            for (int r = 0; r < spawn; r++) {
+                const std::string path = rccl_log + ".rank" + std::to_string(r);
+                if (FILE* f = std::fopen(path.c_str(), "r")) {
+                    char line[1024];
+                    while (std::fgets(line, sizeof(line), f)) {
+                        const char* via = std::strstr(line, " via ");
+                        if (!via || !std::strstr(line, "Channel")) continue;
+                        std::string kind(via + 5);
+                        kind = kind.substr(0, kind.find_first_of(" \n"));   // "P2P/IPC", "NET/Socket/0" - what follows is the communicator
+                        bool found = false;
+                        for (auto& t : transports) if (t.first == kind) { t.second++; found = true; }
+                        if (!found) transports.emplace_back(kind, 1);
+                    }
+                    std::fclose(f);
+                    std::remove(path.c_str());
+                }
+            }
+            std::printf("self-test: RCCL channels by transport:");
+            if (transports.empty()) std::printf(" none reported (one rank, or RCCL's log is not where NCCL_DEBUG_FILE says)");
+            for (auto& t : transports) std::printf("  %s x %d", t.first.c_str(), t.second);
+            std::printf("\n");
+        }
         return failed ? 1 : 0;
     }
     if (world > 1 && id_file.empty()) { std::fprintf(stderr, "--world > 1 needs --id-file\n"); return 2; }

@@ -139,6 +139,8 @@ _SIGNATURES = {
     "gr_program_manager_current": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int)]),
     "gr_program_manager_dynamic": (c_void_p, [c_void_p]),
     "gr_program_manager_destroy": (None, [c_void_p]),
+    "gr_do_generic_rays_scheduled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gr_sort_tiles_by_cost": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "gr_program_manager_counters": (None, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gr_program_kernel_info": (c_int, [c_void_p, c_char_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gr_cart_to_generic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),

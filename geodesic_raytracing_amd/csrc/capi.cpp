@@ -89,11 +89,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_setup", "gr_order_tiles", "gr_adaptive_refine", "gr_trace_pending", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_setup", "gr_order_tiles", "gr_adaptive_refine", "gr_trace_pending", "gr_do_generic_rays_scheduled", "gr_sort_tiles_count", "gr_sort_tiles_place", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_SETUP, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_TRACE_PENDING, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_SETUP, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_TRACE_PENDING, K_DO_RAYS_SCHEDULED, K_SORT_TILES_COUNT, K_SORT_TILES_PLACE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -282,7 +282,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     // GR_VECTOR_RUN_LIMIT=0: no pass (the build still goes through the code-object manager, see below).
     int run_limit = GR_DEFAULT_VECTOR_RUN_LIMIT;
     if (const char* e = getenv("GR_VECTOR_RUN_LIMIT")) run_limit = atoi(e);
-    if (run_limit > 0) h = fnv1a("vector runs <= " + std::to_string(run_limit), h);
+    if (run_limit > 0) h = fnv1a("vector runs <= " + std::to_string(run_limit) + " in the integrator kernels, list of round 5", h);   // (the list below is part of what is built)
     char name[64];
     snprintf(name, sizeof(name), "%016llx.hsaco", (unsigned long long)h);
     if (key_out) key_out->assign(name, 16);
@@ -304,7 +304,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
                 if (run_limit <= 0 && gr::assemble_code_object(assembly, out, log)) return GR_OK;
                 // the kernels that hold a Verlet loop; the others (set-up, shading, tile order ...) are left as compiled
                 static const std::vector<std::string> integrators = {"gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused",
-                                                                     "gr_do_generic_rays"};
+                                                                     "gr_do_generic_rays", "gr_do_generic_rays_scheduled"};
                 std::string patched = assembly;
                 const gr::vector_run_stats st = gr::break_vector_runs(patched, run_limit, integrators);
                 if (gr::assemble_code_object(patched, out, log)) {
@@ -1417,6 +1417,36 @@ int gr_trace_pending(gr_program* p, void* stream, const void* camera_generic, co
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &pending_list,
                     &block_cost};
     return launch(p, K_TRACE_PENDING, stream, (unsigned)groups, 1, wg, 1, args);
+}
+
+// gr_do_generic_rays over ray records in 8x8-tile slot order with the fused trace's scheduling (kernels/trace.hip): the device filled
+// once, tiles drawn from a ticket counter in `tile_order`'s order (NULL: slot order), each tile's cost left in `tile_cost` (NULL: not).
+int gr_do_generic_rays_scheduled(gr_program* p, void* stream, void* rays, const void* ray_count, int tile_count, const void* cfg, const void* dfg,
+                                 void* attempt_counter, const void* tile_order, void* tile_cost) {
+    if (!p || !rays || !ray_count) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_do_generic_rays_scheduled: null argument");
+    if (tile_count < 1) return GR_OK;
+    long long groups = resident_trace_groups(p, K_DO_RAYS_SCHEDULED, 64);
+    if (groups < 0) return (int)-groups;
+    groups = std::max(1LL, std::min(groups, (long long)tile_count));
+    unsigned int* tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
+    void* args[] = {&rays, &ray_count, &cfg, &dfg, &attempt_counter, &tickets, &tile_count, &tile_order, &tile_cost};
+    return launch(p, K_DO_RAYS_SCHEDULED, stream, (unsigned)groups, 1, 64, 1, args);
+}
+
+int gr_sort_tiles_by_cost(gr_program* p, void* stream, const void* tile_cost, int tiles_x, int tiles_y, void* tile_order, void* work) {
+    if (!p || !tile_cost || !tile_order || !work) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_sort_tiles_by_cost: null argument");
+    const int tile_count = tiles_x * tiles_y;
+    if (tile_count < 1) return GR_OK;
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipMemsetAsync(work, 0, 128 * sizeof(unsigned int), (hipStream_t)stream));
+    void* count_args[] = {&tile_cost, &tiles_x, &tiles_y, &work};
+    int rc = launch(p, K_SORT_TILES_COUNT, stream, blocks(tile_count, 256), 1, 256, 1, count_args);
+    if (rc != GR_OK) return rc;
+    int n = tile_count;
+    void* place_args[] = {&n, &work, &tile_order};
+    return launch(p, K_SORT_TILES_PLACE, stream, blocks(tile_count, 256), 1, 256, 1, place_args);
 }
 
 int gr_adaptive_refine(gr_program* p, void* stream, void* rdata, void* pending_count, int width, int height, const void* dfg,

@@ -190,6 +190,109 @@ gr_do_generic_rays(lightray* __restrict__ generic_rays_in, const int* __restrict
     if (attempt_counter) atomicAdd(attempt_counter, (unsigned long long)tries);   // one add per wave after compiler coalescing
 }
 
+// gr_do_generic_rays for ray records in 8x8-tile slot order (gr_init_rays_generic's `tiled`), scheduled: as many waves as the device
+// holds, each drawing tiles - 64 consecutive records - from a ticket counter, in the order of `tile_order` when there is one (the frame
+// driver sorts the tiles dearest first by what they cost in the frame before: gr_sort_tiles_by_cost), and leaving what each tile cost -
+// the attempts of its longest ray - in `tile_cost`.  Scheduling only: every record is what gr_do_generic_rays writes.  (Round 5: the
+// reference-shaped sequence ran its trace in slot order, one workgroup per tile - a launch on its own then drains for a sixth of its time.)
+#ifndef GR_SCHEDULED_WAVES
+#define GR_SCHEDULED_WAVES GR_TRACE_WAVES
+#endif
+extern "C" __global__ void __launch_bounds__(64, GR_SCHEDULED_WAVES)
+gr_do_generic_rays_scheduled(lightray* __restrict__ generic_rays_in, const int* __restrict__ generic_count_in, cfg_t cfg_in, dfg_t dfg_in,
+                             unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tickets, int tile_count,
+                             const unsigned int* __restrict__ tile_order, unsigned int* __restrict__ tile_cost) {
+    GR_PARAMETERS_IN_REGISTERS
+    const int count = *generic_count_in;
+    unsigned long long attempts_of_wave = 0;
+    for (;;) {
+        unsigned int ticket = 0;
+        if (threadIdx.x == 0) ticket = atomicAdd(tickets, 1u);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket >= (unsigned int)tile_count) break;
+        const unsigned int tile = tile_order ? tile_order[ticket] : ticket;
+        const int id = (int)(tile * 64u + threadIdx.x);
+        unsigned int tries = 0;
+        if (id < count) {
+            lightray* ray = &generic_rays_in[id];
+            if (ray->terminated != 2) {
+                ray_state s;
+                s.position = ray->position;
+                s.velocity = ray->velocity;
+                s.acceleration = ray->acceleration;
+                const int res = integrate_ray(s, cfg, dfg, &tries);
+                if (res == RAY_TERMINATED) {
+                    ray->position = s.position;
+                    ray->velocity = s.velocity;
+                    ray->running_dlambda_dnew = s.running_dlambda_dnew;
+                    ray->terminated = 1;
+                }
+            }
+        }
+        attempts_of_wave += tries;
+        if (tile_cost) {
+            unsigned int longest = tries;
+#pragma unroll
+            for (int offset = 32; offset > 0; offset >>= 1) longest = max(longest, (unsigned int)__shfl_xor((int)longest, offset, 64));
+            if (threadIdx.x == 0) tile_cost[tile] = longest;
+        }
+    }
+    if (attempt_counter) atomicAdd(attempt_counter, attempts_of_wave);   // (one add per wave after the compiler's coalescing)
+}
+
+// The tiles of a frame sorted dearest first by `cost` (one word per tile, tiles_x to a row: what gr_do_generic_rays_scheduled left in the
+// frame before): a tile takes the largest cost among itself and its eight neighbours - the long rays are filaments a pixel or two wide,
+// and the picture moves a little from frame to frame -, classes of half an octave, dearest class first, any order inside a class.
+// Two launches over `work` = 64 counts, 64 cursors (both zeroed by the caller), then a class per tile: count, then place.  (As ONE
+// workgroup walking 130 000 tiles it took 0.4 ms - a tenth of the launch it was to shorten.)
+__device__ __forceinline__ int tile_cost_class_of(const unsigned int* __restrict__ cost, int tile, int tiles_x, int tiles_y) {
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    unsigned int c = 0;
+    for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+            const int x = tx + dx, y = ty + dy;
+            if (x >= 0 && y >= 0 && x < tiles_x && y < tiles_y) c = max(c, cost[y * tiles_x + x]);
+        }
+    if (c == 0) return 63;                                       // nothing traced around it: last
+    const int octave = 31 - __clz((int)c);
+    const int half = octave > 0 ? (int)((c >> (octave - 1)) & 1u) : 0;
+    const int k = 2 * octave + half;                             // 0 .. 63, dear = large
+    return k >= 62 ? 0 : 62 - k;                                 // dearest class first
+}
+extern "C" __global__ void __launch_bounds__(256)
+gr_sort_tiles_count(const unsigned int* __restrict__ cost, int tiles_x, int tiles_y, unsigned int* __restrict__ work) {
+    __shared__ unsigned int counts[64];
+    if (threadIdx.x < 64) counts[threadIdx.x] = 0;
+    __syncthreads();
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile < tiles_x * tiles_y) {
+        const int k = tile_cost_class_of(cost, tile, tiles_x, tiles_y);
+        work[128 + tile] = (unsigned int)k;
+        atomicAdd(&counts[k], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && counts[threadIdx.x]) atomicAdd(&work[threadIdx.x], counts[threadIdx.x]);
+}
+extern "C" __global__ void __launch_bounds__(256)
+gr_sort_tiles_place(int tile_count, unsigned int* __restrict__ work, unsigned int* __restrict__ order) {
+    // a workgroup reserves one range per class for its 256 tiles (one global atomic per class and workgroup: a cursor bumped once per
+    // tile - 130 000 atomics on a handful of addresses, most of them on the class of the untraced tiles - took 0.86 ms)
+    __shared__ unsigned int base[64], mine[64], taken[64];
+    if (threadIdx.x < 64) { mine[threadIdx.x] = 0; taken[threadIdx.x] = 0; }
+    __syncthreads();
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned int k = tile < tile_count ? work[128 + tile] : 0u;
+    if (tile < tile_count) atomicAdd(&mine[k], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned int first = 0;
+        for (unsigned int c = 0; c < threadIdx.x; c++) first += work[c];
+        base[threadIdx.x] = first + (mine[threadIdx.x] ? atomicAdd(&work[64 + threadIdx.x], mine[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    if (tile < tile_count) order[base[k] + atomicAdd(&taken[k], 1u)] = (unsigned int)tile;
+}
+
 extern "C" __global__ void gr_calculate_singularities(const lightray* __restrict__ finished_rays, const int* __restrict__ finished_count,
                                                       int* __restrict__ termination_buffer, int width, int height) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;

@@ -117,6 +117,15 @@ int gr_camera_prepass(gr_program* p, void* stream, const void* position_cart, fl
 long long gr_tile_order_bytes(int width, int height, int block_rows, int strip_rank, int strip_count);
 int gr_order_tiles(gr_program* p, void* stream, const void* termination_buffer, const void* cell_attempts, int prepass_width,
                    int prepass_height, int width, int height, int block_rows, int strip_rank, int strip_count, void* tile_order);
+/* The reference-shaped trace with the fused trace's scheduling (round 5; what gr_render_frame's reference mode launches for ray records in
+ * 8x8-tile slot order): persistent waves draw tiles - 64 consecutive records - from a ticket counter, in tile_order's order (unsigned per
+ * tile; NULL = slot order), and leave each tile's cost (attempts of its longest ray) in tile_cost (unsigned per tile; NULL = not).  The
+ * records are gr_do_generic_rays'.  gr_sort_tiles_by_cost: the tiles dearest first by such costs (largest among a tile and its neighbours);
+ * work: (128 + tiles) unsigned words of scratch. */
+int gr_do_generic_rays_scheduled(gr_program* p, void* stream, void* rays, const void* ray_count, int tile_count, const void* cfg, const void* dfg,
+                                 void* attempt_counter, const void* tile_order, void* tile_cost);
+int gr_sort_tiles_by_cost(gr_program* p, void* stream, const void* tile_cost, int tiles_x, int tiles_y, void* tile_order, void* work);
+
 /* The same list from what the tiles cost in an earlier frame of the same size and strip description (tile_history: the tile_cost a
  * gr_trace_fused_launch left): exact where the prepass rays sample - the long rays near the photon orbits are filaments a pixel or
  * two wide - as long as the camera moves little between the two frames (a tile takes the largest cost among itself and its eight

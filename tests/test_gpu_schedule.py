@@ -620,3 +620,65 @@ def test_adaptive_list_ordered_by_the_frame_before_changes_no_pixel():
         want, rd_fresh = frame(gra.RenderState(w, h, 0), cam)
         assert (rd["terminated"] >= 0).all()
         assert rd.tobytes() == rd_fresh.tobytes() and got.tobytes() == want.tobytes(), k
+
+
+def test_scheduled_reference_trace_writes_the_records_of_the_reference_launch():
+    """gr_do_generic_rays_scheduled (round 5; what gr_render_frame's reference mode launches for rays in tile slot order: persistent waves,
+    tiles by ticket, dearest first by gr_sort_tiles_by_cost) against gr_do_generic_rays on the same initial rays: the same 96-byte records
+    bit for bit - in slot order, and in the order sorted from the costs the first launch left; the sorted list holds every tile once, dear
+    ones first; and two reference-mode frames of one state (the second follows the first's costs) are equal"""
+    from geodesic_raytracing_amd.pipeline import LIGHTRAY_DTYPE
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv, feats = metric.cfg_values(a=0.45), metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    w, h = 640, 360
+    state = gra.RenderState(w, h, 0)
+    dbg, levels = background()
+    out = DeviceBuffer(0, w * h * 16)
+    frames = []
+    for _ in range(2):
+        state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv, gra.frame_options(mode=gra.MODE_REFERENCE, tiled=1))
+        state.synchronize()
+        frames.append(out.to_numpy(np.float32, (h, w, 4)).copy())
+    assert np.array_equal(frames[0], frames[1])
+    recorded, followed, _ = state.tile_history()
+    assert recorded == 2 and followed == 1            # the second frame followed the first one's costs
+    # the stage on its own: initial rays in tile slot order (left in the state's buffer by a frame with use_prepass = 0 they would be traced;
+    # so they are made again here through the launcher)
+    b = state.buffer
+    slots = lib.gr_tiled_slot_count(w, h)
+    tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
+    rays0 = DeviceBuffer(0, slots * 96)
+    count = DeviceBuffer.from_numpy(0, np.zeros(1, dtype=np.int32))
+    term = DeviceBuffer.from_numpy(0, np.ones(w * h, dtype=np.int32))
+    check(lib.gr_init_rays_generic(prog.handle, None, b(gra.BUF_CAMERA_GENERIC), b(gra.BUF_CAMERA_QUAT), rays0.ptr, count.ptr, w, h, term.ptr, w, h, 0,
+                                   b(gra.BUF_TETRAD0), b(gra.BUF_TETRAD1), b(gra.BUF_TETRAD2), b(gra.BUF_TETRAD3), b(gra.BUF_CFG), b(gra.BUF_DFG), 0, 1))
+    check(lib.gr_device_synchronize(0))
+    initial = rays0.to_numpy(LIGHTRAY_DTYPE, slots).copy()
+
+    def traced(launch):
+        rays = DeviceBuffer.from_numpy(0, initial)
+        launch(rays)
+        check(lib.gr_device_synchronize(0))
+        return rays.to_numpy(LIGHTRAY_DTYPE, slots)
+
+    plain = traced(lambda r: check(lib.gr_do_generic_rays(prog.handle, None, r.ptr, count.ptr, slots, None, None, b(gra.BUF_CFG), b(gra.BUF_DFG), w, h, 0, 0,
+                                                         None, None, 0, None)))
+    cost = DeviceBuffer.from_numpy(0, np.zeros(tiles_x * tiles_y, dtype=np.uint32))
+    in_slot_order = traced(lambda r: check(lib.gr_do_generic_rays_scheduled(prog.handle, None, r.ptr, count.ptr, tiles_x * tiles_y, b(gra.BUF_CFG), b(gra.BUF_DFG),
+                                                                           None, None, cost.ptr)))
+    assert in_slot_order.tobytes() == plain.tobytes()
+    order = DeviceBuffer.from_numpy(0, np.zeros(tiles_x * tiles_y, dtype=np.uint32))
+    work = DeviceBuffer(0, (tiles_x * tiles_y + 128) * 4)
+    check(lib.gr_sort_tiles_by_cost(prog.handle, None, cost.ptr, tiles_x, tiles_y, order.ptr, work.ptr))
+    check(lib.gr_device_synchronize(0))
+    costs, listed = cost.to_numpy(np.uint32, (tiles_y, tiles_x)), order.to_numpy(np.uint32, (tiles_x * tiles_y,))
+    assert np.array_equal(np.sort(listed), np.arange(tiles_x * tiles_y, dtype=np.uint32))
+    padded = np.pad(costs, 1)
+    around = np.max([padded[1 + dy:1 + dy + tiles_y, 1 + dx:1 + dx + tiles_x] for dy in (-1, 0, 1) for dx in (-1, 0, 1)], axis=0).reshape(-1)
+    along = around[listed].astype(np.float64)
+    assert costs.max() > 3 * np.median(costs[costs > 0]) and along[0] >= 0.7 * around.max()
+    assert (along[1:] <= along[:-1] * 1.5 + 1).all()          # half-octave classes, dearest first
+    dearest_first = traced(lambda r: check(lib.gr_do_generic_rays_scheduled(prog.handle, None, r.ptr, count.ptr, tiles_x * tiles_y, b(gra.BUF_CFG),
+                                                                           b(gra.BUF_DFG), None, order.ptr, None)))
+    assert dearest_first.tobytes() == plain.tobytes()
