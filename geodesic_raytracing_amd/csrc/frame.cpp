@@ -41,25 +41,31 @@ extern "C" int gr_internal_fail(int code, const char* msg);   // capi.cpp
 // gr_render_frame and the caller's structs.  With the device to itself a frame's uploads ran at once and nothing showed; eight
 // processes sharing one GPU (the inter-process rehearsal of a split frame, tests/test_gpu_two_ranks.py) delayed the streams, and
 // a state's first frame read its features off a dead stack frame - one share of one frame rendered with garbage parameters.
-// A ring of 256-byte chunks; a chunk is reused 64 uploads later at the earliest, after the event that covers its last use.
+// A ring of 256-byte chunks; a chunk is reused 64 uploads later at the earliest, after the event recorded behind ITS copy on the stream
+// that copy went to (round 5: one event per 16 uploads, recorded on whichever stream issued the 16th, did not cover the copies the
+// caller's stream and the look-ahead slots' streams had queued in between - the host never blocks in the pipelined path and can run
+// 64 uploads ahead of a delayed stream).  One lock: two threads may drive one state's look-ahead.
 struct upload_ring {
-    static const int CHUNK = 256, CHUNKS = 64, SEGMENT = 16;
+    static const int CHUNK = 256, CHUNKS = 64;
     char* base = nullptr;
-    hipEvent_t used[CHUNKS / SEGMENT] = {};
-    bool recorded[CHUNKS / SEGMENT] = {};
+    hipEvent_t used[CHUNKS] = {};
+    bool recorded[CHUNKS] = {};
     unsigned long long next = 0;
+    std::mutex lock;
     int copy(void* dst, const void* src, size_t bytes, hipStream_t stream) {
         if (bytes > (size_t)CHUNK) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "upload_ring: too large");
+        std::lock_guard<std::mutex> guard(lock);
         if (!base) {
             HIP_CHECK(hipHostMalloc((void**)&base, (size_t)CHUNK * CHUNKS, hipHostMallocDefault));
             for (auto& e : used) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        const int chunk = (int)(next % CHUNKS), segment = chunk / SEGMENT;
-        if (chunk % SEGMENT == 0 && recorded[segment]) HIP_CHECK(hipEventSynchronize(used[segment]));   // (64 uploads ago: long done)
+        const int chunk = (int)(next % CHUNKS);
+        if (recorded[chunk]) HIP_CHECK(hipEventSynchronize(used[chunk]));   // (64 uploads ago: long done, whichever stream it was on)
         memcpy(base + (size_t)chunk * CHUNK, src, bytes);
         HIP_CHECK(hipMemcpyAsync(dst, base + (size_t)chunk * CHUNK, bytes, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipEventRecord(used[chunk], stream));
+        recorded[chunk] = true;
         next++;
-        if (next % SEGMENT == 0) { HIP_CHECK(hipEventRecord(used[segment], stream)); recorded[segment] = true; }
         return GR_OK;
     }
     void release() {

@@ -353,31 +353,81 @@ int gr_tiled_create_ipc(int world, int rank, int device, const char* session, in
         l->world = world; l->rank = rank;
         l->next.assign((size_t)world, 0);
         l->bytes = sizeof(ipc_shared) + sizeof(ipc_slot) * ((size_t)world * IPC_DEPTH);
-        int fd = -1;
+        // the inode behind the session's name right now (0: no such region)
+        auto name_inode = [&]() -> unsigned long long {
+            const int probe = shm_open(l->name.c_str(), O_RDWR, 0600);
+            if (probe < 0) return 0ull;
+            struct stat st;
+            const unsigned long long ino = fstat(probe, &st) == 0 ? (unsigned long long)st.st_ino : 0ull;
+            close(probe);
+            return ino;
+        };
         if (rank == 0) {
             shm_unlink(l->name.c_str());   // a stale region of an earlier run of the same session
-            fd = shm_open(l->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            const int fd = shm_open(l->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
             if (fd < 0 || ftruncate(fd, (off_t)l->bytes) != 0) { if (fd >= 0) close(fd); return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: cannot create the shared region"); }
             l->owner = true;
-        } else if (!ipc_wait([&] { fd = shm_open(l->name.c_str(), O_RDWR, 0600); if (fd < 0) return false;
-                                   struct stat st; if (fstat(fd, &st) == 0 && (size_t)st.st_size >= l->bytes) return true; close(fd); fd = -1; return false; })) {
-            return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: rank 0's shared region did not appear in time");
-        }
-        void* mem = mmap(nullptr, l->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        close(fd);
-        if (mem == MAP_FAILED) return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: mmap failed");
-        l->shared = (ipc_shared*)mem;
-        if (rank == 0) {
+            void* mem = mmap(nullptr, l->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (mem == MAP_FAILED) return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: mmap failed");
+            l->shared = (ipc_shared*)mem;
             memset(mem, 0, l->bytes);
             l->shared->world = (unsigned int)world;
             l->shared->magic.store(0x47524950u);
-        } else if (!ipc_wait([&] { return l->shared->magic.load() == 0x47524950u; }) || l->shared->world != (unsigned int)world) {
-            return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: the shared region is not rank 0's for this world");
+            // collective, like ncclCommInitRank: returns when every rank has arrived
+            l->shared->arrived.fetch_add(1);
+            if (!ipc_wait([&] { return l->shared->arrived.load() >= (unsigned int)world; }))
+                return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: not every rank arrived in time");
+        } else {
+            // A rank that starts before rank 0 can find the region a crashed or finished run of the same session left behind: size, magic
+            // and world all look right, and a finished run's arrival counter is already full - it would pass the barrier on the old region
+            // while rank 0 unlinks it and makes a new one, and every send would then wait out its timeout (round 5).  So: a region
+            // whose counter was full BEFORE this rank arrived is a stale one; and whoever waits on a region keeps watching the session's
+            // name - once it points at another inode rank 0 has replaced the region, and the rank starts over on the new one.
+            const auto t0 = std::chrono::steady_clock::now();
+            auto out_of_time = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ipc_timeout_seconds(); };
+            for (;;) {
+                if (out_of_time()) return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: rank 0's shared region did not appear in time");
+                int fd = shm_open(l->name.c_str(), O_RDWR, 0600);
+                struct stat st;
+                if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < l->bytes) {
+                    if (fd >= 0) close(fd);
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                    continue;
+                }
+                const unsigned long long attached = (unsigned long long)st.st_ino;
+                void* mem = mmap(nullptr, l->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                close(fd);
+                if (mem == MAP_FAILED) return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: mmap failed");
+                ipc_shared* region = (ipc_shared*)mem;
+                bool replaced = false;
+                auto wait_on_region = [&](auto ready) {   // true: ready; false: the region was replaced or time ran out
+                    for (int spins = 0; !ready(); spins++) {
+                        if (spins > 1000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                        if (spins % 256 == 255 && name_inode() != attached) { replaced = true; return false; }
+                        if (out_of_time()) return false;
+                    }
+                    return true;
+                };
+                bool joined = wait_on_region([&] { return region->magic.load() == 0x47524950u; });
+                if (joined && region->world != (unsigned int)world) {
+                    munmap(mem, l->bytes);
+                    return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: the shared region is not rank 0's for this world");
+                }
+                if (joined) {
+                    const unsigned int before_me = region->arrived.fetch_add(1);
+                    if (before_me >= (unsigned int)world) {   // everybody of an earlier run had arrived already: not this run's region
+                        joined = false;
+                        (void)wait_on_region([&] { return false; });   // until rank 0 has replaced it (or time runs out)
+                    } else {
+                        joined = wait_on_region([&] { return region->arrived.load() >= (unsigned int)world; });
+                    }
+                }
+                if (joined) { l->shared = region; break; }
+                munmap(mem, l->bytes);
+                if (!replaced) return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: not every rank arrived in time");
+            }
         }
-        // collective, like ncclCommInitRank: returns when every rank has arrived
-        l->shared->arrived.fetch_add(1);
-        if (!ipc_wait([&] { return l->shared->arrived.load() >= (unsigned int)world; }))
-            return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: not every rank arrived in time");
         t->link = gr_transport{l.get(), ipc_group_begin, ipc_group_end, ipc_send, ipc_recv};
         t->ipc = l;
     }

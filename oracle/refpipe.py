@@ -138,6 +138,19 @@ class OraclePipeline:
         self.lib.ref_trace_f64(_p(rays), _p(count), len(rays), _p(cfg), _p(dfg), _p(pos), _p(term), nthreads)
         return pos, term
 
+    def geodesic_path_f64(self, ray, cfg_values, features_bytes, max_len=4096):
+        """the camera's path from its initial ray (geodesic_camera()["ray"]) in float64 (restatement back end only; ref_get_geodesic_path_f64):
+        positions [n, 4], velocities [n, 4], step lengths [n]"""
+        cfg = np.array(list(cfg_values) if len(cfg_values) else [0.0], dtype="<f4")
+        dfg = np.frombuffer(features_bytes, dtype=np.uint8).copy()
+        ray = np.ascontiguousarray(ray)
+        rcount = np.array([1], dtype="<i4")
+        path, vel, ds = np.zeros((max_len, 4), dtype="<f8"), np.zeros((max_len, 4), dtype="<f8"), np.zeros(max_len, dtype="<f8")
+        count = np.zeros(1, dtype="<i4")
+        self.lib.ref_get_geodesic_path_f64(_p(ray), _p(path), _p(vel), _p(ds), _p(rcount), max_len, _p(cfg), _p(dfg), _p(count))
+        n = int(count[0])
+        return path[:n].copy(), vel[:n].copy(), ds[:n].copy()
+
     def geodesic_camera(self, cfg_values, features_bytes, camera_pos=(0, 0, -4, 0), basis_speed=(0, 0, 0), max_len=4096,
                         target_times=(), parallel_transport=True, flip=0.0):
         """Snapshot of the camera's timelike geodesic, main.cpp:2675-2760, then one handle_interpolating_geodesic call per

@@ -644,6 +644,19 @@ d4 geo_accel(d4 pos, d4 vel, cfg_t cfg) {
 }
 d4 to_spherical(d4 in, cfg_t cfg) { POSITION_VARS64(in) return {TO_COORD1, TO_COORD2, TO_COORD3, TO_COORD4}; }
 double distance_to_object(d4 polar, cfg_t cfg) { POSITION_VARS64(polar) return DISTANCE_FUNC; }
+d4 from_spherical(d4 in, cfg_t cfg) { POSITION_VARS64(in) return {FROM_COORD1, FROM_COORD2, FROM_COORD3, FROM_COORD4}; }
+d4 velocity_to_spherical(d4 in, d4 d, cfg_t cfg) {
+    POSITION_VARS64(in)
+    const double dv1 = d.x, dv2 = d.y, dv3 = d.z, dv4 = d.w;
+    (void)dv1; (void)dv2; (void)dv3; (void)dv4;
+    return {TO_DCOORD1, TO_DCOORD2, TO_DCOORD3, TO_DCOORD4};
+}
+d4 velocity_from_spherical(d4 in, d4 d, cfg_t cfg) {
+    POSITION_VARS64(in)
+    const double dv1 = d.x, dv2 = d.y, dv3 = d.z, dv4 = d.w;
+    (void)dv1; (void)dv2; (void)dv3; (void)dv4;
+    return {FROM_DCOORD1, FROM_DCOORD2, FROM_DCOORD3, FROM_DCOORD4};
+}
 }  // namespace gen64
 
 // trace_ray in float64; returns the reference's `terminated` (1 reached the boundary, 0 otherwise) and the final position
@@ -1385,6 +1398,160 @@ void ref_get_geodesic_path(void* rays_v, float* positions, float* velocities, fl
         acceleration = next_acceleration;
         st4(positions + 4 * bufc, pos_out);
         if (velocities) st4(velocities + 4 * bufc, vel_out);
+        if (ds_out) ds_out[bufc] = ds * old_dlambda;
+        bufc++;
+        if (should_break) break;
+    }
+    count_out[0] = bufc;
+}
+
+// get_geodesic_path in float64: NOT a reference kernel - the reference's discrete algorithm (same steps, controller, thresholds, the same
+// float parameters and initial ray) evaluated in double precision, the yardstick for camera paths on which two fp32 builds disagree
+// (a sample that lands next to a horizon, free fall at velocity 1e3, a path past the polar axis: tests/golden/paths/soak_*).  Same
+// role as trace_ray_f64 for rays.  positions / velocities: 4 doubles per sample.
+void ref_get_geodesic_path_f64(void* rays_v, double* positions, double* velocities, double* ds_out, int* count_in, int max_len,
+                               const void* cfg_v, const void* dfg_v, int* count_out) {
+    using gen64::d4;
+    cfg_t cfg = (cfg_t)cfg_v;
+    dfg_t dfg = (dfg_t)dfg_v;
+    count_out[0] = 0;
+    if (*count_in < 1) return;
+    const lightray* ray = (const lightray*)rays_v;
+    auto widen = [](v4 v) { return d4{v.x, v.y, v.z, v.w}; };
+    d4 position = widen(ray->position), velocity = widen(ray->velocity), acceleration = widen(ray->acceleration);
+    const d4 quat = widen(ray->initial_quat);
+    const double f_in_x = std::fabs(velocity.x);
+    const double half_pi = (double)(PIf / 2);
+    (void)f_in_x; (void)quat;
+#ifdef IS_CONSTANT_THETA
+    position.z = half_pi; velocity.z = 0; acceleration.z = 0;
+#endif
+    double next_ds = (double)0.00001f;
+#ifdef ADAPTIVE_PRECISION
+    const double max_accel = std::fmin((double)0.00001000f, (double)GET_FEATURE(max_acceleration_change, dfg));
+    const double min_step = GET_FEATURE(min_step, dfg);
+    auto precision = [&](d4 acc, double* out) {
+        const double divisor = (double)std::max(std::max(W_V1, W_V2), std::max(W_V3, W_V4));
+        const double ax = acc.x * (double)(W_V1), ay = acc.y * (double)(W_V2), az = acc.z * (double)(W_V3), aw = acc.w * (double)(W_V4);
+        const double current = std::sqrt(ax * ax + ay * ay + az * az + aw * aw) * (double)0.01f / divisor;
+        const double big = 256 * 256;
+        double diff = current * big;
+        const double lowest = max_accel * big / 1e10;
+        if (diff < lowest) diff = lowest;
+        *out = std::sqrt((max_accel * big) / diff);
+        return diff;
+    };
+    (void)precision(acceleration, &next_ds);
+#endif
+    const double subambient = 0.5, ambient = (double)0.2f;
+    const double new_max = GET_FEATURE(max_precision_radius, dfg), new_min = 3;
+    int bufc = 0;
+    const v4 periods_f = coordinate_period(cfg);
+    const double periods[4] = {periods_f.x, periods_f.y, periods_f.z, periods_f.w};
+    d4 last_generic{0, 0, 0, 0};
+    double running = 1;
+    (void)periods; (void)last_generic;
+    auto degenerate64 = [](d4 v) { return !std::isfinite(v.x) || !std::isfinite(v.y) || !std::isfinite(v.z) || !std::isfinite(v.w); };
+    for (int i = 0; i < max_len; i++) {
+#ifdef IS_CONSTANT_THETA
+        position.z = half_pi; velocity.z = 0; acceleration.z = 0;
+#endif
+        d4 polar = gen64::to_spherical(position, cfg);
+#ifdef IS_CONSTANT_THETA
+        polar.z = half_pi;
+#endif
+        const double ar = std::fabs(gen64::distance_to_object(polar, cfg));
+        double ds = ambient + (subambient - ambient) * ((std::fmin(std::fmax(ar, new_min), new_max) - new_min) / (new_max - new_min));
+#ifdef ADAPTIVE_PRECISION
+        ds = next_ds;
+#endif
+        if (ar < new_max) ds = std::fmin(ds, ambient);
+        else ds = 0.1 * (ar - new_max) + ambient;
+        bool should_break = std::fabs(polar.y) >= (double)GET_FEATURE(universe_size, dfg);
+#ifdef SINGULAR
+        should_break |= std::fabs(polar.y) < SINGULAR_TERMINATOR;
+#endif
+        d4 next_position = position + velocity * ds + acceleration * (0.5 * ds * ds);
+        d4 half_velocity = velocity + acceleration * ds;
+        d4 next_acceleration = gen64::geo_accel(next_position, half_velocity, cfg);
+        d4 next_velocity = velocity + (acceleration + next_acceleration) * (0.5 * ds);
+        double K = 1;
+        if (GET_FEATURE(reparameterisation, dfg)) {
+            K = 1 / std::fmax(std::fmax(std::fabs(next_velocity.x), std::fabs(next_velocity.y)),
+                              std::fmax(std::fabs(next_velocity.z), std::fabs(next_velocity.w)));
+            next_velocity = next_velocity * K;
+            next_acceleration = next_acceleration * (K * K);
+        }
+        const double old_dlambda = running;
+        running *= K;
+#ifdef ADAPTIVE_PRECISION
+        if (ar < new_max) {
+            double suggested = 0;
+            const double diff = precision(next_acceleration, &suggested);
+            double nds = (double)0.99f * ds * std::fmin(std::fmax(suggested / ds, (double)0.3f), 2.0);
+            nds = std::fmax(nds, min_step);
+            next_ds = nds;
+#ifdef SINGULARITY_DETECTION
+            if (nds == min_step && (diff / (256 * 256)) > max_accel * 10000) should_break = true;
+#endif
+            (void)diff;
+            if (nds < ds / (double)1.95f) continue;
+        }
+#endif
+#ifndef UNCONDITIONALLY_NONSINGULAR
+        if (std::fabs(velocity.x / running) > 1000 + f_in_x && std::fabs(acceleration.x / running) > 100) should_break = true;
+#endif
+        d4 pos_out = position, vel_out = velocity * (1 / old_dlambda);
+#ifdef GENERIC_CONSTANT_THETA
+        {   // the sample rotated back out of the equatorial plane, in double (cl.cl:4864-4902)
+            d4 pos_sph = gen64::to_spherical(position, cfg);
+            d4 vel_sph = gen64::velocity_to_spherical(position, velocity * (1 / old_dlambda), cfg);
+            const double sgn = pos_sph.y > 0 ? 1.0 : (pos_sph.y < 0 ? -1.0 : 0.0);
+            pos_sph.y = std::fabs(pos_sph.y);
+            const double qn = std::sqrt(quat.x * quat.x + quat.y * quat.y + quat.z * quat.z + quat.w * quat.w);
+            const double qx = quat.x / qn, qy = quat.y / qn, qz = quat.z / qn, qw = quat.w / qn;
+            auto rotate = [&](double x, double y, double z, double out[3]) {   // rot_quat, cl.cl:176-183
+                const double tx = 2 * (qy * z - qz * y), ty = 2 * (qz * x - qx * z), tz = 2 * (qx * y - qy * x);
+                out[0] = x + qw * tx + (qy * tz - qz * ty);
+                out[1] = y + qw * ty + (qz * tx - qx * tz);
+                out[2] = z + qw * tz + (qx * ty - qy * tx);
+            };
+            const double r = pos_sph.y, th = pos_sph.z, ph = pos_sph.w, dr = vel_sph.y, dth = vel_sph.z, dph = vel_sph.w;
+            const double cart[3] = {r * std::sin(th) * std::cos(ph), r * std::sin(th) * std::sin(ph), r * std::cos(th)};
+            const double cvel[3] = {-r * std::sin(th) * std::sin(ph) * dph + r * std::cos(th) * std::cos(ph) * dth + std::sin(th) * std::cos(ph) * dr,
+                                    std::sin(th) * std::sin(ph) * dr + r * std::sin(th) * std::cos(ph) * dph + r * std::cos(th) * std::sin(ph) * dth,
+                                    std::cos(th) * dr - r * std::sin(th) * dth};
+            double p[3], v[3];
+            rotate(cart[0], cart[1], cart[2], p);
+            rotate(cvel[0], cvel[1], cvel[2], v);
+            const double nr = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+            double npos[3] = {nr, std::acos(p[2] / nr), std::atan2(p[1], p[0])};
+            const double repeated = nr * std::sqrt(1 - (p[2] * p[2] / (nr * nr)));
+            const double rdot = (p[0] * v[0] + p[1] * v[1] + p[2] * v[2]) / nr;
+            const double nvel[3] = {rdot, ((p[2] * rdot) / (nr * repeated)) - v[2] / repeated, (p[0] * v[1] - p[1] * v[0]) / (p[0] * p[0] + p[1] * p[1])};
+            if (sgn < 0) npos[0] = -npos[0];
+            d4 next_generic = gen64::from_spherical(d4{pos_sph.x, npos[0], npos[1], npos[2]}, cfg);
+            d4 next_vel_generic = gen64::velocity_from_spherical(d4{pos_sph.x, npos[0], npos[1], npos[2]}, d4{vel_sph.x, nvel[0], nvel[1], nvel[2]}, cfg);
+            if (i != 0) {
+                double* g = &next_generic.x;
+                const double* l = &last_generic.x;
+                for (int c = 0; c < 4; c++)
+                    if (periods[c] != 0) {
+                        const double d = (g[c] - l[c]) * (2 * PId / periods[c]);
+                        g[c] = l[c] + periods[c] * std::atan2(std::sin(d), std::cos(d)) / (2 * PId);
+                    }
+            }
+            last_generic = next_generic;
+            pos_out = next_generic;
+            vel_out = next_vel_generic;
+        }
+#endif
+        if (degenerate64(next_position) || degenerate64(next_velocity) || degenerate64(next_acceleration)) break;
+        position = next_position;
+        velocity = next_velocity;
+        acceleration = next_acceleration;
+        positions[4 * bufc + 0] = pos_out.x; positions[4 * bufc + 1] = pos_out.y; positions[4 * bufc + 2] = pos_out.z; positions[4 * bufc + 3] = pos_out.w;
+        if (velocities) { velocities[4 * bufc + 0] = vel_out.x; velocities[4 * bufc + 1] = vel_out.y; velocities[4 * bufc + 2] = vel_out.z; velocities[4 * bufc + 3] = vel_out.w; }
         if (ds_out) ds_out[bufc] = ds * old_dlambda;
         bufc++;
         if (should_break) break;

@@ -26,13 +26,10 @@ METRICS = {  # as tests/fuzz_parity.py (the oracle libraries are its `fuzz_<metr
 TIMES = (0.0, 0.37, 1.5, 7.3, 19.0, 1.0e6)
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 71
+def draw_cases(cases, seed):
+    """the soak's cases from one random stream: (index, metric name, metric, cfg, start, observer speed, transport, features, start radius)"""
     rng = np.random.default_rng(seed)
     names = sorted(METRICS)
-    failed = skipped = 0
-    worst = {"path": 0.0, "transported": 0.0, "interpolated": 0.0}
     for case in range(cases):
         name = names[case % len(names)]
         metric = gra.Metric(name, SCRIPTS)
@@ -44,6 +41,15 @@ def main():
         speed = [float(x) for x in rng.uniform(-0.4, 0.4, 3)]
         transport = bool(rng.random() < 0.7)
         feats = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change, reparameterisation=int(rng.random() < 0.25))
+        yield case, name, metric, cfg, pos, speed, transport, feats, r
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 71
+    failed = skipped = 0
+    worst = {"path": 0.0, "transported": 0.0, "interpolated": 0.0}
+    for case, name, metric, cfg, pos, speed, transport, feats, r in draw_cases(cases, seed):
         only = int(sys.argv[3]) if len(sys.argv) > 3 else None   # replay one case (the stream is advanced through the earlier ones) with details
         if only is not None and case != only:
             continue

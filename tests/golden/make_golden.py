@@ -7,6 +7,7 @@ cases (boosted tetrad, path, velocities, step lengths, transported tetrads, inte
 
     python tests/golden/make_golden.py            # everything
     python tests/golden/make_golden.py paths      # only the geodesic-camera cases
+    python tests/golden/make_golden.py path_soak  # only the outliers of the path soaks (tests/golden/paths/soak/)
     python tests/golden/make_golden.py polar      # only the polar-axis cases of the round-1 soak
     python tests/golden/make_golden.py refscripts # only the cases of the reference's own scripts/ folder (tests/golden/refscripts/)
 """
@@ -285,7 +286,31 @@ PATH_CASES = {
 }
 
 
-def make_path_case(name, spec):
+# The paths of the randomised path soaks (tests/fuzz_paths.py) that were outside the fixtures' tolerances - 7 of 220 with seed 71 (round 3),
+# 4 of 220 with seed 84 (round 4): samples that land within 2e-4 rs of a horizon, observers asymptoting to it, free fall at velocity 1e3,
+# a path past the polar axis, a path one step longer than the reference's.  Inputs as the soak drew them (replayed from its random stream);
+# held to the rule of the polar-axis cases: the GPU is not further from a float64 evaluation of the same algorithm than the reference's
+# own fp32 run is (tests/test_gpu_geodesic_camera.py::test_path_soak_outliers).  tests/golden/paths/soak/.
+PATH_SOAK = {71: [20, 24, 75, 84, 152, 183, 206], 84: [9, 24, 62, 152]}
+
+
+def path_soak_specs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_paths", os.path.join(ROOT, "tests", "fuzz_paths.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    out = {}
+    for seed, wanted in PATH_SOAK.items():
+        for case, name, metric, cfg, pos, speed, transport, feats, r in fuzz.draw_cases(max(wanted) + 1, seed):
+            if case in wanted:
+                params = dict(zip(metric.dynamic_vars, cfg))
+                out[f"{name}_{seed}_{case}"] = dict(metric=name, scripts=True, cfg=params, camera_pos=pos, basis_speed=speed, parallel_transport=transport,
+                                                   features={k: v for k, v in feats.items() if k not in ("adaptive_sampling", "max_acceleration_change")},
+                                                   tag="fuzz_" + name)
+    return out
+
+
+def make_path_case(name, spec, subdir="paths"):
     own_scripts = os.path.join(ROOT, "geodesic_raytracing_amd", "scripts")
     metric = gra.Metric(spec["metric"], own_scripts if spec.get("scripts") else None)
     so = build_ref.build(spec.get("tag", spec["metric"]), metric.argument_string())
@@ -303,8 +328,8 @@ def make_path_case(name, spec):
     arrays["interp_camera"] = np.stack([i["camera"] for i in res["interpolated"]])
     arrays["interp_tetrad"] = np.stack([i["tetrad"] for i in res["interpolated"]])
     arrays["interp_velocity"] = np.stack([i["velocity"] for i in res["interpolated"]])
-    os.makedirs(os.path.join(HERE, "paths"), exist_ok=True)
-    np.savez_compressed(os.path.join(HERE, "paths", name + ".npz"), meta=json.dumps(meta), **arrays)
+    os.makedirs(os.path.join(HERE, subdir), exist_ok=True)
+    np.savez_compressed(os.path.join(HERE, subdir, name + ".npz"), meta=json.dumps(meta), **arrays)
     print(f"path {name}: {res['count']} steps, proper time {res['ds'].sum():.3f}, end {res['path'][-1].round(3).tolist()}")
 
 
@@ -373,3 +398,6 @@ if __name__ == "__main__":
         if only and ("path_" + name) not in only and "paths" not in only:
             continue
         make_path_case(name, spec)
+    if not only or "path_soak" in only:
+        for name, spec in path_soak_specs().items():
+            make_path_case(name, spec, subdir=os.path.join("paths", "soak"))

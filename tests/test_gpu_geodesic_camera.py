@@ -14,7 +14,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from gpu_stages import GeodesicCamera, buf, load_path_golden, path_golden_names, rel_err, vec_err  # noqa: E402
+from gpu_stages import (GeodesicCamera, assert_path_against_float64, buf, load_path_golden, path_golden_names, path_soak_golden_names, rel_err,  # noqa: E402
+                        vec_err)
 
 
 @pytest.mark.parametrize("name", path_golden_names())
@@ -30,6 +31,25 @@ def test_snapshot_matches_reference(name):
     assert vec_err(r["velocity"], z["velocity"]).max() <= 1e-3
     assert rel_err(r["ds"], z["ds"], floor=1e-6).max() <= 1e-3
     assert np.abs(r["transported"] - z["transported"]).max() <= 1e-3 * max(1.0, np.abs(z["transported"]).max())
+
+
+@pytest.mark.parametrize("name", path_soak_golden_names())
+def test_path_soak_outliers(name):
+    """the eleven paths of the randomised path soaks (seeds 71 and 84, 440 paths) that were outside the tolerances above, as fixtures
+    (round 5; until then they were prose in DESIGN.md): boosted tetrad and initial ray as everywhere (the tetrad relative to its largest
+    component: a camera 3 degrees from the polar axis has components of 1.5); the path by gpu_stages.assert_path_against_float64 - not
+    further from a float64 evaluation of the same algorithm than the reference's own fp32 run is; the transported tetrads, where the path
+    has the reference's length and both agree with the float64 path, to 5e-3 of their largest component (a path past the polar axis:
+    components of 22, 1 / sin theta)"""
+    meta, z = load_path_golden(name)
+    r = GeodesicCamera(meta).snapshot()
+    assert np.abs(r["tetrad_boosted"] - z["tetrad_boosted"]).max() <= 1e-4 * max(1.0, np.abs(z["tetrad_boosted"]).max())
+    for f in ("position", "velocity", "acceleration"):
+        assert vec_err(r["ray"][f], z["ray"][f]).max() <= 1e-4, f
+    mine, reference = assert_path_against_float64(name, meta, z, r)
+    if r["count"] == meta["count"] and max(mine, reference) <= 2e-3:
+        n = meta["count"]
+        assert np.abs(r["transported"][:, :n] - z["transported"][:, :n]).max() <= 5e-3 * max(1.0, np.abs(z["transported"]).max())
 
 
 @pytest.mark.parametrize("name", path_golden_names())

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import geodesic_raytracing_amd as gra
-from gpu_stages import ILL_CONDITIONED, assert_ill_conditioned_trace, assert_pixels, backgrounds, assert_traced_positions, circ_diff, golden_names, refscript_golden_names, load_golden, load_path_golden, metric_for, ordinary_rays, path_golden_names, rel_err, vec_err
+from gpu_stages import ILL_CONDITIONED, assert_ill_conditioned_trace, assert_path_against_float64, assert_pixels, backgrounds, path_soak_golden_names, assert_traced_positions, circ_diff, golden_names, refscript_golden_names, load_golden, load_path_golden, metric_for, ordinary_rays, path_golden_names, rel_err, vec_err
 from oracle import build_ref, build_restate
 from oracle.refpipe import OraclePipeline, pack_features
 
@@ -314,3 +314,14 @@ def test_float64_evaluation_agrees_with_the_reference_on_well_conditioned_rays()
     both = (t64 == 1) & (z["rays"]["terminated"] == 1)
     azimuth_off = (np.abs(z["rays"]["position"][both][:, 3].astype(np.float64) - p64[both][:, 3]) > 1e-3).sum()
     assert 20 <= azimuth_off <= 100
+
+
+@pytest.mark.parametrize("name", path_soak_golden_names())
+def test_restatement_on_the_path_soak_outliers(name):
+    """the CPU restatement's camera path on the eleven outliers of the path soaks, by the rule the GPU is held to
+    (gpu_stages.assert_path_against_float64: not further from the float64 path than the reference's own fp32 run, steps within one)"""
+    meta, z = load_path_golden(name)
+    pipe = OraclePipeline(build_restate.build(metric_for(meta).argument_string()))
+    r = pipe.geodesic_camera(meta["cfg"], pack_features(**meta["features"]), camera_pos=meta["camera_pos"], basis_speed=meta["basis_speed"],
+                             max_len=meta["max_len"], target_times=(), parallel_transport=meta["parallel_transport"])
+    assert_path_against_float64(name, meta, z, r)
