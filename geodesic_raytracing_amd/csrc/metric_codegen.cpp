@@ -583,14 +583,18 @@ std::string build_argument_string(const MetricDescriptor& desc, const MetricImpl
         // only (their parameters are literals: the exponential splits at build time).
         bool lowered_differs = false;
         const std::vector<E> lowered = sym::lower_for_device(impl.accel, tanh_in_sums_only, &lowered_differs);
-        if (lowered_differs) {
+        // ... and every negation written at a leaf (sym::to_c_negations_pushed): the accelerations are -g^{im} w_m, and a sign that
+        // sits on the finished sum costs an instruction of its own per component and attempt
+        bool any_negation = false;
+        for (E a : lowered) any_negation |= a->op == sym::NEG;
+        if (lowered_differs || any_negation) {
             const Temporaries device_temps = hoist_position_temporaries(lowered, "qv");
             std::string t;
-            for (auto& [name, e] : device_temps.defs) t += name + "=" + to_c(e, &device_temps.names, true) + ",";
+            for (auto& [name, e] : device_temps.defs) t += name + "=" + sym::to_c_negations_pushed(e, &device_temps.names, true) + ",";
             if (t.empty()) t = "qv_unused=0.0f,";
             t.pop_back();
             s += "-DGR_DEVICE_TEMPORARIES=" + t + " ";
-            for (int i = 0; i < 4; i++) s += "-DGR_DEVICE_ACCEL" + std::to_string(i) + "=" + to_c(lowered[i], &device_temps.names) + " ";
+            for (int i = 0; i < 4; i++) s += "-DGR_DEVICE_ACCEL" + std::to_string(i) + "=" + sym::to_c_negations_pushed(lowered[i], &device_temps.names) + " ";
         }
     }
     for (int i = 0; i < 4; i++) s += "-DFIX_LIGHT" + std::to_string(i) + "=" + to_c(impl.fix_light[i]) + " ";

@@ -771,6 +771,24 @@ std::string const_to_c(double v) {
 }
 
 namespace {
+thread_local bool g_push_negations = false;
+void to_c_rec(E e, const std::unordered_map<E, std::string>* names, std::string& out, bool top);
+// -e, the negation carried down to a leaf
+void to_c_negated(E e, const std::unordered_map<E, std::string>* names, std::string& out) {
+    if (names) {
+        auto it = names->find(e);
+        if (it != names->end()) { out += "(-" + it->second + ")"; return; }
+    }
+    switch (e->op) {
+        case CONST: out += const_to_c(-e->c); break;
+        case NEG: to_c_rec(e->a, names, out, false); break;
+        case ADD: out += "("; to_c_negated(e->a, names, out); out += "-"; to_c_rec(e->b, names, out, false); out += ")"; break;
+        case SUB: out += "("; to_c_rec(e->b, names, out, false); out += "-"; to_c_rec(e->a, names, out, false); out += ")"; break;
+        case MUL:
+        case DIV: out += "("; to_c_negated(e->a, names, out); out += e->op == MUL ? "*" : "/"; to_c_rec(e->b, names, out, false); out += ")"; break;
+        default: out += "(-"; to_c_rec(e, names, out, false); out += ")"; break;
+    }
+}
 void to_c_rec(E e, const std::unordered_map<E, std::string>* names, std::string& out, bool top) {
     if (names && !top) {
         auto it = names->find(e);
@@ -794,6 +812,7 @@ void to_c_rec(E e, const std::unordered_map<E, std::string>* names, std::string&
             break;
         }
         case NEG:
+            if (g_push_negations) { to_c_negated(e->a, names, out); break; }
             out += "(-";
             to_c_rec(e->a, names, out, false);
             out += ")";
@@ -844,6 +863,14 @@ void to_c_rec(E e, const std::unordered_map<E, std::string>* names, std::string&
 std::string to_c(E e, const std::unordered_map<E, std::string>* names, bool is_definition) {
     std::string out;
     to_c_rec(e, names, out, is_definition);
+    return out;
+}
+
+std::string to_c_negations_pushed(E e, const std::unordered_map<E, std::string>* names, bool is_definition) {
+    g_push_negations = true;
+    std::string out;
+    to_c_rec(e, names, out, is_definition);
+    g_push_negations = false;
     return out;
 }
 

@@ -108,6 +108,10 @@ std::vector<E> lower_for_device(const std::vector<E>& roots, bool fast_tanh, boo
 // `names` maps node -> identifier for nodes that were hoisted into temporaries.
 // `is_definition` prints the body of `e` even when `e` itself has a name (used for "pvN=<body>").
 std::string to_c(E e, const std::unordered_map<E, std::string>* names = nullptr, bool is_definition = false);
+// the same text with every negation pushed down to a leaf: -(a + b) as ((-a) - b), -(a * b) as ((-a) * b), -(a - b) as (b - a) - the same
+// values bit for bit (negation is exact), written so that a compiler folds each into a source modifier of the instruction that consumes it
+// instead of negating a finished result with an instruction of its own (the device's copies of the accelerations, GR_DEVICE_ACCEL*)
+std::string to_c_negations_pushed(E e, const std::unordered_map<E, std::string>* names = nullptr, bool is_definition = false);
 std::string const_to_c(double v);
 
 // operation count of the DAG reachable from `roots` (shared nodes counted once);

@@ -9,6 +9,7 @@ for W in $WORKLOADS; do
     a09)  SEL="--spin 0.9"; JSON=pmc_kerr_a09_4k.json;;
     dk)   SEL="--config 3"; JSON=pmc_double_unequal_kerr_4k.json;;
     alc)  SEL="--config 4"; JSON=pmc_alcubierre_8k_redshift.json;;
+    refseq) SEL="--mode reference"; JSON=pmc_reference_sequence_4k.json;;
   esac
   for K in stats exclusive_stats; do
     DB=$(find gpurun_out/${TAG}_${W}_${K} -name "*.db" 2>/dev/null | head -1)

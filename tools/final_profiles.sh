@@ -18,6 +18,7 @@ for W in $WORKLOADS; do
     a09)  SEL="--spin 0.9"; STEPS=20;;
     dk)   SEL="--config 3"; STEPS=10;;
     alc)  SEL="--config 4"; STEPS=10;;
+    refseq) SEL="--mode reference"; STEPS=10;;   # the reference-shaped kernel sequence (one launch per reference kernel), 4K Kerr a = 0.45
     *) echo "unknown workload $W"; continue;;
   esac
   ARGS="$SEL --steps $STEPS --warmup 3 --no-cpu-baseline --no-secondary"

@@ -28,16 +28,23 @@ if __name__ == "__main__":
     for k in sorted(data):
         for n in sorted(data[k]):
             lines.append(f"{k:22s} {n:26s} {data[k][n]:16.6g}")
-    t = data.get("gr_trace_fused", {})
+    # the dominant kernel: the fused trace, or - a profile of the reference-shaped sequence (bench.py --mode reference) - its Verlet kernel,
+    # whose algorithmic traffic is SURVEY.md 8d's 140 B per ray
+    main_kernel, bytes_per_ray = "gr_trace_fused", 32
+    if "gr_trace_fused" not in data:
+        candidates = [k for k in data if k.startswith("gr_do_generic_rays") and "SQ_INSTS_VALU" in data[k]]
+        if candidates:
+            main_kernel, bytes_per_ray = max(candidates, key=lambda k: data[k]["SQ_INSTS_VALU"]), 140
+    t = data.get(main_kernel, {})
     if t:
         lane_util = t["SQ_THREAD_CYCLES_VALU"] / (t["SQ_ACTIVE_INST_VALU"] * 64)
         fetch, write = t.get("FETCH_SIZE", 0) * 1024, t.get("WRITE_SIZE", 0) * 1024
         hbm = 2 * fetch + write       # gfx950: FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM)
-        lines += ["", "# derived, gr_trace_fused:",
+        lines += ["", f"# derived, {main_kernel}:",
                   f"#   VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64) = {lane_util:.3f}",
                   f"#   SQ_INSTS_VALU = {t['SQ_INSTS_VALU']:.4g} wave-instructions per launch",
                   f"#   wave time: WAIT_INST_ANY {t['SQ_WAIT_INST_ANY'] / t['SQ_WAVE_CYCLES']:.2f}, WAIT_ANY {t['SQ_WAIT_ANY'] / t['SQ_WAVE_CYCLES']:.2f} of SQ_WAVE_CYCLES",
-                  f"#   HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE = 2 x {fetch:.4g} + {write:.4g} = {hbm:.4g} B  (algorithmic: 32 B x {pixels} = {32 * pixels:.4g} B)"]
+                  f"#   HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE = 2 x {fetch:.4g} + {write:.4g} = {hbm:.4g} B  (algorithmic: {bytes_per_ray} B x {pixels} = {bytes_per_ray * pixels:.4g} B)"]
         if "SQ_INSTS_VALU_FMA_F32" in t:
             flops = 64 * (t["SQ_INSTS_VALU_ADD_F32"] + t["SQ_INSTS_VALU_MUL_F32"] + 2 * t["SQ_INSTS_VALU_FMA_F32"] + t["SQ_INSTS_VALU_TRANS_F32"])
             other = t["SQ_INSTS_VALU"] - (t["SQ_INSTS_VALU_ADD_F32"] + t["SQ_INSTS_VALU_MUL_F32"] + t["SQ_INSTS_VALU_FMA_F32"] +
@@ -50,7 +57,7 @@ if __name__ == "__main__":
         flop_counters = None
         if "SQ_INSTS_VALU_FMA_F32" in t:
             flop_counters = round(64 * (t["SQ_INSTS_VALU_ADD_F32"] + t["SQ_INSTS_VALU_MUL_F32"] + 2 * t["SQ_INSTS_VALU_FMA_F32"] + t["SQ_INSTS_VALU_TRANS_F32"]))
-        json.dump({"kernel": "gr_trace_fused", "workload": workload, "build_key": build_key,
+        json.dump({"kernel": main_kernel, "workload": workload, "build_key": build_key,
                    "fp32_flop_per_launch": flop_counters, "valu_wave_instructions_per_launch": round(t["SQ_INSTS_VALU"]), "hbm_bytes_per_launch": round(hbm), "fetch_size_bytes": round(fetch), "write_size_bytes": round(write),
                    "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)", "valu_lane_utilisation": round(lane_util, 4),
                    "source": "profiles/" + os.path.basename(out_txt)}, open(out_json, "w"), indent=1)
