@@ -189,9 +189,10 @@ def main():
             os.remove(rccl_log)
         except OSError:
             pass
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
-        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,NET,SHM")
-        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+            os.environ["NCCL_DEBUG"] = "INFO"
+        os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,P2P,NET,SHM"
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log
 
     import torch
     import torch.distributed as dist
@@ -641,7 +642,7 @@ def main():
             # The drop-in path as a maintainer binds it (one launch per reference kernel, 96-byte ray records in HBM, rays
             # in 8x8-tile slot order) with the roofline SURVEY.md 8d defines for THAT Verlet kernel: 140 B per ray (96 read + 12 of the
             # header re-read + 32 written back on termination) over the time of gr_do_generic_rays; counter traffic of the same launches:
-            # profiles/r05_reference_sequence_pmc.txt (tools/final_profiles.sh ... refseq)
+            # profiles/r05_pmc_refseq.txt, profiles/pmc_reference_sequence_4k.json (tools/final_profiles.sh r05 refseq)
             def reference_sequence(prog, wall_s):
                 acc = {}
                 for _ in range(5):
@@ -655,10 +656,11 @@ def main():
                 attempts_ref = int(state.attempts())
                 flops_per_attempt = valu["flops_per_attempt"]
                 hbm = 140 * W * H / trace_s / 1e9
+                pmc_ref, pmc_ref_note = committed_counters("reference_sequence_4k", prog.build_key)
                 return {"fps": round(1 / wall_s, 1), "ms_per_frame": round(wall_s * 1e3, 3), "stage_ms": stage,
                         "roofline": {"bound": "hbm", "kernel": "gr_do_generic_rays", "achieved": round(hbm, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(hbm / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": 140 * W * H, "launch_ms": stage["trace"],
-                                     "traffic": None, "traffic_source": "profiles/r05_reference_sequence_pmc.txt (FETCH_SIZE / WRITE_SIZE of gr_do_generic_rays)"},
+                                     "traffic": pmc_ref.get("hbm_bytes_per_launch") if pmc_ref else None, "traffic_source": pmc_ref_note},
                         "valu_frac": round(flops_per_attempt * attempts_ref / trace_s / 1e12 / VALU_PEAK_TFLOPS, 4),
                         "step_attempts_per_frame": attempts_ref, "trace_over_fused_trace": round(stage["trace"] / max(stages.get("trace", 0.0), 1e-9), 3)}
             secondary["reference_kernel_sequence"] = {"dynamic_program": reference_sequence(manager.dynamic, t)}
@@ -780,12 +782,14 @@ def main():
         mine = {}
         try:
             ctypes.CDLL(None).fflush(None)
-            for text in open(os.environ.get("NCCL_DEBUG_FILE", rccl_log), errors="replace"):
+            for text in open(rccl_log, errors="replace"):
                 if "Channel" in text and " via " in text:
                     kind = text.split(" via ", 1)[1].split()[0]
                     mine[kind] = mine.get(kind, 0) + 1
         except OSError as e:
-            print(f"[bench] rank {rank}: no RCCL log to read ({e})", file=sys.stderr)
+            import glob
+            print(f"[bench] rank {rank}: no RCCL log to read ({e}); NCCL_DEBUG={os.environ.get('NCCL_DEBUG')} NCCL_DEBUG_FILE={os.environ.get('NCCL_DEBUG_FILE')} "
+                  f"in {os.path.dirname(rccl_log)}: {glob.glob(os.path.join(os.path.dirname(rccl_log), 'gr_bench_rccl*'))}", file=sys.stderr)
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
         if rank == 0:
