@@ -42,6 +42,30 @@ __device__ __forceinline__ sincos_pair sincos_reduced(float x) {
     c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, c) ^ (((q + 1u) & 2u) << 30));
     return {s, c};
 }
+// sin^2, cos^2 and sin cos of one angle (the code generator's gr_sin2 / gr_cos2 / gr_sincos, csrc/sym.cpp lower_for_device): the bits of
+// s * s, c * c, s * c with s, c = sincos_reduced(x) - a square has no sign, the product's is the quadrant's low bit, and its magnitude
+// is the two polynomials' product whichever of them is the sine - without the four instructions that sign s and c themselves.
+struct sincos_products_t { float s2, c2, sc; };
+template <bool POISON_LARGE = false>
+__device__ __forceinline__ sincos_products_t sincos_products(float x) {
+#pragma clang fp reassociate(off)
+    float t = __builtin_fmaf(x, 0.636619772367581343f, 12582912.f);
+    float j = t - 12582912.f;
+    unsigned int q = __builtin_bit_cast(unsigned int, t);
+    float r = __builtin_fmaf(-j, 1.57079637050628662109375f, x);
+    r = __builtin_fmaf(-j, -4.37113900018624283e-8f, r);
+    if (POISON_LARGE) r = __builtin_fmaf(x * 4.1539e34f, 0.f, r);
+    float r2 = r * r;
+    float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+    float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
+                              r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
+    const float sp2 = sp * sp, cp2 = cp * cp;
+    sincos_products_t p;
+    p.s2 = (q & 1) ? cp2 : sp2;
+    p.c2 = (q & 1) ? sp2 : cp2;
+    p.sc = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, sp * cp) ^ (q << 31));
+    return p;
+}
 // the polynomial is evaluated unconditionally (so sin and cos of one angle stay in one basic block and share it);
 // the libm call only overrides the result in the never-in-practice large-argument case
 __device__ __forceinline__ float sin(float x) {
@@ -81,6 +105,10 @@ __device__ __forceinline__ float tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.88539008177792681472f) + 1.f);
 #endif
 }
+// outside the Verlet loop (and in builds with another trigonometry flavour): the products from sin and cos as they are there
+__device__ __forceinline__ float gr_sin2(float x) { const float s = sin(x); return s * s; }
+__device__ __forceinline__ float gr_cos2(float x) { const float c = cos(x); return c * c; }
+__device__ __forceinline__ float gr_sincos(float x) { return sin(x) * cos(x); }
 // device-only forms the code generator lowers to (csrc/sym.cpp lower_for_device; GR_DEVICE_ACCEL*): bare v_exp_f32 and v_rsq_f32
 __device__ __forceinline__ float gr_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float gr_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -209,7 +237,10 @@ __device__ __forceinline__ float4 coordinate_period(cfg_t cfg) {
 #define GR_ACCEL_TRIG(LIBM)                                                                              \
     auto sin = [&](float x) -> float { return LIBM ? ::sinf(x) : sincos_reduced<true>(x).s; };           \
     auto cos = [&](float x) -> float { return LIBM ? ::cosf(x) : sincos_reduced<true>(x).c; };           \
-    (void)sin; (void)cos;
+    auto gr_sin2 = [&](float x) -> float { if (LIBM) { const float s = ::sinf(x); return s * s; } return sincos_products<true>(x).s2; };             \
+    auto gr_cos2 = [&](float x) -> float { if (LIBM) { const float c = ::cosf(x); return c * c; } return sincos_products<true>(x).c2; };             \
+    auto gr_sincos = [&](float x) -> float { if (LIBM) return ::sinf(x) * ::cosf(x); return sincos_products<true>(x).sc; };                          \
+    (void)sin; (void)cos; (void)gr_sin2; (void)gr_cos2; (void)gr_sincos;
 #endif
 template <bool LIBM>
 __device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 vel, cfg_t cfg) {

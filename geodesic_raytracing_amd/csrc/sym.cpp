@@ -139,6 +139,9 @@ double apply1(Fn f, double x) {
         case F_SIGN: return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0);
         case F_EXP2_FAST: return std::exp2(x);
         case F_RSQRT_FAST: return 1.0 / std::sqrt(x);
+        case F_SIN2: return std::sin(x) * std::sin(x);
+        case F_COS2: return std::cos(x) * std::cos(x);
+        case F_SINCOS: return std::sin(x) * std::cos(x);
         default: throw std::runtime_error("apply1: bad function");
     }
 }
@@ -179,6 +182,9 @@ const char* fn_name(Fn f) {
         case F_SIGN: return "sign";
         case F_EXP2_FAST: return "gr_exp2";
         case F_RSQRT_FAST: return "gr_rsqrt";
+        case F_SIN2: return "gr_sin2";
+        case F_COS2: return "gr_cos2";
+        case F_SINCOS: return "gr_sincos";
         case F_ATAN2: return "atan2";
         case F_POW: return "pow";
         case F_FMOD: return "fmod";
@@ -706,7 +712,17 @@ struct DeviceLowering {
         switch (e->op) {
             case ADD: r = add(run(e->a), run(e->b)); break;
             case SUB: r = sub(run(e->a), run(e->b)); break;
-            case MUL: r = mul(run(e->a), run(e->b)); break;
+            case MUL: {
+                E a = run(e->a), b = run(e->b);
+                auto trig = [](E x, Fn f) { return x->op == FN1 && x->fn == f; };
+                if ((trig(a, F_SIN) || trig(a, F_COS)) && (trig(b, F_SIN) || trig(b, F_COS)) && a->a == b->a && (a->a->deps & ~DEP_CFG) != 0) {
+                    r = fn1(a->fn != b->fn ? F_SINCOS : a->fn == F_SIN ? F_SIN2 : F_COS2, a->a);
+                    changed = true;
+                } else {
+                    r = mul(a, b);
+                }
+                break;
+            }
             case NEG: r = neg(run(e->a)); break;
             case DIV:
                 if (e->b->op == FN1 && e->b->fn == F_SQRT) {

@@ -34,7 +34,11 @@ enum Fn : uint8_t {
     F_CSQRT_RE, F_CSQRT_IM,
     // comparisons (binary, value is 1.0f / 0.0f)
     F_LT, F_LE, F_EQ, F_GT, F_GE,
-    F_NONE
+    F_NONE,
+    // (appended, not inserted: a node's structural hash takes the numeric value of its function - F_NONE for everything that is not a call -
+    // and that hash orders the operands of sums and products, i.e. it is part of every generated string and of the fixtures made from them)
+    // device-only: sin^2 x, cos^2 x, sin x cos x from one argument reduction - the squares need no quadrant sign, the product one bit of it
+    F_SIN2, F_COS2, F_SINCOS
 };
 
 struct Node {
@@ -101,6 +105,9 @@ E share_reciprocals(E e, std::unordered_map<E, E>& memo);
 //     function, tanh(sigma (r + R)) and tanh(sigma (r - R)), then share ONE exponential;
 //   * x / sqrt(s) -> x rsqrt(s), and where that reciprocal root exists sqrt(s) -> s rsqrt(s): one v_rsq_f32 instead of
 //     v_sqrt_f32 + v_rcp_f32 (not an identity at s = 0, where the quotient it replaces is not a number either).
+//   * sin x sin x, cos x cos x, sin x cos x -> gr_sin2(x), gr_cos2(x), gr_sincos(x): the same bits (a square has no sign, the product's
+//     sign is the quadrant's low bit) without the instructions that put the quadrant's signs on sin x and cos x themselves - all a
+//     Boyer-Lindquist chart ever asks of its angle.
 // `changed` reports whether any rule fired.
 std::vector<E> lower_for_device(const std::vector<E>& roots, bool fast_tanh, bool* changed);
 

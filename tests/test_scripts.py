@@ -281,15 +281,19 @@ def test_fast_tanh_only_where_sums_of_tanh_are_all_there_is(tmp_path):
 def test_device_lowering_of_the_accelerations_is_the_same_function():
     """GR_DEVICE_ACCEL0..3 / GR_DEVICE_TEMPORARIES (csrc/sym.cpp lower_for_device; substituted programs): the accelerations rewritten for
     the device - tanh u -> 1 - 2 / (2^(k u) + 1) with ONE exponential for the two tanh of a shape function, x / sqrt(s) -> x rsqrt(s),
-    sqrt(s) -> s rsqrt(s) - against GEO_ACCEL0..3 of the same string in float64 at random states; the strings cl.cl and the oracle
+    sqrt(s) -> s rsqrt(s), sin x sin x / cos x cos x / sin x cos x -> gr_sin2 / gr_cos2 / gr_sincos - against GEO_ACCEL0..3 of the same string in float64 at random states; the strings cl.cl and the oracle
     compile (GEO_ACCEL*, TEMPORARIES0) hold none of the device-only functions; a dynamic program carries no lowering"""
     import math
     import random
     from macro_eval import _FUNCS
     _FUNCS.setdefault("gr_exp2", lambda x: 2.0 ** x if x < 1000 else math.inf)
     _FUNCS.setdefault("gr_rsqrt", lambda x: 1.0 / math.sqrt(x))
+    _FUNCS.setdefault("gr_sin2", lambda x: math.sin(x) ** 2)
+    _FUNCS.setdefault("gr_cos2", lambda x: math.cos(x) ** 2)
+    _FUNCS.setdefault("gr_sincos", lambda x: math.sin(x) * math.cos(x))
     rng = random.Random(5)
-    for name, expect in (("alcubierre", dict(exp2=1, rsqrt=1)), ("kerr_schild", dict(rsqrt=1)), ("double_unequal_kerr", dict(rsqrt=1))):
+    for name, expect in (("alcubierre", dict(exp2=1, rsqrt=1)), ("kerr_schild", dict(rsqrt=1)), ("double_unequal_kerr", dict(rsqrt=1)),
+                         ("kerr_boyer", dict(rsqrt=0, products=True)), ("kerr_newman_boyer", dict(rsqrt=0, products=True))):
         metric = gra.Metric(name, OWN)
         assert "GR_DEVICE_ACCEL0" not in metric.argument_string()
         text = metric.argument_string(features=metric.features(adaptive_sampling=0), static=True, cfg_values=metric.cfg_values())
@@ -301,6 +305,9 @@ def test_device_lowering_of_the_accelerations_is_the_same_function():
         if "exp2" in expect:
             assert device.count("gr_exp2(") == expect["exp2"] and "tanh(" not in device
         assert device.count("gr_rsqrt(") >= expect["rsqrt"]
+        if expect.get("products"):   # a Boyer-Lindquist chart asks nothing of its angle but sin^2, cos^2 and sin cos
+            assert "gr_sin2(v3)" in device and "gr_cos2(v3)" in device and "gr_sincos(v3)" in device
+            assert "sin(v3)" not in device.replace("gr_sin2(v3)", "").replace("gr_sincos(v3)", "") and "cos(v3)" not in device.replace("gr_cos2(v3)", "").replace("gr_sincos(v3)", "")
         original = MacroSet(text)
         lowered = MacroSet(text.replace("-DTEMPORARIES0=", "-DUNUSED_TEMPORARIES0=").replace("-DGR_DEVICE_TEMPORARIES=", "-DTEMPORARIES0="))
         for _ in range(20):
