@@ -46,7 +46,8 @@ class Camera(ctypes.Structure):
 class FrameTuning(ctypes.Structure):
     """gr_frame_tuning (include/geodesic_hip_internal.h): which fused kernel, schedule and launch size gr_render_frame takes"""
     _fields_ = [("ray_compaction", c_int), ("rays_per_lane", c_int), ("fused_shading", c_int), ("inline_prepass", c_int),
-                ("trace_waves_per_simd", c_int), ("tile_history", c_int), ("next_strip_rank", c_int), ("next_strip_rank2", c_int),
+                ("trace_waves_per_simd", c_int), ("tile_history", c_int), ("park_lanes", c_int), ("park_trips", c_int),
+                ("next_strip_rank", c_int), ("next_strip_rank2", c_int),
                 ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float), ("count_attempts", c_int)]
 
 
@@ -90,13 +91,18 @@ class TraceShading(ctypes.Structure):
                 ("bg_levels", c_int), ("max_probes", c_int), ("compact_out", c_int)]
 
 
+class ParkingLot(ctypes.Structure):
+    """gr_parking_lot (gr_trace_fused_parking)"""
+    _fields_ = [("records", c_void_p), ("words", c_void_p), ("lanes", c_int), ("trips", c_int), ("slots", c_int), ("groups", c_int)]
+
+
 class TraceFusedArgs(ctypes.Structure):
     _fields_ = [("camera_generic", c_void_p), ("camera_quat", c_void_p), ("render_data", c_void_p), ("width", c_int), ("height", c_int),
                 ("block_rows", c_int), ("strip_rank", c_int), ("strip_count", c_int), ("termination_buffer", c_void_p),
                 ("prepass_width", c_int), ("prepass_height", c_int), ("e0", c_void_p), ("e1", c_void_p), ("e2", c_void_p),
                 ("e3", c_void_p), ("cfg", c_void_p), ("dfg", c_void_p), ("attempt_counter", c_void_p), ("tile_order", c_void_p),
                 ("waves_per_simd", c_int), ("shading", TraceShading), ("lattice", c_int), ("pending_only", c_int), ("inline_prepass", c_int),
-                ("tile_cost", c_void_p), ("tile_order_by_history", c_int), ("lattice_rays", c_void_p)]
+                ("tile_cost", c_void_p), ("tile_order_by_history", c_int), ("lattice_rays", c_void_p), ("parking", ParkingLot)]
 
 
 class Transport(ctypes.Structure):
@@ -170,6 +176,8 @@ _SIGNATURES = {
     "gr_order_tiles_by_history": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int]),
     "gr_trace_fused_launch": (c_int, [c_void_p, c_void_p, ctypes.POINTER(TraceFusedArgs)]),
     "gr_trace_fused_wave_slots": (ctypes.c_longlong, [c_void_p]),
+    "gr_parking_lot_bytes": (c_size_t, [c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "gr_program_has_parking": (c_int, [c_void_p]),
     "gr_render_state_tile_history": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(c_int)]),
     "gr_camera_origin_on_screen": (c_int, [ctypes.POINTER(Camera), c_float, c_int, c_int, ctypes.POINTER(c_float)]),
     "gr_picture_motion": (c_float, [ctypes.POINTER(Camera), ctypes.POINTER(Camera), c_float, c_int]),

@@ -89,11 +89,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_setup", "gr_order_tiles", "gr_adaptive_refine", "gr_trace_pending", "gr_do_generic_rays_scheduled", "gr_sort_tiles_count", "gr_sort_tiles_place", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_setup", "gr_order_tiles", "gr_adaptive_refine", "gr_trace_pending", "gr_do_generic_rays_scheduled", "gr_sort_tiles_count", "gr_sort_tiles_place", "gr_trace_fused_parking", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_SETUP, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_TRACE_PENDING, K_DO_RAYS_SCHEDULED, K_SORT_TILES_COUNT, K_SORT_TILES_PLACE, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_SETUP, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_TRACE_PENDING, K_DO_RAYS_SCHEDULED, K_SORT_TILES_COUNT, K_SORT_TILES_PLACE, K_TRACE_FUSED_PARKING, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -304,7 +304,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
                 if (run_limit <= 0 && gr::assemble_code_object(assembly, out, log)) return GR_OK;
                 // the kernels that hold a Verlet loop; the others (set-up, shading, tile order ...) are left as compiled
                 static const std::vector<std::string> integrators = {"gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused",
-                                                                     "gr_do_generic_rays", "gr_do_generic_rays_scheduled"};
+                                                                     "gr_do_generic_rays", "gr_do_generic_rays_scheduled", "gr_trace_fused_parking"};
                 std::string patched = assembly;
                 const gr::vector_run_stats st = gr::break_vector_runs(patched, run_limit, integrators);
                 if (gr::assemble_code_object(patched, out, log)) {
@@ -750,7 +750,7 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
             HIP_CHECK(hipModuleGetFunction(&p->fn[k], p->setup_module, KERNEL_NAMES[k]));
             continue;
         }
-        if (k == K_TRACE_PAIR) {   // built for some metrics only (pair_kernel_applies)
+        if (k == K_TRACE_PAIR || k == K_TRACE_FUSED_PARKING) {   // built for some metrics only (pair_kernel_applies) / with -DGR_PARKING in the argument string only
             if (hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]) != hipSuccess) { p->fn[k] = nullptr; (void)hipGetLastError(); }
             continue;
         }
@@ -1230,6 +1230,11 @@ static long long resident_trace_groups(gr_program* p, int kernel_index, int wg) 
     return (long long)p->compute_units * p->resident_groups_per_cu[kernel_index];
 }
 
+size_t gr_parking_lot_bytes(int slots, int groups, size_t* words_bytes) {
+    if (words_bytes) *words_bytes = (16 + (size_t)(groups > 0 ? groups : 0)) * sizeof(unsigned int);
+    return (size_t)(slots > 0 ? slots : 0) * 6 * 16;
+}
+
 long long gr_trace_fused_wave_slots(gr_program* p) {
     if (!p) return 0;
     const long long groups = resident_trace_groups(p, K_TRACE_FUSED, 256);
@@ -1242,7 +1247,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
                         int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
                         const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0, const void* tile_order = nullptr,
                         int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr, int inline_prepass = 0, void* tile_cost = nullptr,
-                        int tile_order_by_history = 0, void* lattice_rays = nullptr) {
+                        int tile_order_by_history = 0, void* lattice_rays = nullptr, const gr_parking_lot* parking = nullptr) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
     // the prepass inside the launch: its cell waves are the first tickets (gr_trace_fused's prepass_tickets)
@@ -1256,6 +1261,16 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     }
     if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && rays_per_lane != 1))
         return fail(GR_ERROR_INVALID_ARGUMENT, "lattice / pending_only: gr_trace_fused only");
+    const bool parks = parking && parking->lanes > 0;
+    if (parks) {
+        if (!p->fn[K_TRACE_FUSED_PARKING])
+            return fail(GR_ERROR_INVALID_ARGUMENT, "parking: the program was built without -DGR_PARKING in its argument string (gr_program_has_parking)");
+        if (rays_per_lane != 1 || lattice != 1 || pending_only || (shading_in && shading_in->out))
+            return fail(GR_ERROR_INVALID_ARGUMENT, "parking: gr_trace_fused on every pixel of its rows, one ray per lane, no in-tile shading");
+        if (!parking->records || !parking->words || parking->lanes > 64 || parking->trips < 1 || parking->slots < 64 || parking->slots > (1 << 24) ||
+            parking->groups < 1)
+            return fail(GR_ERROR_INVALID_ARGUMENT, "parking: records and words (gr_parking_lot_bytes), 1 <= lanes <= 64, trips >= 1, 64 <= slots <= 2^24, groups >= 1");
+    }
     if (rays_per_lane == 2 && !p->fn[K_TRACE_PAIR])
         return fail(GR_ERROR_INVALID_ARGUMENT, "this program has no gr_trace_pair kernel (its expressions do not instantiate on pairs)");
     if (strip_count <= 1) {   // one block covering the image
@@ -1291,7 +1306,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     // experiment hook: GR_TRACE_WAVES_PER_SIMD=k launches k persistent waves per SIMD whatever fits (occupancy studies)
     static const int forced_waves_per_simd = [] { const char* e = getenv("GR_TRACE_WAVES_PER_SIMD"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 0; }();
     // (the lattice launch of adaptive sampling that leaves its rays behind is a kernel of its own: gr_trace_fused is not touched by it)
-    const int kernel_index = rays_per_lane == 2 ? K_TRACE_PAIR : (lattice == 2 && lattice_rays) ? K_TRACE_FUSED_LATTICE : K_TRACE_FUSED;
+    const int kernel_index = parks ? K_TRACE_FUSED_PARKING : rays_per_lane == 2 ? K_TRACE_PAIR : (lattice == 2 && lattice_rays) ? K_TRACE_FUSED_LATTICE : K_TRACE_FUSED;
     long long resident_groups = resident_trace_groups(p, kernel_index, wg);
     if (resident_groups < 0) return (int)-resident_groups;
     // a caller that keeps several frames in flight may take fewer slots per launch: two smaller launches then share the device
@@ -1300,7 +1315,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         resident_groups = (long long)p->compute_units * 4 * forced_waves_per_simd * 64 / wg;
     else if (waves_per_simd >= 1 && waves_per_simd <= 8)
         resident_groups = std::min(resident_groups, (long long)p->compute_units * 4 * waves_per_simd * 64 / wg);
-    if ((persistent && groups > resident_groups) || prepass_tickets) {   // prepass tickets need the ticket order whatever the size
+    if ((persistent && groups > resident_groups) || prepass_tickets || parks) {   // prepass tickets need the ticket order whatever the size, and so does a lot
         tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
         HIP_CHECK(hipSetDevice(p->device));
         HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
@@ -1339,10 +1354,18 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     // flag only says which he thinks it is, for the checks above.
     int last_class_is_skipped = 0;   // (kept in the kernel's parameter list: 1 would force the promise, nothing passes it)
     (void)tile_order_by_history;
+    // the kernel's parking_lot, by value (same layout); an empty lot before every launch
+    struct { void* records; void* words; int lanes, trips, slots, groups; } lot = {};
+    if (parks) {
+        lot.records = parking->records; lot.words = parking->words; lot.lanes = parking->lanes; lot.trips = parking->trips;
+        lot.slots = parking->slots; lot.groups = parking->groups;
+        HIP_CHECK(hipSetDevice(p->device));
+        HIP_CHECK(hipMemsetAsync(parking->words, 0, (16 + (size_t)parking->groups) * sizeof(unsigned int), (hipStream_t)stream));
+    }
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
                     &lattice, &pending_only, &tile_order, &shading, &prepass_tickets, &ticket_tiles, &tile_cost,
-                    &last_class_is_skipped, &lattice_rays};   // the last nine: gr_trace_fused only (gr_trace_pair's parameter list ends before them)
+                    &last_class_is_skipped, &lattice_rays, &lot};   // the last ten: gr_trace_fused only (gr_trace_pair's parameter list ends before them), the very last gr_trace_fused_parking only
     return launch(p, kernel_index, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
@@ -1467,7 +1490,7 @@ int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args
     return trace_launch(p, 1, stream, a->camera_generic, a->camera_quat, a->render_data, a->width, a->height, a->block_rows, a->strip_rank,
                         a->strip_count, a->termination_buffer, a->prepass_width, a->prepass_height, a->e0, a->e1, a->e2, a->e3, a->cfg, a->dfg,
                         a->attempt_counter, a->lattice == 2 ? 2 : 1, a->pending_only ? 1 : 0, a->tile_order, a->waves_per_simd, &a->shading,
-                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0, a->lattice == 2 ? a->lattice_rays : nullptr);
+                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0, a->lattice == 2 ? a->lattice_rays : nullptr, &a->parking);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
@@ -1480,6 +1503,7 @@ int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const
 
 int gr_program_has_trace_pair(const gr_program* p) { return p && p->fn[K_TRACE_PAIR] ? 1 : 0; }
 int gr_program_has_tile_shading(const gr_program* p) { return p && p->tile_shading ? 1 : 0; }
+int gr_program_has_parking(const gr_program* p) { return p && p->fn[K_TRACE_FUSED_PARKING] ? 1 : 0; }
 
 int gr_trace_compact(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,
                      int height, int block_rows, int strip_rank, int strip_count, const void* term, int prepass_width,

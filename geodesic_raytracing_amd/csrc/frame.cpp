@@ -100,6 +100,9 @@ struct gr_render_state {
     // what each tile of the last fused frame cost (gr_trace_fused_args.tile_cost) and the frame shape that goes with it: the next
     // frame's tiles are handed out dearest first by it (gr_frame_options.tile_history)
     void* lattice_rays = nullptr;   // adaptive sampling on the fused path: gr_lattice_rays_bytes (allocated on first use)
+    void* parking_records = nullptr;   // gr_trace_fused_parking's lot (gr_parking_lot_bytes; allocated the first time a frame parks)
+    void* parking_words = nullptr;
+    int parking_slots = 0;
     void* pending_list = nullptr;   // ... the pixels of its second launch, dearest first: gr_pending_list_bytes
     // ... and what the rays of each 2x2 block cost in this frame / in the frame before (the two alternate): the order of the next
     // frame's list while the picture moves little
@@ -386,6 +389,8 @@ void gr_frame_tuning_default(gr_frame_tuning* t) {
     t->inline_prepass = -1;
     t->trace_waves_per_simd = 0;
     t->tile_history = -1;
+    t->park_lanes = -1;
+    t->park_trips = 0;
     t->next_strip_rank = -1;
     t->next_strip_rank2 = -1;
     t->next_geodesic_time = 0;
@@ -524,7 +529,7 @@ void gr_render_state_destroy(gr_render_state* s) {
     std::vector<void*> ptrs = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
                                s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
                                s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->tile_order,
-                               s->tile_cost, s->lattice_rays, s->pending_list, s->block_cost, s->block_cost_before, s->ref_cost[0], s->ref_cost[1], s->ref_order, s->ref_sort_work};
+                               s->tile_cost, s->lattice_rays, s->pending_list, s->block_cost, s->block_cost_before, s->ref_cost[0], s->ref_cost[1], s->ref_order, s->ref_sort_work, s->parking_records, s->parking_words};
     for (auto& slot : s->pre) {
         if (slot.stream) { (void)hipStreamSynchronize(slot.stream); (void)hipStreamDestroy(slot.stream); }
         if (slot.ready) (void)hipEventDestroy(slot.ready);
@@ -1169,6 +1174,30 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 }
                 a.waves_per_simd = tune.trace_waves_per_simd;
                 a.inline_prepass = inline_prepass ? 1 : 0;
+                // parking (gr_trace_fused_parking): the lot is the state's, allocated the first time a frame asks for it - room for an
+                // eighth of the frame's rays (a = 0.9 at 4K parks 4 % of them, re-parked ones counted again; a full lot is not an error)
+                static const int park_default[2] = {[] { const char* e = getenv("GR_PARK"); return e ? atoi(e) : 0; }(),
+                                                    [] { const char* e = getenv("GR_PARK"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }()};
+                const int park_lanes = tune.park_lanes < 0 ? park_default[0] : tune.park_lanes;
+                const int park_trips = tune.park_trips > 0 ? tune.park_trips : park_default[1] > 0 ? park_default[1] : 512;
+                if (tune.park_lanes > 1 && !gr_program_has_parking(p))
+                    return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "park_lanes: needs a program built with -DGR_PARKING appended to its argument string");
+                if (park_lanes > 1 && tune.fused_shading != 1 && gr_program_has_parking(p)) {
+                    const int slots = (int)std::min<long long>(1 << 24, std::max<long long>(65536, (long long)width * height / 8));
+                    if (!s->parking_records || s->parking_slots != slots) {
+                        if (s->parking_records) (void)hipFree(s->parking_records);
+                        if (s->parking_words) (void)hipFree(s->parking_words);
+                        s->parking_records = s->parking_words = nullptr;
+                        size_t words_bytes = 0;
+                        const size_t bytes = gr_parking_lot_bytes(slots, slots, &words_bytes);
+                        HIP_CHECK(hipMalloc(&s->parking_records, bytes));
+                        HIP_CHECK(hipMalloc(&s->parking_words, words_bytes));
+                        s->parking_slots = slots;
+                    }
+                    a.parking.records = s->parking_records; a.parking.words = s->parking_words;
+                    a.parking.lanes = std::min(park_lanes, 64); a.parking.trips = park_trips;
+                    a.parking.slots = slots; a.parking.groups = slots;
+                }
                 // the trace shades the pixels whose filter neighbours are in their own tile; gr_render_seams below does the rest
                 shade_in_trace = out && tune.fused_shading == 1 && width % 8 == 0 && height % 8 == 0 && gr_program_has_tile_shading(p);
                 if (tune.fused_shading == 1 && !shade_in_trace && out)   // default: off, on measurement

@@ -113,17 +113,25 @@ struct step_controller {
 
 template <bool LIBM> struct trig_flavour { static constexpr bool value = LIBM; };
 
-template <bool RESUMABLE>
-__device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t dfg, unsigned int* attempts, int keep_lanes, bool& paused) {
+//
+// PARKABLE (parking, trace.hip): the plain loop - a ray starts exactly as it does there - that can also be left, once per trip (two
+// attempts) and not before park_trips trips of this visit, when fewer than keep_lanes lanes are still iterating; `resumed` (wave-uniform)
+// says that `s` holds a ray left that way, which then goes on as if it had never stopped.
+template <bool RESUMABLE, bool PARKABLE = false>
+__device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t dfg, unsigned int* attempts, int keep_lanes, bool& paused,
+                                                  bool resumed = false, unsigned int park_trips = 0) {
     float4 p0 = s.position, v0 = s.velocity, a0 = s.acceleration;
     float4 p1 = p0, v1 = v0, a1 = a0;
-    const float f_in_x = RESUMABLE ? s.f_in_x : __builtin_fabsf(v0.x);
+    const bool carried = RESUMABLE || (PARKABLE && resumed);   // what the loop carries between attempts comes from `s`
+    if (PARKABLE && !resumed) { s.steps = 0; s.tries = 0; }
+    const float f_in_x = carried ? s.f_in_x : __builtin_fabsf(v0.x);
+    if (PARKABLE) s.f_in_x = f_in_x;
     const float subambient_precision = 0.5f;
     const float ambient_precision = 0.2f;
     float next_ds = 0.00001f;
 #ifdef ADAPTIVE_PRECISION
     const step_controller controller(GET_FEATURE(max_acceleration_change, dfg), GET_FEATURE(min_step, dfg), ambient_precision);
-    if (RESUMABLE) next_ds = s.next_ds;
+    if (carried) next_ds = s.next_ds;
     else {
         float4 a = a0;
 #ifdef IS_CONSTANT_THETA
@@ -139,11 +147,11 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
     const float new_min = 3;
     const float universe = GET_FEATURE(universe_size, dfg);
     const bool reparam = GET_FEATURE(reparameterisation, dfg) != 0;
-    float running = RESUMABLE ? s.running_dlambda_dnew : 1.f;
+    float running = carried ? s.running_dlambda_dnew : 1.f;
     const int loop_limit = 4096 * 4;
     // accepted steps the ray may still take (cl.cl:3974: 16384 in all).  Every attempt() entered takes one - the borrow of that very
     // subtraction is the step-cap test - and a rejection (rare) gives it back.
-    const unsigned int budget_before = (unsigned int)(loop_limit - (RESUMABLE ? s.steps : 0));
+    const unsigned int budget_before = (unsigned int)(loop_limit - (carried ? s.steps : 0));
     unsigned int budget = budget_before;
     unsigned int rejections = 0;
     paused = false;
@@ -356,7 +364,16 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         const trig_flavour<false> polynomial;
 #if GR_PRIORITY_TRIPS > 0
         unsigned trips = 0, next_level = GR_PRIORITY_TRIPS;
+        // (the wave of rays that were parked: GR_PARK_PRIORITY for the visit.  0, on measurement - DESIGN.md section 4)
+#ifndef GR_PARK_PRIORITY
+#define GR_PARK_PRIORITY 0
 #endif
+        if (PARKABLE && resumed) { __builtin_amdgcn_s_setprio(GR_PARK_PRIORITY); next_level = 0xffffffffu; }
+#endif
+        // (wave-uniform, and said to be: the test below is then three scalar instructions)
+        unsigned int visit_trips = 0;
+        const int park_below = PARKABLE ? __builtin_amdgcn_readfirstlane(keep_lanes) : 0;
+        const unsigned int park_after = PARKABLE ? __builtin_amdgcn_readfirstlane(park_trips) : 0u;
         for (;;) {
             float4 p1, v1, a1;
             float ds_used, running_before;
@@ -385,6 +402,15 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
                 if (!(RESUMABLE && pause_wave)) { overwrite(p0, p1); overwrite(v0, v1); overwrite(a0, a1); }
                 asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "+v"(exit_ds), "+v"(exit_running) : "v"(ds_used), "v"(running_before));
                 break;
+            }
+            if (PARKABLE) {
+                // the trip is complete, the state in set 0: a wave down to its last few rays after a long time hands them over (scalar
+                // work only: a count of the exec mask and two compares)
+                visit_trips = __builtin_amdgcn_readfirstlane(visit_trips) + 1u;
+                if (__builtin_expect(visit_trips >= park_after && __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < park_below, 0)) {
+                    pause_wave = true;
+                    break;
+                }
             }
         }
     }
@@ -431,7 +457,7 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
         classify();
     }
 #endif
-    paused = RESUMABLE && pause_wave;
+    paused = (RESUMABLE || PARKABLE) && pause_wave;
     const bool left_at_top = !capped && !paused && (lost_at_top | terminated_at_top);
     int result = RAY_LOST;
     if (!paused) {
@@ -442,12 +468,12 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
     }
     // every attempt() entered took one step off the budget; the entry that found the ray finished (or the budget empty) made none
     const unsigned int taken = capped ? budget_before : budget_before - budget - (left_at_top ? 1u : 0u);
-    if (RESUMABLE) { s.next_ds = next_ds; s.steps += (int)taken; s.tries += taken + rejections; }
+    if (RESUMABLE || PARKABLE) { s.next_ds = next_ds; s.steps += (int)taken; s.tries += taken + rejections; }
     s.position = position;
     s.velocity = velocity;
     s.acceleration = acceleration;
     s.running_dlambda_dnew = running;
-    if (attempts) *attempts = RESUMABLE ? s.tries : taken + rejections;
+    if (attempts) *attempts = (RESUMABLE || PARKABLE) ? s.tries : taken + rejections;
     return result;
 }
 

@@ -366,10 +366,136 @@ struct trace_shading {
 };
 __device__ __attribute__((noinline)) float4 shade_pixel_in_tile(const render_data& self, float2 beside, float2 below, const trace_shading& shading, dfg_t dfg);
 
+// ---- parking ----------------------------------------------------------------------------------------
+// gr_trace_fused_parking (PARKING below): a tile-wave that is down to its last few rays after a long time - a naked singularity's
+// frame (BASELINE.json configs[2] read literally) has rays of 10 000 attempts scattered one or two to a tile, and a wave issues every
+// instruction for 64 lanes whether 2 or 64 of them hold a ray: 9 % of that frame's issue slots - writes the state of those rays to a
+// lot in device memory and draws its next tile; whoever draws next (any wave of the launch) first looks at the lot and, when 64 parked
+// rays have come together, takes those instead of a tile and goes on with them (and may park again under the same rule).  Nothing
+// waits for anything: a wave that finds no tile ticket left takes whatever the lot holds, and leaves when it holds nothing - the wave
+// that parks last looks last, so nothing stays behind.  The arithmetic of a ray does not know where it is integrated: the loop's
+// carried state (step suggestion, reparameterisation factor, step and attempt counts) travels with the ray.
+//   records  GR_PARKED_FLOAT4 float4 per ray: position, velocity, acceleration, initial quaternion, (step suggestion, dlambda/dnew,
+//            |v.x| at the start, k.u of the observer), (accepted steps, attempts, pixel x | y << 16, the tile-wave the ray came from)
+//   words    [0] groups reserved | [1] records reserved (one 64-bit atomic), [2] groups handed out | [3] records handed out (one
+//            64-bit compare-and-swap), [4] groups the lot had no room for (their wave went on itself), [5] waves that took parked rays,
+//            [GR_LOT_HEADER + g] group g: 0 until its records are written, then 1 << 31 | rays << 24 | first record
+// A group is what one wave parked at once (1 .. lanes - 1 rays).
+struct parking_lot {
+    float4* records;
+    unsigned int* words;
+    int lanes, trips;   // hand over when fewer than `lanes` rays are left after `trips` trips (two attempts each) of a visit; lanes 0: never
+    int slots, groups;  // capacity
+};
+#define GR_PARKED_FLOAT4 6
+#define GR_LOT_REFUSED 4
+#define GR_LOT_WAVES 5
+#define GR_LOT_HEADER 16
+
+// The lot's records are written and read as device-scope accesses (the sc1 flavour of the load / store: coherent between the XCDs' L2s
+// without any cache maintenance).  A release / acquire fence pair would be the textbook way and costs 100 ms a frame here: on this chip
+// it is a write-back and an invalidation of an XCD's whole L2, for every parking event (measured: a = 0.9 at 4K, 15.6 -> 31.5 ms).
+__device__ __forceinline__ void lot_store(float4* at, float4 v) {
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(at);
+    __hip_atomic_store(words, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(words + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 lot_load(const float4* at) {
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(const_cast<float4*>(at));
+    const unsigned long long lo = __hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f4(__uint_as_float((unsigned int)lo), __uint_as_float((unsigned int)(lo >> 32)), __uint_as_float((unsigned int)hi), __uint_as_float((unsigned int)(hi >> 32)));
+}
+
+__device__ __forceinline__ bool park_rays(const parking_lot& lot, int lane, bool parked, const ray_state& s, float4 initial_quat, float ku_uobsu,
+                                          int cx, int cy, int home_wave) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(parked);
+    const unsigned int n = (unsigned int)__builtin_popcountll(mask);
+    const bool leader = lane == (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+    unsigned long long old = 0;
+    if (leader) old = atomicAdd(reinterpret_cast<unsigned long long*>(lot.words), ((unsigned long long)n << 32) | 1ull);
+    const unsigned int g = __builtin_amdgcn_readfirstlane((unsigned int)old), base = __builtin_amdgcn_readfirstlane((unsigned int)(old >> 32));
+    if (g >= (unsigned int)lot.groups || base + n > (unsigned int)lot.slots) {
+        // no room: the group stays empty (whoever walks the groups steps over it) and the wave goes on with its rays itself
+        if (leader) {
+            if (g < (unsigned int)lot.groups) __hip_atomic_store(lot.words + GR_LOT_HEADER + g, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(lot.words + GR_LOT_REFUSED, 1u);
+        }
+        return false;
+    }
+    if (parked) {
+        const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+        float4* record = lot.records + GR_PARKED_FLOAT4 * (size_t)(base + rank);
+        lot_store(record + 0, s.position);
+        lot_store(record + 1, s.velocity);
+        lot_store(record + 2, s.acceleration);
+        lot_store(record + 3, initial_quat);
+        lot_store(record + 4, f4(s.next_ds, s.running_dlambda_dnew, s.f_in_x, ku_uobsu));
+        lot_store(record + 5, f4(__int_as_float(s.steps), __int_as_float((int)s.tries), __int_as_float(cx | (cy << 16)), __int_as_float(home_wave)));
+    }
+    // the records have arrived before the word that announces them is sent
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (leader) __hip_atomic_store(lot.words + GR_LOT_HEADER + g, 0x80000000u | (n << 24) | base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+// Called by a whole wave.  Takes the groups at the front of the lot, as many as fill 64 lanes - or fewer when `anything` (no tile ticket
+// is left) - and returns how many rays that is (0: nothing taken); record = this lane's, or -1.
+__device__ __forceinline__ int claim_parked(const parking_lot& lot, int lane, bool anything, int& record) {
+    record = -1;
+    for (int round = 0; round < 8; round++) {
+        // (one address for the whole wave, but read past the scalar cache: said to be uniform by hand)
+        const unsigned long long reserved_now = __hip_atomic_load(reinterpret_cast<unsigned long long*>(lot.words), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long handed_now = __hip_atomic_load(reinterpret_cast<unsigned long long*>(lot.words + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int reserved_groups = __builtin_amdgcn_readfirstlane((unsigned int)reserved_now), reserved_rays = __builtin_amdgcn_readfirstlane((unsigned int)(reserved_now >> 32));
+        const unsigned int g0 = __builtin_amdgcn_readfirstlane((unsigned int)handed_now), handed_rays = __builtin_amdgcn_readfirstlane((unsigned int)(handed_now >> 32));
+        const unsigned long long handed = (unsigned long long)g0 | ((unsigned long long)handed_rays << 32);
+        const unsigned int groups = min(reserved_groups, (unsigned int)lot.groups);
+        if (g0 >= groups) return 0;
+        // (cheap first look while tiles are left: not even 64 rays in the lot)
+        if (!anything && reserved_rays - handed_rays < 64u) return 0;
+        unsigned int info = 0;
+        if ((unsigned int)lane < groups - g0) info = __hip_atomic_load(lot.words + GR_LOT_HEADER + g0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long unwritten = __builtin_amdgcn_ballot_w64((info >> 31) == 0u);
+        const int leading = unwritten ? (int)__builtin_ctzll(unwritten) : 64;
+        if (leading == 0) return 0;   // the group in front is being written this very moment: its wave will look again after it
+        const unsigned int n = lane < leading ? (info >> 24) & 63u : 0u;
+        unsigned int sum = n;   // running sum of the groups' rays
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int before = (unsigned int)__shfl_up((int)sum, d);
+            if (lane >= d) sum += before;
+        }
+        const int G = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < leading && sum <= 64u));   // (>= 1: a group is < 64 rays)
+        const unsigned int total = __builtin_amdgcn_readfirstlane((unsigned int)__shfl((int)sum, G - 1));   // (uniform, and known to be)
+        if (!anything && G == leading && total < 64u) return 0;   // more will come
+        bool won = false;
+        if (lane == 0)
+            won = atomicCAS(reinterpret_cast<unsigned long long*>(lot.words + 2), handed,
+                            (unsigned long long)(g0 + (unsigned int)G) | ((unsigned long long)(handed_rays + total) << 32)) == handed;
+        if (!__builtin_amdgcn_readfirstlane((int)won)) continue;   // another wave was quicker: look again
+        if (total == 0u) continue;                                  // nothing but groups that found no room
+        asm volatile("" ::: "memory");   // (the records are read after the words: device-scope loads, issued in order)
+        // lane j takes ray j: the first group whose running sum exceeds j
+        int lo = 0, hi = G - 1;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int mid = (lo + hi) >> 1;
+            const unsigned int sum_mid = (unsigned int)__shfl((int)sum, mid);
+            if (lo < hi) { if (sum_mid > (unsigned int)lane) hi = mid; else lo = mid + 1; }
+        }
+        const unsigned int info_l = (unsigned int)__shfl((int)info, lo), sum_l = (unsigned int)__shfl((int)sum, lo);
+        const unsigned int first = sum_l - ((info_l >> 24) & 63u);
+        if ((unsigned int)lane < total) record = (int)((info_l & 0xffffffu) + ((unsigned int)lane - first));
+        if (lane == 0) atomicAdd(lot.words + GR_LOT_WAVES, 1u);
+        return (int)total;
+    }
+    return 0;
+}
+
 // LATTICE_RAYS: the instantiation of gr_trace_fused_lattice, which also leaves its rays' end states behind (below).  A kernel of its
 // own so that gr_trace_fused stays exactly the code it was: as a run-time option the three stores cost the headline kernel its
 // seventh wave per SIMD (72 VGPRs + 48 B -> 80 + 36 B at six).
-template <bool LATTICE_RAYS>
+template <bool LATTICE_RAYS, bool PARKING = false>
 __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __restrict__ camera, const float4* __restrict__ camera_quat,
                                            render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank,
                                            int strip_count, const int* __restrict__ termination_buffer, int prepass_width,
@@ -377,7 +503,9 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            const float4* __restrict__ e2, const float4* __restrict__ e3, cfg_t cfg, dfg_t dfg,
                                            unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
                                            const trace_shading& shading, bool known_skipped, int cell_wave, bool cells_in_flight,
-                                           unsigned int* __restrict__ tile_cost, float4* __restrict__ lattice_rays) {
+                                           unsigned int* __restrict__ tile_cost, float4* __restrict__ lattice_rays,
+                                           const parking_lot* lot = nullptr, int record = -1, bool from_lot = false) {
+    // PARKING with from_lot (wave-uniform): this "tile" is up to 64 parked rays (claim_parked), lane by lane the record it was dealt.
     // cell_wave >= 0: this "tile" is 64 cells of the low-resolution prepass (prepass_cell, below) traced by the launch itself:
     // the ray of cell (cx, cy) of the prepass grid, and its verdict goes to the termination buffer instead of a record.
     // cells_in_flight: the launch has such waves, so a tile waits for the cells its pixels look at.
@@ -400,7 +528,13 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     const int r0 = (local_block * strip_count + strip_rank) * block_rows;
     int cx, cy;
     int ray_grid_width = image_width, ray_grid_height = image_height;   // the grid the ray's direction is a pixel of
-    if (cell_wave >= 0) {
+    if (PARKING && from_lot) {
+        if (record < 0) return;
+        const float4 where = lot_load(lot->records + GR_PARKED_FLOAT4 * (size_t)record + 5);
+        cx = __float_as_int(where.z) & 0xffff;
+        cy = (int)((unsigned int)__float_as_int(where.z) >> 16);
+        wave = __float_as_int(where.w);   // (per lane here: only the ray's cost, at its end, is filed under it)
+    } else if (cell_wave >= 0) {
         const int cell = cell_wave * 64 + lane;
         if (cell >= prepass_width * prepass_height) return;
         cx = cell % prepass_width;
@@ -429,7 +563,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     // known_skipped: a tile of gr_order_tiles' last class - the 5x5 cells around it are all in the shadow, and the stencil of every
     // one of its pixels lies inside those (a pixel rounds to a cell at most one from the tile centre's) - needs no look-up at all
     int terminated = known_skipped ? 2 : 0;
-    if (cell_wave < 0 && !known_skipped && !pending_only && termination_buffer && prepass_width != width && prepass_height != height) {
+    if (cell_wave < 0 && !known_skipped && !pending_only && !(PARKING && from_lot) && termination_buffer && prepass_width != width && prepass_height != height) {
         float fx = exact_ratio(cx, width);
         float fy = exact_ratio(cy, height);
         int lx = (int)roundf(fx * prepass_width);
@@ -440,6 +574,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     }
     render_data dat;
     unsigned int tries = 0;
+    bool parked_here = false;   // PARKING: this lane's ray went to the lot - whoever ends it writes its record
     if (terminated == 2) {
         dat.tex_coord = make_float2(0, 0);
         dat.z_shift = 0;
@@ -450,13 +585,77 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     } else {
         // camera and tetrad are re-read (scalar loads) for every tile: 24 wave-uniform values held across the integrator
         // loop would spill scalar registers
-        lightray ray = make_pixel_ray(cx, cy, ray_grid_width, ray_grid_height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+        lightray ray;
         ray_state s;
-        s.position = ray.position;
-        s.velocity = ray.velocity;
-        s.acceleration = ray.acceleration;
-        s.running_dlambda_dnew = 1;
-        int res = integrate_ray(s, cfg, dfg, &tries);
+        int res = RAY_LOST;
+        if (PARKING) {
+            unsigned int tries_before = 0;
+#ifdef GR_PROBE_LOT   // (-DGR_PROBE_LOT: how long the waves that took parked rays were at it - counter words 4..6: ticks, attempts of each visit's longest stay, visits)
+            const unsigned long long visit_began = (attempt_counter && from_lot) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
+            if (from_lot) {
+                const float4* parked = lot->records + GR_PARKED_FLOAT4 * (size_t)record;
+                s.position = lot_load(parked + 0);
+                s.velocity = lot_load(parked + 1);
+                s.acceleration = lot_load(parked + 2);
+                ray.initial_quat = lot_load(parked + 3);
+                const float4 carried = lot_load(parked + 4), counts = lot_load(parked + 5);
+                s.next_ds = carried.x; s.running_dlambda_dnew = carried.y; s.f_in_x = carried.z; ray.ku_uobsu = carried.w;
+                s.steps = __float_as_int(counts.x); s.tries = (unsigned int)__float_as_int(counts.y);
+                tries_before = s.tries;
+                ray.position = ray.velocity = f4(0, 0, 0, 0);   // (where the ray started: nothing in a record depends on it, make_render_data)
+            } else {
+                ray = make_pixel_ray(cx, cy, ray_grid_width, ray_grid_height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+                s.position = ray.position;
+                s.velocity = ray.velocity;
+                s.acceleration = ray.acceleration;
+                s.running_dlambda_dnew = 1;
+            }
+            // one call site for a fresh ray, a parked one, and a ray the lot had no room for (it goes on here, never to be parked again)
+            bool going = true, resumed = from_lot;
+#ifndef GR_PARK_AGAIN
+#define GR_PARK_AGAIN 1   // 0: rays that were parked once are integrated to their ends by the wave that took them
+#endif
+            int keep_lanes = (cell_wave >= 0 || (from_lot && !GR_PARK_AGAIN)) ? 0 : lot->lanes;
+            for (;;) {
+                bool paused = false;
+                if (going) res = integrate_pingpong<false, true>(s, cfg, dfg, &tries, keep_lanes, paused, resumed, (unsigned int)lot->trips);
+                going = going && paused;
+                if (__builtin_amdgcn_ballot_w64(going) == 0) break;
+                if (park_rays(*lot, lane, going, s, ray.initial_quat, ray.ku_uobsu, cx, cy, wave)) { parked_here = going; break; }
+                keep_lanes = 0;
+                resumed = true;
+            }
+            // a ray that ends here after a stay in the lot: what it cost in all is its tile's cost for the next frame's order (the tile's wave
+            // only saw it to the lot) - one atomic per such ray
+            if (from_lot && tile_cost && !parked_here) atomicMax(tile_cost + wave, tries);
+            tries -= tries_before;   // (the attempts made here: what the counters below add up)
+#ifdef GR_PROBE_LOT
+            if (attempt_counter && from_lot) {
+                unsigned long long lanes_here = __builtin_amdgcn_ballot_w64(true);
+                const bool leader = lane == (int)__builtin_ctzll(lanes_here);
+                unsigned int longest = 0;
+                while (lanes_here) {
+                    const int l = (int)__builtin_ctzll(lanes_here);
+                    const unsigned int v = (unsigned int)__builtin_amdgcn_readlane((int)tries, l);
+                    longest = v > longest ? v : longest;
+                    lanes_here &= lanes_here - 1;
+                }
+                if (leader) {
+                    atomicAdd(attempt_counter + 4, (unsigned long long)__builtin_amdgcn_s_memrealtime() - visit_began);
+                    atomicAdd(attempt_counter + 5, (unsigned long long)longest);
+                    atomicAdd(attempt_counter + 6, 1ull);
+                }
+            }
+#endif
+        } else {
+            ray = make_pixel_ray(cx, cy, ray_grid_width, ray_grid_height, *camera, *camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
+            s.position = ray.position;
+            s.velocity = ray.velocity;
+            s.acceleration = ray.acceleration;
+            s.running_dlambda_dnew = 1;
+            res = integrate_ray(s, cfg, dfg, &tries);
+        }
         if (cell_wave >= 0) {
             // calculate_singularities (cl.cl:5008-5020): 1 = the ray did not reach the boundary.  Device scope: tiles on other
             // XCDs (each with an L2 of its own) are polling for it.
@@ -487,7 +686,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         const size_t lattice_pixels = (size_t)(image_width / 2) * (image_height / 2);
         reinterpret_cast<unsigned int*>(lattice_rays + 3 * lattice_pixels)[(size_t)(cy / 2) * (image_width / 2) + cx / 2] = tries;
     }
-    rdata[cy * width + cx] = dat;
+    if (!(PARKING && parked_here)) rdata[cy * width + cx] = dat;
 #ifdef GR_TILE_SHADING   // programs built with -DGR_TILE_SHADING only: carried along unused, the call's spills add 0.12 GB of scratch traffic per 4K launch
     if (shading.out && lattice == 1 && !pending_only && within < tiles_x * tile_rows) {
         // every lane of the tile that holds a pixel hands its sky coordinates to the lanes left of and above it
@@ -512,7 +711,8 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     if (attempt_counter) atomicAdd(attempt_counter + GR_ATTEMPT_COUNTERS_AT + (blockIdx.x % GR_ATTEMPT_COUNTERS), (unsigned long long)tries);
     // what the tile cost - the attempts of its longest ray, which is how long the wave was busy - for the next frame's order
     // (gr_order_tiles_by_history): again one atomic per tile-wave after the compiler's wave reduction, every tile to a word of its own
-    if (tile_cost) atomicMax(tile_cost + __builtin_amdgcn_readfirstlane(wave), tries);   // (uniform by construction; said so for the reduction)
+    // (a tile that parked rays: how long its wave was busy with it, which is what the order is for)
+    if (tile_cost && !(PARKING && from_lot)) atomicMax(tile_cost + __builtin_amdgcn_readfirstlane(wave), tries);   // (uniform by construction; said so for the reduction)
 }
 
 // workgroup size of the fused trace kernel: 4 tile-waves, one per SIMD of a CU (capi.cpp launches with the same number)
@@ -523,7 +723,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
 // persistent waves - the launch only fills the machine and every wave keeps drawing the next tile from the device-side
 // counter until total_waves are handed out, so a SIMD slot never idles between the end of a short tile (prepass-skipped
 // tiles finish in a few hundred cycles) and the dispatcher's next workgroup.
-template <bool LATTICE_RAYS>
+template <bool LATTICE_RAYS, bool PARKING = false>
 __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
                const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
@@ -531,7 +731,7 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
                int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
                int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped,
-               float4* __restrict__ lattice_rays) {
+               float4* __restrict__ lattice_rays, parking_lot lot = parking_lot()) {
     // prepass_tickets > 0 (persistent launches in image order only): the first prepass_tickets tickets are the waves of the
     // low-resolution prepass, then come the tiles, which wait for the cells they look at (trace_tile).  A frame whose camera was not
     // known in advance then pays the prepass's single-ray latency once per cell wave alongside the first tiles instead of as a
@@ -557,7 +757,20 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
     const int singles = (tile_counter && tile_order) ? tickets_total - (int)tile_order[GR_TILE_CLASSES - 1] : tickets_total;
     // the list says itself whether its last class is a promise (program.hip GR_LIST_BY_PREPASS)
     const bool list_promises = tile_order && (last_class_is_skipped || tile_order[GR_TILE_ORDER_HEADER + total_waves] == GR_LIST_BY_PREPASS);
+    bool tickets_gone = false;   // PARKING: no tile left to draw, what the lot holds is all there is
     for (;;) {
+        // (the pointers laundered - below - at the top of the loop here: one value on every way back to it)
+        if (PARKING) asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
+        // PARKING (persistent launches only): before a ticket is drawn, a look at the lot - 64 parked rays are the longest work there is
+        bool from_lot = false;
+        int record = -1;
+        if (PARKING && held == 0) {
+            from_lot = __builtin_amdgcn_readfirstlane(claim_parked(lot, lane, tickets_gone, record)) > 0;
+            if (!from_lot && tickets_gone) break;
+        }
+        int cell_wave = -1;
+        if (PARKING && from_lot) { wave = 0; known_skipped = false; }
+        else {
         if (tile_counter) {
             if (held == 0) {
                 unsigned int ticket = 0;
@@ -575,26 +788,29 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
                     cursor = singles + (drawn - single_tickets) * GR_SKIP_CHUNK;
                     held = tickets_total - cursor < GR_SKIP_CHUNK ? tickets_total - cursor : GR_SKIP_CHUNK;
                 }
-                if (held <= 0) break;
+                if (held <= 0) {
+                    if (PARKING) { tickets_gone = true; held = 0; continue; }
+                    break;
+                }
             }
             wave = (tile_order && cursor >= cell_tickets) ? cell_tickets + (int)tile_order[GR_TILE_ORDER_HEADER + cursor - cell_tickets] : cursor;
             cursor++;
             held--;
         }
-        int cell_wave = -1;
         if (prepass_tickets > 0) {
             if (wave < prepass_tickets) { cell_wave = wave; wave = 0; }
             else wave -= prepass_tickets;
         }
         if (wave >= total_waves) break;
+        }
         // Launder the camera / tetrad pointers once per tile: otherwise everything in the ray set-up that depends only on
         // them is hoisted out of the tile loop and held in registers across the integrator (94 instead of 64 VGPRs, i.e.
         // 5 instead of 8 waves per SIMD).  Re-reading 96 bytes through the scalar cache per tile is free by comparison.
-        asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
+        if (!PARKING) asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
         GR_PROBE_TILE_BEGAN
-        trace_tile<LATTICE_RAYS>(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
+        trace_tile<LATTICE_RAYS, PARKING>(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
                    termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
-                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost, lattice_rays);
+                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost, lattice_rays, &lot, record, from_lot);
         GR_PROBE_TILE_ENDED
         if (!tile_counter) break;
     }
@@ -630,6 +846,22 @@ gr_trace_fused_lattice(const float4* __restrict__ g_generic_camera_in, const flo
                float4* __restrict__ lattice_rays) {
     trace_fused_body<true>(g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg_in, dfg_in, attempt_counter, tile_counter, total_waves, lattice, pending_only, tile_order, shading, prepass_tickets, ticket_tiles, tile_cost, last_class_is_skipped, lattice_rays);
 }
+
+// gr_trace_fused with parking (above): persistent launches of whole-image or strip frames, every pixel (no lattice, no list).
+// Programs built with -DGR_PARKING in their argument string only (gr_program_has_parking).
+#ifdef GR_PARKING
+extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
+gr_trace_fused_parking(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
+               render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
+               const int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
+               const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2, const float4* __restrict__ e3,
+               cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
+               int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
+               int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped,
+               float4* __restrict__ lattice_rays, parking_lot lot) {
+    trace_fused_body<false, true>(g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg_in, dfg_in, attempt_counter, tile_counter, total_waves, 1, 0, tile_order, shading, prepass_tickets, ticket_tiles, tile_cost, last_class_is_skipped, nullptr, lot);
+}
+#endif
 
 // ---- ray compaction ------------------------------------------------------------------------------
 // slot t of a device's work list = lane t % 64 of tile-wave t / 64 (the mapping of trace_tile); false for padding slots

@@ -30,6 +30,12 @@ struct gr_frame_tuning {
                             * render state's previous frame (gr_order_tiles_by_history, shifted by how far the camera has moved the
                             * picture since); 0 = no; -1 = library default: whole frames of at most 32 tiles per wave slot that find no
                             * frame of ANOTHER stream still running on the device when they are submitted.  Scheduling only. */
+    int park_lanes;        /* fused mode, one ray per lane, every pixel: 2..64 = gr_trace_fused_parking - a tile's wave with fewer than this many
+                            * rays left after park_trips trips of the Verlet loop hands them over (gr_parking_lot); 0 = no; -1 = library
+                            * default (GR_PARK="lanes,trips" in the environment, else off).  Scheduling only.  The program must have been
+                            * built with -DGR_PARKING appended to its argument string (gr_program_has_parking): an error if asked for
+                            * explicitly without it, ignored when it only comes from the environment. */
+    int park_trips;        /* ... trips (two attempts each); <= 0 = library default (512) */
     /* -- what rides with the look-ahead cameras of gr_frame_options (next_camera, next_camera2) -- */
     int next_strip_rank;   /* strip_rank of the next_camera / next_camera2 frames when a device's share rotates from frame to frame; */
     int next_strip_rank2;  /*   -1 (default) = the same as this frame's.  gr_render_frame_tiled fills both in (gr_tiled_look_ahead). */
@@ -167,6 +173,21 @@ typedef struct gr_trace_shading {
     const void* background2;
     int bg_width, bg_height, bg_levels, max_probes, compact_out;
 } gr_trace_shading;
+/* Parking (kernels/trace.hip, gr_trace_fused_parking): a tile's wave that has fewer than `lanes` rays left after `trips` trips of the
+ * Verlet loop (two attempts each) writes their state to the lot and draws its next tile; parked rays are picked up 64 to a wave by
+ * whichever wave draws next.  Scheduling only: the records are those of the unparked launch bit for bit.  lanes = 0 (or a NULL
+ * lot): the plain kernel.  records: gr_parking_lot_bytes(slots, groups, &words_bytes) bytes, words: words_bytes; a lot that runs
+ * out of room is not an error (the wave goes on with its rays itself; words[4] counts the times). */
+typedef struct gr_parking_lot {
+    void* records;
+    void* words;
+    int lanes, trips;
+    int slots, groups;   /* capacity: parked rays (<= 2^24), and groups of rays parked together (each parking event is one) */
+} gr_parking_lot;
+size_t gr_parking_lot_bytes(int slots, int groups, size_t* words_bytes);
+/* 1 when the program's argument string (or GR_EXTRA_FLAGS) carried -DGR_PARKING: it has the gr_trace_fused_parking kernel.  A build option,
+ * like -DGR_TILE_SHADING: measured on MI355X the kernel does not pay, and every program would carry its compile time. */
+int gr_program_has_parking(const gr_program* p);
 typedef struct gr_trace_fused_args {
     const void* camera_generic;
     const void* camera_quat;
@@ -191,6 +212,7 @@ typedef struct gr_trace_fused_args {
                          * each tile cost there (the attempts of its longest ray) for gr_order_tiles_by_history.  Every pixel, one ray per lane. */
     int tile_order_by_history;   /* 1: tile_order is gr_order_tiles_by_history's list (its last class is looked up like any tile) */
     void* lattice_rays;          /* lattice = 2: where the launch leaves its rays' end states for gr_adaptive_refine (see there); may be NULL */
+    gr_parking_lot parking;      /* lanes > 0: gr_trace_fused_parking (every pixel, one ray per lane, no in-tile shading) */
 } gr_trace_fused_args;
 int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args* args);
 /* waves of gr_trace_fused the program's device holds at once (what a persistent launch fills it with): a frame of many more tiles than
