@@ -363,7 +363,7 @@ def main():
     lookahead = ctypes.pointer(camera) if (fused and not args.no_lookahead) else None
     depth = 0 if lookahead is None else (args.lookahead_depth if args.lookahead_depth in (1, 2) else (2 if world > 1 else 1))
 
-    def frame(prog=None, cfgv=None, transfer=True, feats=None):
+    def frame(prog=None, cfgv=None, transfer=True, feats=None, use_prepass=None):
         prog = program if prog is None else prog
         cfgv = cfg_values if cfgv is None else cfgv
         features = feats if feats is not None else globals_features[0]
@@ -387,7 +387,7 @@ def main():
                 opts.count_attempts = 1
             opts.trace_waves_per_simd = waves_per_launch
             opts.fused_shading = args.fused_shading
-            opts.use_prepass = args.use_prepass
+            opts.use_prepass = args.use_prepass if use_prepass is None else use_prepass
             opts.inline_prepass = args.inline_prepass
             if lookahead is not None:
                 opts.next_camera = lookahead
@@ -632,6 +632,21 @@ def main():
             roof09, valu09, stages09 = roofline_blocks(prog09, cfg09, "kerr_a09_4k", t)
             secondary["superextremal_a0.9_substituted"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "roofline": roof09,
                                                           "valu_roofline": valu09, "stage_ms_sequential_frame": {k: round(v, 4) for k, v in stages09.items()}}
+            # ... and the same frames with the prepass left to the policy (gr_frame_options.use_prepass = -2: a prepass that skipped less
+            # than 5 % of the pixels in this state's last frames is dropped - it costs 6.7 ms of single-ray latency here to skip 4 %).
+            # Opt-in, because it is not output-neutral: the pixels the prepass would have skipped are traced.
+            for _ in range(3 * in_flight + 2):
+                frame(prog09, cfg09, use_prepass=-2)
+            barrier()
+            t = time.perf_counter()
+            for _ in range(8):
+                frame(prog09, cfg09, use_prepass=-2)
+            barrier()
+            t = (time.perf_counter() - t) / 8
+            with_, without, skipped = ring[0].state.prepass_policy()
+            secondary["superextremal_a0.9_substituted"]["prepass_by_policy"] = {
+                "Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "frames_with_prepass": int(with_), "frames_without_prepass": int(without),
+                "last_skipped_fraction": round(float(skipped), 4)}
             for slot in ring:
                 slot.state.trace_log(reset=True)
         if timed:
