@@ -632,21 +632,18 @@ def main():
             roof09, valu09, stages09 = roofline_blocks(prog09, cfg09, "kerr_a09_4k", t)
             secondary["superextremal_a0.9_substituted"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "roofline": roof09,
                                                           "valu_roofline": valu09, "stage_ms_sequential_frame": {k: round(v, 4) for k, v in stages09.items()}}
-            # ... and the same frames with the prepass left to the policy (gr_frame_options.use_prepass = -2: a prepass that skipped less
-            # than 5 % of the pixels in this state's last frames is dropped - it costs 6.7 ms of single-ray latency here to skip 4 %).
-            # Opt-in, because it is not output-neutral: the pixels the prepass would have skipped are traced.
-            for _ in range(3 * in_flight + 2):
-                frame(prog09, cfg09, use_prepass=-2)
+            # ... and the same frames without the prepass (gr_frame_options.use_prepass = 0): at a = 0.9 it skips 3 % of the pixels - above the
+            # 2 % under which the opt-in policy (use_prepass = -2) would drop it by itself - for 6.7 ms of single-ray latency, which frames in
+            # flight hide and a frame on its own pays unless it rides in the trace launch.  Not output-neutral: the skipped pixels are traced.
+            for _ in range(in_flight + 1):
+                frame(prog09, cfg09, use_prepass=0)
             barrier()
             t = time.perf_counter()
             for _ in range(8):
-                frame(prog09, cfg09, use_prepass=-2)
+                frame(prog09, cfg09, use_prepass=0)
             barrier()
             t = (time.perf_counter() - t) / 8
-            with_, without, skipped = ring[0].state.prepass_policy()
-            secondary["superextremal_a0.9_substituted"]["prepass_by_policy"] = {
-                "Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "frames_with_prepass": int(with_), "frames_without_prepass": int(without),
-                "last_skipped_fraction": round(float(skipped), 4)}
+            secondary["superextremal_a0.9_substituted"]["without_prepass"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2)}
             for slot in ring:
                 slot.state.trace_log(reset=True)
         if timed:
