@@ -370,7 +370,8 @@ def test_odd_frame_sizes_are_traced_in_full_on_the_fused_path():
         frames = []
         for adaptive in (1, 0):
             state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
-            check(lib.gr_device_upload(0, out.ptr, np.full((h, w, 4), -7.0, np.float32).ctypes.data, w * h * 16))
+            marker = np.full((h, w, 4), -7.0, np.float32)   # (held in a name: .ctypes.data of a temporary is the address of freed memory)
+            check(lib.gr_device_upload(0, out.ptr, marker.ctypes.data, w * h * 16))
             state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), metric.features(adaptive_sampling=adaptive),
                          metric.cfg_values(a=0.45), gra.frame_options(mode=gra.MODE_FUSED))
             state.synchronize()
@@ -433,7 +434,8 @@ def test_prepass_inside_the_trace_launch_changes_nothing(size, strip):
     got = []
     for inline in (0, 1):
         state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
-        check(lib.gr_device_upload(0, out.ptr, np.zeros((h, w, 4), np.float32).ctypes.data, w * h * 16))
+        blank = np.zeros((h, w, 4), np.float32)
+        check(lib.gr_device_upload(0, out.ptr, blank.ctypes.data, w * h * 16))
         for cam in (gra.default_camera(), gra.default_camera([0, 0.3, -4.5, 0.2])):   # the second frame re-uses the state's flag buffer
             state.render(prog, metric, cam, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv,
                          gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1, inline_prepass=inline, count_attempts=1, strip_rank=strip[0],
@@ -446,6 +448,12 @@ def test_prepass_inside_the_trace_launch_changes_nothing(size, strip):
     known = term1 != -1                            # a device of a split frame leaves the cells it does not look at unknown
     assert set(np.unique(term1[known])) <= {0, 1} and np.array_equal(term0[known], term1[known])
     assert known.all() if strip[1] == 1 else 0.05 < known.mean() < 0.9
+    # the records of the rows this device traces - its blocks and the halo row under each; the others are never written (and a render
+    # state's record buffer is not cleared: what a fresh allocation holds there is nobody's business)
+    rows = np.arange(h)
+    traced = ((rows // 48) % strip[1] == strip[0]) | ((rows % 48 == 0) & (((rows // 48) - 1) % strip[1] == strip[0]) & (rows >= 48))
+    rd0, rd1 = rd0.reshape(h, w)[traced], rd1.reshape(h, w)[traced]
+    assert (rd0["sy"] == rows[traced][:, None]).all() and (rd1["sx"] == np.arange(w)[None, :]).all()   # every one of them was written
     assert rd0.tobytes() == rd1.tobytes()
     assert np.array_equal(px0, px1)
     assert (rd1["terminated"] == 2).mean() > (0.2 if strip[1] == 1 else 0.02)   # the shadow was skipped, i.e. the tiles did see the flags
