@@ -53,6 +53,40 @@ def test_init_rays(name):
     assert np.abs(got["running_dlambda_dnew"] - 1).max() == 0
 
 
+@pytest.mark.parametrize("size", [(50, 30), (67, 3), (8, 8), (1, 1)])
+def test_init_rays_of_frames_that_do_not_fill_their_last_wave(size):
+    """gr_init_rays_generic stores a wave's 64 records as one run of bytes (staged through LDS): frames whose slot count is no multiple
+    of 64 - the last wave's run is shorter - in reference slot order and in tile order (where slots outside the image are dead records):
+    the records of a pixel are the same bits in both orders and in a larger frame's launch shape, nothing is written behind the last
+    record, and the struct's padding is zero"""
+    from geodesic_raytracing_amd.pipeline import DeviceBuffer
+    from gpu_stages import LIGHTRAY_DTYPE, buf
+    meta, z = load_golden("kerr")
+    w, h = size
+    st = Stages(dict(meta, width=w, height=h))
+    e = [buf(z["tetrad"][i].astype(np.float32)) for i in range(4)]
+    cam = buf(z["camera_generic"].astype(np.float32))
+    term = buf(np.zeros(w * h, dtype=np.int32))
+    records = {}
+    for tiled in (0, 1):
+        slots = gra.lib.gr_tiled_slot_count(w, h) if tiled else w * h
+        raw = DeviceBuffer.from_numpy(0, np.full((slots + 8) * 96, 0xA5, dtype=np.uint8))   # eight records of guard bytes behind the list
+        count = buf(np.zeros(1, dtype=np.int32))
+        gra.check(gra.lib.gr_init_rays_generic(st.p, None, cam.ptr, st.quat.ptr, raw.ptr, count.ptr, w, h, term.ptr, w, h, 0, e[0].ptr, e[1].ptr,
+                                               e[2].ptr, e[3].ptr, st.cfg.ptr, st.dfg.ptr, 0, tiled))
+        got = raw.to_numpy(np.uint8, ((slots + 8) * 96,))
+        assert int(count.to_numpy(np.int32, 1)[0]) == slots
+        assert (got[slots * 96:] == 0xA5).all()
+        rays = got[:slots * 96].view(LIGHTRAY_DTYPE)
+        assert (rays["pad"] == 0).all()
+        inside = rays["sx"] >= 0
+        assert inside.sum() == w * h and (rays["terminated"][~inside] == 2).all()
+        order = np.argsort(rays["sy"][inside].astype(np.int64) * w + rays["sx"][inside], kind="stable")
+        records[tiled] = rays[inside][order]
+    assert records[0].tobytes() == records[1].tobytes()
+    assert (records[0]["sx"] == np.tile(np.arange(w), h)).all() and (records[0]["sy"] == np.repeat(np.arange(h), w)).all()
+
+
 @pytest.mark.parametrize("name", PLAIN)
 def test_trace(name):
     meta, z = load_golden(name)
