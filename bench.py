@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--trace-waves-per-simd", type=int, default=-1, help="persistent waves per SIMD of a trace launch in the timed frames "
                     "(0 = all that fit, -1 = 4 with three or more frames in flight on one GPU, else all)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="render states / streams cycled through (1 = strictly one frame at a time)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "single-process"],
+                    help="--gpus N > 1 started as a plain command (no WORLD_SIZE): auto = start the N ranks through torch.distributed.run and print rank "
+                         "0's line (one process driving all devices through peer copies if they cannot be started); single-process = that path directly")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--measure-clock", action="store_true", help="count attempts in the timed frames too, so that the shader clock of the "
                     "overlapped launches can be read afterwards (two timestamp reads per wave; the counters cost an atomic per tile)")
@@ -170,13 +173,220 @@ def program_build_seconds(metric_name, spin, redshift):
             "note": "substituted program, both code objects (ray kernels + set-up module), one host core, compiler cache off"}
 
 
+def plan_launch(gpus, world_env, devices_seen, rehearsal, launch="auto"):
+    """What `bench.py --gpus N` does, however it was started - (action, reason); pure, tests/test_distributed_cpu.py holds it:
+    "rank"    this process is one rank of N (torch.distributed.run set WORLD_SIZE = N), or N = 1: run the frames
+    "spawn"   a plain `python bench.py --gpus N`, N > 1: start the N ranks (torch.distributed.run) and print rank 0's line
+    "single"  one process driving the N devices through peer copies (gr_tiled_create_local): asked for, or the fallback of "spawn"
+    "refuse"  exit non-zero: never a line whose n_gpus is smaller than --gpus"""
+    if gpus < 1:
+        return "refuse", f"--gpus {gpus}"
+    if world_env is not None:
+        if world_env != gpus:
+            return "refuse", f"--gpus {gpus} does not match WORLD_SIZE {world_env}"
+        return "rank", "one rank of %d" % gpus
+    if gpus == 1:
+        return "rank", "one GPU"
+    if devices_seen < 1:
+        return "refuse", f"--gpus {gpus}: no GPU visible (the HIP path has no CPU fallback)"
+    if devices_seen < gpus and not rehearsal:
+        return "refuse", (f"--gpus {gpus}: {devices_seen} GPU(s) visible.  On a box with fewer GPUs than ranks only a rehearsal of the N-GPU code path "
+                          f"is possible: GR_BENCH_ONE_DEVICE=1 (inter-process transport), =rccl (RCCL over loopback) or =peer (one process, peer copies)")
+    if launch == "single-process" or rehearsal == "peer":
+        return "single", "one process, peer copies"
+    return "spawn", f"{gpus} ranks through torch.distributed.run"
+
+
+def last_json_line(text):
+    for ln in reversed(text.splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def spawn_ranks(args, reason):
+    """`python bench.py --gpus N` as a plain command: N ranks under torch.distributed.run (what the driver's N > 1 command does), rank 0's line
+    printed as this process's one JSON line; when the ranks cannot be brought up (no process group, RCCL refuses) the same frames from one
+    process over peer copies; and a non-zero exit when neither produced a line for N GPUs."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    print(f"[bench] {reason}: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = last_json_line(r.stdout or "")
+    how = "bench.py started its own ranks (torch.distributed.run --nproc-per-node %d)" % args.gpus
+    if r.returncode != 0 or line is None or line.get("n_gpus") != args.gpus:
+        print(f"[bench] the {args.gpus} ranks did not produce a line (exit code {r.returncode}); the same frames from one process over peer copies",
+              file=sys.stderr, flush=True)
+        sys.stderr.write((r.stdout or "")[-2000:])
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--launch", "single-process"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        line = last_json_line(r.stdout or "")
+        how = "one process driving every device (gr_tiled_create_local, peer copies): the ranks could not be started"
+        if r.returncode != 0 or line is None or line.get("n_gpus") != args.gpus:
+            sys.stderr.write((r.stdout or "")[-2000:])
+            print(f"[bench] no line for {args.gpus} GPUs (exit code {r.returncode})", file=sys.stderr, flush=True)
+            return r.returncode or 1
+    line.setdefault("config", {})["launch"] = how
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+def single_process(args):
+    """--gpus N from ONE process: a participant per device (gr_tiled_create_local, csrc/tiled.cpp: GR_TRANSPORT_PEER), every participant's
+    share of a frame rendered on its own device and stream, its finished blocks copied (hipMemcpyPeerAsync over xGMI) straight to their
+    rows of device 0's frame.  The split, the rotation of the shares, frames in flight and the look-ahead are those of the N-rank run; what
+    differs is who issues the launches (one host thread for all devices) and the transport.  The fallback of a plain `bench.py --gpus N`
+    whose ranks cannot be started, and `--launch single-process`.  GR_BENCH_ONE_DEVICE=peer: every participant on device 0 (rehearsal)."""
+    import torch
+    import geodesic_raytracing_amd as gra
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    n, seen = args.gpus, torch.cuda.device_count()
+    rehearsal = seen < n
+    if rehearsal and not os.environ.get("GR_BENCH_ONE_DEVICE"):
+        raise SystemExit(f"--gpus {n}: {seen} GPU(s) visible")
+    devices = [0] * n if rehearsal else list(range(n))
+    W, H = args.width, args.height
+    metric = gra.Metric(args.metric, os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"))
+    cfg_values = metric.cfg_values(a=args.spin) if "a" in metric.dynamic_vars else metric.cfg_values()
+    features = metric.features(adaptive_sampling=0, redshift=args.redshift)
+    text = metric.argument_string(features=features, static=(args.program == "static"), cfg_values=cfg_values)
+    bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
+    programs, skies = {}, {}
+    for d in sorted(set(devices)):
+        programs[d] = gra.Program(text, d)
+        skies[d] = torch.from_numpy(bg_np).to(torch.device("cuda", d))
+    camera = gra.default_camera([float(x) for x in args.camera.split(",")] if args.camera else None)
+    parts = gra.TiledFrame.local(devices, W, H, args.block_rows)
+    in_flight = max(1, min(args.frames_in_flight, 4))   # a participant stages 4 frames (GR_TILED_STAGING)
+    waves = args.trace_waves_per_simd if args.trace_waves_per_simd >= 0 else (2 if n >= 4 else 0)
+    states = [[gra.RenderState(W, H, d) for _ in range(in_flight)] for d in devices]
+    streams = [[torch.cuda.Stream(device=torch.device("cuda", d)) for _ in range(in_flight)] for d in devices]
+    outs = [torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", devices[0])) for _ in range(in_flight)]
+    lookahead = None if args.no_lookahead else ctypes.pointer(camera)
+    depth = 0 if lookahead is None else (args.lookahead_depth if args.lookahead_depth in (1, 2) else 2)
+    count = [0]
+
+    def sync():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    def frame(only=None, **more):
+        k = count[0]
+        count[0] += 1
+        j = k % in_flight
+        for r in (range(n) if only is None else [only]):
+            o = gra.frame_options(mode=gra.MODE_FUSED, time_kernels=2, **more)
+            o.trace_waves_per_simd = waves
+            o.fused_shading, o.use_prepass, o.inline_prepass = args.fused_shading, args.use_prepass, args.inline_prepass
+            if lookahead is not None:
+                o.next_camera = lookahead
+                o.next_strip_rank = parts[r].share(k + in_flight)
+                if depth == 2:
+                    o.next_camera2 = lookahead
+                    o.next_strip_rank2 = parts[r].share(k + 2 * in_flight)
+            parts[r].render(states[r][j], programs[devices[r]], metric, camera, outs[j].data_ptr(), (skies[devices[r]].data_ptr(), 4096, 2048, levels),
+                            features, cfg_values, o, streams[r][j].cuda_stream, rotation=k)
+        parts[0].join(streams[0][j].cuda_stream)
+        return j
+
+    # the first frame against device 0's own whole frame: a device's share of a split frame equals those rows bit for bit
+    j = frame()
+    sync()
+    alone = torch.zeros_like(outs[0])
+    check_state = gra.RenderState(W, H, devices[0])
+    check_state.render(programs[devices[0]], metric, camera, alone.data_ptr(), (skies[devices[0]].data_ptr(), 4096, 2048, levels), features, cfg_values,
+                       gra.frame_options(mode=gra.MODE_FUSED), streams[0][0].cuda_stream)
+    sync()
+    if not torch.equal(alone, outs[j]):
+        raise SystemExit("[bench] the frame assembled from the devices' shares differs from device 0's own frame")
+    del alone, check_state
+    for _ in range(max(args.warmup - 1, in_flight)):
+        frame()
+    sync()
+    for row in states:
+        for st in row:
+            st.trace_log(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    sync()
+    elapsed = time.perf_counter() - t0
+    logged = [st.trace_log(reset=True) for row in states for st in row]
+    launches = sum(c for _, c in logged)
+    ms_per_step = elapsed / args.steps * 1e3
+    # participant 0's share on its own, one launch at a time: the kernel's duration the roofline divides by
+    stage = {}
+    for i in range(4):
+        count[0] = 0
+        o = gra.frame_options(mode=gra.MODE_FUSED, time_kernels=1, count_attempts=1, inline_prepass=0)
+        parts[0].render(states[0][0], programs[devices[0]], metric, camera, outs[0].data_ptr(), (skies[devices[0]].data_ptr(), 4096, 2048, levels),
+                        features, cfg_values, o, streams[0][0].cuda_stream, rotation=0)
+        sync()
+        if i:
+            for key, v in states[0][0].stage_ms().items():
+                stage.setdefault(key, []).append(v)
+    stage = {key: float(np.mean(v)) for key, v in stage.items()}
+    plan_rows = sum(1 for b in range((H + args.block_rows - 1) // args.block_rows) if b % n == 0)
+    local_pixels = min(plan_rows * args.block_rows, H) * W
+    launch_s = max(stage.get("trace", 0.0), 1e-6) * 1e-3
+    achieved = TRACE_BYTES_PER_RAY * local_pixels / launch_s / 1e9
+    line = {
+        "metric": f"Mrays/sec at {W}x{H} {'Kerr' if args.metric == 'kerr_boyer' else args.metric} (whole frame: prepass + init + adaptive Verlet + render-data + anisotropic render)",
+        "value": round(W * H / (elapsed / args.steps) / 1e6, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.metric}{f' (Boyer-Lindquist rs=1 a={args.spin})' if args.metric == 'kerr_boyer' else ''} {W}x{H}, camera (0,0,-4,0) fov 90, "
+                               f"adaptive_sampling off, prepass {'on' if metric.info.use_prepass else 'off'}, tol {metric.info.max_acceleration_change:g}, "
+                               f"background 4096x2048 RGBA8 10 mips, anisotropy 8",
+                   "mode": "fused", "frames_in_flight": in_flight, "trace_waves_per_simd": waves, "prepass_lookahead_depth": depth,
+                   "build_key": programs[devices[0]].build_key,
+                   "parallelism": f"{args.block_rows}-row blocks, block-cyclic over {n} devices driven by ONE process (assignment rotating per frame); "
+                                  f"gr_render_frame_tiled with peer copies (hipMemcpyPeerAsync per block into device 0's frame)"},
+        "roofline": {"bound": "hbm", "kernel": "gr_trace_fused", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "traffic_source": "counters are collected on one GPU",
+                     "algorithmic_bytes_per_launch": TRACE_BYTES_PER_RAY * local_pixels, "avg_launch_ms": round(launch_s * 1e3, 4),
+                     "avg_launch_basis": "participant 0's share, launches one at a time after the timed region (HIP events on the launch's stream)",
+                     "avg_launch_ms_overlapped": round(sum(ms for ms, _ in logged) / max(launches, 1), 4), "launches_timed": launches,
+                     "note": "register-resident ODE integrator: fp32 VALU bound (SURVEY.md 8d); the one-GPU line carries valu_roofline"},
+        "cpu_baseline": None, "fps": round(1e3 / ms_per_step, 2),
+        "stage_ms_sequential_frame": {key: round(v, 4) for key, v in stage.items()},
+        "first_frame_check": "the assembled frame equals device 0's own whole frame bit for bit",
+    }
+    if rehearsal:
+        line["rehearsal"] = f"GR_BENCH_ONE_DEVICE: {n} participants on ONE GPU, one process, peer-copy transport - a run of the single-process N-device path, not a measurement"
+    for p in parts:
+        p.close()
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    world_env = int(os.environ["WORLD_SIZE"]) if os.environ.get("WORLD_SIZE") else None
+    seen = 0
+    if world_env is None and args.gpus > 1:
+        import torch
+        seen = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    action, reason = plan_launch(args.gpus, world_env, seen, os.environ.get("GR_BENCH_ONE_DEVICE", ""), args.launch)
+    if action == "refuse":
+        print(f"[bench] {reason}", file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    if action == "spawn":
+        raise SystemExit(spawn_ranks(args, reason))
+    if action == "single":
+        return single_process(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
     rccl_log = None
     if world > 1:

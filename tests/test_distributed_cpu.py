@@ -389,3 +389,48 @@ def test_c_abi_exchange_hands_a_transport_error_back():
     assert gra.lib.gr_tiled_exchange(h, buf.ctypes.data, None, 0, None) == 7
     assert calls == ["end"]   # the group is closed even then
     gra.lib.gr_tiled_destroy(h)
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, root
+
+
+def test_bench_gpus_n_means_n_gpus_however_it_is_started():
+    """bench.py --gpus N: a rank of N under torch.distributed.run, the N ranks started by bench.py itself when run as a plain command, one
+    process over peer copies on request - and a refusal, never a line for fewer GPUs, in every other case (VERDICT r05 weak #7)"""
+    bench, _ = _bench_module()
+    plan = bench.plan_launch
+    assert plan(1, None, 0, "")[0] == "rank" and plan(1, None, 8, "")[0] == "rank"
+    for n in (2, 4, 8):
+        assert plan(n, n, 0, "")[0] == "rank"                       # torch.distributed.run set WORLD_SIZE = N
+        assert plan(n, None, n, "")[0] == "spawn"                   # a plain command on a box that has the GPUs
+        assert plan(n, None, 8, "", "single-process")[0] == "single"
+        assert plan(n, None, 1, "")[0] == "refuse"                  # fewer GPUs than asked for, no rehearsal requested
+        assert plan(n, None, 0, "1")[0] == "refuse"                 # no GPU at all
+        assert plan(n, None, 1, "1")[0] == "spawn" and plan(n, None, 1, "rccl")[0] == "spawn"   # rehearsals: ranks sharing device 0
+        assert plan(n, None, 1, "peer")[0] == "single"
+        assert plan(n, 1, 8, "")[0] == "refuse"                     # WORLD_SIZE disagrees with --gpus
+        assert plan(n, n + 1, 8, "")[0] == "refuse"
+    assert plan(0, None, 8, "")[0] == "refuse"
+    line = bench.last_json_line('noise\n{"metric": "m", "n_gpus": 4}\nRCCL banner\n')
+    assert line == {"metric": "m", "n_gpus": 4}
+    assert bench.last_json_line("nothing here\n{broken") is None
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the refusal of a box without GPUs")
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_plain_invocation_without_the_gpus_exits_non_zero(n):
+    import subprocess
+    import sys
+    _, root = _bench_module()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout           # no line at all rather than a line for fewer GPUs
+    assert f"--gpus {n}" in r.stderr

@@ -326,3 +326,36 @@ def test_c_abi_tiled_frames_over_rccl_with_several_ranks_on_one_gpu(world, block
     session = f"r{os.getpid()}w{world}"
     mp.spawn(_ipc_worker, args=(world, block, session, str(tmp_path), "rccl"), nprocs=world, join=True)
     assert os.path.exists(tmp_path / f"rccl_ok_{world}.npy")
+
+
+def _plain_bench(n, env_extra, *more):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GR_BENCH_ONE_DEVICE")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--width", "640", "--height", "360",
+                        "--block-rows", "16", "--no-secondary", "--no-cpu-baseline", "--no-build-timing", *more], env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("n,how", [(2, "1"), (4, "peer"), (3, "rccl")])
+def test_plain_bench_invocation_reports_the_gpus_it_was_asked_for(n, how):
+    """`python bench.py --gpus N` as a plain command (no torch.distributed.run around it): bench.py starts its own N ranks
+    (or drives N participants from one process) and the one line on stdout says n_gpus = N.  On a box with fewer GPUs that is a rehearsal
+    (GR_BENCH_ONE_DEVICE), marked as one; on a box that has them it is the measurement."""
+    have = torch.cuda.device_count()
+    r, line = _plain_bench(n, {} if have >= n else {"GR_BENCH_ONE_DEVICE": how}, *(["--launch", "single-process"] if how == "peer" and have >= n else []))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line is not None and line["n_gpus"] == n and line["value"] > 0
+    assert ("rehearsal" in line) == (have < n)
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1      # ONE JSON line
+
+
+def test_plain_bench_invocation_refuses_more_gpus_than_the_box_has():
+    have = torch.cuda.device_count()
+    r, line = _plain_bench(have + 1, {})
+    assert r.returncode != 0 and line is None
+    assert f"{have} GPU(s) visible" in r.stderr
