@@ -806,9 +806,9 @@ def main():
         extra["prepass_skipped_fraction"] = round(skipped / (W * H), 4)
 
         # secondary figures SURVEY.md 8d asks for (same resolution, outside the headline timing)
-        def timed(cam, feats, cfg, prog, mode, n=5):
+        def timed(cam, feats, cfg, prog, mode, n=8):
             opts = gra.frame_options(mode=mode, tiled=1)
-            for _ in range(2):
+            for _ in range(3):
                 state.render(prog, metric, cam, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), feats, cfg, opts, stream)
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -816,6 +816,21 @@ def main():
                 state.render(prog, metric, cam, out.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), feats, cfg, opts, stream)
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
+
+        def steady(submit, finish, warm=3, n=12, repeats=3):
+            """seconds per frame of a steady run: `warm` untimed frames (buffers touched, tile history settled, clocks up), `n` timed, `repeats`
+            times - the median, and all repeats so that a line shows its own spread (r05 timed 3 frames after 1 and put a 20 % swing on record)"""
+            reps = []
+            for _ in range(repeats):
+                for _ in range(warm):
+                    submit()
+                finish()
+                t = time.perf_counter()
+                for _ in range(n):
+                    submit()
+                finish()
+                reps.append((time.perf_counter() - t) / n)
+            return float(np.median(reps)), [round(x * 1e3, 4) for x in reps]
 
         secondary = {}
         if args.no_secondary:
@@ -829,31 +844,17 @@ def main():
             # way the headline is: substituted program, frames in flight
             cfg09 = metric.cfg_values(a=0.9)
             prog09 = gra.Program(metric.argument_string(features=features, static=True, cfg_values=cfg09), local_rank)
-            for _ in range(in_flight + 1):
-                frame(prog09, cfg09)
-            barrier()
-            t = time.perf_counter()
-            for _ in range(8):
-                frame(prog09, cfg09)
-            barrier()
-            t = (time.perf_counter() - t) / 8
+            t, reps09 = steady(lambda: frame(prog09, cfg09), barrier, warm=in_flight + 1)
             secondary["superextremal_a0.9_substituted_pipelined_Mrays_per_s"] = round(W * H / t / 1e6, 1)
             # ... with its own roofline objects: every pixel is traced here (no shadow for the prepass to skip)
             roof09, valu09, stages09 = roofline_blocks(prog09, cfg09, "kerr_a09_4k", t)
-            secondary["superextremal_a0.9_substituted"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "roofline": roof09,
+            secondary["superextremal_a0.9_substituted"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "ms_per_frame_repeats": reps09, "roofline": roof09,
                                                           "valu_roofline": valu09, "stage_ms_sequential_frame": {k: round(v, 4) for k, v in stages09.items()}}
             # ... and the same frames without the prepass (gr_frame_options.use_prepass = 0): at a = 0.9 it skips 3 % of the pixels - above the
             # 2 % under which the opt-in policy (use_prepass = -2) would drop it by itself - for 6.7 ms of single-ray latency, which frames in
             # flight hide and a frame on its own pays unless it rides in the trace launch.  Not output-neutral: the skipped pixels are traced.
-            for _ in range(in_flight + 1):
-                frame(prog09, cfg09, use_prepass=0)
-            barrier()
-            t = time.perf_counter()
-            for _ in range(8):
-                frame(prog09, cfg09, use_prepass=0)
-            barrier()
-            t = (time.perf_counter() - t) / 8
-            secondary["superextremal_a0.9_substituted"]["without_prepass"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2)}
+            t, reps = steady(lambda: frame(prog09, cfg09, use_prepass=0), barrier, warm=in_flight + 1)
+            secondary["superextremal_a0.9_substituted"]["without_prepass"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "ms_per_frame_repeats": reps}
             for slot in ring:
                 slot.state.trace_log(reset=True)
         if timed:
@@ -939,14 +940,9 @@ def main():
 
                 def once():
                     st2.render(p2, m2, c2, out2.data_ptr(), (bg.data_ptr(), 4096, 2048, levels), f2, m2.cfg_values(), o2, stream)
-                once()
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for _ in range(3):
-                    once()
-                torch.cuda.synchronize()
-                t = (time.perf_counter() - t) / 3
-                secondary[label] = {"Mrays_per_s": round(cw * ch / t / 1e6, 1), "fps": round(1 / t, 1)}
+                t, reps = steady(once, torch.cuda.synchronize)
+                secondary[label] = {"Mrays_per_s": round(cw * ch / t / 1e6, 1), "fps": round(1 / t, 1), "ms_per_frame": round(t * 1e3, 4), "ms_per_frame_repeats": reps,
+                                    "timing": "one frame at a time on one render state; 3 warm-up + 12 timed frames, median of three repeats"}
                 if counters_tag:   # BASELINE configs[3] / [4]: their own roofline objects (one frame at a time on this GPU)
                     wl = Workload(m2, st2, c2, f2, out2.data_ptr(), cw * ch)
                     roof2, valu2, stages2 = roofline_blocks(p2, m2.cfg_values(), counters_tag, t, wl=wl)
