@@ -19,6 +19,20 @@ def load_golden(name):
     return meta, z
 
 
+FROZEN = ["kerr", "kerr_script", "alcubierre", "double_unequal_kerr", "schwarzschild_adaptive", "kerr_schild", "kerr_ingoing_ef", "krasnikov_cartesian"]
+
+
+def load_frozen(name):
+    """(meta with TODAY's argument strings, arrays of the fixture as cl.cl computed it before the round-5 generator change)"""
+    z = np.load(os.path.join(GOLDEN_DIR, "frozen", name + ".npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    if meta.get("reference_script"):
+        today, _ = load_golden("refscripts/" + name)
+        assert [today[k] for k in ("cfg", "camera_pos", "camera_quat", "features", "width", "height")] == [meta[k] for k in ("cfg", "camera_pos", "camera_quat", "features", "width", "height")]
+        meta["argument_string"], meta["argument_string_substituted"] = today["argument_string"], today["argument_string_substituted"]
+    return meta, z
+
+
 def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
 

@@ -24,7 +24,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import geodesic_raytracing_amd as gra  # noqa: E402
-from gpu_stages import Stages, assert_traced_positions, backgrounds, circ_diff, golden_names, load_golden, metric_for, ordinary_rays, rel_err  # noqa: E402
+from gpu_stages import FROZEN, Stages, assert_pixels, assert_traced_positions, load_frozen, backgrounds, circ_diff, golden_names, load_golden, metric_for, ordinary_rays, rel_err  # noqa: E402
 
 ADAPTIVE = ["kerr_adaptive_sampling", "schwarzschild_adaptive_black_features"]
 PLAIN = [n for n in golden_names() if not n.endswith("_prepass") and n not in ADAPTIVE]
@@ -365,3 +365,14 @@ def test_polar_axis_cases_of_the_soak(name):
         bad = np.abs(d).max(axis=2) > 1e-3
         assert bad.sum() <= 2 * max(cpu_bad, reference_off) + 4, (int(bad.sum()), cpu_bad, reference_off)
         assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
+
+
+@pytest.mark.parametrize("program", ["dynamic", "substituted"])
+@pytest.mark.parametrize("name", FROZEN)
+def test_frames_match_the_fixtures_frozen_before_the_generator_changed(name, program):
+    """tests/golden/frozen/ (README there): cl.cl's pixels from the strings the generator wrote BEFORE round 5 added cancellation rules and
+    re-ordered operands - never regenerated - against today's programs (today's strings, today's device lowering) on the GPU, with the
+    end-to-end rule of the ordinary fixtures.  What moves values rather than roundings fails here."""
+    meta, z = load_frozen(name)
+    px, _ = _frame(meta, gra.MODE_FUSED, substituted=program == "substituted")
+    assert_pixels(name, meta, z, px)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import geodesic_raytracing_amd as gra
-from gpu_stages import ILL_CONDITIONED, assert_ill_conditioned_trace, assert_path_against_float64, assert_pixels, backgrounds, path_soak_golden_names, assert_traced_positions, circ_diff, golden_names, refscript_golden_names, load_golden, load_path_golden, metric_for, ordinary_rays, path_golden_names, rel_err, vec_err
+from gpu_stages import FROZEN, load_frozen, ILL_CONDITIONED, assert_ill_conditioned_trace, assert_path_against_float64, assert_pixels, backgrounds, path_soak_golden_names, assert_traced_positions, circ_diff, golden_names, refscript_golden_names, load_golden, load_path_golden, metric_for, ordinary_rays, path_golden_names, rel_err, vec_err
 from oracle import build_ref, build_restate
 from oracle.refpipe import OraclePipeline, pack_features
 
@@ -47,6 +47,23 @@ def test_restatement_reproduces_reference_golden_vectors(name):
     bad = np.abs(d).max(axis=2) > 1e-3
     assert bad.mean() <= (0.10 if name in CHAOTIC else 0.005)
     assert np.sqrt((d[~bad] ** 2).mean()) <= 1e-4
+
+
+@pytest.mark.parametrize("name", FROZEN)
+def test_generator_changes_do_not_move_the_values(name):
+    """tests/golden/frozen/: cl.cl's outputs from strings of the generator as it was BEFORE round 5 rewrote its simplifier (never
+    regenerated), against the restatement built from today's strings - the ordinary fixtures' tolerances, so that a rewrite rule
+    which is not an identity shows here although every other fixture was regenerated with it"""
+    meta, z = load_frozen(name)
+    r = run_oracle(build_restate.build(metric_for(meta).argument_string()), meta)
+    assert np.abs(r["camera_generic"] - z["camera_generic"]).max() <= 2e-6
+    assert np.abs(r["tetrad"] - z["tetrad"]).max() <= 2e-6 * max(1.0, float(np.abs(z["tetrad"]).max()))
+    for f in ("position", "velocity", "acceleration"):
+        scale = max(1.0, float(np.percentile(np.abs(z["rays_init"][f]), 99)))
+        assert np.abs(r["rays_init"][f] - z["rays_init"][f]).max() <= 5e-5 * scale, f
+    assert (r["rays"]["terminated"] != z["rays"]["terminated"]).mean() <= 0.005
+    assert_traced_positions(name, r["rays"], z["rays"], ordinary_rays(meta, z), slack=0.002)
+    assert_pixels(name, meta, z, r["pixels"])
 
 
 @pytest.mark.skipif(not build_ref.reference_available(), reason="reference sources only exist in the build container")
