@@ -83,8 +83,9 @@ def run(out_path, names):
             f"# repeats), fused path, prepass per the script's JSON.  gui = adaptive sampling on, threshold 32 (the reference's default); all = every pixel traced.\n"
             f"# dyn = dynamic program, sub = substituted.  att/ray = Verlet attempts per pixel (all, sub).  kernel = the trace kernel that ran (f = gr_trace_fused, p = gr_trace_pair:\n"
             f"# fixed-step programs, two rays per lane), its VGPRs and scratch bytes per lane (dyn | sub).  valu = (generator's op count + {STEP_OVERHEAD_FLOPS}) x attempts / trace launch / 157.3 TF (all, sub).\n"
-            f"# lit = fraction of pixels whose ray reached the sky (all, sub).\n"
-            f"{'script':34s} {'fps gui dyn':>11s} {'fps gui sub':>11s} {'fps all dyn':>11s} {'fps all sub':>11s} {'att/ray':>8s} {'ops':>5s} {'kernel dyn | sub':>24s} {'trace ms':>9s} {'valu':>6s} {'lit':>5s}")
+            f"# lit = fraction of pixels whose ray reached the sky (all, sub).  x3 = three frames in flight on three render states with the next camera announced\n"
+            f"# (the reference's main loop cycles a ring of render states: main.cpp:1463-1469; how bench.py times its headline).  GR_OCCUPANCY_TUNING={os.environ.get('GR_OCCUPANCY_TUNING', '1')}\n"
+            f"{'script':34s} {'fps gui dyn':>11s} {'fps gui sub':>11s} {'fps all dyn':>11s} {'fps all sub':>11s} {'gui sub x3':>10s} {'all sub x3':>10s} {'att/ray':>8s} {'ops':>5s} {'kernel dyn | sub':>24s} {'trace ms':>9s} {'valu':>6s} {'lit':>5s}")
     print(head, flush=True)
 
     def fps_of(prog, m, feats, cfg):
@@ -104,6 +105,34 @@ def run(out_path, names):
             torch.cuda.synchronize()
             reps.append((time.perf_counter() - t) / 12)
         return 1.0 / float(np.median(reps)), st
+
+    def pipelined_fps(prog, m, feats, cfg, in_flight=3):
+        """frames per second the way the reference's main loop produces them (a ring of render states, each frame on the next one:
+        main.cpp:1463-1469, 1505-1510) and bench.py's headline is timed: three states / streams, the next frame's camera announced"""
+        import ctypes
+        states = [gra.RenderState(W, H, 0) for _ in range(in_flight)]
+        streams = [torch.cuda.Stream() for _ in range(in_flight)]
+        outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(in_flight)]
+        o = gra.frame_options(mode=gra.MODE_FUSED)
+        o.next_camera = ctypes.pointer(camera)
+        o.trace_waves_per_simd = 4
+        k = [0]
+
+        def once():
+            j = k[0] % in_flight
+            k[0] += 1
+            states[j].render(prog, m, camera, outs[j].data_ptr(), (bg.data_ptr(), 4096, 2048, levels), feats, cfg, o, streams[j].cuda_stream)
+        reps = []
+        for _ in range(3):
+            for _ in range(in_flight + 1):
+                once()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(12):
+                once()
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t) / 12)
+        return 1.0 / float(np.median(reps))
 
     def kernel_of(prog):
         pair = prog.has_trace_pair
@@ -125,6 +154,8 @@ def run(out_path, names):
                 m = gra.Metric.from_info(name, info, e["dynamic_vars"], cfg, {False: e["dynamic"], True: e[key]})
                 feats = m.features(adaptive_sampling=adaptive, adaptive_sampling_threshold=32.0)
                 fp[label], st = fps_of(progs[key], m, feats, cfg)
+                if label in ("gui_sub", "all_sub"):
+                    fp[label + "_pipe"] = pipelined_fps(progs[key], m, feats, cfg)
                 if label == "all_sub":
                     o = gra.frame_options(mode=gra.MODE_FUSED, time_kernels=1, count_attempts=1, inline_prepass=0)
                     tr = []
@@ -143,7 +174,7 @@ def run(out_path, names):
             row = dict(name=name, **fp, attempts_per_ray=attempts / (W * H), ops=ops, kernel_dyn=kernel_of(progs["dynamic"]),
                        kernel_sub=kernel_of(progs["substituted_every_pixel"]), trace_ms=trace_ms, valu=valu, lit=lit)
             rows.append(row)
-            print(f"{name:34s} {fp['gui_dyn']:11.1f} {fp['gui_sub']:11.1f} {fp['all_dyn']:11.1f} {fp['all_sub']:11.1f} {row['attempts_per_ray']:8.1f} {ops:5d} "
+            print(f"{name:34s} {fp['gui_dyn']:11.1f} {fp['gui_sub']:11.1f} {fp['all_dyn']:11.1f} {fp['all_sub']:11.1f} {fp['gui_sub_pipe']:10.1f} {fp['all_sub_pipe']:10.1f} {row['attempts_per_ray']:8.1f} {ops:5d} "
                   f"{row['kernel_dyn'] + ' | ' + row['kernel_sub']:>24s} {trace_ms:9.3f} {valu:6.3f} {lit:5.2f}", flush=True)
             del progs
         except Exception as ex:   # noqa: BLE001
@@ -158,7 +189,10 @@ def run(out_path, names):
                                                         "slowest": min(good, key=lambda r: r["gui_sub"])["name"]},
                    "every_pixel_substituted_program": {"min_fps": round(min(r["all_sub"] for r in good), 1), "median_fps": round(float(np.median([r["all_sub"] for r in good])), 1),
                                                        "slowest": min(good, key=lambda r: r["all_sub"])["name"]},
-                   "below_30_fps": sorted(r["name"] for r in good if min(r["gui_dyn"], r["gui_sub"], r["all_dyn"], r["all_sub"]) < 30.0)}
+                   "pipelined_gui_defaults_substituted_program": {"min_fps": round(min(r["gui_sub_pipe"] for r in good), 1), "median_fps": round(float(np.median([r["gui_sub_pipe"] for r in good])), 1),
+                                                                  "slowest": min(good, key=lambda r: r["gui_sub_pipe"])["name"]},
+                   "below_30_fps_one_frame_at_a_time": sorted(r["name"] for r in good if min(r["gui_dyn"], r["gui_sub"], r["all_dyn"], r["all_sub"]) < 30.0),
+                   "below_30_fps_pipelined": sorted(r["name"] for r in good if min(r["gui_sub_pipe"], r["all_sub_pipe"]) < 30.0)}
         print("# summary " + json.dumps(summary), flush=True)
     if out_path:
         with open(out_path, "w") as f:
@@ -167,7 +201,7 @@ def run(out_path, names):
                 if "error" in r:
                     f.write(f"{r['name']:34s} FAILED: {r['error']}\n")
                 else:
-                    f.write(f"{r['name']:34s} {r['gui_dyn']:11.1f} {r['gui_sub']:11.1f} {r['all_dyn']:11.1f} {r['all_sub']:11.1f} {r['attempts_per_ray']:8.1f} {r['ops']:5d} "
+                    f.write(f"{r['name']:34s} {r['gui_dyn']:11.1f} {r['gui_sub']:11.1f} {r['all_dyn']:11.1f} {r['all_sub']:11.1f} {r['gui_sub_pipe']:10.1f} {r['all_sub_pipe']:10.1f} {r['attempts_per_ray']:8.1f} {r['ops']:5d} "
                             f"{r['kernel_dyn'] + ' | ' + r['kernel_sub']:>24s} {r['trace_ms']:9.3f} {r['valu']:6.3f} {r['lit']:5.2f}\n")
             if good:
                 f.write("# summary " + json.dumps(summary) + "\n")
