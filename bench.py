@@ -148,7 +148,8 @@ def program_build_seconds(metric_name, spin, redshift):
     """Cold build times of the substituted program on this host, in a process and a cache directory of their own with the compiler's own
     result cache off (AMD_COMGR_CACHE=0): (a) the first program of a shape - the free build, the occupancy rule's capped builds, the
     set-up module; (b) the next parameter set of the same shape (a slider moved: the remembered occupancy decision, one compiler run + the
-    set-up module).  What a maintainer waits for between a parameter change and the swap of the substituted program."""
+    set-up module).  What a maintainer waits for between a parameter change and the swap of the substituted program: since round 6 the
+    part of the program a fused frame launches (gr_program_precompile_frame_path), the rest is built behind the swap."""
     import subprocess
     import tempfile
     code = (
@@ -160,17 +161,21 @@ def program_build_seconds(metric_name, spin, redshift):
         "for k in range(2):\n"
         "    cfg = m.cfg_values(a=spin + 0.01 * k) if 'a' in m.dynamic_vars else [v * (1 + 0.01 * k) for v in m.cfg_values()]\n"
         "    text = m.argument_string(features=m.features(adaptive_sampling=0, redshift=redshift), static=True, cfg_values=cfg)\n"
+        "    t = time.perf_counter(); gra.check(gra.lib.gr_program_precompile_frame_path(text.encode())); out.append(time.perf_counter() - t)\n"
         "    t = time.perf_counter(); gra.Program.precompile(text); out.append(time.perf_counter() - t)\n"
-        "print(out[0], out[1])\n")
+        "print(*out)\n")
     with tempfile.TemporaryDirectory(prefix="gr_build_timing") as d:
         env = dict(os.environ, GR_CACHE_DIR=d, AMD_COMGR_CACHE="0", PYTHONPATH=ROOT)
         r = subprocess.run([sys.executable, "-c", code, metric_name, os.path.join(ROOT, "geodesic_raytracing_amd", "scripts"), str(spin), str(redshift)],
                            env=env, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         return {"error": r.stderr[-400:]}
-    first, again = (float(x) for x in r.stdout.split()[-2:])
+    first, first_rest, again, again_rest = (float(x) for x in r.stdout.split()[-4:])
     return {"first_of_its_shape": round(first, 2), "next_parameters_same_shape": round(again, 2),
-            "note": "substituted program, both code objects (ray kernels + set-up module), one host core, compiler cache off"}
+            "the_rest_of_the_program_behind_the_swap": [round(first_rest, 2), round(again_rest, 2)],
+            "note": "substituted program, compiler cache off: seconds until it can be swapped in = the code object of the kernels a fused frame launches + the set-up "
+                    "module, built side by side on two host threads (gr_program_create_async's worker); the kernels of the reference-shaped sequence are a second "
+                    "code object built behind the swap on one thread (the third figure; whoever first launches one of them waits for it)"}
 
 
 def plan_launch(gpus, world_env, devices_seen, rehearsal, launch="auto"):
@@ -599,6 +604,8 @@ def main():
             opts.fused_shading = args.fused_shading
             opts.use_prepass = args.use_prepass if use_prepass is None else use_prepass
             opts.inline_prepass = args.inline_prepass
+            if args.no_lookahead:
+                opts.guess_still_camera = 0
             if lookahead is not None:
                 opts.next_camera = lookahead
                 if depth == 2:
@@ -695,7 +702,7 @@ def main():
         def __init__(self, metric, state, camera, features, target, pixels):
             self.metric, self.state, self.camera, self.features, self.target, self.pixels = metric, state, camera, features, target, pixels
 
-    def exclusive_frames(prog, cfgv, n=5, wl=None, inline_prepass=0):
+    def exclusive_frames(prog, cfgv, n=5, wl=None, inline_prepass=0, guess=0):
         """n frames one at a time with per-stage events and the attempt / shader-clock counters: stage ms (means), attempts,
         MHz.  inline_prepass = 0: the prepass as a launch of its own, so that the trace stage is the trace kernel's own work (what
         the roofline blocks describe); -1: as the library renders a frame whose camera was not announced (prepass inside the trace
@@ -703,7 +710,7 @@ def main():
         stage_sum, attempts, clocks, shares = {}, 0, [], []
         for _ in range(n):
             if wl is not None:
-                opts = gra.frame_options(mode=gra.MODE_FUSED, time_kernels=1, count_attempts=1, inline_prepass=inline_prepass)
+                opts = gra.frame_options(mode=gra.MODE_FUSED, time_kernels=1, count_attempts=1, inline_prepass=inline_prepass, guess_still_camera=guess)
                 wl.state.render(prog, wl.metric, wl.camera, wl.target, (bg.data_ptr(), 4096, 2048, levels), wl.features, cfgv, opts, stream)
             elif multi:
                 opts = gra.frame_options(mode=gra.MODE_FUSED, strip_rank=rank, strip_count=world, block_rows=plan.block_rows, compact_out=1,
@@ -711,7 +718,7 @@ def main():
                 target = ring[0].gather.local_buffer().data_ptr()
             else:
                 opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=1, count_attempts=1,
-                                         use_prepass=args.use_prepass, inline_prepass=inline_prepass)
+                                         use_prepass=args.use_prepass, inline_prepass=inline_prepass, guess_still_camera=guess)
                 target = out.data_ptr()
             if wl is None:
                 state.render(prog, metric, camera, target, (bg.data_ptr(), 4096, 2048, levels), features, cfgv, opts, stream)
@@ -776,8 +783,12 @@ def main():
                            "unit": "TFLOP/s", "frac": round(tflops_wall / VALU_PEAK_TFLOPS, 4)}
         # ... and the frame as the library renders it one at a time when the next camera is not known (prepass inside the trace launch)
         as_rendered, _, _ = exclusive_frames(prog, cfgv, n=4, wl=wl, inline_prepass=-1)
+        # ... and as the library renders it by default when the camera has stopped moving (gr_frame_tuning.guess_still_camera: the next frame's
+        # set-up + prepass on the side stream while this frame traces, used because the next frame's camera turns out to be the same)
+        still, _, _ = exclusive_frames(prog, cfgv, n=6, wl=wl, inline_prepass=-1, guess=-1)
         roof["frame_one_at_a_time_ms"] = {"prepass_as_its_own_launch": round(sum(stages.values()), 4),
-                                          "prepass_inside_the_trace_launch": round(sum(as_rendered.values()), 4)}
+                                          "prepass_inside_the_trace_launch": round(sum(as_rendered.values()), 4),
+                                          "still_camera_next_prepass_guessed": round(sum(still.values()), 4)}
         return roof, valu, stages
 
     kerr_4k = args.metric == "kerr_boyer" and (W, H) == (3840, 2160) and fused and args.program == "static"

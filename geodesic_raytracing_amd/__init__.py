@@ -48,7 +48,7 @@ class FrameTuning(ctypes.Structure):
     _fields_ = [("ray_compaction", c_int), ("rays_per_lane", c_int), ("fused_shading", c_int), ("inline_prepass", c_int),
                 ("trace_waves_per_simd", c_int), ("tile_history", c_int), ("park_lanes", c_int), ("park_trips", c_int),
                 ("next_strip_rank", c_int), ("next_strip_rank2", c_int),
-                ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float), ("count_attempts", c_int)]
+                ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float), ("count_attempts", c_int), ("guess_still_camera", c_int)]
 
 
 class FrameOptions(ctypes.Structure):
@@ -135,6 +135,8 @@ _SIGNATURES = {
     "gr_metric_substituted_op_counts": (c_int, [c_void_p, ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                                 ctypes.POINTER(c_int)]),
     "gr_program_create": (c_int, [c_char_p, c_int, ctypes.POINTER(c_void_p)]),
+    "gr_program_complete": (c_int, [c_void_p]),
+    "gr_program_precompile_frame_path": (c_int, [c_char_p]),
     "gr_program_precompile": (c_int, [c_char_p]),
     "gr_program_create_async": (c_int, [c_char_p, c_int, ctypes.POINTER(c_void_p)]),
     "gr_program_future_poll": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),

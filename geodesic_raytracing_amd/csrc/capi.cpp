@@ -22,6 +22,7 @@
 #include <fstream>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -211,7 +212,12 @@ int build_through_hiprtc(const std::string& source, const char* name, const std:
     return GR_OK;
 }
 
-int compile_code_object(const std::string& argument_string, std::string& code, std::string* key_out = nullptr) {
+// A program's ray kernels are two code objects (kernels/program.hip): PART_FRAME - what a fused frame launches - and PART_REST, the
+// reference-shaped sequence and ray compaction.  cache_only: an empty `code` and GR_OK when the part is not in the cache (the caller
+// builds it later, or on another thread).
+enum BuildPart { PART_FRAME = 0, PART_REST = 1 };
+int compile_code_object(const std::string& argument_string, std::string& code, std::string* key_out = nullptr, BuildPart part = PART_FRAME,
+                        bool cache_only = false) {
     // the kernel source: the parts under csrc/kernels/ in this order, as one translation unit (GR_KERNEL_SOURCE: one file instead)
     static const char* const KERNEL_PARTS[] = {"program.hip",       // structs of the boundary, build switches
                                                "probes.inc",        // measurement hooks (all off by default)
@@ -268,6 +274,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     if (pair_kernel_applies(opts)) opts.push_back("-DGR_TWO_RAYS_PER_LANE");
     if (const char* extra = getenv("GR_EXTRA_FLAGS"))
         for (auto& tok : split_arguments(extra)) opts.push_back(tok);
+    opts.push_back(part == PART_FRAME ? "-DGR_BUILD_FRAME_PATH" : "-DGR_BUILD_REST");
 
     int rtc_major = 0, rtc_minor = 0;
     hiprtcVersion(&rtc_major, &rtc_minor);
@@ -292,6 +299,8 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     else cache_dir = library_dir() + "/_cache";
     std::string cache_path = cache_dir + "/" + name;
     if (read_file(cache_path, code) && !code.empty()) return GR_OK;
+    code.clear();
+    if (cache_only) return GR_OK;
 
     // one build of the kernel source with `options`: through the assembly pass when it is on and the code-object manager is
     // there, else through hiprtc (a source error shows up there with its diagnostics)
@@ -332,11 +341,16 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     bool tuned_by_caller = false;
     for (auto& o : opts) tuned_by_caller |= o.rfind("-DGR_FUSED_WAVES", 0) == 0 || o.rfind("-DGR_TRACE_WAVES", 0) == 0;
     const char* tuning = getenv("GR_OCCUPANCY_TUNING");
-    const bool rule_applies = !tuned_by_caller && !(tuning && tuning[0] == '0');
+    // (the rule is about gr_trace_fused: the other part is built as the compiler allocates it)
+    const bool rule_applies = part == PART_FRAME && !tuned_by_caller && !(tuning && tuning[0] == '0');
     std::string shape_path;
     {
         uint64_t sh = fnv1a(source);
         for (auto& o : opts) {
+            // (round 6: the device's own rendering of the accelerations - GR_DEVICE_ACCEL*, GR_DEVICE_TEMPORARIES - shares other
+            // sub-expressions from one parameter set to the next, so its text has another length and another set of temporaries; with it
+            // in the key no two parameter sets of round 5 ever had the same shape and every slider move paid the rule's three builds)
+            if (o.rfind("-DGR_DEVICE_", 0) == 0) continue;
             std::string blank;
             for (size_t i = 0; i < o.size();) {
                 const bool starts_number = isdigit((unsigned char)o[i]) && (i == 0 || !(isalnum((unsigned char)o[i - 1]) || o[i - 1] == '_'));
@@ -549,6 +563,24 @@ struct gr_program {
     int compute_units = 256;
     bool tile_shading = false;   // built with -DGR_TILE_SHADING: gr_trace_fused can shade the inner pixels of its tiles
     int resident_groups_per_cu[K_COUNT] = {};   // of the trace kernels at the launch's workgroup size: 0 = not asked yet
+    // The kernels a fused frame does not launch (PART_REST) are a code object of their own, loaded when first asked for: from the
+    // cache when gr_program_create found it there, else from a build that started on a worker thread when the program was created.
+    // Whoever asks first (launch of such a kernel, gr_program_kernel_info, gr_program_complete) waits for that build.
+    struct rest_build {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false;
+        int rc = GR_OK;
+        std::string code, error;
+    };
+    std::shared_ptr<rest_build> rest;     // shared with the worker, which may outlive the program
+    std::thread rest_worker;
+    std::mutex rest_mu;                   // serialises the load
+    bool rest_loaded = false;
+    int rest_rc = GR_OK;
+    std::string rest_error;
+    hipModule_t module_rest = nullptr;
+    bool in_rest[K_COUNT] = {};           // kernels expected in the other code object
     std::string arguments;
     std::string key;   // what the code object was built from: kernel source, every compile option, hiprtc version (16 hex digits)
     // identity for caches keyed by program (frame.cpp prefetch slots): an address can be reused by a later program, this cannot
@@ -558,7 +590,14 @@ struct gr_program {
         if (tickets) (void)hipFree(tickets);
         if (huge_count) (void)hipFree(huge_count);
         if (module) (void)hipModuleUnload(module);
+        if (module_rest) (void)hipModuleUnload(module_rest);
         if (setup_module) (void)hipModuleUnload(setup_module);
+        // a build still inside the compiler cannot be interrupted; it holds its own state (rest_build) and is left to finish
+        if (rest_worker.joinable()) {
+            bool done;
+            { std::lock_guard<std::mutex> lock(rest->mu); done = rest->done; }
+            if (done) rest_worker.join(); else rest_worker.detach();
+        }
     }
 };
 
@@ -710,19 +749,75 @@ int gr_metric_substituted_op_counts(const gr_metric* m, const float* cfg_values,
 
 int gr_program_precompile(const char* argument_string) {
     if (!argument_string) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument string");
-    std::string code, setup;
+    std::string code, rest, setup;
     int rc = compile_code_object(argument_string, code);
+    if (rc != GR_OK) return rc;
+    rc = compile_code_object(argument_string, rest, nullptr, PART_REST);
     if (rc != GR_OK) return rc;
     return compile_setup_module(argument_string, setup);
 }
 
+// the frame path of a program: its PART_FRAME code object and the set-up module, each from the cache or built - the two builds side by
+// side on two threads when both are missing (the compiler runs are independent; ~1.3 s and ~2.5 s of one core each for Kerr)
+static int build_frame_path(const std::string& arguments, std::string& code, std::string& setup_code, std::string* key) {
+    std::string setup_error;
+    int setup_rc = GR_OK;
+    std::thread side([&]() {
+        setup_rc = compile_setup_module(arguments, setup_code);
+        if (setup_rc != GR_OK) setup_error = g_error;
+    });
+    const int rc = compile_code_object(arguments, code, key);
+    side.join();
+    if (rc != GR_OK) return rc;
+    if (setup_rc != GR_OK) return fail((gr_status)setup_rc, setup_error);
+    return GR_OK;
+}
+
+// the function of kernel k, loading the program's other code object when the kernel lives there (blocks while that is still being
+// built); nullptr with the error set when it cannot be had
+static hipFunction_t function_of(gr_program* p, int k) {
+    if (p->fn[k] || !p->in_rest[k]) return p->fn[k];
+    std::lock_guard<std::mutex> lock(p->rest_mu);
+    if (!p->rest_loaded) {
+        auto& b = *p->rest;
+        {
+            std::unique_lock<std::mutex> wait(b.mu);
+            b.cv.wait(wait, [&] { return b.done; });
+        }
+        if (p->rest_worker.joinable()) p->rest_worker.join();
+        p->rest_rc = b.rc;
+        p->rest_error = b.error;
+        if (p->rest_rc == GR_OK) {
+            hipError_t e = hipSetDevice(p->device);
+            if (e == hipSuccess) e = hipModuleLoadData(&p->module_rest, b.code.data());
+            for (int i = 0; i < K_COUNT && e == hipSuccess; i++)
+                if (p->in_rest[i] && !p->fn[i]) e = hipModuleGetFunction(&p->fn[i], p->module_rest, KERNEL_NAMES[i]);
+            if (e != hipSuccess) { p->rest_rc = GR_ERROR_DEVICE; p->rest_error = std::string("loading the program's second code object: ") + hipGetErrorString(e); }
+        }
+        b.code.clear();
+        p->rest_loaded = true;
+    }
+    if (p->rest_rc != GR_OK) { (void)fail((gr_status)p->rest_rc, p->rest_error); return nullptr; }
+    return p->fn[k];
+}
+
+int gr_program_precompile_frame_path(const char* argument_string) {
+    if (!argument_string) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument string");
+    std::string code, setup;
+    return build_frame_path(argument_string, code, setup, nullptr);
+}
+
+int gr_program_complete(gr_program* p) {
+    if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
+    for (int k = 0; k < K_COUNT; k++)
+        if (p->in_rest[k] && !function_of(p, k)) return p->rest_rc != GR_OK ? p->rest_rc : fail(GR_ERROR_DEVICE, std::string("kernel missing: ") + KERNEL_NAMES[k]);
+    return GR_OK;
+}
+
 int gr_program_create(const char* argument_string, int device, gr_program** out) {
     if (!argument_string || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
-    std::string code, key;
-    int rc = compile_code_object(argument_string, code, &key);
-    if (rc != GR_OK) return rc;
-    std::string setup_code;
-    rc = compile_setup_module(argument_string, setup_code);
+    std::string code, key, setup_code;
+    int rc = build_frame_path(argument_string, code, setup_code, &key);
     if (rc != GR_OK) return rc;
     HIP_CHECK(hipSetDevice(device));
     auto p = std::make_unique<gr_program>();
@@ -750,11 +845,34 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
             HIP_CHECK(hipModuleGetFunction(&p->fn[k], p->setup_module, KERNEL_NAMES[k]));
             continue;
         }
-        if (k == K_TRACE_PAIR || k == K_TRACE_FUSED_PARKING) {   // built for some metrics only (pair_kernel_applies) / with -DGR_PARKING in the argument string only
-            if (hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]) != hipSuccess) { p->fn[k] = nullptr; (void)hipGetLastError(); }
-            continue;
+        // what the frame-path code object does not hold is in the other one - but for the two kernels that are built for some programs
+        // only (gr_trace_pair: pair_kernel_applies; gr_trace_fused_parking: -DGR_PARKING) and belong to the frame path when they exist
+        if (hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]) != hipSuccess) {
+            p->fn[k] = nullptr;
+            (void)hipGetLastError();
+            p->in_rest[k] = !(k == K_TRACE_PAIR || k == K_TRACE_FUSED_PARKING);
         }
-        HIP_CHECK(hipModuleGetFunction(&p->fn[k], p->module, KERNEL_NAMES[k]));
+    }
+    if (!p->fn[K_TRACE_FUSED] || !p->fn[K_RENDER] || !p->fn[K_PREPASS_FUSED] || !p->fn[K_ORDER_TILES])
+        return fail(GR_ERROR_COMPILE, "the frame-path code object lacks one of gr_trace_fused / gr_render / gr_prepass_fused / gr_order_tiles");
+    // the other kernels: from the cache now, or from a build that starts here and is waited for by whoever first needs one of them
+    p->rest = std::make_shared<gr_program::rest_build>();
+    rc = compile_code_object(argument_string, p->rest->code, nullptr, PART_REST, /*cache_only=*/true);
+    if (rc != GR_OK) return rc;
+    if (!p->rest->code.empty()) p->rest->done = true;
+    else {
+        auto state = p->rest;
+        const std::string arguments = argument_string;
+        p->rest_worker = std::thread([state, arguments]() {
+            std::string built;
+            const int build_rc = compile_code_object(arguments, built, nullptr, PART_REST);   // compiler only: no device work on this thread
+            std::lock_guard<std::mutex> lock(state->mu);
+            state->rc = build_rc;
+            if (build_rc != GR_OK) state->error = g_error;
+            state->code.swap(built);
+            state->done = true;
+            state->cv.notify_all();
+        });
     }
     const int huge = 0x7fffffff;
     HIP_CHECK(hipMalloc((void**)&p->tickets, gr_program::TICKET_RING * sizeof(unsigned int)));
@@ -785,9 +903,10 @@ int gr_program_create_async(const char* argument_string, int device, gr_program_
     f->arguments = argument_string;
     f->device = device;
     f->worker = std::thread([f]() {
+        // the program's frame path (compiler only: no device work on this thread); its other kernels are built behind the swap, by the
+        // program itself (gr_program_create)
         std::string code, setup;
-        int rc = compile_code_object(f->arguments, code);   // compiler only: no device work on this thread
-        if (rc == GR_OK && !f->cancelled.load()) rc = compile_setup_module(f->arguments, setup);
+        int rc = build_frame_path(f->arguments, code, setup, nullptr);
         std::lock_guard<std::mutex> lock(f->mu);
         f->rc = rc;
         if (rc != GR_OK) f->error = g_error;
@@ -987,8 +1106,10 @@ int gr_program_kernel_info(const gr_program* p, const char* kernel_name, int* vg
     for (int k = 0; k < K_COUNT; k++) {
         if (strcmp(kernel_name, KERNEL_NAMES[k]) != 0) continue;
         int v = 0, l = 0;
-        HIP_CHECK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, p->fn[k]));
-        HIP_CHECK(hipFuncGetAttribute(&l, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, p->fn[k]));
+        hipFunction_t f = function_of(const_cast<gr_program*>(p), k);
+        if (!f) return p->in_rest[k] ? p->rest_rc : fail(GR_ERROR_INVALID_ARGUMENT, std::string("this program has no ") + kernel_name);
+        HIP_CHECK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, f));
+        HIP_CHECK(hipFuncGetAttribute(&l, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f));
         if (vgprs) *vgprs = v;
         if (sgprs) *sgprs = 0;
         if (scratch_bytes) *scratch_bytes = l;
@@ -1002,7 +1123,9 @@ int gr_program_kernel_info(const gr_program* p, const char* kernel_name, int* vg
 static int launch(gr_program* p, int k, void* stream, unsigned gx, unsigned gy, unsigned bx, unsigned by, void** args) {
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
     if (gx == 0 || gy == 0) return GR_OK;
-    HIP_CHECK(hipModuleLaunchKernel(p->fn[k], gx, gy, 1, bx, by, 1, 0, (hipStream_t)stream, args, nullptr));
+    hipFunction_t f = function_of(p, k);
+    if (!f) return p->in_rest[k] && p->rest_rc != GR_OK ? p->rest_rc : fail(GR_ERROR_INVALID_ARGUMENT, std::string("this program has no ") + KERNEL_NAMES[k]);
+    HIP_CHECK(hipModuleLaunchKernel(f, gx, gy, 1, bx, by, 1, 0, (hipStream_t)stream, args, nullptr));
     return GR_OK;
 }
 
@@ -1221,7 +1344,7 @@ static long long resident_trace_groups(gr_program* p, int kernel_index, int wg) 
     if (!p->resident_groups_per_cu[kernel_index]) {
         int n = 0;
         if (hipSetDevice(p->device) != hipSuccess) return -(long long)fail(GR_ERROR_DEVICE, "hipSetDevice");
-        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, p->fn[kernel_index], wg, 0) != hipSuccess || n < 1) {
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, function_of(p, kernel_index), wg, 0) != hipSuccess || n < 1) {
             (void)hipGetLastError();
             n = 4 * 8 * 64 / wg;
         }

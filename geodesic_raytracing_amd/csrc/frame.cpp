@@ -173,6 +173,8 @@ struct gr_render_state {
     };
     static const int LOOKAHEAD = 2;
     prefetch_slot pre[LOOKAHEAD];
+    prefetch_key previous_key;          // of the last fused frame with a prepass (gr_frame_tuning.guess_still_camera)
+    bool previous_key_valid = false;
     // Prepass policy (use_prepass = -2, whole frames on the fused path; opt-in: see the last sentence).  The prepass pays for itself through the pixels it lets the
     // trace skip; where it skips next to nothing (Kerr with a = 0.9 in the script's units: a naked singularity, no shadow - 8.4 ms of
     // single-ray latency in front of every 4K frame, for nothing) it is left out: its flags are copied to the host after a frame
@@ -396,6 +398,7 @@ void gr_frame_tuning_default(gr_frame_tuning* t) {
     t->next_geodesic_time = 0;
     t->next_geodesic_time2 = 0;
     t->count_attempts = 0;
+    t->guess_still_camera = -1;
 }
 
 int gr_device_count(int* count) {
@@ -1041,6 +1044,11 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         if (use_prepass) {
             request asked[2] = {{opt.next_camera, tune.next_geodesic_time, tune.next_strip_rank},
                                 {opt.next_camera2, tune.next_geodesic_time2, tune.next_strip_rank2}};
+            // nobody announced the next camera, and this frame is the previous one over again: the guess "the same once more"
+            // (gr_frame_tuning.guess_still_camera) - used by the next frame only if its key matches bit for bit
+            if (!opt.next_camera && !opt.next_camera2 && !gc && strip_count == 1 && tune.guess_still_camera != 0 && s->previous_key_valid &&
+                s->previous_key == make_key(camera, opt.geodesic_time, opt.strip_rank))
+                asked[0] = {camera, opt.geodesic_time, -1};
             for (auto& r : asked) {
                 if (!r.camera) continue;
                 if (r.strip_rank < 0 || r.strip_rank >= strip_count) r.strip_rank = strip_rank;
@@ -1252,6 +1260,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             slot->age = s->frame_counter;
             slot->key = make_key(r.camera, r.time, r.strip_rank);
         }
+        s->previous_key_valid = use_prepass;
+        if (use_prepass) s->previous_key = make_key(camera, opt.geodesic_time, opt.strip_rank);
         if (out) {
             GR_CHECK(begin(GR_STAGE_RENDER));
             if (shade_in_trace)

@@ -103,6 +103,31 @@ struct dynamic_feature_config {
 #define IS_CONSTANT_THETA
 #endif
 
+// Which kernels a build of this translation unit holds (capi.cpp: compile_code_object).  A program is two code objects: the kernels a
+// fused frame launches (-DGR_BUILD_FRAME_PATH: gr_trace_fused, gr_trace_pair, gr_prepass_fused, gr_order_tiles, gr_render - and the
+// adaptive-sampling kernels unless the program is substituted with adaptive sampling off), built first, and the others
+// (-DGR_BUILD_REST: the reference-shaped sequence, ray compaction), built behind them: after a parameter change the substituted
+// program is swapped in when its frame path is there (metric_manager.hpp:172-219 waits for the whole cl::program).  Neither macro: all.
+#if defined(GR_BUILD_FRAME_PATH)
+#define GR_FRAME_KERNELS 1
+#define GR_OTHER_KERNELS 0
+#elif defined(GR_BUILD_REST)
+#define GR_FRAME_KERNELS 0
+#define GR_OTHER_KERNELS 1
+#else
+#define GR_FRAME_KERNELS 1
+#define GR_OTHER_KERNELS 1
+#endif
+#if defined(KERNEL_IS_STATIC) && defined(FEATURE_adaptive_sampling)
+#if FEATURE_adaptive_sampling
+#define GR_ADAPTIVE_KERNELS GR_FRAME_KERNELS
+#else
+#define GR_ADAPTIVE_KERNELS GR_OTHER_KERNELS
+#endif
+#else
+#define GR_ADAPTIVE_KERNELS GR_FRAME_KERNELS
+#endif
+
 #ifndef GR_TILE
 #define GR_TILE 8
 #endif

@@ -203,6 +203,7 @@ __device__ __attribute__((noinline)) float4 shade_pixel_in_tile(const render_dat
 // The launch of the reference (num_pixels = block_pixels = width * height, strip_rank 0, strip_count 1, compact_out 0) shades the
 // whole image; the extension shades one device's row blocks of a split image: work item gid is pixel `off` of local block `lb`,
 // the global block being lb * strip_count + strip_rank, and with compact_out the device's blocks are written back to back.
+#if GR_FRAME_KERNELS
 extern "C" __global__ void gr_render(const render_data* __restrict__ rdata, const int* __restrict__ rdata_count, float4* __restrict__ out,
                                      const uchar4* __restrict__ bg1_texels, const uchar4* __restrict__ bg2_texels,
                                      int bg_width, int bg_height, int bg_levels,
@@ -240,4 +241,5 @@ extern "C" __global__ void gr_render(const render_data* __restrict__ rdata, cons
     out[out_index] = shade_pixel(self, beside, last_column, below, last_row, near_sky, far_sky, most_probes, dfg);
     (void)cfg;
 }
+#endif  // GR_FRAME_KERNELS
 

@@ -102,6 +102,7 @@ __device__ __forceinline__ render_data make_render_data(float4 position, float4 
 // ================================================================================================
 // kernels
 
+#if GR_OTHER_KERNELS   // the reference-shaped sequence's kernels: not launched by a fused frame (program.hip: GR_BUILD_FRAME_PATH / GR_BUILD_REST)
 extern "C" __global__ void gr_clear_termination_buffer(int* __restrict__ termination_buffer, int width, int height) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= width * height) return;
@@ -333,6 +334,7 @@ extern "C" __global__ void gr_calculate_render_data(const lightray* __restrict__
                                        ray->terminated, sx, sy, cfg, dfg, true);
     rdata[sy * width + sx] = dat;
 }
+#endif  // GR_OTHER_KERNELS
 
 
 // init -> integrate -> render-data for one pixel per lane, 8x8 tiles, nothing but the 32-byte result is stored.
@@ -840,6 +842,7 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
     }
 }
 
+#if GR_FRAME_KERNELS
 extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
 gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
@@ -851,8 +854,10 @@ gr_trace_fused(const float4* __restrict__ g_generic_camera_in, const float4* __r
                float4* __restrict__ lattice_rays) {
     trace_fused_body<false>(g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg_in, dfg_in, attempt_counter, tile_counter, total_waves, lattice, pending_only, tile_order, shading, prepass_tickets, ticket_tiles, tile_cost, last_class_is_skipped, lattice_rays);
 }
+#endif  // GR_FRAME_KERNELS
 
 // the lattice launch of adaptive sampling (lattice = 2 with lattice_rays): the same tiles, tickets and integrator
+#if GR_ADAPTIVE_KERNELS
 extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
 gr_trace_fused_lattice(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
@@ -864,10 +869,11 @@ gr_trace_fused_lattice(const float4* __restrict__ g_generic_camera_in, const flo
                float4* __restrict__ lattice_rays) {
     trace_fused_body<true>(g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg_in, dfg_in, attempt_counter, tile_counter, total_waves, lattice, pending_only, tile_order, shading, prepass_tickets, ticket_tiles, tile_cost, last_class_is_skipped, lattice_rays);
 }
+#endif  // GR_ADAPTIVE_KERNELS
 
 // gr_trace_fused with parking (above): persistent launches of whole-image or strip frames, every pixel (no lattice, no list).
 // Programs built with -DGR_PARKING in their argument string only (gr_program_has_parking).
-#ifdef GR_PARKING
+#if defined(GR_PARKING) && GR_FRAME_KERNELS
 extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
 gr_trace_fused_parking(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
@@ -956,6 +962,7 @@ __device__ __forceinline__ void trace_tile_pair(int pair_wave, int lane, const f
     if (attempt_counter && (has0 | has1)) atomicAdd(attempt_counter, (unsigned long long)tries0 + (unsigned long long)tries1);
 }
 
+#if GR_FRAME_KERNELS
 extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
 gr_trace_pair(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
               render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
@@ -980,6 +987,7 @@ gr_trace_pair(const float4* __restrict__ g_generic_camera_in, const float4* __re
         if (!tile_counter) break;
     }
 }
+#endif  // GR_FRAME_KERNELS
 #endif  // GR_TWO_RAYS_PER_LANE
 
 // gr_trace_fused with ray compaction: a persistent wave keeps one ray per lane and, as soon as fewer than keep_lanes of them
@@ -991,6 +999,7 @@ gr_trace_pair(const float4* __restrict__ g_generic_camera_in, const float4* __re
 // of BASELINE.json - 8x8 tiles already keep 97 % (a = 0.45) and 94 % (the a = 0.9 naked singularity) of the lanes busy,
 // and the visits cost more than the idle lanes (7.1 -> 9.6 ms at keep_lanes 16..48) - so the frame driver leaves it off
 // unless asked (gr_frame_options.ray_compaction).
+#if GR_OTHER_KERNELS
 extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_TRACE_WAVES)
 gr_trace_compact(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                  render_data* __restrict__ rdata, int width, int height, int block_rows, int strip_rank, int strip_count,
@@ -1069,6 +1078,7 @@ gr_trace_compact(const float4* __restrict__ g_generic_camera_in, const float4* _
         }
     }
 }
+#endif  // GR_OTHER_KERNELS
 
 // termination flags of the low-resolution prepass, straight from a fused trace (role of
 // clear_termination_buffer + init_rays_generic(prepass) + do_generic_rays + calculate_singularities).
@@ -1094,6 +1104,7 @@ __device__ __forceinline__ void prepass_cell(int id, float4 camera, float4 camer
     if (cell_attempts) cell_attempts[id] = tries;   // what the ray cost: gr_order_tiles' estimate for the tiles around the cell
 }
 
+#if GR_FRAME_KERNELS
 extern "C" __global__ void __launch_bounds__(64, GR_TRACE_WAVES)
 gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat,
                  int* __restrict__ termination_buffer, int prepass_width, int prepass_height,
@@ -1104,6 +1115,7 @@ gr_prepass_fused(const float4* __restrict__ g_generic_camera_in, const float4* _
     prepass_cell(blockIdx.x * blockDim.x + threadIdx.x, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, termination_buffer,
                  prepass_width, prepass_height, cfg, dfg, image_height, block_rows, strip_rank, strip_count, cell_attempts, row_margin);
 }
+#endif  // GR_FRAME_KERNELS
 
 // ---- the order the persistent trace hands its tiles out in -----------------------------------------
 // A persistent launch ends when its slowest wave ends, and a wave that draws a long tile late ends late: with the tiles handed
@@ -1194,6 +1206,7 @@ __device__ __forceinline__ int tile_history_class(int tile, int width, int block
     return GR_TILE_CLASSES - 2 - (octave > GR_TILE_CLASSES - 2 ? GR_TILE_CLASSES - 2 : octave);
 }
 
+#if GR_FRAME_KERNELS
 extern "C" __global__ void __launch_bounds__(1024)
 gr_order_tiles(const int* __restrict__ termination_buffer, const unsigned int* __restrict__ cell_attempts, int prepass_width,
                int prepass_height, int width, int height, int block_rows, int strip_rank, int strip_count, int total_tiles,
@@ -1241,6 +1254,7 @@ gr_order_tiles(const int* __restrict__ termination_buffer, const unsigned int* _
     }
     if (phase == 1 && tile == 0) classes[0] = tile_history ? GR_LIST_BY_HISTORY : GR_LIST_BY_PREPASS;   // (tile 0's own class was read above)
 }
+#endif  // GR_FRAME_KERNELS
 
 // ------------------------------------------------------------------------------------------------
 // adaptive sampling (cl.cl:5215-5345)
@@ -1294,6 +1308,7 @@ __device__ __forceinline__ int pending_class(unsigned int cost) {
     if (fine > 4 * 15 + 3) fine = 4 * 15 + 3;                      // (the step cap is 16 384 = octave 14)
     return GR_PENDING_CLASSES - 1 - fine;
 }
+#if GR_ADAPTIVE_KERNELS
 extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, int* __restrict__ pending_count, int width, int height,
                                               dfg_t dfg, int block_rows, int strip_rank, int strip_count,
                                               const float4* __restrict__ lattice_rays, cfg_t cfg, unsigned int* __restrict__ pending_list, int phase,
@@ -1400,11 +1415,13 @@ extern "C" __global__ void gr_adaptive_refine(render_data* __restrict__ rdat, in
         entry[2] = (unsigned int)((lsy + 1) * width + lsx + 1);
     }
 }
+#endif  // GR_ADAPTIVE_KERNELS
 
 // The second launch of adaptive sampling over gr_adaptive_refine's list: persistent waves, a ticket is 64 consecutive entries, every
 // lane traces the pixel of its entry exactly as a tile-wave of gr_trace_fused would (make_pixel_ray, integrate_ray, make_render_data)
 // and writes its record.  No prepass look-ups: a marked pixel is traced whatever the prepass said about its cell, as in the reference,
 // whose second do_generic_rays runs over the rays handle_adaptive_sampling appended.
+#if GR_ADAPTIVE_KERNELS
 extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
 gr_trace_pending(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat, render_data* __restrict__ rdata,
                  int width, int height, const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2,
@@ -1442,7 +1459,9 @@ gr_trace_pending(const float4* __restrict__ g_generic_camera_in, const float4* _
         if (attempt_counter) atomicAdd(attempt_counter + GR_ATTEMPT_COUNTERS_AT + (blockIdx.x % GR_ATTEMPT_COUNTERS), (unsigned long long)tries);
     }
 }
+#endif  // GR_ADAPTIVE_KERNELS
 
+#if GR_OTHER_KERNELS
 extern "C" __global__ void gr_handle_adaptive_sampling(const lightray* __restrict__ rays_in, const int* __restrict__ rays_in_count,
                                                        render_data* __restrict__ rdat, int* __restrict__ rdata_count,
                                                        lightray* __restrict__ unprocessed_rays_out, int* __restrict__ unprocessed_rays_out_count,
@@ -1503,4 +1522,5 @@ extern "C" __global__ void gr_handle_adaptive_sampling(const lightray* __restric
         rdat[(lsy + 1) * width + lsx + 1] = interpolate_render_data(cdata, drdata);
     }
 }
+#endif  // GR_OTHER_KERNELS
 

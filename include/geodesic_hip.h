@@ -96,6 +96,10 @@ typedef struct gr_program gr_program;
  * and ignored; -cl-fp32-correctly-rounded-divide-sqrt, OpenCL's own switch, is honoured) and loads them on HIP device `device`.
  * Code objects are cached on disk keyed by a hash of source + arguments. */
 int gr_program_create(const char* argument_string, int device, gr_program** out);
+/* A program is usable as soon as the kernels a fused frame launches are there; the kernels of the reference-shaped sequence are a second
+ * code object that - when it is not in the cache yet - is still being built when gr_program_create returns, and the first launcher that
+ * needs one of them waits for it.  gr_program_complete waits now (and reports that build's error, if any). */
+int gr_program_complete(gr_program* p);
 
 /* Compile only (no device needed): fills the on-disk cache; used by the build step. */
 int gr_program_precompile(const char* argument_string);

@@ -42,6 +42,14 @@ struct gr_frame_tuning {
     float next_geodesic_time, next_geodesic_time2;   /* current_geodesic_time of the look-ahead frames (gr_frame_options.geodesic) */
     /* -- measurement -- */
     int count_attempts;    /* 1: accumulate the Verlet step attempts of this frame (gr_render_state_attempts) */
+    /* -- an interactive caller that does not know the next camera (round 6) -- */
+    int guess_still_camera;   /* fused mode, whole frames with a prepass, no next_camera given: 1 = when this frame's camera (and parameters,
+                            * features, program) equal the previous frame's of this render state, take "the same again" as the next frame's
+                            * camera - its camera set-up and prepass then run on the side stream while this frame traces, exactly as for an
+                            * announced next_camera, and are used only if the next frame's key matches bit for bit (else the frame traces
+                            * its prepass inside its trace launch as before: a wrong guess costs one prepass on a side stream).  A viewer
+                            * whose user has stopped moving renders the same camera again and again; the reference pays the prepass's
+                            * single-ray latency on each of those frames (main.cpp:2384-2437).  0 = never; -1 = library default (on). */
 };
 void gr_frame_tuning_default(gr_frame_tuning* out);
 
@@ -64,6 +72,9 @@ void gr_program_manager_counters(const gr_program_manager* pm, unsigned long lon
  * returns at once; poll returns 1 and a loaded program when it is ready, 0 while pending, < 0 on a build error. */
 typedef struct gr_program_future gr_program_future;
 int gr_program_create_async(const char* argument_string, int device, gr_program_future** out);
+/* compile only (no device): what gr_program_create_async's worker builds before the program can be swapped in - the code object of the
+ * kernels a fused frame launches and the set-up module, side by side on two threads; fills the cache (bench.py: startup.program_build_s) */
+int gr_program_precompile_frame_path(const char* argument_string);
 int gr_program_future_poll(gr_program_future* f, gr_program** out);
 void gr_program_future_destroy(gr_program_future* f);
 

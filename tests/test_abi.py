@@ -125,16 +125,33 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
 def test_precompile_produces_gfx950_code_object(tmp_path, monkeypatch):
     monkeypatch.setenv("GR_CACHE_DIR", str(tmp_path))
     gra.Program.precompile(gra.Metric("schwarzschild").argument_string())
-    # two code objects per program: the ray kernels (OpenCL's relaxed arithmetic) and the set-up module (camera, tetrad, the camera's
-    # own geodesic: once per frame on one lane, IEEE arithmetic - kernels/camera.hip)
-    files = sorted(tmp_path.glob("*.hsaco"), key=lambda f: f.name.endswith(".setup.hsaco"))
-    assert len(files) == 2 and files[1].name.endswith(".setup.hsaco") and not files[0].name.endswith(".setup.hsaco")
-    blob, setup = files[0].read_bytes(), files[1].read_bytes()
-    assert blob[:4] == b"\x7fELF" and b"gfx950" in blob and setup[:4] == b"\x7fELF" and b"gfx950" in setup
-    for k in (b"gr_do_generic_rays", b"gr_trace_fused", b"gr_render", b"gr_init_rays_generic", b"gr_calculate_render_data", b"gr_prepass_fused"):
-        assert k in blob
+    # three code objects per program: the ray kernels (OpenCL's relaxed arithmetic) in two parts - what a fused frame launches, and the
+    # reference-shaped sequence + ray compaction, built behind it (round 6: the swap after a parameter change waits for the first only) -
+    # and the set-up module (camera, tetrad, the camera's own geodesic: once per frame on one lane, IEEE arithmetic - kernels/camera.hip)
+    files = sorted(tmp_path.glob("*.hsaco"))
+    setups = [f for f in files if f.name.endswith(".setup.hsaco")]
+    parts = [f.read_bytes() for f in files if f not in setups]
+    assert len(setups) == 1 and len(parts) == 2
+    setup = setups[0].read_bytes()
+    frame = [b for b in parts if b"gr_trace_fused" in b]
+    rest = [b for b in parts if b"gr_do_generic_rays" in b]
+    assert len(frame) == 1 and len(rest) == 1 and frame[0] is not rest[0]
+    frame, rest = frame[0], rest[0]
+    for blob in (frame, rest, setup):
+        assert blob[:4] == b"\x7fELF" and b"gfx950" in blob
+    for k in (b"gr_trace_fused", b"gr_render", b"gr_prepass_fused", b"gr_order_tiles", b"gr_trace_fused_lattice", b"gr_adaptive_refine", b"gr_trace_pending", b"gr_trace_pair"):
+        assert k in frame, k       # (a dynamic program: adaptive sampling is a run-time feature, its kernels are on the frame's path)
+    for k in (b"gr_do_generic_rays", b"gr_do_generic_rays_scheduled", b"gr_init_rays_generic", b"gr_calculate_render_data", b"gr_calculate_singularities",
+              b"gr_handle_adaptive_sampling", b"gr_clear_termination_buffer", b"gr_trace_compact", b"gr_sort_tiles_count"):
+        assert k in rest and k not in frame, k
+    assert b"gr_render" not in rest.replace(b"gr_render_data", b"").replace(b"gr_calculate_render", b"")
     for k in (b"gr_cart_to_generic", b"gr_init_basis_vectors", b"gr_camera_setup", b"gr_get_geodesic_path", b"gr_handle_interpolating_geodesic"):
-        assert k in setup and k not in blob
+        assert k in setup and k not in frame and k not in rest
+    # a substituted program without adaptive sampling: its adaptive kernels are off the frame's path
+    m = gra.Metric("schwarzschild")
+    gra.check(gra.lib.gr_program_precompile_frame_path(m.argument_string(features=m.features(adaptive_sampling=0), static=True, cfg_values=m.cfg_values()).encode()))
+    newest = max((f for f in tmp_path.glob("*.hsaco") if not f.name.endswith(".setup.hsaco") and f not in files), key=lambda f: f.stat().st_mtime).read_bytes()
+    assert b"gr_trace_fused" in newest and b"gr_trace_fused_lattice" not in newest and b"gr_trace_pending" not in newest
 
 
 def test_both_modules_build_without_the_code_object_manager(tmp_path):
@@ -237,8 +254,8 @@ def test_pair_kernel_is_built_for_fixed_step_programs_only(tmp_path, monkeypatch
         d.mkdir()
         monkeypatch.setenv("GR_CACHE_DIR", str(d))
         gra.Program.precompile(argument_string)
-        (path,) = [f for f in glob.glob(os.path.join(str(d), "*.hsaco")) if not f.endswith(".setup.hsaco")]
-        blob = open(path, "rb").read()
+        # (the ray kernels are two code objects - the frame path's holds gr_trace_fused)
+        (blob,) = [b for b in (open(f, "rb").read() for f in glob.glob(os.path.join(str(d), "*.hsaco")) if not f.endswith(".setup.hsaco")) if b"gr_render" in b.replace(b"gr_render_data", b"")]
         return b"gr_trace_pair" in blob, b"gr_trace_fused" in blob
 
     fixed = gra.Metric("schwarzschild")
@@ -273,8 +290,9 @@ def test_assembly_pass_cuts_the_vector_runs_of_the_integrator(tmp_path, monkeypa
         monkeypatch.setenv("GR_CACHE_DIR", str(d))
         monkeypatch.setenv("GR_VECTOR_RUN_LIMIT", str(limit))
         gra.Program.precompile(args)
-        (path,) = [f for f in glob.glob(os.path.join(str(d), "*.hsaco")) if not f.endswith(".setup.hsaco")]
-        text = subprocess.run([objdump, "-d", "--no-show-raw-insn", path], capture_output=True, text=True, check=True).stdout
+        paths = [f for f in glob.glob(os.path.join(str(d), "*.hsaco")) if not f.endswith(".setup.hsaco")]
+        assert len(paths) == 2   # the kernels of a fused frame, and the others
+        text = "".join(subprocess.run([objdump, "-d", "--no-show-raw-insn", path], capture_output=True, text=True, check=True).stdout for path in paths)
         runs, kernel, run = {}, None, 0
         for line in text.splitlines():
             m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)

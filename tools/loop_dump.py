@@ -14,7 +14,7 @@ def hot_loop(name="kerr_boyer", cfg=None, kernel="gr_trace_fused", features=None
     d = os.environ.get("GR_CACHE_DIR") or tempfile.mkdtemp(prefix="loopdump")
     os.environ["GR_CACHE_DIR"] = d
     before = set(os.listdir(d))
-    gra.Program.precompile(s)
+    gra.check(gra.lib.gr_program_precompile_frame_path(s.encode()))   # the code object of the kernels a fused frame launches (+ the set-up module)
     new = [f for f in os.listdir(d) if f not in before and f.endswith(".hsaco") and not f.endswith(".setup.hsaco")]
     path = os.path.join(d, new[0]) if new else None
     if path is None:   # already cached: find by content
