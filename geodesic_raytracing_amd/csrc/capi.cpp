@@ -186,7 +186,18 @@ int resident_waves_per_simd(int vgprs, int sgprs) {
 }
 
 // Compiles (or fetches from the on-disk cache) the code object for one macro string.
-int compile_setup_module(const std::string& argument_string, std::string& code);
+int compile_setup_module(const std::string& argument_string, std::string& code, bool cache_only = false);
+
+// hiprtc's version (part of every cache key), asked once per process: the first call into hiprtc initialises the HIP runtime behind it,
+// and two threads doing that at the same moment (the two builds of build_frame_path) left one of them without a device on the GPU box
+// ("hipSetDevice: no ROCm-capable device is detected" in the first program a process created)
+void rtc_version(int& major, int& minor) {
+    static int v[2] = {0, 0};
+    static std::once_flag once;
+    std::call_once(once, [] { hiprtcVersion(&v[0], &v[1]); });
+    major = v[0];
+    minor = v[1];
+}
 
 // the fallback of both modules' builds: hiprtc itself (no pass over the code; a source error shows up here with its diagnostics)
 int build_through_hiprtc(const std::string& source, const char* name, const std::vector<std::string>& options, std::string& out) {
@@ -277,7 +288,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
     opts.push_back(part == PART_FRAME ? "-DGR_BUILD_FRAME_PATH" : "-DGR_BUILD_REST");
 
     int rtc_major = 0, rtc_minor = 0;
-    hiprtcVersion(&rtc_major, &rtc_minor);
+    rtc_version(rtc_major, rtc_minor);
     uint64_t h = fnv1a(source);
     for (auto& o : opts) h = fnv1a(o + "\n", h);
     h = fnv1a("hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor), h);
@@ -473,7 +484,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
 // The set-up module of a program: the kernels that run once per frame on one lane - camera coordinates, tetrad, the camera's own
 // geodesic - from program + probes + metric + setup + camera + geodesic_camera, built with IEEE arithmetic (kernels/camera.hip says
 // why).  Same macro string, a cache file of its own; no pass over the code, no occupancy rule: nothing here is issue-bound.
-int compile_setup_module(const std::string& argument_string, std::string& code) {
+int compile_setup_module(const std::string& argument_string, std::string& code, bool cache_only) {
     static const char* const PARTS[] = {"program.hip", "probes.inc", "metric.hip", "setup.hip", "camera.hip", "geodesic_camera.hip"};
     std::string source;
     // GR_SETUP_KERNEL_SOURCE: one file instead of the parts, as GR_KERNEL_SOURCE is for the ray kernels' module.  (GR_KERNEL_SOURCE
@@ -506,7 +517,7 @@ int compile_setup_module(const std::string& argument_string, std::string& code) 
     if (const char* extra = getenv("GR_SETUP_EXTRA_FLAGS"))
         for (auto& tok : split_arguments(extra)) opts.push_back(tok);
     int rtc_major = 0, rtc_minor = 0;
-    hiprtcVersion(&rtc_major, &rtc_minor);
+    rtc_version(rtc_major, rtc_minor);
     uint64_t h = fnv1a(source);
     for (auto& o : opts) h = fnv1a(o + "\n", h);
     h = fnv1a("set-up module, hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor), h);
@@ -517,6 +528,8 @@ int compile_setup_module(const std::string& argument_string, std::string& code) 
     else cache_dir = library_dir() + "/_cache";
     const std::string cache_path = cache_dir + "/" + name;
     if (read_file(cache_path, code) && !code.empty()) return GR_OK;
+    code.clear();
+    if (cache_only) return GR_OK;
     std::string assembly, log;
     if (!gr::compile_to_assembly(source, opts, assembly, log) || !gr::assemble_code_object(assembly, code, log)) {
         // the code-object manager could not be loaded (or is the copy bundled with another library): hiprtc, as for the ray kernels'
@@ -762,11 +775,16 @@ int gr_program_precompile(const char* argument_string) {
 static int build_frame_path(const std::string& arguments, std::string& code, std::string& setup_code, std::string* key) {
     std::string setup_error;
     int setup_rc = GR_OK;
+    { int a, b; rtc_version(a, b); }   // (before the second thread exists)
+    // (both in the cache - every program after its first use: no thread at all)
+    int rc = compile_setup_module(arguments, setup_code, /*cache_only=*/true);
+    if (rc != GR_OK) return rc;
+    if (!setup_code.empty()) return compile_code_object(arguments, code, key);
     std::thread side([&]() {
         setup_rc = compile_setup_module(arguments, setup_code);
         if (setup_rc != GR_OK) setup_error = g_error;
     });
-    const int rc = compile_code_object(arguments, code, key);
+    rc = compile_code_object(arguments, code, key);
     side.join();
     if (rc != GR_OK) return rc;
     if (setup_rc != GR_OK) return fail((gr_status)setup_rc, setup_error);
