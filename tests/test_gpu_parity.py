@@ -376,3 +376,35 @@ def test_frames_match_the_fixtures_frozen_before_the_generator_changed(name, pro
     meta, z = load_frozen(name)
     px, _ = _frame(meta, gra.MODE_FUSED, substituted=program == "substituted")
     assert_pixels(name, meta, z, px)
+
+
+@pytest.mark.parametrize("name,scripts,cfg_kw,camera_pos,size", [
+    ("kerr_boyer", True, dict(a=0.45), [0.0, 0.0, -4.0, 0.0], (96, 54)),
+    ("kerr_boyer", False, dict(a=0.45), [0.0, 0.5, -5.0, 1.0], (64, 36)),
+    ("alcubierre", True, {}, [0.0, 0.0, -6.0, 0.5], (64, 36)),
+    ("schwarzschild", True, {}, [0.0, 0.0, -4.0, 0.0], (64, 36)),
+    ("double_unequal_kerr", True, {}, [0.0, 0.0, -6.0, 0.5], (48, 27))])
+def test_gpu_frames_against_the_reference_object_itself(name, scripts, cfg_kw, camera_pos, size):
+    """a GPU-box parity job whose checker is the reference's own code - /root/reference/cl.cl compiled for x86-64 in the build
+    container (oracle/_ref/libref_<metric>.so, oracle/build_ref.py; it travels with the tree since round 6) - RUN HERE on a pose no
+    fixture holds, not read back from a fixture and not the restatement.  Whole frames, fused path, dynamic and substituted program,
+    the end-to-end rule of the fixtures.  Skipped where the object did not travel (a fresh clone: the fixtures and the restatement remain)."""
+    import os
+    from oracle import build_ref
+    from oracle.refpipe import OraclePipeline, pack_features
+    from gpu_stages import SCRIPTS_DIR
+    metric = gra.Metric(name, SCRIPTS_DIR if scripts else None)
+    so = build_ref.prebuilt(name + ("_script" if scripts else ""), metric.argument_string())
+    if so is None:
+        pytest.skip("no oracle/_ref object for this macro string on this box")
+    w, h = size
+    cfg = metric.cfg_values(**cfg_kw)
+    fkw = dict(adaptive_sampling=0, max_acceleration_change=metric.info.max_acceleration_change)
+    meta = dict(metric=name, scripts=scripts, width=w, height=h, cfg=cfg, features=fkw, camera_pos=camera_pos, camera_quat=list(gra.default_camera().quat),
+                prepass=False, bg_size=[256, 128], bg_seed=1234, bg_seed2=4321, basis_speed=[0.0, 0.0, 0.0], max_probes=8)
+    bg, bg2, levels = backgrounds(meta)
+    ref = OraclePipeline(so).frame(w, h, cfg, pack_features(**fkw), camera_pos=camera_pos, camera_quat=meta["camera_quat"], use_prepass=False,
+                                   background=(bg, bg2, levels), basis_speed=[0.0, 0.0, 0.0], nthreads=os.cpu_count() or 4, max_probes=8)
+    for substituted in (False, True):
+        px, _ = _frame(meta, gra.MODE_FUSED, substituted=substituted)
+        assert_pixels(name, meta, {"pixels": ref["pixels"]}, px)
