@@ -322,7 +322,7 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
 #ifdef SINGULARITY_DETECTION
             dead = inside & (q > controller.singular_q) & (nds == controller.min_step);   // DS_RETURN: lost
 #endif
-            const bool reject = inside & (nds < ds * (1 / 1.95f));   // DS_SKIP: retry from the same state with the smaller step
+            bool reject = inside & (nds < ds * (1 / 1.95f));   // DS_SKIP: retry from the same state with the smaller step
             // IS_DEGENERATE on the accepted state.  A rejected attempt is not tested (the reference `continue`s before its test: an
             // overshoot into a singularity is retried with the smaller step).
             bool degenerate = !(q == q);
@@ -331,6 +331,16 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
                 degenerate |= !(__builtin_fabsf(poison) <= 3.402823466e+38f);
             }
             dead |= !reject & degenerate;
+            if (!decltype(libm)::value) {
+                // The polynomial sin / cos poisons an argument outside its range with a NaN (metric.hip) - which the reference, with a
+                // full-range sine, would never have seen.  Such an attempt must not run through the controller (v_med3 hands a NaN error
+                // back as the smallest step: a rejection, then ~10 more down to min_step, `running` multiplied by a garbage K on each
+                // with reparameterisation on): a NaN on the fast path leaves the loop AT ONCE, nothing rejected, and the attempt is done
+                // again below with libm from the step and the `running` it started with - where a NaN that is the metric's own (a
+                // singularity overshot) then takes the reference's course.  
+                dead |= degenerate;
+                reject &= !degenerate;
+            }
             if (reject) {
                 overwrite(po, position);
                 overwrite(vo, velocity);

@@ -882,11 +882,17 @@ std::string to_c(E e, const std::unordered_map<E, std::string>* names, bool is_d
     return out;
 }
 
+// (values, not bits: -(a - b) -> (b - a) and -(a + b) -> ((-a) - b) give +0 where the negated form gives -0 when the operands cancel
+// exactly - observable through a division or an atan2 of the result; the device's rendering is used inside the Verlet loop only, where
+// the relaxed build carries -fno-signed-zeros anyway.  The flag is put back by a guard: to_c_rec throws on an expression it cannot
+// write, and a flag left set would push negations into the strings the next to_c() of this thread writes for cl.cl and the oracle.)
 std::string to_c_negations_pushed(E e, const std::unordered_map<E, std::string>* names, bool is_definition) {
-    g_push_negations = true;
+    struct guard {
+        guard() { g_push_negations = true; }
+        ~guard() { g_push_negations = false; }
+    } pushed;
     std::string out;
     to_c_rec(e, names, out, is_definition);
-    g_push_negations = false;
     return out;
 }
 

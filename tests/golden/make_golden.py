@@ -68,6 +68,13 @@ CASES = {
                                                   camera_quat=[-0.6049168524805493, -0.42006472218706736, -0.14871616353429276, 0.6599278244342851],
                                                   features=dict(adaptive_sampling=1, adaptive_sampling_threshold=16.0, redshift=1)),
     "alcubierre": dict(metric="alcubierre", size=(48, 27), features=dict(redshift=1), camera_pos=[0.0, 0.0, -6.0, 0.5]),
+    # round 6: sin / cos of an argument beyond the range of the Verlet loop's polynomial (|x| >= 8192: coordinate time 9000 in a
+    # metric that ripples in t) - every ray leaves the fast loop on its first attempt and is integrated by the libm rescue loop, which must
+    # start from the step and the reparameterisation factor the abandoned attempt started with
+    "time_ripple_late": dict(metric="time_ripple", scripts=True, size=(48, 27), features=dict(redshift=1), camera_pos=[9000.0, 0.5, -4.0, 0.3]),
+    "time_ripple_late_reparameterised": dict(metric="time_ripple", scripts=True, size=(48, 27), features=dict(redshift=1, reparameterisation=1),
+                                             camera_pos=[9000.0, 0.5, -4.0, 0.3]),
+    "time_ripple": dict(metric="time_ripple", scripts=True, size=(48, 27), features=dict(redshift=1), camera_pos=[3.0, 0.5, -4.0, 0.3]),
     "double_unequal_kerr": dict(metric="double_unequal_kerr", scripts=True, size=(48, 27), camera_pos=[0.0, 0.0, -6.0, 0.5]),
     # a HYPER-EXTREME constituent (fa2 = a2 / m2 > 1: complex rod half-length, the principal complex roots stay complex; a naked
     # singularity with chaotic orbits around it): case 46 of the round-3 soak (seed 31), inputs as drawn
