@@ -798,8 +798,12 @@ def main():
                                           "still_camera_next_prepass_guessed": round(sum(still.values()), 4)}
         return roof, valu, stages
 
-    kerr_4k = args.metric == "kerr_boyer" and (W, H) == (3840, 2160) and fused and args.program == "static"
+    kerr_4k = args.metric == "kerr_boyer" and (W, H) == (3840, 2160)
     tag = ("kerr_a045_4k" if abs(args.spin - 0.45) < 1e-9 else "kerr_a09_4k" if abs(args.spin - 0.9) < 1e-9 else None) if kerr_4k else None
+    if tag and not fused:
+        tag = "reference_sequence_4k" if abs(args.spin - 0.45) < 1e-9 else None
+    if tag and args.program == "dynamic":
+        tag += "_dynamic"
     if args.config in OTHER_CONFIGS:
         tag = OTHER_CONFIGS[args.config]["tag"]
     tag = tag or f"{args.metric}_{W}x{H}"
@@ -875,6 +879,18 @@ def main():
             secondary["superextremal_a0.9_substituted"]["without_prepass"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "ms_per_frame_repeats": reps}
             for slot in ring:
                 slot.state.trace_log(reset=True)
+        if timed and args.program == "static":
+            # the headline frame through the DYNAMIC program - what a user sees for the seconds between a parameter change and the swap of the
+            # substituted program (metric_manager.hpp:19-170) - measured the way the headline is (frames in flight, look-ahead)
+            dyn = manager.dynamic
+            t, reps = steady(lambda: frame(dyn, cfg_values), barrier, warm=in_flight + 1)
+            pmc_dyn, pmc_dyn_note = committed_counters("kerr_a045_4k_dynamic", dyn.build_key) if tag == "kerr_a045_4k" else (None, "counters are collected for the headline workload")
+            secondary["dynamic_program_fused"] = {"Mrays_per_s": round(W * H / t / 1e6, 1), "fps": round(1 / t, 2), "ms_per_frame_repeats": reps, "build_key": dyn.build_key,
+                                                  "trace_kernel": dyn.kernel_info("gr_trace_fused"),
+                                                  "hbm_bytes_per_launch": pmc_dyn.get("hbm_bytes_per_launch") if pmc_dyn else None,
+                                                  "valu_instructions_per_launch": pmc_dyn.get("valu_wave_instructions_per_launch") if pmc_dyn else None, "counters": pmc_dyn_note}
+            for slot in ring:
+                slot.state.trace_log(reset=True)
         if timed:
             t = timed(camera, metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0), cfg_values, manager.dynamic, gra.MODE_REFERENCE)
             secondary["adaptive_sampling_on_threshold32_fps"] = round(1 / t, 1)
@@ -897,7 +913,7 @@ def main():
                 attempts_ref = int(state.attempts())
                 flops_per_attempt = valu["flops_per_attempt"]
                 hbm = 140 * W * H / trace_s / 1e9
-                pmc_ref, pmc_ref_note = committed_counters("reference_sequence_4k", prog.build_key)
+                pmc_ref, pmc_ref_note = committed_counters("reference_sequence_4k" + ("" if prog is program else "_dynamic"), prog.build_key)
                 return {"fps": round(1 / wall_s, 1), "ms_per_frame": round(wall_s * 1e3, 3), "stage_ms": stage,
                         "roofline": {"bound": "hbm", "kernel": "gr_do_generic_rays", "achieved": round(hbm, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(hbm / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": 140 * W * H, "launch_ms": stage["trace"],

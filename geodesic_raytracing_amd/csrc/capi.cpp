@@ -770,6 +770,28 @@ int gr_program_precompile(const char* argument_string) {
     return compile_setup_module(argument_string, setup);
 }
 
+// Builds that outlive their program (a program destroyed while its second code object is still inside the compiler detaches the
+// worker): the process must not run its exit handlers - which tear down the compiler's own static state - under such a thread.  They
+// are counted, and an atexit handler waits for the count to reach zero (a build is seconds; bounded at two minutes).
+static std::mutex g_background_mu;
+static std::condition_variable g_background_cv;
+static int g_background_builds = 0;
+static void background_builds_wait() {
+    std::unique_lock<std::mutex> lock(g_background_mu);
+    g_background_cv.wait_for(lock, std::chrono::seconds(120), [] { return g_background_builds == 0; });
+}
+static void background_builds_begin() {
+    static std::once_flag once;
+    std::call_once(once, [] { atexit(background_builds_wait); });
+    std::lock_guard<std::mutex> lock(g_background_mu);
+    g_background_builds++;
+}
+static void background_builds_end() {
+    std::lock_guard<std::mutex> lock(g_background_mu);
+    g_background_builds--;
+    g_background_cv.notify_all();
+}
+
 // the frame path of a program: its PART_FRAME code object and the set-up module, each from the cache or built - the two builds side by
 // side on two threads when both are missing (the compiler runs are independent; ~1.3 s and ~2.5 s of one core each for Kerr)
 static int build_frame_path(const std::string& arguments, std::string& code, std::string& setup_code, std::string* key) {
@@ -881,15 +903,19 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
     else {
         auto state = p->rest;
         const std::string arguments = argument_string;
+        background_builds_begin();
         p->rest_worker = std::thread([state, arguments]() {
             std::string built;
             const int build_rc = compile_code_object(arguments, built, nullptr, PART_REST);   // compiler only: no device work on this thread
-            std::lock_guard<std::mutex> lock(state->mu);
-            state->rc = build_rc;
-            if (build_rc != GR_OK) state->error = g_error;
-            state->code.swap(built);
-            state->done = true;
-            state->cv.notify_all();
+            {
+                std::lock_guard<std::mutex> lock(state->mu);
+                state->rc = build_rc;
+                if (build_rc != GR_OK) state->error = g_error;
+                state->code.swap(built);
+                state->done = true;
+                state->cv.notify_all();
+            }
+            background_builds_end();
         });
     }
     const int huge = 0x7fffffff;

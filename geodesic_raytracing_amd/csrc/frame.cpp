@@ -1046,7 +1046,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                 {opt.next_camera2, tune.next_geodesic_time2, tune.next_strip_rank2}};
             // nobody announced the next camera, and this frame is the previous one over again: the guess "the same once more"
             // (gr_frame_tuning.guess_still_camera) - used by the next frame only if its key matches bit for bit
-            if (!opt.next_camera && !opt.next_camera2 && !gc && strip_count == 1 && tune.guess_still_camera != 0 && s->previous_key_valid &&
+            static const int guess_default = [] { const char* e = getenv("GR_GUESS_STILL_CAMERA"); return !e ? 1 : e[0] != '0'; }();
+            if (!opt.next_camera && !opt.next_camera2 && !gc && strip_count == 1 && (tune.guess_still_camera < 0 ? guess_default : tune.guess_still_camera) != 0 && s->previous_key_valid &&
                 s->previous_key == make_key(camera, opt.geodesic_time, opt.strip_rank))
                 asked[0] = {camera, opt.geodesic_time, -1};
             for (auto& r : asked) {

@@ -42,28 +42,32 @@ __device__ __forceinline__ sincos_pair sincos_reduced(float x) {
     c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, c) ^ (((q + 1u) & 2u) << 30));
     return {s, c};
 }
-// sin^2, cos^2 and sin cos of one angle (the code generator's gr_sin2 / gr_cos2 / gr_sincos, csrc/sym.cpp lower_for_device): the bits of
-// s * s, c * c, s * c with s, c = sincos_reduced(x) - a square has no sign, the product's is the quadrant's low bit, and its magnitude
-// is the two polynomials' product whichever of them is the sine - without the four instructions that sign s and c themselves.
+// sin^2, cos^2 and sin cos of one angle (the code generator's gr_sin2 / gr_cos2 / gr_sincos, csrc/sym.cpp lower_for_device - all a
+// Boyer-Lindquist chart ever asks of its polar angle).  All three have period pi and none of them cares which of sin, cos carries a
+// sign, so the angle is reduced by multiples of PI to [-pi/2, pi/2] and that is the end of it: no quadrant, no "which polynomial is
+// the sine", no sign bits (round 5 reduced by pi/2 and paid v_and + v_cmp + two v_cndmask + v_lshlrev + v_xor = 21 issue cycles per
+// attempt for them; the two polynomials for the wider interval cost one fma each more: 4.5 cycles).  Minimax fits for |r| <= pi/2
+// (tools/ubench/fit_sincos.py): |sin error| <= 1.3e-7, |cos error| <= 7.5e-8 (1.1 / 0.6 ulp of 1) in fp32 with fmas - the sine keeps
+// its RELATIVE accuracy at the poles of the chart (r -> 0: sin r = r (1 + ...)), where 1 / sin^2 amplifies it; the cosine's zero at the
+// equator gets absolute accuracy.
 struct sincos_products_t { float s2, c2, sc; };
 template <bool POISON_LARGE = false>
 __device__ __forceinline__ sincos_products_t sincos_products(float x) {
 #pragma clang fp reassociate(off)
-    float t = __builtin_fmaf(x, 0.636619772367581343f, 12582912.f);
+    float t = __builtin_fmaf(x, 0.318309886183790672f, 12582912.f);   // nearest multiple of pi by the 1.5 * 2^23 trick (sincos_reduced)
     float j = t - 12582912.f;
-    unsigned int q = __builtin_bit_cast(unsigned int, t);
-    float r = __builtin_fmaf(-j, 1.57079637050628662109375f, x);
-    r = __builtin_fmaf(-j, -4.37113900018624283e-8f, r);
+    float r = __builtin_fmaf(-j, 3.1415927410125732421875f, x);       // pi = hi + lo, the fma keeps the product exact
+    r = __builtin_fmaf(-j, -8.74227800037248566e-8f, r);
     if (POISON_LARGE) r = __builtin_fmaf(x * 4.1539e34f, 0.f, r);
     float r2 = r * r;
-    float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
-    float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
-                              r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
-    const float sp2 = sp * sp, cp2 = cp * cp;
+    float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.599902700239909e-06f, r2, -0.00019806546333711594f), r2, 0.008333016186952591f), r2,
+                                             -0.16666656732559204f), r2 * r, r);
+    float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-2.6192478230768756e-07f, r2, 2.4769240553723648e-05f), r2, -0.0013888567918911576f), r2,
+                                             0.041666656732559204f), r2 * r2, __builtin_fmaf(-0.5f, r2, 1.0f));
     sincos_products_t p;
-    p.s2 = (q & 1) ? cp2 : sp2;
-    p.c2 = (q & 1) ? sp2 : cp2;
-    p.sc = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, sp * cp) ^ (q << 31));
+    p.s2 = sp * sp;
+    p.c2 = cp * cp;
+    p.sc = sp * cp;
     return p;
 }
 // the polynomial is evaluated unconditionally (so sin and cos of one angle stay in one basic block and share it);

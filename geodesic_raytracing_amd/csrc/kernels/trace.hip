@@ -87,11 +87,23 @@ __device__ __forceinline__ render_data make_render_data(float4 position, float4 
     if (__builtin_fabsf(ipos.y) <= 1) return dat;
 #endif
     if (need_redshift) {
-        tetrad t;
-        calculate_tetrads(position, f3(0, 0, 0), t, cfg, 0);
+        // The emitter's 4-velocity is the timelike leg of calculate_tetrads(position, no speed, no orientation) (cl.cl:5188-5208) - the only
+        // leg the redshift reads.  Where the t axis of the chart is timelike at the ray's end (g_tt < -eps: everywhere but inside an
+        // ergosphere or a superluminal warp wall) that leg is decided before any Gram-Schmidt: d/dt is the first non-null coordinate
+        // vector, so it leads unswapped, and normalised it is the one leg of negative norm, so it is slot 0 - e0 = d/dt / sqrt|g_tt|, the
+        // value the full construction returns (same functions, same operands).  The other three legs - six projections, three
+        // normalisations, four norms: most of what an Alcubierre ray of 43 attempts costs outside its loop - are built only for a ray
+        // that ends where g_tt >= -eps, or at a degenerate position.  (round 6)
         float g[16];
         gm::metric_big_at(position, g, cfg);
-        float4 obvs_low = lower_index_big(t.e[0], g);
+        float4 e0;
+        if (!degenerate4(position) && g[0] < -0.00001f) e0 = normalise_metric(f4(1, 0, 0, 0), g);
+        else {
+            tetrad t;
+            calculate_tetrads(position, f3(0, 0, 0), t, cfg, 0);
+            e0 = t.e[0];
+        }
+        float4 obvs_low = lower_index_big(e0, g);
         float z_shift = (dot4(generic_velocity, obvs_low) / ku_uobsu) - 1;
         dat.z_shift = __builtin_fmaxf(z_shift, -0.999f);
     }

@@ -235,3 +235,42 @@ def test_distance_of_generic_is_the_distance_of_the_polar_coordinates(name):
         polar = [ms.value(f"TO_COORD{i + 1}", env) for i in range(4)]
         long_way = ms.value("DISTANCE_FUNC", ms.env(polar, cfg=cfg))
         assert ms.value("GR_DISTANCE_OF_GENERIC", env) == pytest.approx(long_way, rel=1e-9, abs=1e-12), pos
+
+
+def test_pi_periodic_sincos_products_of_the_verlet_loop():
+    """kernels/metric.hip: sincos_products (gr_sin2 / gr_cos2 / gr_sincos of the device's rendering of a Boyer-Lindquist chart) reduces its
+    angle by multiples of pi and evaluates one sine and one cosine polynomial on [-pi/2, pi/2] - no quadrant logic (round 6).  The constants
+    are read out of the kernel source and the function is replayed in emulated fp32 (an fma = one rounding of the exact a*b + c): sin^2,
+    cos^2 and sin cos within 3e-7 of float64 for |x| < 8192 (the polynomial's range; beyond it the loop's libm rescue takes over), the
+    sine relatively accurate at the chart's poles."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "geodesic_raytracing_amd", "csrc", "kernels", "metric.hip")).read()
+    body = src[src.index("__device__ __forceinline__ sincos_products_t sincos_products(float x)"):]
+    body = body[:body.index("return p;")]
+    nums = [np.float32(float(t.rstrip("f"))) for t in re.findall(r"(?<![\w.])-?\d+\.\d*(?:e[-+]?\d+)?f", body)]
+    inv_pi, magic, magic2, pi_hi, pi_lo = nums[0], nums[1], nums[2], nums[3], nums[4]
+    assert magic == magic2 == np.float32(12582912.0) and abs(float(inv_pi) - 1 / np.pi) < 1e-7
+    assert abs(float(pi_hi) + float(pi_lo) - np.pi) < 1e-14
+    poison_at = nums.index(np.float32(4.1539e34))
+    sin_c, cos_c = nums[poison_at + 2:poison_at + 6], nums[poison_at + 6:poison_at + 10]
+    assert nums[poison_at + 10:poison_at + 12] == [np.float32(-0.5), np.float32(1.0)]
+
+    def fma(a, b, c):
+        return (np.float64(a) * np.float64(b) + np.float64(c)).astype(np.float32)
+
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-8191, 8191, 400000), rng.uniform(-7, 7, 400000), np.pi / 2 + rng.uniform(-1e-3, 1e-3, 50000),
+                        rng.uniform(-1e-2, 1e-2, 50000), np.pi * np.arange(-20, 21) + 1e-4]).astype(np.float32)
+    t = fma(x, inv_pi, magic)
+    j = (t - magic).astype(np.float32)
+    r = fma(-j, pi_lo, fma(-j, pi_hi, x))
+    assert np.abs(r).max() <= np.pi / 2 * 1.0005
+    r2 = (r * r).astype(np.float32)
+    sp = fma(fma(fma(fma(sin_c[0], r2, sin_c[1]), r2, sin_c[2]), r2, sin_c[3]), (r2 * r).astype(np.float32), r)
+    cp = fma(fma(fma(fma(cos_c[0], r2, cos_c[1]), r2, cos_c[2]), r2, cos_c[3]), (r2 * r2).astype(np.float32), fma(np.float32(-0.5), r2, np.float32(1.0)))
+    xs = x.astype(np.float64)
+    for got, want in (((sp * sp).astype(np.float32), np.sin(xs) ** 2), ((cp * cp).astype(np.float32), np.cos(xs) ** 2), ((sp * cp).astype(np.float32), np.sin(xs) * np.cos(xs))):
+        assert np.abs(got - want).max() <= 3e-7
+    pole = np.abs(xs) < 1e-2
+    assert np.max(np.abs((sp * sp).astype(np.float32)[pole] - np.sin(xs[pole]) ** 2) / np.maximum(np.sin(xs[pole]) ** 2, 1e-30)) <= 3e-7

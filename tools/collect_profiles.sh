@@ -10,6 +10,8 @@ for W in $WORKLOADS; do
     dk)   SEL="--config 3"; JSON=pmc_double_unequal_kerr_4k.json;;
     alc)  SEL="--config 4"; JSON=pmc_alcubierre_8k_redshift.json;;
     refseq) SEL="--mode reference"; JSON=pmc_reference_sequence_4k.json;;
+    a045dyn) SEL="--spin 0.45 --program dynamic"; JSON=pmc_kerr_a045_4k_dynamic.json;;
+    refseqdyn) SEL="--mode reference --program dynamic"; JSON=pmc_reference_sequence_4k_dynamic.json;;
   esac
   for K in stats exclusive_stats; do
     DB=$(find gpurun_out/${TAG}_${W}_${K} -name "*.db" 2>/dev/null | head -1)

@@ -19,6 +19,8 @@ for W in $WORKLOADS; do
     dk)   SEL="--config 3"; STEPS=10;;
     alc)  SEL="--config 4"; STEPS=10;;
     refseq) SEL="--mode reference"; STEPS=10;;   # the reference-shaped kernel sequence (one launch per reference kernel), 4K Kerr a = 0.45
+    a045dyn) SEL="--spin 0.45 --program dynamic"; STEPS=20;;             # the headline frame through the DYNAMIC program (what runs after a slider moved)
+    refseqdyn) SEL="--mode reference --program dynamic"; STEPS=10;;      # ... and the reference-shaped sequence through it
     *) echo "unknown workload $W"; continue;;
   esac
   ARGS="$SEL --steps $STEPS --warmup 3 --no-cpu-baseline --no-secondary"
