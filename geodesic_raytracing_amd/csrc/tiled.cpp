@@ -423,6 +423,11 @@ int gr_tiled_create_ipc(int world, int rank, int device, const char* session, in
                         joined = wait_on_region([&] { return region->arrived.load() >= (unsigned int)world; });
                     }
                 }
+                // ... and a region a CRASHED run left behind with fewer than `world` arrivals can be filled up to `world` by the early ranks of
+                // this run while rank 0 is still on its way to unlink it: the barrier above then completes on the stale inode.  Once more
+                // after the barrier: the name must still point at the region this rank is attached to - rank 0 makes its region
+                // before it arrives, so a barrier that rank 0 took part in completes on the inode the name has.
+                if (joined && name_inode() != attached) { joined = false; replaced = true; }
                 if (joined) { l->shared = region; break; }
                 munmap(mem, l->bytes);
                 if (!replaced) return gr_internal_fail(GR_ERROR_DEVICE, "ipc transport: not every rank arrived in time");
