@@ -120,7 +120,7 @@ std::vector<std::string> split_arguments(const std::string& s) {
 //    programs: Schwarzschild 1.96 -> 1.38 ms, Minkowski 1.80 -> 1.16, wormhole 1.83 -> 1.42; with the adaptive controller
 //    Kerr 7.9 -> 9.3 ms, Alcubierre 3.0 -> 3.3: the controller (sqrt, rsq, clamps, compares, the per-ray commit) has no
 //    packed form, costs twice per lane what it costs the one-ray kernel per lane, and at 133 instead of 92 VGPRs only three
-//    waves per SIMD are left to hide its serial tail - that outweighs what the packed multiplies save.
+//    waves per SIMD are left to hide its serial tail - that outweighs what the packed multiplies save (EXPERIMENTS.md C.2).
 // GR_TRACE_PAIR_BUILD=0 never builds it, =1 builds it for adaptive programs too (it is correct there, only slower).
 bool pair_kernel_applies(const std::vector<std::string>& opts) {
     int mode = -1;

@@ -25,7 +25,7 @@ struct vector_run_stats {
 };
 
 // Inserts `s_nop 0` so that no basic block issues more than `limit` vector-ALU instructions in a row without a scalar one
-// (a wave that issues a long pure-vector stretch leaves the SIMD's vector port idle part of the time; one
+// (EXPERIMENTS.md C.2: a wave that issues a long pure-vector stretch leaves the SIMD's vector port idle part of the time; one
 // scalar instruction per <= 32 vector instructions restores the rate).  A run of L > limit instructions is cut into
 // ceil(L / limit) pieces of equal length.  Only lines between two vector instructions are touched, so nothing that must stay
 // adjacent (s_getpc_b64 + its offset add, the branch of a waitcnt sequence) is separated.  `only_functions`: restrict the pass to

@@ -20,7 +20,7 @@ struct gr_frame_tuning {
     int fused_shading;     /* fused mode: 1 = the trace launch shades the 49 of every 64 pixels whose filter neighbours are in the same
                             * tile and gr_render_seams the rest (needs a program built with -DGR_TILE_SHADING, width and height
                             * multiples of 8, one ray per lane, no compaction, no adaptive sampling; an error otherwise);
-                            * 0 or -1 (library default) = gr_render shades every pixel (measured faster: DESIGN.md section 4) */
+                            * 0 or -1 (library default) = gr_render shades every pixel (measured faster: EXPERIMENTS.md C.2) */
     int inline_prepass;    /* fused mode, a frame whose prepass was not computed ahead (next_camera): trace the prepass grid inside
                             * the trace launch (gr_trace_fused_args.inline_prepass).  -1 (default): on whole frames that do not order
                             * their tiles; 1: also on a device's share of a split frame; 0: the prepass as a launch of its own in front */
@@ -197,7 +197,7 @@ typedef struct gr_parking_lot {
 } gr_parking_lot;
 size_t gr_parking_lot_bytes(int slots, int groups, size_t* words_bytes);
 /* 1 when the program's argument string (or GR_EXTRA_FLAGS) carried -DGR_PARKING: it has the gr_trace_fused_parking kernel.  A build option,
- * like -DGR_TILE_SHADING: measured on MI355X the kernel does not pay, and every program would carry its compile time. */
+ * like -DGR_TILE_SHADING: measured on MI355X the kernel does not pay (EXPERIMENTS.md C.2), and every program would carry its compile time. */
 int gr_program_has_parking(const gr_program* p);
 typedef struct gr_trace_fused_args {
     const void* camera_generic;
@@ -306,7 +306,7 @@ const char* gr_program_build_key(const gr_program* p);
  * waves hold one ray per lane; whenever fewer than keep_lanes (1..64) of a wave's rays are still integrating, the finished
  * ones are written out and the idle lanes draw new pixels from a device-side counter.  Every ray is integrated exactly as
  * in gr_trace_fused (results agree to rounding); it can only pay when neighbouring rays need very different numbers of
- * steps - not the case for the BASELINE workloads, where 8x8 tiles keep >= 94 % of the lanes busy. */
+ * steps - not the case for the BASELINE workloads, where 8x8 tiles keep >= 94 % of the lanes busy (EXPERIMENTS.md C.2). */
 int gr_trace_compact(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat,
                      void* render_data, int width, int height, int block_rows, int strip_rank, int strip_count,
                      const void* termination_buffer, int prepass_width, int prepass_height,

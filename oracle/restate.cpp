@@ -16,7 +16,7 @@
 // depends on un-vendored submodules) and the OpenCL built-in library oracle/ref_shim.cpp.  A build
 // with stand-ins pins nothing by the rules of this exercise.  What backs the fixtures beyond that:
 // tests/test_oracle.py compiles the same cl.cl with macro strings derived independently by sympy
-// (tools/sympy_macros.py) and requires the same frames; DESIGN.md section 6.
+// (tools/sympy_macros.py) and requires the same frames; EXPERIMENTS.md C.4.
 //
 // Exports the same ref_* driver functions as oracle/ref_shim.cpp, so oracle/refpipe.py drives both.
 #include <cmath>

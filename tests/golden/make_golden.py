@@ -198,7 +198,7 @@ POLAR_CASES = {
                                     features=dict(universe_size=30.0)),
 }
 
-# The frames of the round-3 soaks that were outside the tolerance WITHOUT being ill-conditioned in the reference (profiles/
+# The frames of the round-3 soaks that were outside the tolerance WITHOUT being ill-conditioned in the reference (EXPERIMENTS.md C.4; profiles/
 # r03_fuzz_parity_prepass_seed61.txt, r03_fuzz_parity_adaptive_prepass_seed51.txt, r03_fuzz_parity_seed44.txt): inputs as the soak
 # drew them (frame and sky sizes of the soak mode they came from), expected output from the reference's cl.cl.  tests/golden/soak/.
 SOAK_CASES = {

@@ -1,6 +1,6 @@
 """GPU parity tests (-m gpu): the frames of the round-3 randomised soaks that were outside the end-to-end tolerance without being
 ill-conditioned in the reference (tests/golden/soak/, inputs as the soak drew them, expected output from the reference's cl.cl;
-DESIGN.md section 6).  Round 3 left them ungated; what they were and what became of them:
+EXPERIMENTS.md C.4).  Round 3 left them ungated; what they were and what became of them:
 
   minkowski_off_axis_44_171(+_prepass)  flat space, camera 0.9 degrees off the polar axis of its chart: masked RMSE 1.2e-4 / 1.9e-4.
       Owner: the camera's TETRAD (every later stage agrees with the reference to 3e-6 when fed the reference's tetrad) -
