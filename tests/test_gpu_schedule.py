@@ -690,3 +690,35 @@ def test_scheduled_reference_trace_writes_the_records_of_the_reference_launch():
     dearest_first = traced(lambda r: check(lib.gr_do_generic_rays_scheduled(prog.handle, None, r.ptr, count.ptr, tiles_x * tiles_y, b(gra.BUF_CFG),
                                                                            b(gra.BUF_DFG), None, order.ptr, None)))
     assert dearest_first.tobytes() == plain.tobytes()
+
+
+def test_a_guessed_next_camera_changes_no_pixel_and_is_used_only_when_it_was_right():
+    """gr_frame_tuning.guess_still_camera (round 6): a frame that repeats the previous frame's camera takes "the same again" as the next
+    camera - its prepass runs on the side stream during this frame's trace - and the next frame uses it only if its own key (camera,
+    parameters, features, program) matches bit for bit.  Frames with the guess on are the frames of a state that never guesses; a hit shows as
+    a frame without a prepass stage of its own, a miss (the camera moved) traces its prepass as before."""
+    w, h = 1280, 720
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv = metric.cfg_values(a=0.45)
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    dbg, levels = background()
+    still, moved = gra.default_camera(), gra.default_camera([0, 0.2, -4.3, 0.1])
+    cameras = [still, still, still, still, moved, moved, moved, still]
+    frames, prepass_ms = {}, {}
+    for guess in (0, 1):
+        state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+        frames[guess], prepass_ms[guess] = [], []
+        for cam in cameras:
+            state.render(prog, metric, cam, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv,
+                         gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1, inline_prepass=0, time_kernels=1, guess_still_camera=guess))
+            state.synchronize()
+            frames[guess].append(out.to_numpy(np.float32, (h, w, 4)))
+            prepass_ms[guess].append(state.stage_ms()["prepass"])
+    for a, b in zip(frames[0], frames[1]):
+        assert np.array_equal(a, b)
+    assert (frames[1][0][..., :3].max(axis=2) == 0).mean() > 0.2          # the shadow is there (the prepass verdicts were used)
+    assert all(ms > 0.05 for ms in prepass_ms[0])                          # never guessing: every frame runs its own prepass (a launch of its own here)
+    hit = [ms == 0.0 for ms in prepass_ms[1]]
+    # frame 0: no previous frame; 1: repeats 0 -> guesses; 2, 3: hits; 4: the camera moved -> miss; 5: repeats 4 -> guesses; 6: hit; 7: moved back -> miss
+    assert hit == [False, False, True, True, False, False, True, False], prepass_ms[1]
