@@ -3,6 +3,13 @@
 The library is the product: metric code generator (host C++), hiprtc-specialised gfx950 kernels and
 the frame driver.  This module only binds it for tests, bench.py and scripting; it contains no
 compute path of its own and raises immediately if the shared library is missing.
+
+Import order in a process that also uses torch's CUDA side: `import torch` FIRST (bench.py, smoke() and the CLI do).  PyTorch's wheel
+bundles its own libamdhip64.so and asks the loader for it by a name that does not match the soname of the copy this library pulls in
+from /opt/rocm/lib; imported second, this library shares torch's copy (it asks by soname), imported first, the process ends up with two
+HIP runtimes and the one that touches the device second finds none.  (Preloading torch's copy from here was tried in round 6 and
+withdrawn: it drags torch's older libamd_comgr in with it, which cannot build these kernels through the hiprtc fallback.)  A process
+that never calls torch.cuda.* - the test suite - may import in any order.
 """
 import ctypes
 import os
