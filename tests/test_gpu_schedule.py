@@ -720,5 +720,7 @@ def test_a_guessed_next_camera_changes_no_pixel_and_is_used_only_when_it_was_rig
     assert (frames[1][0][..., :3].max(axis=2) == 0).mean() > 0.2          # the shadow is there (the prepass verdicts were used)
     assert all(ms > 0.05 for ms in prepass_ms[0])                          # never guessing: every frame runs its own prepass (a launch of its own here)
     hit = [ms == 0.0 for ms in prepass_ms[1]]
-    # frame 0: no previous frame; 1: repeats 0 -> guesses; 2, 3: hits; 4: the camera moved -> miss; 5: repeats 4 -> guesses; 6: hit; 7: moved back -> miss
-    assert hit == [False, False, True, True, False, False, True, False], prepass_ms[1]
+    # frame 0: no previous frame; 1: repeats 0 -> guesses; 2, 3: hits; 4: the camera moved -> miss; 5: repeats 4 -> guesses; 6: hit;
+    # 7: back to the first camera - the prepass frame 3 guessed for a frame 4 that never came is still in its slot, and its key (camera,
+    # parameters, features, program) is this frame's bit for bit: a hit, and a right one (the pixels above are those of the state that never guesses)
+    assert hit == [False, False, True, True, False, False, True, True], prepass_ms[1]
