@@ -26,6 +26,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -904,6 +905,7 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
         auto state = p->rest;
         const std::string arguments = argument_string;
         background_builds_begin();
+        try {
         p->rest_worker = std::thread([state, arguments]() {
             std::string built;
             const int build_rc = compile_code_object(arguments, built, nullptr, PART_REST);   // compiler only: no device work on this thread
@@ -917,6 +919,13 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
             }
             background_builds_end();
         });
+        } catch (const std::system_error& e) {   // no thread to be had: built here and now, on the caller's thread
+            background_builds_end();
+            const int build_rc = compile_code_object(arguments, state->code, nullptr, PART_REST);
+            state->rc = build_rc;
+            if (build_rc != GR_OK) state->error = g_error;
+            state->done = true;
+        }
     }
     const int huge = 0x7fffffff;
     HIP_CHECK(hipMalloc((void**)&p->tickets, gr_program::TICKET_RING * sizeof(unsigned int)));
