@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+--gpus N means N GPUs however the script is started (plan_launch): under torch.distributed.run it is one rank of N; as a plain command with
+N > 1 it starts its own N ranks and prints rank 0's line (one process driving the N devices over peer copies if the ranks cannot be
+brought up: --launch single-process); on a box with fewer GPUs it exits with code 2 and no line, unless GR_BENCH_ONE_DEVICE=1|rccl|peer
+asks for a rehearsal of the N-GPU code path on one GPU (marked "rehearsal": not a measurement).
+
 One "step" = one complete frame of BASELINE.json configs[2]: Kerr (Boyer-Lindquist, rs=1, a=0.45 i.e.
 a/M=0.9 - SURVEY.md section 8d), 3840x2160, adaptive sampling off (one primary ray per pixel), prepass
 as in the metric's config, all hot-path stages (camera tetrad, prepass, fused init+Verlet+render-data,
