@@ -116,6 +116,15 @@ __device__ __forceinline__ float gr_sincos(float x) { return sin(x) * cos(x); }
 // device-only forms the code generator lowers to (csrc/sym.cpp lower_for_device; GR_DEVICE_ACCEL*): bare v_exp_f32 and v_rsq_f32
 __device__ __forceinline__ float gr_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float gr_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+// ... and its quotients: the device's rendering writes a / b as gr_div(a, b) and 1 / b as gr_rcp(b).  By default they ARE the operator
+// (under the build's relaxed arithmetic: a * v_rcp_f32(b)).  A program whose argument string carries -DGR_REFINED_RECIPROCALS evaluates
+// them inside the Verlet loop as the correctly rounded quotient instead (geodesic_acceleration_with, below): v_rcp_f32 is the correctly
+// rounded reciprocal for 89.3 % of operands and one ulp off for the rest, one Newton step r + r (1 - b r) makes it the correctly rounded one
+// for all of 2^26 random operands, and q + r (a - b q) does the same for the quotient q = a r (71 % -> 100 %; tools/ubench/
+// reciprocal_refinement.hip, profiles/r06_refined_reciprocals.txt) - what the reference's x86 build divides with, for 2 and 5 full-rate
+// instructions instead of the ten of the compiler's IEEE sequence.  v_sqrt_f32 needs nothing: it is correctly rounded on gfx950.
+template <class A, class B> __device__ __forceinline__ auto gr_div(A a, B b) -> decltype(a / b) { return a / b; }
+template <class B> __device__ __forceinline__ auto gr_rcp(B b) -> decltype(1.0f / b) { return 1.0f / b; }
 __device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
 __device__ __forceinline__ float fmod(float x, float y) { return ::fmodf(x, y); }
 __device__ __forceinline__ float fmin(float x, float y) { return __builtin_fminf(x, y); }
@@ -256,6 +265,11 @@ __device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 
     const float iv1 = vel.x; const float iv2 = vel.y; const float iv3 = vel.z; const float iv4 = vel.w;
     (void)iv1; (void)iv2; (void)iv3; (void)iv4;
     GR_ACCEL_TRIG(LIBM)
+#ifdef GR_REFINED_RECIPROCALS
+    auto gr_rcp = [&](float b) -> float { const float r = __builtin_amdgcn_rcpf(b); return __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r); };
+    auto gr_div = [&](float n, float b) -> float { const float r = gr_rcp(b), q = n * r; return __builtin_fmaf(__builtin_fmaf(-b, q, n), r, q); };
+    (void)gr_rcp; (void)gr_div;
+#endif
     float4 a;
 #if defined(GR_DEVICE_ACCEL0) && !defined(GR_NO_DEVICE_LOWERING)
     // the Verlet loop's own form of the same expressions (metric_codegen.cpp: GR_DEVICE_ACCEL*)

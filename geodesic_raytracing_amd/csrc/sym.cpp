@@ -800,8 +800,10 @@ void to_c_negated(E e, const std::unordered_map<E, std::string>* names, std::str
         case NEG: to_c_rec(e->a, names, out, false); break;
         case ADD: out += "("; to_c_negated(e->a, names, out); out += "-"; to_c_rec(e->b, names, out, false); out += ")"; break;
         case SUB: out += "("; to_c_rec(e->b, names, out, false); out += "-"; to_c_rec(e->a, names, out, false); out += ")"; break;
-        case MUL:
-        case DIV: out += "("; to_c_negated(e->a, names, out); out += e->op == MUL ? "*" : "/"; to_c_rec(e->b, names, out, false); out += ")"; break;
+        case MUL: out += "("; to_c_negated(e->a, names, out); out += "*"; to_c_rec(e->b, names, out, false); out += ")"; break;
+        case DIV:   // (the device's rendering: quotients as calls - below)
+            if (e->a->op == CONST && std::fabs(e->a->c) == 1.0) { out += e->a->c > 0 ? "(-gr_rcp(" : "(gr_rcp("; to_c_rec(e->b, names, out, false); out += "))"; break; }
+            out += "gr_div("; to_c_negated(e->a, names, out); out += ","; to_c_rec(e->b, names, out, false); out += ")"; break;
         default: out += "(-"; to_c_rec(e, names, out, false); out += ")"; break;
     }
 }
@@ -816,10 +818,20 @@ void to_c_rec(E e, const std::unordered_map<E, std::string>* names, std::string&
     switch (e->op) {
         case CONST: out += const_to_c(e->c); break;
         case VAR: out += e->name; break;
+        case DIV:
+            // The device's rendering (to_c_negations_pushed: GR_DEVICE_ACCEL*, GR_DEVICE_TEMPORARIES) writes a quotient as gr_div(a, b) and a
+            // reciprocal as gr_rcp(b): kernels/metric.hip makes a / b and 1.0f / b of them - the same instructions as the operator - or,
+            // in a program built with -DGR_REFINED_RECIPROCALS, the correctly rounded quotient from v_rcp_f32 and a Newton step (round 6).
+            // The boundary strings (cl.cl, the oracle) keep the operator.
+            if (g_push_negations) {
+                if (e->a->op == CONST && std::fabs(e->a->c) == 1.0) { out += e->a->c > 0 ? "gr_rcp(" : "(-gr_rcp("; to_c_rec(e->b, names, out, false); out += e->a->c > 0 ? ")" : "))"; break; }
+                out += "gr_div("; to_c_rec(e->a, names, out, false); out += ","; to_c_rec(e->b, names, out, false); out += ")";
+                break;
+            }
+            [[fallthrough]];
         case ADD:
         case SUB:
-        case MUL:
-        case DIV: {
+        case MUL: {
             out += "(";
             to_c_rec(e->a, names, out, false);
             out += e->op == ADD ? "+" : e->op == SUB ? "-" : e->op == MUL ? "*" : "/";

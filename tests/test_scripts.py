@@ -291,6 +291,8 @@ def test_device_lowering_of_the_accelerations_is_the_same_function():
     _FUNCS.setdefault("gr_sin2", lambda x: math.sin(x) ** 2)
     _FUNCS.setdefault("gr_cos2", lambda x: math.cos(x) ** 2)
     _FUNCS.setdefault("gr_sincos", lambda x: math.sin(x) * math.cos(x))
+    _FUNCS.setdefault("gr_div", lambda a, b: a / b)      # round 6: the device's rendering writes its quotients as calls (kernels/metric.hip: the operator, or - a
+    _FUNCS.setdefault("gr_rcp", lambda b: 1.0 / b)       # program built with -DGR_REFINED_RECIPROCALS - the correctly rounded quotient)
     rng = random.Random(5)
     for name, expect in (("alcubierre", dict(exp2=1, rsqrt=1)), ("kerr_schild", dict(rsqrt=1)), ("double_unequal_kerr", dict(rsqrt=1)),
                          ("kerr_boyer", dict(rsqrt=0, products=True)), ("kerr_newman_boyer", dict(rsqrt=0, products=True))):
@@ -300,8 +302,9 @@ def test_device_lowering_of_the_accelerations_is_the_same_function():
         macros = parse_macros(text)
         assert "GR_DEVICE_ACCEL0" in macros and "GR_DEVICE_TEMPORARIES" in macros
         for k in ("GEO_ACCEL0", "GEO_ACCEL1", "GEO_ACCEL2", "GEO_ACCEL3", "TEMPORARIES0"):
-            assert "gr_exp2" not in macros[k] and "gr_rsqrt" not in macros[k]
+            assert "gr_exp2" not in macros[k] and "gr_rsqrt" not in macros[k] and "gr_div" not in macros[k] and "gr_rcp" not in macros[k]
         device = macros["GR_DEVICE_TEMPORARIES"] + "".join(macros["GR_DEVICE_ACCEL%d" % i] for i in range(4))
+        assert "/" not in device and ("gr_div(" in device or "gr_rcp(" in device)   # every quotient of the device's rendering is a call
         if "exp2" in expect:
             assert device.count("gr_exp2(") == expect["exp2"] and "tanh(" not in device
         assert device.count("gr_rsqrt(") >= expect["rsqrt"]
