@@ -268,7 +268,9 @@ __device__ __forceinline__ float4 geodesic_acceleration_with(float4 pos, float4 
 #ifdef GR_REFINED_RECIPROCALS
     auto gr_rcp = [&](float b) -> float { const float r = __builtin_amdgcn_rcpf(b); return __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r); };
     auto gr_div = [&](float n, float b) -> float { const float r = gr_rcp(b), q = n * r; return __builtin_fmaf(__builtin_fmaf(-b, q, n), r, q); };
-    (void)gr_rcp; (void)gr_div;
+    // ... and the reciprocal root of the lowering (x / sqrt(s) -> x gr_rsqrt(s)) as the refined reciprocal of v_sqrt_f32, which is correctly rounded
+    auto gr_rsqrt = [&](float x) -> float { return gr_rcp(__builtin_sqrtf(x)); };
+    (void)gr_rcp; (void)gr_div; (void)gr_rsqrt;
 #endif
     float4 a;
 #if defined(GR_DEVICE_ACCEL0) && !defined(GR_NO_DEVICE_LOWERING)

@@ -106,12 +106,19 @@ def test_near_extreme_double_kerr_with_ieee_divide(mode):
     assert_pixels(NEAR_EXTREME, meta, z, px)
 
 
-@pytest.mark.parametrize("mode", ["fused", "reference"])
-def test_near_extreme_double_kerr_with_refined_reciprocals(mode):
-    """-DGR_REFINED_RECIPROCALS in the argument string (round 6; the middle form VERDICT r05 asked for): the quotients of the Verlet loop's
-    acceleration as the correctly rounded a / b from v_rcp_f32 + a Newton step + a residual correction (kernels/metric.hip: gr_div, gr_rcp;
-    tools/ubench/reciprocal_refinement.hip: exact for all of 2^26 operands) - the division the reference's x86 build does, for five
-    full-rate instructions instead of the compiler's IEEE sequence.  The frame inside the standard tolerance, as with the IEEE build."""
+def test_refined_reciprocals_do_not_bring_the_near_extreme_frame_inside():
+    """-DGR_REFINED_RECIPROCALS (round 6, the middle form VERDICT r05 asked for): the quotients and reciprocal roots of the Verlet loop's
+    acceleration as the correctly rounded a / b - v_rcp_f32 + a Newton step + a residual correction (kernels/metric.hip: gr_div, gr_rcp;
+    tools/ubench/reciprocal_refinement.hip: exact for all of 2^26 operands) - for 12 more full-rate instructions per Kerr attempt (-5.7 % on
+    the headline).  Measured (profiles/r06_refined_reciprocals.txt): the frame goes from 59 to 56 pixels off where the IEEE build has 11 -
+    the acceleration's quotients are not what owns it - so the gate of test_soak_frames_match_reference stays.  What this test holds: the
+    option builds, renders the frame no worse than the default build (within the same gate), and an ordinary fixture inside the standard rule."""
     meta, z = load_golden(NEAR_EXTREME)
-    px, _ = _frame(meta, gra.MODE_FUSED if mode == "fused" else gra.MODE_REFERENCE, substituted=True, extra_arguments=" -DGR_REFINED_RECIPROCALS")
-    assert_pixels(NEAR_EXTREME, meta, z, px)
+    px, _ = _frame(meta, gra.MODE_FUSED, substituted=True, extra_arguments=" -DGR_REFINED_RECIPROCALS")
+    ulp_px, ulp_rmse = one_ulp_sensitivity(meta, z)
+    d = px[..., :3] - z["pixels"][..., :3]
+    bad = ~(np.abs(d).max(axis=2) <= 1e-3)
+    assert float(np.sqrt((d[~bad] ** 2).mean())) <= 2.5 * ulp_rmse and bad.mean() <= 0.0125
+    meta, z = load_golden("kerr_script")
+    px, _ = _frame(meta, gra.MODE_FUSED, substituted=True, extra_arguments=" -DGR_REFINED_RECIPROCALS")
+    assert_pixels("kerr_script", meta, z, px)
