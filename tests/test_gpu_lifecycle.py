@@ -1,0 +1,141 @@
+"""GPU tests (-m gpu) of what a long-running host of this library needs and no parity test looks at: every object of the C ABI gives
+its device memory back when it is destroyed, and a frame loop that keeps creating and dropping programs, render states, split-frame
+participants, camera paths and program managers (the reference's GUI does this on every metric change and window resize,
+main.cpp:1262-1460) neither grows on the device nor on the host.  Device memory is read with hipMemGetInfo of the HIP runtime
+the library itself is linked against."""
+import ctypes
+import gc
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import geodesic_raytracing_amd as gra  # noqa: E402
+from geodesic_raytracing_amd import check, lib  # noqa: E402
+from geodesic_raytracing_amd.pipeline import DeviceBuffer  # noqa: E402
+from test_gpu_fullsize import SCRIPTS, background  # noqa: E402
+
+MiB = 1 << 20
+
+
+def _hip():
+    """the libamdhip64 the library is linked against (already mapped: dlopen returns the same copy)"""
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64" in line and "torch" not in line})
+    assert paths, "the library's HIP runtime is not mapped"
+    return ctypes.CDLL(paths[0])
+
+
+def device_bytes_in_use():
+    hip = _hip()
+    check(lib.gr_device_synchronize(0))
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipSetDevice(0) == 0
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return total.value - free.value
+
+
+def host_rss_bytes():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+
+
+def one_session(size, k):
+    """what a GUI session does between two metric changes: program (code objects from the cache), render state of the window's size,
+    frames on the fused path and through the reference-shaped sequence, an adaptive frame, a frame split over two participants of
+    this process, the camera's own geodesic - then everything dropped"""
+    w, h = size
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv = metric.cfg_values(a=0.45)
+    dbg, levels = background()
+    bg = (dbg.ptr, 1024, 512, levels)
+    out = DeviceBuffer(0, w * h * 16)
+    for adaptive in (0, 1):
+        feats = metric.features(adaptive_sampling=adaptive)
+        prog = gra.Program(metric.argument_string(feats), 0)           # the dynamic program
+        state = gra.RenderState(w, h, 0)
+        for mode in (gra.MODE_FUSED, gra.MODE_REFERENCE):
+            state.render(prog, metric, gra.default_camera(), out.ptr, bg, feats, cfgv, gra.frame_options(mode=mode, use_prepass=1))
+        state.synchronize()
+        del state, prog
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)   # the substituted one
+    frame = out.to_numpy(np.float32, (h, w, 4))
+    assert np.isfinite(frame).all()
+    # a split frame: two participants on this device, peer copies
+    parts = gra.TiledFrame.local([0, 0], w, h, 16)
+    states = [gra.RenderState(w, h, 0) for _ in parts]
+    for r in (0, 1):
+        parts[r].render(states[r], prog, metric, gra.default_camera(), out.ptr, bg, feats, cfgv,
+                        gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1), rotation=k)
+    parts[0].join()
+    check(lib.gr_device_synchronize(0))
+    for p in parts:
+        p.close()
+    del states, parts
+    # the camera's own geodesic
+    path = gra.GeodesicCamera(2048, 0)
+    del path
+    del prog, out, metric
+    gc.collect()
+
+
+def test_objects_give_their_device_memory_back():
+    one_session((320, 180), 0)     # first use: runtime pools, code objects, the background's upload (cached by the test module)
+    one_session((322, 181), 1)
+    before_device, before_host = device_bytes_in_use(), host_rss_bytes()
+    sizes = [(320, 180), (641, 359), (160, 96), (1280, 720), (322, 181)]
+    for k in range(25):
+        one_session(sizes[k % len(sizes)], k)
+    after_device, after_host = device_bytes_in_use(), host_rss_bytes()
+    # a 1280x720 render state alone is > 60 MiB: one leaked object of any kind shows
+    assert after_device - before_device < 4 * MiB, (before_device, after_device)
+    assert after_host - before_host < 64 * MiB, (before_host, after_host)
+
+
+def test_program_managers_come_and_go(tmp_path):
+    """a manager that is closed while its substituted build is still running waits for the worker and frees both programs"""
+    metric = gra.Metric("schwarzschild_adaptive", SCRIPTS)
+    feats = metric.features(adaptive_sampling=0)
+
+    def session(rs, wait):
+        manager = gra.pipeline.ProgramManager(metric, 0, feats, metric.cfg_values(rs=rs))
+        prog = manager.current(wait=wait)
+        state, out = gra.RenderState(256, 144, 0), DeviceBuffer(0, 256 * 144 * 16)
+        dbg, levels = background()
+        state.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, metric.cfg_values(rs=rs),
+                     gra.frame_options(mode=gra.MODE_FUSED))
+        state.synchronize()
+        manager.update(feats, metric.cfg_values(rs=rs + 0.25))   # a build is started and, when wait is False, very likely still running ...
+        del prog
+        manager.close()                                          # ... when the manager goes
+        del state, out
+
+    session(1.0, True)
+    session(1.5, False)
+    gc.collect()
+    before_device, before_host = device_bytes_in_use(), host_rss_bytes()
+    for k in range(6):
+        session(1.0 if k % 2 else 1.5, bool(k % 2))
+    gc.collect()
+    after_device, after_host = device_bytes_in_use(), host_rss_bytes()
+    assert after_device - before_device < 4 * MiB, (before_device, after_device)
+    assert after_host - before_host < 96 * MiB, (before_host, after_host)
+
+
+def test_streams_and_buffers_of_the_abi_are_returned():
+    before = device_bytes_in_use()
+    held = DeviceBuffer(0, 64 * MiB)             # the yardstick itself: an allocation that is held shows in full
+    assert device_bytes_in_use() - before >= 60 * MiB
+    del held
+    assert device_bytes_in_use() - before < 2 * MiB
+    for _ in range(50):
+        stream = ctypes.c_void_p()
+        check(lib.gr_stream_create(0, 1, ctypes.byref(stream)))
+        buf = DeviceBuffer(0, 8 * MiB)
+        check(lib.gr_stream_synchronize(stream))
+        check(lib.gr_stream_destroy(stream))
+        del buf
+    assert device_bytes_in_use() - before < 2 * MiB
