@@ -139,3 +139,60 @@ def test_streams_and_buffers_of_the_abi_are_returned():
         check(lib.gr_stream_destroy(stream))
         del buf
     assert device_bytes_in_use() - before < 2 * MiB
+
+
+def test_host_threads_each_with_a_render_state_share_one_program():
+    """four host threads, each with its own render state, stream and output, all launching from ONE program (and one background) at the same
+    time: every thread's frames are the frames of the same cameras rendered one after the other (the library's per-device and
+    per-state bookkeeping - upload ring, frame-end marks, tile history, the program's lazily loaded second code object - is behind locks)"""
+    import threading
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv = metric.cfg_values(a=0.45)
+    feats = metric.features(adaptive_sampling=0)
+    prog = gra.Program(metric.argument_string(feats, static=True, cfg_values=cfgv), 0)
+    dbg, levels = background()
+    bg = (dbg.ptr, 1024, 512, levels)
+    w, h, frames, threads = 480, 270, 6, 4
+    cameras = [[gra.default_camera([0, 0.05 * t, -4 - 0.1 * k, 0.02 * k]) for k in range(frames)] for t in range(threads)]
+    modes = [gra.MODE_FUSED, gra.MODE_REFERENCE, gra.MODE_FUSED, gra.MODE_REFERENCE]   # the reference-shaped kernels load on first use: two threads race for it
+
+    def run(t, stream, results):
+        state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+        got = []
+        for cam in cameras[t]:
+            state.render(prog, metric, cam, out.ptr, bg, feats, cfgv, gra.frame_options(mode=modes[t], use_prepass=1), stream=stream)
+            if stream is not None:
+                check(lib.gr_stream_synchronize(stream))
+            else:
+                state.synchronize()
+            got.append(out.to_numpy(np.float32, (h, w, 4)).copy())
+        results[t] = got
+
+    concurrent, errors = {}, []
+
+    def guarded(t, stream):
+        try:
+            run(t, stream, concurrent)
+        except Exception as e:   # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    streams = []
+    for t in range(threads):
+        s = ctypes.c_void_p()
+        check(lib.gr_stream_create(0, 0, ctypes.byref(s)))
+        streams.append(s)
+    workers = [threading.Thread(target=guarded, args=(t, streams[t])) for t in range(threads)]
+    for x in workers:
+        x.start()
+    for x in workers:
+        x.join(timeout=120)
+    assert not errors, errors
+    assert sorted(concurrent) == list(range(threads))
+    serial = {}
+    for t in range(threads):
+        run(t, None, serial)
+    for t in range(threads):
+        for k in range(frames):
+            assert np.array_equal(concurrent[t][k], serial[t][k]), (t, k)
+    for s in streams:
+        check(lib.gr_stream_destroy(s))
