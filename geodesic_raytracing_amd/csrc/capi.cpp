@@ -1626,6 +1626,9 @@ int gr_do_generic_rays_scheduled(gr_program* p, void* stream, void* rays, const 
     if (tile_count < 1) return GR_OK;
     long long groups = resident_trace_groups(p, K_DO_RAYS_SCHEDULED, 64);
     if (groups < 0) return (int)-groups;
+    // experiment hook: GR_SCHEDULED_WAVES_PER_SIMD=k launches k persistent waves per SIMD whatever fits (occupancy studies)
+    static const int forced = [] { const char* e = getenv("GR_SCHEDULED_WAVES_PER_SIMD"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 8) ? v : 0; }();
+    if (forced) groups = (long long)p->compute_units * 4 * forced;
     groups = std::max(1LL, std::min(groups, (long long)tile_count));
     unsigned int* tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
     HIP_CHECK(hipSetDevice(p->device));

@@ -184,6 +184,13 @@ float4 o_read_imagef(ref_image* im, void*, float4 c) {
     if (i1 > im->width - 1) i1 -= im->width;
     if (j0 < 0) j0 += im->height;
     if (j1 > im->height - 1) j1 -= im->height;
+    // an image read is memory-safe whatever the coordinates (the spec guarantees that much and leaves the value open): a NaN or infinite
+    // coordinate - a ray that ended in a coordinate singularity with terminated = 1 - converts to INT_MIN on x86; any texel will do, the
+    // weights below are NaN then and so is the result (tests/fuzz_refscripts.py: kerr_rational_polynomial)
+    i0 = i0 < 0 ? 0 : (i0 > im->width - 1 ? im->width - 1 : i0);
+    i1 = i1 < 0 ? 0 : (i1 > im->width - 1 ? im->width - 1 : i1);
+    j0 = j0 < 0 ? 0 : (j0 > im->height - 1 ? im->height - 1 : j0);
+    j1 = j1 < 0 ? 0 : (j1 > im->height - 1 ? im->height - 1 : j1);
     float a = (u - 0.5f) - floorf(u - 0.5f);
     float b = (v - 0.5f) - floorf(v - 0.5f);
     return (1 - a) * (1 - b) * texel(im, i0, j0, layer) + a * (1 - b) * texel(im, i1, j0, layer) +

@@ -853,6 +853,11 @@ void sample(const image& im, float s, float t, float layer_f, float out[4]) {
     if (i1 > im.width - 1) i1 -= im.width;
     if (j0 < 0) j0 += im.height;
     if (j1 > im.height - 1) j1 -= im.height;
+    // memory-safe whatever the coordinates, as an image read is (a NaN coordinate converts to INT_MIN here; the weights are NaN then)
+    i0 = i0 < 0 ? 0 : (i0 > im.width - 1 ? im.width - 1 : i0);
+    i1 = i1 < 0 ? 0 : (i1 > im.width - 1 ? im.width - 1 : i1);
+    j0 = j0 < 0 ? 0 : (j0 > im.height - 1 ? im.height - 1 : j0);
+    j1 = j1 < 0 ? 0 : (j1 > im.height - 1 ? im.height - 1 : j1);
     float a = (u - 0.5f) - std::floor(u - 0.5f), b = (v - 0.5f) - std::floor(v - 0.5f);
     float t00[4], t10[4], t01[4], t11[4];
     texel(im, i0, j0, layer, t00); texel(im, i1, j0, layer, t10); texel(im, i0, j1, layer, t01); texel(im, i1, j1, layer, t11);
