@@ -13,7 +13,8 @@ tests/golden/refscripts/ hold the other twenty-two at one pose each.  Test infra
         GPU box: one line per case, a summary; exit status 1 if a case is outside the end-to-end tolerance of the parity tests and
         is not ill-conditioned by the rule of tests/fuzz_parity.py (the reference's x86 build against the restatement and against a
         float64 evaluation of the same rays differ in as many places)
-FUZZ_MODE=reference: the reference-shaped kernel sequence instead of the fused kernels."""
+FUZZ_MODE=reference: the reference-shaped kernel sequence instead of the fused kernels.  FUZZ_ADAPTIVE=1 (both modes): adaptive sampling on
+in every case (the reference GUI's default), threshold 16 / 32 / 64; FUZZ_PREPASS=1: the low-resolution prepass on, frames of 128 x 72."""
 import ctypes
 import json
 import os
@@ -31,16 +32,19 @@ from oracle.refpipe import OraclePipeline, pack_features  # noqa: E402
 from fuzz_parity import quat_from_axis_angle, quat_mul  # noqa: E402
 
 REFERENCE_SCRIPTS = "/root/reference/scripts"
-W, H = 64, 36
+ADAPTIVE = os.environ.get("FUZZ_ADAPTIVE", "0") not in ("", "0")
+PREPASS = os.environ.get("FUZZ_PREPASS", "0") not in ("", "0")
+W, H = (128, 72) if PREPASS else (64, 36)
 
 
 def manifest_path(seed):
-    return os.path.join(ROOT, "tools", "_manifests", f"fuzz_refscripts_{seed}.json")
+    return os.path.join(ROOT, "tools", "_manifests", f"fuzz_refscripts_{seed}{'_adaptive' if ADAPTIVE else ''}.json")
 
 
 def draw(per_script, seed, names):
     import glob
     rng = np.random.default_rng(seed)
+    thresholds = np.random.default_rng(seed + 1000003)   # (a stream of its own: a seed names the same cameras with and without)
     out = {"scripts": {}, "cases": []}
     scripts = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(REFERENCE_SCRIPTS, "*.js")))
     for name in scripts:
@@ -63,6 +67,8 @@ def draw(per_script, seed, names):
                        min_step=float(rng.choice([1e-6, 1e-6, 1e-3])))
             if fkw["redshift"]:
                 fkw["use_old_redshift"] = int(rng.random() < 0.5)
+            if ADAPTIVE:
+                fkw.update(adaptive_sampling=1, adaptive_sampling_threshold=float(thresholds.choice([16.0, 32.0, 64.0])))
             sub = m.argument_string(features=gra.default_features(**fkw), static=True, cfg_values=cfg)
             out["cases"].append({"script": name, "k": k, "cfg": cfg, "pos": pos, "quat": [float(q) for q in quat], "speed": speed, "features": fkw,
                                  "r": r, "max_probes": int(rng.choice([1, 4, 8, 8, 16])), "substituted": sub})
@@ -103,8 +109,9 @@ def main():
         return 0
     man = json.load(open(manifest_path(seed)))
     names = set(rest)
-    bg_np, levels = gra.pack_background(gra.synthetic_background(256, 128))
-    bg2_np, _ = gra.pack_background(gra.synthetic_background(256, 128, seed=0x2B5EED))
+    sky_size = (512, 256) if PREPASS else (256, 128)   # four sky texels to a pixel either way (tests/fuzz_parity.py)
+    bg_np, levels = gra.pack_background(gra.synthetic_background(*sky_size))
+    bg2_np, _ = gra.pack_background(gra.synthetic_background(*sky_size, seed=0x2B5EED))
     bg, bg2 = DeviceBuffer.from_numpy(0, bg_np), DeviceBuffer.from_numpy(0, bg2_np)
     out = DeviceBuffer(0, W * H * 16)
     state = gra.RenderState(W, H, 0)
@@ -127,7 +134,7 @@ def main():
         metric, fkw, cfg = metrics[name], c["features"], c["cfg"]
         feats = gra.default_features(**fkw)
         frame_args = dict(camera_pos=c["pos"], camera_quat=c["quat"], basis_speed=c["speed"], background=(bg_np, bg2_np, levels), nthreads=threads,
-                          use_prepass=False, max_probes=c["max_probes"])
+                          use_prepass=PREPASS, max_probes=c["max_probes"])
         ref = references[name].frame(W, H, cfg, pack_features(**fkw), **frame_args)
         cam = gra.default_camera(c["pos"], c["quat"])
         cam.basis_speed = (gra.c_float * 3)(*c["speed"])
@@ -135,7 +142,7 @@ def main():
         line = (f"{name:34s} {c['k']} r={c['r']:5.2f} speed={int(any(c['speed']))} redshift={fkw['redshift']}{'o' if fkw.get('use_old_redshift') else ' '} "
                 f"reparam={fkw['reparameterisation']} min_step={fkw['min_step']:.0e} probes={c['max_probes']:2d} lit {lit:4.2f}")
         for label, prog in (("dyn", dynamic_programs[name]), ("sub", gra.Program(c["substituted"], 0))):
-            o = gra.frame_options(mode=gra.MODE_REFERENCE if os.environ.get("FUZZ_MODE") == "reference" else gra.MODE_FUSED, use_prepass=0,
+            o = gra.frame_options(mode=gra.MODE_REFERENCE if os.environ.get("FUZZ_MODE") == "reference" else gra.MODE_FUSED, use_prepass=1 if PREPASS else 0,
                                   count_attempts=1, max_probes=c["max_probes"])
             state.render(prog, metric, cam, out.ptr, ((bg.ptr, bg2.ptr), bg_np.shape[2], bg_np.shape[1], levels), feats, cfg, o)
             state.synchronize()
