@@ -478,7 +478,8 @@ def main():
     # 0.93 -> 0.87 ms at 8 ranks, 1.56 -> 1.47 at 4, 2.91 -> 2.79 at 2 (half the halo rows, a third of the redundant prepass
     # cells); the coarser deal is evened out by the rotation of the strips over the frames
     plan = grd.StripPlan(H, world, block_rows=args.block_rows)
-    in_flight = max(1, min(args.frames_in_flight, 8)) if fused else 1
+    # (the reference-shaped sequence is timed one frame at a time unless asked: GR_BENCH_REFERENCE_IN_FLIGHT=1 keeps --frames-in-flight render states busy with it too)
+    in_flight = max(1, min(args.frames_in_flight, 8)) if (fused or os.environ.get("GR_BENCH_REFERENCE_IN_FLIGHT", "0") not in ("", "0")) else 1
     # with frames in flight a trace launch takes 4 of the SIMDs' wave slots instead of all (6 for the Kerr kernel): the launches
     # then share the device and one drains while the next is in full swing (measured +2-3 %; one frame at a time: all slots).
     # A rank's share of a frame split 4 or 8 ways is so few tiles that 2 slots are best (tools/strip_probe.py, one of 8 ranks:
@@ -586,7 +587,7 @@ def main():
     lookahead = ctypes.pointer(camera) if (fused and not args.no_lookahead) else None
     depth = 0 if lookahead is None else (args.lookahead_depth if args.lookahead_depth in (1, 2) else (2 if world > 1 else 1))
 
-    def frame(prog=None, cfgv=None, transfer=True, feats=None, use_prepass=None):
+    def frame(prog=None, cfgv=None, transfer=True, feats=None, use_prepass=None, reference_shaped=False):
         prog = program if prog is None else prog
         cfgv = cfg_values if cfgv is None else cfgv
         features = feats if feats is not None else globals_features[0]
@@ -594,7 +595,7 @@ def main():
         frame_index[0] += 1
         with torch.cuda.stream(slot.stream):
             if not multi:
-                opts = gra.frame_options(mode=gra.MODE_FUSED if fused else gra.MODE_REFERENCE, tiled=1, time_kernels=2)
+                opts = gra.frame_options(mode=gra.MODE_FUSED if (fused and not reference_shaped) else gra.MODE_REFERENCE, tiled=1, time_kernels=2)
                 target = slot.out.data_ptr()
             else:
                 # this rank's row blocks (block-cyclic) -> compact strip buffer -> ONE gather to rank 0 + local un-permute.  The
@@ -614,7 +615,7 @@ def main():
             opts.inline_prepass = args.inline_prepass
             if args.no_lookahead:
                 opts.guess_still_camera = 0
-            if lookahead is not None:
+            if lookahead is not None and not reference_shaped:
                 opts.next_camera = lookahead
                 if depth == 2:
                     opts.next_camera2 = lookahead
@@ -928,6 +929,16 @@ def main():
             secondary["reference_kernel_sequence"] = {"dynamic_program": reference_sequence(manager.dynamic, t)}
             t = timed(camera, features, cfg_values, program, gra.MODE_REFERENCE)
             secondary["reference_kernel_sequence"]["substituted_program"] = reference_sequence(program, t)
+            if not multi and in_flight > 1:
+                # ... and the way the reference's main loop would run it: a ring of render states (main.cpp:1463-1469), here the headline's
+                # ring - each frame's fourteen launches on its state's stream, the next frame's filling their gaps (one frame at a time
+                # the device clocks down between them: 2.10 against 2.23 GHz, EXPERIMENTS.md round 6)
+                t, reps = steady(lambda: frame(program, cfg_values, reference_shaped=True), barrier, warm=in_flight + 1)
+                secondary["reference_kernel_sequence"]["substituted_program"]["frames_in_flight"] = {
+                    "render_states": in_flight, "ms_per_frame": round(t * 1e3, 3), "fps": round(1 / t, 1), "Mrays_per_s": round(W * H / t / 1e6, 1),
+                    "ms_per_frame_repeats": reps}
+                for slot in ring:
+                    slot.state.trace_log(reset=True)
             # the reference's own speed-up on the fused path with its substituted program: a quarter of the primary rays, the blocks
             # that need it refined (cl.cl:5223-5345), one frame at a time
             fa = metric.features(adaptive_sampling=1, adaptive_sampling_threshold=32.0)
