@@ -5,7 +5,7 @@
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CACHE = os.path.join(ROOT, "tools", "_variants", "cache")
-VARIANTS = [0, 4, 6, 8, 10, 12, 16, 24, 32]
+VARIANTS = [4, 5, 6, 7, 8, 9, 10, 12, 16]
 
 
 def env_of(limit):
