@@ -121,6 +121,7 @@ class Transport(ctypes.Structure):
 
 
 MODE_REFERENCE, MODE_FUSED = 0, 1
+EVAL_METRIC_TENSOR, EVAL_METRIC_DERIVATIVES, EVAL_ACCELERATION, EVAL_TO_POLAR, EVAL_FROM_POLAR, EVAL_ORIGIN_DISTANCE = range(6)
 (STAGE_CAMERA, STAGE_PREPASS, STAGE_INIT, STAGE_TRACE, STAGE_RENDER_DATA, STAGE_ADAPTIVE, STAGE_RENDER) = range(7)
 STAGE_NAMES = ["camera", "prepass", "init", "trace", "render_data", "adaptive", "render"]
 (BUF_RAYS_IN, BUF_RAYS_COUNT, BUF_RENDER_DATA, BUF_TERMINATION, BUF_CAMERA_GENERIC, BUF_TETRAD0, BUF_TETRAD1, BUF_TETRAD2,
@@ -141,6 +142,9 @@ _SIGNATURES = {
                                           c_char_p, c_size_t, ctypes.POINTER(c_size_t)]),
     "gr_metric_substituted_op_counts": (c_int, [c_void_p, ctypes.POINTER(c_float), c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                                 ctypes.POINTER(c_int)]),
+    "gr_metric_evaluate_count": (c_int, [c_int]),
+    "gr_metric_evaluate": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_float), c_int,
+                                   ctypes.POINTER(ctypes.c_double), c_int]),
     "gr_program_create": (c_int, [c_char_p, c_int, ctypes.POINTER(c_void_p)]),
     "gr_program_complete": (c_int, [c_void_p]),
     "gr_program_precompile_frame_path": (c_int, [c_char_p]),

@@ -744,6 +744,67 @@ int gr_metric_argument_string(const gr_metric* m, const gr_features* features, i
     GR_TRY_END
 }
 
+int gr_metric_evaluate_count(int what) {
+    switch (what) {
+        case GR_EVAL_METRIC_TENSOR: return 16;
+        case GR_EVAL_METRIC_DERIVATIVES: return 64;
+        case GR_EVAL_ACCELERATION: case GR_EVAL_TO_POLAR: case GR_EVAL_FROM_POLAR: return 4;
+        case GR_EVAL_ORIGIN_DISTANCE: return 1;
+        default: return 0;
+    }
+}
+
+// The host-side evaluator of the generated expressions: sym::eval over the metric's DAGs (the same graphs build_argument_string prints),
+// position / velocity / $cfg bound by name.  One point per call; a graph node is visited once per call (memoised).
+int gr_metric_evaluate(const gr_metric* m, int what, const double position[4], const double velocity[4], const float* cfg_values,
+                       int num_cfg_values, double* out, int out_count) {
+    if (!m || !position || !out) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_metric_evaluate: null argument");
+    if (m->settings_only) return fail(GR_ERROR_INVALID_ARGUMENT, "a metric made by gr_metric_from_info has no expressions to evaluate");
+    const int count = gr_metric_evaluate_count(what);
+    if (count == 0) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_metric_evaluate: unknown kind");
+    if (out_count < count) return fail(GR_ERROR_BUFFER_TOO_SMALL, "gr_metric_evaluate: out_count too small");
+    if (what == GR_EVAL_ACCELERATION && !velocity) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_metric_evaluate: the acceleration needs a velocity");
+    if (cfg_values && num_cfg_values != (int)m->vars.names.size())
+        return fail(GR_ERROR_INVALID_ARGUMENT, "gr_metric_evaluate: num_cfg_values is not the metric's number of $cfg parameters");
+    GR_TRY_BEGIN
+    std::map<std::string, double> env;
+    static const char* const pos_names[4] = {"v1", "v2", "v3", "v4"};
+    static const char* const vel_names[4] = {"iv1", "iv2", "iv3", "iv4"};
+    for (int i = 0; i < 4; i++) {
+        env[pos_names[i]] = position[i];
+        env[vel_names[i]] = velocity ? velocity[i] : 0.0;
+    }
+    for (size_t i = 0; i < m->vars.names.size(); i++)
+        env["cfg->" + m->vars.names[i]] = cfg_values ? (double)cfg_values[i] : (double)m->vars.defaults[i];
+    env["always_lightlike"] = 0.0;
+    const gr::MetricImpl& impl = m->desc.raw;
+    auto eval_all = [&](const std::vector<sym::E>& v, double* dst) { for (size_t i = 0; i < v.size(); i++) dst[i] = sym::eval(v[i], env); };
+    switch (what) {
+        case GR_EVAL_METRIC_TENSOR:
+            for (int i = 0; i < 16; i++) out[i] = 0.0;
+            if (impl.real_eq.size() == 4) { for (int i = 0; i < 4; i++) out[i * 4 + i] = sym::eval(impl.real_eq[(size_t)i], env); }
+            else eval_all(impl.real_eq, out);
+            break;
+        case GR_EVAL_METRIC_DERIVATIVES:
+            for (int i = 0; i < 64; i++) out[i] = 0.0;
+            if (impl.derivatives.size() == 16) { for (int k = 0; k < 4; k++) for (int i = 0; i < 4; i++) out[k * 16 + i * 4 + i] = sym::eval(impl.derivatives[(size_t)(k * 4 + i)], env); }
+            else eval_all(impl.derivatives, out);
+            break;
+        case GR_EVAL_ACCELERATION: eval_all(impl.accel, out); break;
+        case GR_EVAL_TO_POLAR: eval_all(impl.to_polar, out); break;
+        case GR_EVAL_FROM_POLAR: eval_all(impl.from_polar, out); break;
+        case GR_EVAL_ORIGIN_DISTANCE: {   // DISTANCE_FUNC is a function of the POLAR point (kernels/metric.hip distance_to_object): composed with TO_COORDn here
+            double polar[4];
+            eval_all(impl.to_polar, polar);
+            for (int i = 0; i < 4; i++) env[pos_names[i]] = polar[i];
+            out[0] = sym::eval(impl.distance_function, env);
+            break;
+        }
+    }
+    return GR_OK;
+    GR_TRY_END
+}
+
 int gr_metric_substituted_op_counts(const gr_metric* m, const float* cfg_values, int num_cfg_values, int* accel_ops,
                                     int* accel_transcendentals, int* coord_ops) {
     if (!m) return fail(GR_ERROR_INVALID_ARGUMENT, "null metric");

@@ -94,6 +94,18 @@ class Metric:
         check(lib.gr_metric_substituted_op_counts(self.handle, (c_float * len(vals))(*vals), len(vals), ctypes.byref(a), ctypes.byref(t), ctypes.byref(c)))
         return a.value, t.value, c.value
 
+    def evaluate(self, what, position, velocity=None, cfg_values=None):
+        """gr_metric_evaluate: the metric's generated expressions at one point, on the host, in double (numpy array: 16 g_ij row-major,
+        64 d g_ij / d x^k as [k][i][j], 4 accelerations, 4 polar / chart coordinates, or 1 distance)"""
+        from . import lib as _lib
+        n = _lib.gr_metric_evaluate_count(int(what))
+        out = (ctypes.c_double * max(n, 1))()
+        pos = (ctypes.c_double * 4)(*[float(x) for x in position])
+        vel = (ctypes.c_double * 4)(*[float(x) for x in velocity]) if velocity is not None else None
+        vals = (c_float * len(cfg_values))(*cfg_values) if cfg_values is not None else None
+        check(_lib.gr_metric_evaluate(self.handle, int(what), pos, vel, vals, len(cfg_values) if cfg_values is not None else 0, out, n))
+        return np.array(out[:n], dtype=np.float64)
+
     def features(self, **overrides):
         """feature struct with this metric's error tolerance (metric_manager.hpp:50)."""
         return default_features(max_acceleration_change=self.info.max_acceleration_change, **overrides)

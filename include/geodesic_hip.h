@@ -88,6 +88,18 @@ float gr_metric_dynamic_var_default(const gr_metric* m, int index);
 int gr_metric_argument_string(const gr_metric* m, const gr_features* features, int is_static, const float* cfg_values, int
                               num_cfg_values, char* buffer, size_t capacity, size_t* needed);
 
+/* The metric's generated expressions evaluated on the HOST at one point, in double: the symbolic graph the macro strings are printed from,
+ * interpreted - no device, no compiler (BASELINE configs[0], SURVEY.md 7.2c: "CPU evaluator of generated metric code").  For a host that
+ * wants to look at a metric; not a rendering path.  position = chart coordinates (v1..v4), velocity = their d/dlambda (iv1..iv4; NULL
+ * where unused), cfg_values NULL = defaults.  Writes gr_metric_evaluate_count(what) doubles: 16 g_ij row-major | 64 d g_ij / d x^k as
+ * [k][i][j] | 4 accelerations -Gamma^i_jk v^j v^k (GEO_ACCEL0..3) | 4 polar coordinates of the chart point (TO_COORDn) | 4 chart
+ * coordinates of the polar point in `position` (FROM_COORDn) | 1 DISTANCE_FUNC of the chart point. */
+enum { GR_EVAL_METRIC_TENSOR = 0, GR_EVAL_METRIC_DERIVATIVES = 1, GR_EVAL_ACCELERATION = 2, GR_EVAL_TO_POLAR = 3, GR_EVAL_FROM_POLAR = 4,
+       GR_EVAL_ORIGIN_DISTANCE = 5 };
+int gr_metric_evaluate_count(int what);
+int gr_metric_evaluate(const gr_metric* m, int what, const double position[4], const double velocity[4], const float* cfg_values,
+                       int num_cfg_values, double* out, int out_count);
+
 /* ---- device program ------------------------------------------------------------------------- */
 typedef struct gr_program gr_program;
 

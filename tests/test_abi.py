@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     (geodesic_hip_internal.h - fused launchers, schedules, measurement hooks); the contract stays small"""
     contract, internal = declared_symbols(), declared_symbols("geodesic_hip_internal.h")
     assert 40 <= len(contract) <= 80 and not set(contract) & set(internal)
-    assert len(open(os.path.join(ROOT, "include", "geodesic_hip.h")).read().splitlines()) <= 340
+    assert len(open(os.path.join(ROOT, "include", "geodesic_hip.h")).read().splitlines()) <= 350
     for header, names in (("geodesic_hip.h", contract), ("geodesic_hip_internal.h", internal)):
         for n in names:
             assert hasattr(gra.lib, n), f"{n} declared in include/{header} but not exported"

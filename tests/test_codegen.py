@@ -274,3 +274,130 @@ def test_pi_periodic_sincos_products_of_the_verlet_loop():
         assert np.abs(got - want).max() <= 3e-7
     pole = np.abs(xs) < 1e-2
     assert np.max(np.abs((sp * sp).astype(np.float32)[pole] - np.sin(xs[pole]) ** 2) / np.maximum(np.sin(xs[pole]) ** 2, 1e-30)) <= 3e-7
+
+
+# ---- the host-side evaluator of the generated expressions (gr_metric_evaluate; BASELINE configs[0]: "CPU evaluator of generated metric code") ----
+SHIPPED = ["minkowski", "schwarzschild", "schwarzschild_adaptive", "schwarzschild_ingoing_ef", "kerr_boyer", "kerr_newman_boyer", "kerr_schild",
+           "alcubierre", "wormhole", "cosmic_string", "double_unequal_kerr", "time_ripple"]
+SCRIPTS_DIR = __import__("os").path.join(__import__("os").path.dirname(gra.__file__), "scripts")
+
+
+def test_minkowski_through_the_host_evaluator_is_flat():
+    """configs[0]'s known answer from the product's own evaluator: g = diag(-1, 1, 1, 1), no derivative, no acceleration, whatever the state"""
+    m = gra.Metric("minkowski", SCRIPTS_DIR)
+    rng = np.random.RandomState(3)
+    for _ in range(5):
+        pos, vel = rng.uniform(-5, 5, 4), rng.uniform(-2, 2, 4)
+        assert np.array_equal(m.evaluate(gra.EVAL_METRIC_TENSOR, pos).reshape(4, 4), np.diag([-1.0, 1.0, 1.0, 1.0]))
+        assert not m.evaluate(gra.EVAL_METRIC_DERIVATIVES, pos).any()
+        assert not m.evaluate(gra.EVAL_ACCELERATION, pos, vel).any()
+        polar = m.evaluate(gra.EVAL_TO_POLAR, pos)
+        assert polar[1] == pytest.approx(np.linalg.norm(pos[1:]), rel=1e-12)
+        assert np.allclose(m.evaluate(gra.EVAL_FROM_POLAR, polar), pos, atol=1e-12)
+        assert m.evaluate(gra.EVAL_ORIGIN_DISTANCE, pos)[0] == pytest.approx(polar[1], rel=1e-12)
+
+
+@pytest.mark.parametrize("name", SHIPPED)
+def test_host_evaluator_agrees_with_the_macro_strings(name):
+    """gr_metric_evaluate interprets the graphs the macro strings are printed from: the strings, evaluated in float64 by the
+    independent Python evaluator (tests/macro_eval.py), give the same numbers up to their float literals"""
+    m = gra.Metric(name, SCRIPTS_DIR)
+    ms = MacroSet(m.argument_string())
+    cfg = dict(zip(m.dynamic_vars, m.dynamic_defaults))
+    rng = np.random.RandomState(11)
+    for _ in range(3):
+        pos = [float(rng.uniform(-1, 1)), float(rng.uniform(2.5, 6.0)), float(rng.uniform(0.4, 2.7)), float(rng.uniform(-3, 3))]
+        vel = [float(x) for x in rng.uniform(-1, 1, 4)]
+        g = m.evaluate(gra.EVAL_METRIC_TENSOR, pos).reshape(4, 4)
+        want = np.array(ms.metric(pos, cfg))
+        # (the strings carry float literals; double Kerr's pinned constants cancel: 7e-7 on a component of 1e-2 next to one of 8.5)
+        assert np.allclose(g, want, rtol=2e-6, atol=1e-6 * max(1.0, float(np.abs(want).max()))), name
+        assert np.allclose(g, g.T)
+        dg = m.evaluate(gra.EVAL_METRIC_DERIVATIVES, pos).reshape(4, 4, 4)
+        for k in range(4):
+            for i in range(4):
+                for j in range(i, 4):
+                    assert dg[k, i, j] == pytest.approx(ms.partial(pos, k, i, j, cfg), rel=5e-6, abs=2e-6 * max(1.0, float(np.abs(dg).max()))), (name, k, i, j)
+        acc = m.evaluate(gra.EVAL_ACCELERATION, pos, vel)
+        scale = max(1.0, float(np.abs(acc).max()))
+        assert np.allclose(acc, ms.accel(pos, vel, cfg), rtol=2e-5, atol=5e-6 * scale), name
+
+
+@pytest.mark.parametrize("name", SHIPPED)
+def test_host_evaluator_acceleration_is_minus_christoffel_v_v(name):
+    """... and are consistent among themselves in double: d g from central differences of g, and -Gamma v v assembled with numpy from g and
+    d g, against the generator's own derivative and acceleration graphs"""
+    m = gra.Metric(name, SCRIPTS_DIR)
+    rng = np.random.RandomState(5)
+    pos = np.array([0.2, float(rng.uniform(3.0, 6.0)), float(rng.uniform(0.6, 2.4)), 0.7])
+    g = m.evaluate(gra.EVAL_METRIC_TENSOR, pos).reshape(4, 4)
+    dg = m.evaluate(gra.EVAL_METRIC_DERIVATIVES, pos).reshape(4, 4, 4)
+    h = 1e-6
+    for k in range(4):
+        step = np.zeros(4)
+        step[k] = h
+        fd = (m.evaluate(gra.EVAL_METRIC_TENSOR, pos + step) - m.evaluate(gra.EVAL_METRIC_TENSOR, pos - step)).reshape(4, 4) / (2 * h)
+        assert np.allclose(dg[k], fd, rtol=1e-6, atol=1e-7 * max(1.0, float(np.abs(fd).max()))), (name, k)
+    ginv = np.linalg.inv(g)
+    gamma = 0.5 * (np.einsum("im,lmk->ikl", ginv, dg) + np.einsum("im,kml->ikl", ginv, dg) - np.einsum("im,mkl->ikl", ginv, dg))
+    for _ in range(3):
+        v = rng.uniform(-1, 1, 4)
+        want = -np.einsum("ikl,k,l->i", gamma, v, v)
+        got = m.evaluate(gra.EVAL_ACCELERATION, pos, v)
+        if m.info.is_constant_theta:   # the constant-theta kernel's acceleration is the equatorial one: theta' = 0 (metric.hpp:590-607)
+            continue
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-10 * max(1.0, float(np.abs(want).max()))), name
+
+
+def test_host_evaluator_refuses_what_it_cannot_do():
+    m = gra.Metric("kerr_boyer", SCRIPTS_DIR)
+    with pytest.raises(gra.GeodesicError):
+        m.evaluate(gra.EVAL_ACCELERATION, [0, 4, 1, 0])                      # no velocity
+    with pytest.raises(gra.GeodesicError):
+        m.evaluate(gra.EVAL_METRIC_TENSOR, [0, 4, 1, 0], cfg_values=[1.0])  # two parameters, one value
+    with pytest.raises(gra.GeodesicError):
+        m.evaluate(17, [0, 4, 1, 0])
+    info = {f: getattr(m.info, f) for f, _ in m.info._fields_}
+    bare = gra.Metric.from_info("kerr_boyer", info, m.dynamic_vars, m.dynamic_defaults)
+    with pytest.raises(gra.GeodesicError):
+        bare.evaluate(gra.EVAL_METRIC_TENSOR, [0, 4, 1, 0])
+    # parameters enter by value: a = 0 is Schwarzschild
+    g = m.evaluate(gra.EVAL_METRIC_TENSOR, [0, 4.0, 1.0, 0], cfg_values=m.cfg_values(rs=1.0, a=0.0)).reshape(4, 4)
+    assert g[0, 0] == pytest.approx(-(1 - 1 / 4.0), rel=1e-12) and g[0, 3] == 0 and g[1, 1] == pytest.approx(1 / (1 - 1 / 4.0), rel=1e-12)
+
+
+REFERENCE_SCRIPTS = "/root/reference/scripts"
+REFERENCE_NAMES = sorted(f[:-3] for f in __import__("os").listdir(REFERENCE_SCRIPTS) if f.endswith(".js")) if __import__("os").path.isdir(REFERENCE_SCRIPTS) else []
+
+
+@pytest.mark.skipif(not REFERENCE_NAMES, reason="the reference's scripts/ folder is only in the build container")
+@pytest.mark.parametrize("name", REFERENCE_NAMES)
+def test_reference_scripts_acceleration_is_minus_christoffel_v_v_on_the_host(name):
+    """every script of the reference's folder, unmodified, through the front-end and the host evaluator: the generated acceleration is
+    -Gamma v v of the generated metric and its generated derivatives, in double, at a generic point"""
+    m = gra.Metric(name, REFERENCE_SCRIPTS)
+    rng = np.random.RandomState(__import__("zlib").crc32(name.encode()) % (2 ** 31))
+    checked = 0
+    for _ in range(6):
+        pos = np.array([float(rng.uniform(-0.5, 0.5)), float(rng.uniform(3.0, 7.0)), float(rng.uniform(0.7, 2.3)), float(rng.uniform(-1.0, 1.0))])
+        g = m.evaluate(gra.EVAL_METRIC_TENSOR, pos).reshape(4, 4)
+        dg = m.evaluate(gra.EVAL_METRIC_DERIVATIVES, pos).reshape(4, 4, 4)
+        if not (np.isfinite(g).all() and np.isfinite(dg).all()) or abs(np.linalg.det(g)) < 1e-9:
+            continue   # (a chart that does not cover the point)
+        h = 1e-6
+        for k in range(4):
+            step = np.zeros(4)
+            step[k] = h
+            fd = (m.evaluate(gra.EVAL_METRIC_TENSOR, pos + step) - m.evaluate(gra.EVAL_METRIC_TENSOR, pos - step)).reshape(4, 4) / (2 * h)
+            assert np.allclose(dg[k], fd, rtol=2e-6, atol=2e-7 * max(1.0, float(np.abs(fd).max()))), (name, k)
+        if m.info.is_constant_theta:
+            checked += 1
+            continue
+        ginv = np.linalg.inv(g)
+        gamma = 0.5 * (np.einsum("im,lmk->ikl", ginv, dg) + np.einsum("im,kml->ikl", ginv, dg) - np.einsum("im,mkl->ikl", ginv, dg))
+        v = rng.uniform(-1, 1, 4)
+        want = -np.einsum("ikl,k,l->i", gamma, v, v)
+        got = m.evaluate(gra.EVAL_ACCELERATION, pos, v)
+        assert np.allclose(got, want, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(want).max()))), name
+        checked += 1
+    assert checked >= 2, name
