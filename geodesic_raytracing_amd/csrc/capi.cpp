@@ -1245,19 +1245,32 @@ static int launch(gr_program* p, int k, void* stream, unsigned gx, unsigned gy, 
 
 static unsigned blocks(long long n, int b) { return n <= 0 ? 0u : (unsigned)((n + b - 1) / b); }
 
+// A launcher refuses a NULL where its kernel dereferences unconditionally: the reference's clSetKernelArg returns CL_INVALID_MEM_OBJECT
+// for a null buffer, a HIP launch takes it and the device faults (and a device fault ends the process).  cfg / dfg are not checked:
+// a substituted program reads neither.
+static int need(const char* who, std::initializer_list<const void*> buffers) {
+    for (const void* b : buffers)
+        if (!b) return fail(GR_ERROR_INVALID_ARGUMENT, std::string(who) + ": a required buffer is NULL");
+    return GR_OK;
+}
+#define GR_NEED(who, ...) do { int rc_ = need(who, {__VA_ARGS__}); if (rc_ != GR_OK) return rc_; } while (0)
+
 int gr_cart_to_generic(gr_program* p, void* stream, const void* in, void* out, int count, float flip, const void* cfg) {
+    GR_NEED("gr_cart_to_generic", in, out);
     void* args[] = {&in, &out, &count, &flip, &cfg};
     return launch(p, K_CART_TO_GENERIC, stream, blocks(count, 64), 1, 64, 1, args);
 }
 
 int gr_init_basis_vectors(gr_program* p, void* stream, const void* generic_in, int count, const float speed[3],
                           void* e0, void* e1, void* e2, void* e3, const void* cfg) {
+    GR_NEED("gr_init_basis_vectors", generic_in, e0, e1, e2, e3);
     float sx = speed ? speed[0] : 0.f, sy = speed ? speed[1] : 0.f, sz = speed ? speed[2] : 0.f;
     void* args[] = {&generic_in, &count, &sx, &sy, &sz, &e0, &e1, &e2, &e3, &cfg};
     return launch(p, K_INIT_BASIS, stream, blocks(count, 64), 1, 64, 1, args);
 }
 
 int gr_clear_termination_buffer(gr_program* p, void* stream, void* buf, int width, int height) {
+    GR_NEED("gr_clear_termination_buffer", buf);
     void* args[] = {&buf, &width, &height};
     return launch(p, K_CLEAR_TERM, stream, blocks((long long)width * height, 256), 1, 256, 1, args);
 }
@@ -1271,6 +1284,8 @@ int gr_init_rays_generic(gr_program* p, void* stream, const void* camera_generic
                          void* ray_count, int width, int height, const void* termination_buffer, int prepass_width,
                          int prepass_height, int flip, const void* e0, const void* e1, const void* e2, const void* e3,
                          const void* cfg, const void* dfg, int i_am_prepass, int tiled) {
+    GR_NEED("gr_init_rays_generic", camera_generic, camera_quat, rays, ray_count, e0, e1, e2, e3);
+    if (!termination_buffer && prepass_width != width && prepass_height != height) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_init_rays_generic: a prepass grid without its termination buffer");
     long long slots = tiled ? gr_tiled_slot_count(width, height) : (long long)width * height;
     void* args[] = {&camera_generic, &camera_quat, &rays, &ray_count, &width, &height, &termination_buffer,
                     &prepass_width, &prepass_height, &flip, &e0, &e1, &e2, &e3, &cfg, &dfg, &i_am_prepass, &tiled};
@@ -1280,6 +1295,7 @@ int gr_init_rays_generic(gr_program* p, void* stream, const void* camera_generic
 int gr_do_generic_rays(gr_program* p, void* stream, void* rays, const void* ray_count, int num_rays, void* tmin, void* tmax,
                        const void* cfg, const void* dfg, int width, int height, int mouse_x, int mouse_y, void* ray_write,
                        void* ray_write_counts, int max_write, void* attempt_counter) {
+    GR_NEED("gr_do_generic_rays", rays, ray_count);
     void* args[] = {&rays, &ray_count, &tmin, &tmax, &cfg, &dfg, &width, &height, &mouse_x, &mouse_y,
                     &ray_write, &ray_write_counts, &max_write, &attempt_counter};
     return launch(p, K_DO_RAYS, stream, blocks(num_rays, 64), 1, 64, 1, args);
@@ -1287,12 +1303,14 @@ int gr_do_generic_rays(gr_program* p, void* stream, void* rays, const void* ray_
 
 int gr_calculate_singularities(gr_program* p, void* stream, const void* rays, const void* count, int num_rays, void* term,
                                int width, int height) {
+    GR_NEED("gr_calculate_singularities", rays, count, term);
     void* args[] = {&rays, &count, &term, &width, &height};
     return launch(p, K_CALC_SING, stream, blocks(num_rays, 256), 1, 256, 1, args);
 }
 
 int gr_calculate_render_data(gr_program* p, void* stream, const void* rays, const void* ray_count, int num_rays, void* rdata,
                              void* rdata_count, int width, int height, const void* cfg, const void* dfg) {
+    GR_NEED("gr_calculate_render_data", rays, ray_count, rdata, rdata_count);
     void* args[] = {&rays, &ray_count, &rdata, &rdata_count, &width, &height, &cfg, &dfg};
     return launch(p, K_CALC_RDATA, stream, blocks(num_rays, 256), 1, 256, 1, args);
 }
@@ -1301,6 +1319,7 @@ int gr_handle_adaptive_sampling(gr_program* p, void* stream, const void* rays, c
                                 void* rdata_count, void* new_rays, void* new_ray_count, const void* camera_generic,
                                 const void* camera_quat, const void* e0, const void* e1, const void* e2, const void* e3,
                                 int width, int height, const void* cfg, const void* dfg) {
+    GR_NEED("gr_handle_adaptive_sampling", rays, ray_count, rdata, rdata_count, new_rays, new_ray_count, camera_generic, camera_quat, e0, e1, e2, e3);
     void* args[] = {&rays, &ray_count, &rdata, &rdata_count, &new_rays, &new_ray_count, &camera_generic, &camera_quat,
                     &e0, &e1, &e2, &e3, &width, &height, &cfg, &dfg};
     return launch(p, K_ADAPTIVE, stream, blocks(width / 2, 8), blocks(height / 2, 8), 8, 8, args);
@@ -1309,6 +1328,8 @@ int gr_handle_adaptive_sampling(gr_program* p, void* stream, const void* rays, c
 int gr_render(gr_program* p, void* stream, const void* rdata, const void* rdata_count, int num_pixels, void* out,
               const void* bg1, const void* bg2, int bg_width, int bg_height, int bg_levels, int width, int height,
               int max_probes, const void* cfg, const void* dfg) {
+    GR_NEED("gr_render", rdata, rdata_count, out, bg1, bg2);
+    if (bg_width <= 0 || bg_height <= 0 || bg_levels <= 0) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_render: the background's width, height and levels");
     int block_pixels = num_pixels > 0 ? num_pixels : 1, rank = 0, count = 1, compact = 0, seams_only = 0;
     void* args[] = {&rdata, &rdata_count, &out, &bg1, &bg2, &bg_width, &bg_height, &bg_levels, &width, &height,
                     &max_probes, &cfg, &dfg, &num_pixels, &block_pixels, &rank, &count, &compact, &seams_only};

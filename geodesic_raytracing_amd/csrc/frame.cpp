@@ -778,6 +778,11 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                     const gr_features* features_in, const float* cfg_values, int num_cfg_values, const void* bg1,
                     const void* bg2, int bg_width, int bg_height, int bg_levels, void* out, const gr_frame_options* opt_in) {
     if (!s || !p || !m || !camera) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    // a frame that is to be shaded needs both skies and their shape (the texture pass reads them unchecked: a NULL sky is a device fault,
+    // not an error code - tests/test_gpu_lifecycle.py found it); out == NULL stops after the render-data
+    if (out && (!bg1 || !bg2 || bg_width <= 0 || bg_height <= 0 || bg_levels <= 0))
+        return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "gr_render_frame: an output frame needs both background textures and their width, height and levels");
+    if (num_cfg_values < 0 || (num_cfg_values > 0 && !cfg_values)) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "gr_render_frame: cfg_values");
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_CHECK(hipSetDevice(s->device));
     gr_frame_options opt;
