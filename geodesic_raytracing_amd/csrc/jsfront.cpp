@@ -619,9 +619,14 @@ struct Interpreter {
 
     // ---- evaluation ----
 
+    int call_depth = 0;
     Value call(const Value& f, std::vector<Value>& args) {
         if (f.k == V_NATIVE) return (*f.native)(args);
         if (f.k != V_FUNC) fail("call of a non-function");
+        // a script that recurses without end is a script error, not the host's stack (QuickJS: "InternalError: stack overflow"); the
+        // deepest chain in the reference's scripts is 6 calls
+        struct depth_guard { int& d; depth_guard(int& x) : d(x) { d++; } ~depth_guard() { d--; } } guard(call_depth);
+        if (call_depth > 256) fail("script recursion deeper than 256 calls");
         auto env = std::make_shared<Env>();
         env->parent = f.fn->env;
         env->is_function = true;

@@ -808,6 +808,10 @@ void to_c_negated(E e, const std::unordered_map<E, std::string>* names, std::str
     }
 }
 void to_c_rec(E e, const std::unordered_map<E, std::string>* names, std::string& out, bool top) {
+    // A graph prints as a tree: what is shared in it and not named is written out at every use, and a script can share exponentially
+    // (s = s*s + s in a loop of sixty).  The largest string of the reference's scripts is 0.3 MB; a macro beyond 64 MiB is refused
+    // instead of being printed until memory runs out.
+    if (out.size() > ((size_t)64 << 20)) throw std::runtime_error("generated expression larger than 64 MiB (a sub-expression shared exponentially often?)");
     if (names && !top) {
         auto it = names->find(e);
         if (it != names->end()) {

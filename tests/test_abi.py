@@ -367,3 +367,48 @@ def test_picture_motion_estimate():
     d = gra.default_camera()
     d.basis_speed[0] = 0.1
     assert gra.lib.gr_picture_motion(ctypes.byref(a), ctypes.byref(d), fov, W) > 1e8
+
+
+def test_png_reader_refuses_what_is_not_a_png_it_can_read(tmp_path):
+    """files that are missing, empty, something else, cut short, lying about their chunk sizes or their pixels, or in a flavour the reader
+    does not do (16-bit, interlaced), and a caller's buffer that is too small: an error code and a message, no crash, no allocation
+    of what a header claims (graphics_settings.cpp:152-243 trusts SFML with this; a library cannot)"""
+    import struct
+    import zlib
+    lib = gra.lib
+
+    def read(path, capacity=1 << 20):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        buf = (ctypes.c_ubyte * capacity)()
+        return lib.gr_read_png_rgba8(str(path).encode(), ctypes.byref(w), ctypes.byref(h), buf, capacity), w.value, h.value
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    img = np.random.RandomState(0).randint(0, 255, (16, 24, 4), dtype=np.uint8)
+    good = tmp_path / "good.png"
+    assert lib.gr_write_png_rgba8(str(good).encode(), img.ctypes.data_as(ctypes.c_void_p), 24, 16) == 0
+    assert read(good) == (0, 24, 16)
+    assert read(good, 100)[0] == -5                      # GR_ERROR_BUFFER_TOO_SMALL, with the size it needs
+    data = good.read_bytes()
+    sig = b"\x89PNG\r\n\x1a\n"
+
+    def header(w, h, depth=8, interlace=0):
+        return chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, 6, 0, 0, interlace))
+    bad = {
+        "empty": b"", "gif": b"GIF89a" + b"\0" * 100, "header_cut": data[:20], "pixels_cut": data[:len(data) // 2],
+        "a_billion_square": data[:16] + struct.pack(">II", 1 << 30, 1 << 30) + data[24:],
+        "no_pixels": data[:16] + struct.pack(">II", 0, 0) + data[24:],
+        "not_deflate": sig + header(4, 4) + chunk(b"IDAT", b"notzlibdata") + chunk(b"IEND", b""),
+        "fewer_pixels_than_claimed": sig + header(64, 64) + chunk(b"IDAT", zlib.compress(b"\0" * 100)) + chunk(b"IEND", b""),
+        "filter_9": sig + header(2, 2) + chunk(b"IDAT", zlib.compress((bytes([9]) + b"\1" * 8) * 2)) + chunk(b"IEND", b""),
+        "sixteen_bit": sig + header(2, 2, depth=16) + chunk(b"IDAT", zlib.compress((b"\0" + b"\1" * 16) * 2)) + chunk(b"IEND", b""),
+        "interlaced": sig + header(2, 2, interlace=1) + chunk(b"IDAT", zlib.compress((b"\0" + b"\1" * 8) * 2)) + chunk(b"IEND", b""),
+        "chunk_of_two_gigabytes": sig + struct.pack(">I", 0x7FFFFFFF) + b"IHDR" + b"\0" * 13,
+    }
+    for name, content in bad.items():
+        path = tmp_path / (name + ".png")
+        path.write_bytes(content)
+        rc = read(path)[0]
+        assert rc < 0 and lib.gr_last_error(), name
+    assert read(tmp_path / "not_there.png")[0] < 0

@@ -1,6 +1,7 @@
 """CPU tests of the script front-end (geodesic_raytracing_amd/csrc/jsfront.cpp): the repository's own metric scripts,
 drop-in loading of the reference's unmodified scripts folder (build container only), and the mathematics of what
 the scripts generate."""
+import ctypes
 import os
 
 import numpy as np
@@ -320,3 +321,72 @@ def test_device_lowering_of_the_accelerations_is_the_same_function():
             for i in range(4):
                 a, b = original.value("GEO_ACCEL%d" % i, e0), lowered.value("GR_DEVICE_ACCEL%d" % i, e1)
                 assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (name, i, a, b)
+
+
+# ---- scripts and settings that are wrong: an error code and a message, never a crash or a hang (GR_ERROR_SCRIPT = -2) ----
+_GOOD = "function metric(t, r, theta, phi) { return [-1, 1, r*r, r*r*CMath.sin(theta)*CMath.sin(theta)]; }\nmetric\n"
+_BAD_SCRIPTS = {
+    "syntax": ("function metric(t, r, theta, phi) { return [-1, 1, r*r, ; }\nmetric\n", b"unexpected"),
+    "unclosed": ("function metric(t, r, theta, phi) { return [-1, 1, r*r, r*r]\n", b"unterminated"),
+    "no_completion_value": ("function metric(t, r, theta, phi) { return [-1, 1, r*r, r*r]; }\n", b"Expected function"),
+    "returns_a_number": ("function metric(t, r, theta, phi) { return 3; }\nmetric\n", b"Must return array"),
+    "returns_three": ("function metric(t, r, theta, phi) { return [-1, 1, r*r]; }\nmetric\n", b"4 or 16"),
+    "undefined_variable": ("function metric(t, r, theta, phi) { return [-1, 1, q*r, r*r]; }\nmetric\n", b"'q' is not defined"),
+    "undefined_function": ("function metric(t, r, theta, phi) { return [-1, 1, CMath.nope(r), r*r]; }\nmetric\n", b"non-function"),
+    "endless_recursion": ("function f(x) { return f(x+1); }\nfunction metric(t, r, theta, phi) { return [f(0), 1, r*r, r*r]; }\nmetric\n", b"recursion"),
+    "endless_loop": ("function metric(t, r, theta, phi) { for (;;) { } return [-1, 1, r*r, r*r]; }\nmetric\n", b"does not terminate"),
+    "a_string_for_a_component": ("function metric(t, r, theta, phi) { return ['a', 1, r*r, r*r]; }\nmetric\n", b"expected a number"),
+    "a_string_for_a_default": ("$cfg.a.$default = 'x';\nfunction metric(t, r, theta, phi) { return [-1, $cfg.a, r*r, r*r]; }\nmetric\n", b"$default"),
+    "empty_file": ("", b"Expected function"),
+    "not_text": ("\x00\x01\x02\xff\xfe", b"unexpected"),
+}
+
+
+def _scripts_copy(tmp_path, js=_GOOD, settings=None, raw_settings=None):
+    import json
+    import shutil
+    d = tmp_path / "scripts"
+    shutil.copytree(OWN, d)
+    if js is not None:
+        (d / "x.js").write_text(js, encoding="latin-1")
+    if raw_settings is not None:
+        (d / "x.json").write_text(raw_settings)
+    else:
+        (d / "x.json").write_text(json.dumps(settings or {"name": "x", "description": "d", "inherit_settings": "polar_base"}))
+    return str(d).encode()
+
+
+@pytest.mark.parametrize("case", sorted(_BAD_SCRIPTS))
+def test_a_wrong_script_is_an_error_with_a_message(case, tmp_path):
+    js, expected = _BAD_SCRIPTS[case]
+    handle = ctypes.c_void_p()
+    rc = gra.lib.gr_metric_load_script(_scripts_copy(tmp_path, js), b"x", ctypes.byref(handle))
+    assert rc == -2 and expected in gra.lib.gr_last_error(), (rc, gra.lib.gr_last_error())
+
+
+@pytest.mark.parametrize("case,settings,raw,js,expected", [
+    ("missing_script", None, None, None, b"No .js file"),
+    ("truncated_settings", None, '{"name": "x", ', _GOOD, b"x.json"),
+    ("settings_not_an_object", None, "[1, 2, 3]", _GOOD, b"JSON object"),
+    ("inherits_nothing_there", {"name": "x", "description": "d", "inherit_settings": "nope_base"}, None, _GOOD, b"Could not lookup"),
+    ("no_such_coordinate_map", {"name": "x", "description": "d", "inherit_settings": "polar_base", "to_polar": "nope"}, None, _GOOD, b"Could not lookup nope"),
+])
+def test_wrong_settings_are_an_error_with_a_message(case, settings, raw, js, expected, tmp_path):
+    handle = ctypes.c_void_p()
+    rc = gra.lib.gr_metric_load_script(_scripts_copy(tmp_path, js, settings, raw), b"x", ctypes.byref(handle))
+    assert rc == -2 and expected in gra.lib.gr_last_error(), (rc, gra.lib.gr_last_error())
+    assert gra.lib.gr_metric_load_script(b"/nonexistent", b"x", ctypes.byref(handle)) == -2
+
+
+def test_an_expression_shared_exponentially_often_is_refused_not_printed(tmp_path):
+    """s = s*s + s sixty times is sixty nodes of a graph and 3^60 characters of a macro: the string is refused at 64 MiB
+    (the largest of the reference's scripts prints 0.3 MB)"""
+    import time
+    js = "function metric(t, r, theta, phi) { var s = r; for (var i = 0; i < 60; i++) { s = s*s + s; } return [-1, 1, s, r*r]; }\nmetric\n"
+    handle = ctypes.c_void_p()
+    assert gra.lib.gr_metric_load_script(_scripts_copy(tmp_path, js), b"x", ctypes.byref(handle)) == 0
+    need = ctypes.c_size_t()
+    t = time.time()
+    rc = gra.lib.gr_metric_argument_string(handle, None, 0, None, 0, None, 0, ctypes.byref(need))
+    assert rc == -2 and b"64 MiB" in gra.lib.gr_last_error() and time.time() - t < 30
+    gra.lib.gr_metric_destroy(handle)
