@@ -553,6 +553,14 @@ void gr_render_state_destroy(gr_render_state* s) {
     delete s;
 }
 
+// (for csrc/tiled.cpp: a participant checks that the state it is handed is of its frame's size)
+extern "C" int gr_internal_render_state_size(const gr_render_state* s, int* width, int* height) {
+    if (!s) return 0;
+    if (width) *width = s->width;
+    if (height) *height = s->height;
+    return 1;
+}
+
 void* gr_render_state_buffer(gr_render_state* s, int which) {
     if (!s) return nullptr;
     switch (which) {

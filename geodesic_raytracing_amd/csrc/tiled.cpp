@@ -41,6 +41,7 @@
 #include "../../include/geodesic_hip_internal.h"
 
 extern "C" int gr_internal_fail(int code, const char* msg);
+extern "C" int gr_internal_render_state_size(const gr_render_state* s, int* width, int* height);
 struct gr_tiled;
 
 namespace {
@@ -549,6 +550,11 @@ int gr_render_frame_tiled(gr_tiled* t, gr_render_state* s, gr_program* p, const 
                           int bg_width, int bg_height, int bg_levels, void* frame_on_root, const gr_frame_options* options, int rotation) {
     if (!t || !s || !p || !m || !camera) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
     if (t->device < 0) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "this participant was created without a device (schedule tests): nothing to render with");
+    {   // (the staging buffers and the blocks' places in the root's frame are those of the participant's frame size)
+        int sw = 0, sh = 0;
+        gr_internal_render_state_size(s, &sw, &sh);
+        if (sw != t->width || sh != t->height) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "the render state is not of the size the participant was created for");
+    }
     hipStream_t stream = (hipStream_t)stream_v;
     const bool is_root = t->rank == t->root;
     if (is_root && !frame_on_root) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "the root needs the frame buffer");

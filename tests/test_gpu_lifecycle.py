@@ -278,3 +278,56 @@ def test_requests_that_cannot_be_served_are_refused_not_attempted():
     rs.render(prog, metric, gra.default_camera(), out.ptr, (dbg.ptr, 1024, 512, levels), feats, metric.cfg_values(), gra.frame_options(mode=gra.MODE_FUSED))
     rs.synchronize()
     assert np.isfinite(out.to_numpy(np.float32, (32, 32, 4))).all()
+
+
+def test_split_frames_camera_paths_and_managers_refuse_what_does_not_fit():
+    """the rest of the C ABI's objects, asked for things they cannot do: an error code each, and the objects stay usable"""
+    one = ctypes.c_void_p()
+    two = (ctypes.c_void_p * 2)()
+    dev = (ctypes.c_int * 2)(0, 0)
+    bad_dev = (ctypes.c_int * 2)(0, -3)
+    assert lib.gr_tiled_create_local(0, dev, 64, 64, 16, two) < 0
+    assert lib.gr_tiled_create_local(2, None, 64, 64, 16, two) < 0
+    assert lib.gr_tiled_create_local(2, bad_dev, 64, 64, 16, two) < 0
+    assert lib.gr_tiled_create_local(2, dev, 64, 64, 12, two) < 0          # blocks of 8-row tiles
+    assert lib.gr_tiled_create_local(2, dev, 64, 0, 16, two) < 0
+    assert lib.gr_tiled_create_local(2, dev, 64, 33, 16, two) < 0          # the last row must not start a block
+    assert lib.gr_tiled_create(2, 5, 0, None, 64, 64, 16, ctypes.byref(one)) < 0
+    assert lib.gr_tiled_create(2, 0, 0, None, 64, 64, 16, ctypes.byref(one)) < 0   # two ranks, no id to meet by
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    feats, cfgv = metric.features(adaptive_sampling=0), metric.cfg_values(a=0.45)
+    prog = gra.Program(metric.argument_string(feats), 0)
+    dbg, levels = background()
+    bg = (dbg.ptr, 1024, 512, levels)
+    w, h = 128, 64
+    parts = gra.TiledFrame.local([0, 0], w, h, 16)
+    right, wrong = gra.RenderState(w, h, 0), gra.RenderState(w, h + 16, 0)
+    frame = DeviceBuffer(0, w * h * 16)
+    with pytest.raises(gra.GeodesicError, match="size"):
+        parts[1].render(wrong, prog, metric, gra.default_camera(), frame.ptr, bg, feats, cfgv, gra.frame_options(mode=gra.MODE_FUSED))
+    with pytest.raises(gra.GeodesicError):
+        parts[0].render(right, prog, metric, gra.default_camera(), None, bg, feats, cfgv, gra.frame_options(mode=gra.MODE_FUSED))   # the root without its frame
+    # ... and the pair still renders the single-GPU frame
+    states = [right, gra.RenderState(w, h, 0)]
+    for r in (0, 1):
+        parts[r].render(states[r], prog, metric, gra.default_camera(), frame.ptr, bg, feats, cfgv, gra.frame_options(mode=gra.MODE_FUSED))
+    parts[0].join()
+    check(lib.gr_device_synchronize(0))
+    whole = DeviceBuffer(0, w * h * 16)
+    single = gra.RenderState(w, h, 0)
+    single.render(prog, metric, gra.default_camera(), whole.ptr, bg, feats, cfgv, gra.frame_options(mode=gra.MODE_FUSED))
+    single.synchronize()
+    assert np.array_equal(frame.to_numpy(np.float32, (h, w, 4)), whole.to_numpy(np.float32, (h, w, 4)))
+    for p in parts:
+        p.close()
+    # camera paths
+    assert lib.gr_geodesic_camera_create(0, 1, ctypes.byref(one)) < 0
+    assert lib.gr_geodesic_camera_create(0, -5, ctypes.byref(one)) < 0
+    assert lib.gr_geodesic_camera_create(0, 64, None) < 0
+    # program managers
+    assert lib.gr_program_manager_create(None, 0, None, None, 0, ctypes.byref(one)) < 0
+    assert lib.gr_program_manager_create(metric.handle, 0, None, None, 0, None) < 0
+    assert lib.gr_program_manager_update(None, None, None, 0) < 0
+    assert lib.gr_program_manager_current(None, 0, ctypes.byref(one), None) < 0
+    bare = gra.Metric.from_info("kerr_boyer", {f: getattr(metric.info, f) for f, _ in metric.info._fields_}, metric.dynamic_vars, metric.dynamic_defaults)
+    assert lib.gr_program_manager_create(bare.handle, 0, None, None, 0, ctypes.byref(one)) < 0   # nothing to build programs from
