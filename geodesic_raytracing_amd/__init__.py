@@ -55,7 +55,7 @@ class FrameTuning(ctypes.Structure):
     _fields_ = [("ray_compaction", c_int), ("rays_per_lane", c_int), ("fused_shading", c_int), ("inline_prepass", c_int),
                 ("trace_waves_per_simd", c_int), ("tile_history", c_int), ("park_lanes", c_int), ("park_trips", c_int),
                 ("next_strip_rank", c_int), ("next_strip_rank2", c_int),
-                ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float), ("count_attempts", c_int), ("guess_still_camera", c_int)]
+                ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float), ("count_attempts", c_int), ("guess_still_camera", c_int), ("reuse_still_camera", c_int)]
 
 
 class FrameOptions(ctypes.Structure):
@@ -242,6 +242,7 @@ _SIGNATURES = {
     "gr_geodesic_camera_interpolate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, ctypes.POINTER(c_float),
                                                ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
     "gr_geodesic_camera_buffer": (c_void_p, [c_void_p, c_int]),
+    "gr_render_state_prepass_reused": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gr_render_state_prepass_policy": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(c_float)]),
     "gr_render_state_stage_ms": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float)]),
     "gr_render_state_trace_log": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int), c_int]),

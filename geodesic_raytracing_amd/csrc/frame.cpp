@@ -128,6 +128,7 @@ struct gr_render_state {
     gr_camera ref_cost_camera{};
     unsigned long long ref_cost_program = 0;
     unsigned long long history_recorded = 0, history_followed = 0;   // frames (gr_render_state_tile_history)
+    unsigned long long prepass_reused = 0;   // frames that took the previous frame's set-up and prepass (gr_render_state_prepass_reused)
     int history_last_shift[2] = {0, 0};
     size_t ray_capacity = 0;
     hipEvent_t ev_start[GR_STAGE_COUNT] = {};
@@ -173,8 +174,9 @@ struct gr_render_state {
     };
     static const int LOOKAHEAD = 2;
     prefetch_slot pre[LOOKAHEAD];
-    prefetch_key previous_key;          // of the last fused frame with a prepass (gr_frame_tuning.guess_still_camera)
-    bool previous_key_valid = false;
+    prefetch_key previous_key;          // of the last whole fused frame with a prepass, whose camera set-up and prepass verdicts are still
+    bool previous_key_valid = false;    // in the current buffer set (gr_frame_tuning.reuse_still_camera); false once anybody was handed a buffer
+    hipStream_t previous_stream = nullptr;
     // Prepass policy (use_prepass = -2, whole frames on the fused path; opt-in: see the last sentence).  The prepass pays for itself through the pixels it lets the
     // trace skip; where it skips next to nothing (Kerr with a = 0.9 in the script's units: a naked singularity, no shadow - 8.4 ms of
     // single-ray latency in front of every 4K frame, for nothing) it is left out: its flags are copied to the host after a frame
@@ -282,6 +284,12 @@ int gr_render_state_tile_history(gr_render_state* s, unsigned long long* frames_
     if (frames_recorded) *frames_recorded = s->history_recorded;
     if (frames_followed) *frames_followed = s->history_followed;
     if (last_shift) { last_shift[0] = s->history_last_shift[0]; last_shift[1] = s->history_last_shift[1]; }
+    return GR_OK;
+}
+
+int gr_render_state_prepass_reused(gr_render_state* s, unsigned long long* frames) {
+    if (!s || !frames) return gr_internal_fail(GR_ERROR_INVALID_ARGUMENT, "null argument");
+    *frames = s->prepass_reused;
     return GR_OK;
 }
 
@@ -399,6 +407,7 @@ void gr_frame_tuning_default(gr_frame_tuning* t) {
     t->next_geodesic_time2 = 0;
     t->count_attempts = 0;
     t->guess_still_camera = -1;
+    t->reuse_still_camera = -1;
 }
 
 int gr_device_count(int* count) {
@@ -563,6 +572,11 @@ extern "C" int gr_internal_render_state_size(const gr_render_state* s, int* widt
 
 void* gr_render_state_buffer(gr_render_state* s, int which) {
     if (!s) return nullptr;
+    // whoever holds a pointer to the camera set, the prepass verdicts or the parameters may write through it: the next frame does its
+    // own set-up and prepass (reuse_still_camera); ray and render-data records are outputs of every frame
+    if (which != GR_BUF_RAYS_IN && which != GR_BUF_RAYS_COUNT && which != GR_BUF_RENDER_DATA && which != GR_BUF_RAYS_ADAPTIVE &&
+        which != GR_BUF_RAYS_ADAPTIVE_COUNT)
+        s->previous_key_valid = false;
     switch (which) {
         case GR_BUF_RAYS_IN: return s->rays_in;
         case GR_BUF_RAYS_COUNT: return s->rays_count_in;
@@ -909,6 +923,20 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             prefetched = true;
         }
     }
+    // ... or is it the previous frame of this state over again - camera, parameters, features, program, bit for bit, on the same stream
+    // (gr_frame_tuning.reuse_still_camera)?  Camera position, tetrad and the prepass verdicts are functions of exactly those, and they are
+    // where that frame left them: a viewer whose user has stopped moving pays neither again (the reference does, every frame:
+    // main.cpp:2311-2437).  Whole frames with a Cartesian camera whose tiles are not ordered by the prepass rays' costs.
+    static const int tile_order_mode = [] { const char* e = getenv("GR_TILE_ORDER"); return !e ? -1 : e[0] == '0' ? 0 : 1; }();
+    static const int reuse_default = [] { const char* e = getenv("GR_REUSE_STILL_CAMERA"); return !e ? 1 : e[0] != '0'; }();
+    const bool repeats_previous_frame = opt.mode == GR_MODE_FUSED && use_prepass && !opt.geodesic && opt.strip_count <= 1 && s->previous_key_valid &&
+                                        s->previous_key == make_key(camera, opt.geodesic_time, opt.strip_rank);
+    const bool reuse_on = (tune.reuse_still_camera < 0 ? reuse_default : tune.reuse_still_camera) != 0 && tile_order_mode != 1;
+    if (!prefetched && repeats_previous_frame && reuse_on && s->previous_stream == stream) {
+        prefetched = true;
+        s->prepass_reused++;
+    }
+    s->previous_key_valid = false;   // until this frame has left its own set-up and prepass behind
     if (!prefetched) {
         GR_CHECK(s->uploads.copy(s->camera_pos_cart, camera->position, 16, stream));
         GR_CHECK(s->uploads.copy(s->camera_quat, camera->quat, 16, stream));
@@ -969,7 +997,6 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // tiles of the trace, longest first (gr_order_tiles).
         // Default: on a device's share of a split frame (+8 % with three frames in flight, +35 % one frame at a time, one of 8
         // devices), not on a whole frame (there image order measured 2 % faster); GR_TILE_ORDER=0 never, =1 always.
-        static const int tile_order_mode = [] { const char* e = getenv("GR_TILE_ORDER"); return !e ? -1 : e[0] == '0' ? 0 : 1; }();
         // The other source of an order: what the tiles of this state's previous frame cost (gr_order_tiles_by_history).
         static const int history_default = [] { const char* e = getenv("GR_TILE_HISTORY"); return !e ? GR_DEFAULT_TILE_HISTORY : e[0] != '0'; }();
         // Default: whole frames that find the device idle when they are submitted (they record their costs, and follow those of
@@ -1058,10 +1085,11 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             request asked[2] = {{opt.next_camera, tune.next_geodesic_time, tune.next_strip_rank},
                                 {opt.next_camera2, tune.next_geodesic_time2, tune.next_strip_rank2}};
             // nobody announced the next camera, and this frame is the previous one over again: the guess "the same once more"
-            // (gr_frame_tuning.guess_still_camera) - used by the next frame only if its key matches bit for bit
-            static const int guess_default = [] { const char* e = getenv("GR_GUESS_STILL_CAMERA"); return !e ? 1 : e[0] != '0'; }();
-            if (!opt.next_camera && !opt.next_camera2 && !gc && strip_count == 1 && (tune.guess_still_camera < 0 ? guess_default : tune.guess_still_camera) != 0 && s->previous_key_valid &&
-                s->previous_key == make_key(camera, opt.geodesic_time, opt.strip_rank))
+            // (gr_frame_tuning.guess_still_camera, off by default since reuse_still_camera does without the prepass altogether) - used
+            // by the next frame only if its key matches bit for bit
+            static const int guess_default = [] { const char* e = getenv("GR_GUESS_STILL_CAMERA"); return !e ? 0 : e[0] != '0'; }();
+            if (!opt.next_camera && !opt.next_camera2 && !gc && strip_count == 1 && (tune.guess_still_camera < 0 ? guess_default : tune.guess_still_camera) != 0 &&
+                repeats_previous_frame && !reuse_on)
                 asked[0] = {camera, opt.geodesic_time, -1};
             for (auto& r : asked) {
                 if (!r.camera) continue;
@@ -1274,8 +1302,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
             slot->age = s->frame_counter;
             slot->key = make_key(r.camera, r.time, r.strip_rank);
         }
-        s->previous_key_valid = use_prepass;
-        if (use_prepass) s->previous_key = make_key(camera, opt.geodesic_time, opt.strip_rank);
+        s->previous_key_valid = use_prepass && strip_count == 1 && !gc;
+        if (s->previous_key_valid) { s->previous_key = make_key(camera, opt.geodesic_time, opt.strip_rank); s->previous_stream = stream; }
         if (out) {
             GR_CHECK(begin(GR_STAGE_RENDER));
             if (shade_in_trace)

@@ -366,6 +366,12 @@ class RenderState:
         check(lib.gr_render_state_prepass_policy(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(f)))
         return a.value, b.value, f.value
 
+    def prepass_reused(self):
+        """frames that took the previous frame's camera set-up and prepass as they stood (gr_frame_tuning.reuse_still_camera)"""
+        n = ctypes.c_ulonglong()
+        check(lib.gr_render_state_prepass_reused(self.handle, ctypes.byref(n)))
+        return n.value
+
     def tile_history(self):
         """(frames that recorded their tiles' costs, frames that followed the costs of the frame before, the last such frame's shift in tiles)"""
         a, b, shift = ctypes.c_ulonglong(), ctypes.c_ulonglong(), (ctypes.c_int * 2)()

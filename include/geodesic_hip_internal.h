@@ -43,13 +43,20 @@ struct gr_frame_tuning {
     /* -- measurement -- */
     int count_attempts;    /* 1: accumulate the Verlet step attempts of this frame (gr_render_state_attempts) */
     /* -- an interactive caller that does not know the next camera (round 6) -- */
-    int guess_still_camera;   /* fused mode, whole frames with a prepass, no next_camera given: 1 = when this frame's camera (and parameters,
-                            * features, program) equal the previous frame's of this render state, take "the same again" as the next frame's
-                            * camera - its camera set-up and prepass then run on the side stream while this frame traces, exactly as for an
-                            * announced next_camera, and are used only if the next frame's key matches bit for bit (else the frame traces
-                            * its prepass inside its trace launch as before: a wrong guess costs one prepass on a side stream).  A viewer
-                            * whose user has stopped moving renders the same camera again and again; the reference pays the prepass's
-                            * single-ray latency on each of those frames (main.cpp:2384-2437).  0 = never; -1 = library default (on). */
+    int guess_still_camera;   /* fused mode, whole frames with a prepass, no next_camera given: 1 = when this frame repeats the previous frame of
+                            * this render state (as below), take "the same again" as the NEXT frame's camera - its camera set-up and prepass
+                            * then run on the side stream while this frame traces, exactly as for an announced next_camera, and are used only
+                            * if the next frame's key matches bit for bit.  The prepass is still computed every frame (a measurement that must
+                            * not skip it uses this with reuse_still_camera = 0); it has to find wave slots beside a trace launch that fills
+                            * the device, and a long one (Kerr a = 0.9: 8 ms) that loses that race ends up in front of the next frame -
+                            * profiles/r06_still_camera.txt.  0 = never; -1 = library default (off: reuse_still_camera supersedes it). */
+    int reuse_still_camera;   /* fused mode, whole frames with a prepass and a Cartesian camera: 1 = a frame whose camera, parameters, features
+                            * and program equal, bit for bit, those of the previous frame of this render state on the same stream takes that
+                            * frame's camera set-up and prepass verdicts as they stand - both are functions of exactly those inputs and
+                            * still sit in the state's buffers (a pointer to them handed out by gr_render_state_buffer ends that) - and
+                            * launches neither.  A viewer whose user has stopped moving renders the same camera again and again; the
+                            * reference pays the prepass's single-ray latency on each of those frames (main.cpp:2384-2437).  0 = never;
+                            * -1 = library default (on).  gr_render_state_prepass_reused counts the frames that did. */
 };
 void gr_frame_tuning_default(gr_frame_tuning* out);
 
@@ -318,6 +325,8 @@ int gr_trace_compact(gr_program* p, void* stream, const void* camera_generic, co
  * the costs of the frame before, and the shift (in tiles) the last one that did applied.  Any pointer may be NULL. */
 int gr_render_state_tile_history(gr_render_state* s, unsigned long long* frames_recorded, unsigned long long* frames_followed,
                                  int last_shift[2]);
+/* How many frames of this render state took the previous frame's camera set-up and prepass (gr_frame_tuning.reuse_still_camera). */
+int gr_render_state_prepass_reused(gr_render_state* s, unsigned long long* frames);
 /* The two estimates tile_history works with (host arithmetic, no device).  gr_camera_origin_on_screen: the pixel at which the
  * camera sees the coordinate origin as if space were flat - the inverse of the kernels' pixel -> direction map (cl.cl:2015-2059) -
  * 1 and pixel_out[0..1] = (x, y), or 0 when the origin is behind the camera or the camera sits on it.  gr_picture_motion: an upper

@@ -692,6 +692,60 @@ def test_scheduled_reference_trace_writes_the_records_of_the_reference_launch():
     assert dearest_first.tobytes() == plain.tobytes()
 
 
+def test_a_repeated_frame_takes_the_previous_frames_prepass_and_nothing_else_does():
+    """gr_frame_tuning.reuse_still_camera (library default: on): a frame whose camera, parameters, features and program are the previous
+    frame's of this render state, bit for bit, on the same stream, launches neither camera set-up nor prepass - what they would compute is
+    still in the state's buffers.  Every frame is the frame of a state that never reuses; a reuse shows as a frame without a prepass stage
+    and in gr_render_state_prepass_reused.  Anything that could have changed the inputs ends it: another camera, parameter, feature,
+    program or stream, a frame of the reference-shaped path in between, a pointer to the verdicts handed out."""
+    w, h = 1280, 720
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv, other_cfg = metric.cfg_values(a=0.45), metric.cfg_values(a=0.4)
+    feats = metric.features(adaptive_sampling=0)
+    other_feats = metric.features(adaptive_sampling=0, field_of_view=80.0)
+    prog = gra.Program(metric.argument_string(feats, static=False), 0)          # dynamic program: parameters and features are read at run time
+    twin = gra.Program(metric.argument_string(feats, static=False) + " -DGR_TWIN=1", 0)   # the same kernels as another program object
+    dbg, levels = background()
+    still, moved = gra.default_camera(), gra.default_camera([0, 0.2, -4.3, 0.1])
+    side = ctypes.c_void_p()
+    check(lib.gr_stream_create(0, 0, ctypes.byref(side)))
+    # (what the frame is rendered with, whether it may reuse)
+    sequence = [("first", dict(), False), ("again", dict(), True), ("again", dict(), True),
+                ("camera moved", dict(cam=moved), False), ("and stays", dict(cam=moved), True),
+                ("parameter", dict(cam=moved, cfg=other_cfg), False), ("same parameter", dict(cam=moved, cfg=other_cfg), True),
+                ("feature", dict(cam=moved, cfg=other_cfg, feats=other_feats), False), ("same feature", dict(cam=moved, cfg=other_cfg, feats=other_feats), True),
+                ("program", dict(cam=moved, cfg=other_cfg, feats=other_feats, prog=twin), False),
+                ("same program", dict(cam=moved, cfg=other_cfg, feats=other_feats, prog=twin), True),
+                ("other stream", dict(cam=moved, cfg=other_cfg, feats=other_feats, prog=twin, stream=side), False),
+                ("same other stream", dict(cam=moved, cfg=other_cfg, feats=other_feats, prog=twin, stream=side), True),
+                ("back to the first frame's", dict(), False), ("again", dict(), True),
+                ("reference-shaped frame in between", dict(mode=gra.MODE_REFERENCE), False), ("fused after it", dict(), False), ("again", dict(), True),
+                ("pointer handed out", dict(poke=True), False), ("again", dict(), True),
+                ("without a prepass", dict(use_prepass=0), False), ("with one again", dict(), False), ("again", dict(), True)]
+    frames, reused = {}, {}
+    for reuse in (0, 1):
+        state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+        frames[reuse], reused[reuse] = [], []
+        for label, how, _ in sequence:
+            if how.get("poke"):
+                assert state.buffer(gra.BUF_TERMINATION)
+            before = state.prepass_reused()
+            state.render(how.get("prog", prog), metric, how.get("cam", still), out.ptr, (dbg.ptr, 1024, 512, levels), how.get("feats", feats),
+                         how.get("cfg", cfgv), gra.frame_options(mode=how.get("mode", gra.MODE_FUSED), use_prepass=how.get("use_prepass", 1), time_kernels=1,
+                                                                  guess_still_camera=0, reuse_still_camera=reuse), how.get("stream"))
+            state.synchronize()
+            frames[reuse].append(out.to_numpy(np.float32, (h, w, 4)))
+            reused[reuse].append(state.prepass_reused() - before == 1)
+            if reused[reuse][-1]:
+                assert state.stage_ms()["prepass"] == 0.0 and state.stage_ms()["camera"] == 0.0, label
+    for (label, _, _), a, b in zip(sequence, frames[0], frames[1]):
+        assert np.array_equal(a, b), label
+    assert not any(reused[0])
+    assert reused[1] == [may for _, _, may in sequence], [(label, got) for (label, _, _), got in zip(sequence, reused[1])]
+    assert (frames[1][1][..., :3].max(axis=2) == 0).mean() > 0.2          # the shadow is there (the verdicts were used)
+    check(lib.gr_stream_destroy(side))
+
+
 def test_a_guessed_next_camera_changes_no_pixel_and_is_used_only_when_it_was_right():
     """gr_frame_tuning.guess_still_camera (round 6): a frame that repeats the previous frame's camera takes "the same again" as the next
     camera - its prepass runs on the side stream during this frame's trace - and the next frame uses it only if its own key (camera,
@@ -711,7 +765,8 @@ def test_a_guessed_next_camera_changes_no_pixel_and_is_used_only_when_it_was_rig
         frames[guess], prepass_ms[guess] = [], []
         for cam in cameras:
             state.render(prog, metric, cam, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv,
-                         gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1, inline_prepass=0, time_kernels=1, guess_still_camera=guess))
+                         gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1, inline_prepass=0, time_kernels=1, guess_still_camera=guess,
+                                           reuse_still_camera=0))
             state.synchronize()
             frames[guess].append(out.to_numpy(np.float32, (h, w, 4)))
             prepass_ms[guess].append(state.stage_ms()["prepass"])
