@@ -261,7 +261,13 @@ REFSCRIPT_CASES = {
     "janis_newman_winicour": dict(size=(48, 27), features=dict(redshift=1)),
     "krasnikov_cartesian": dict(size=(48, 27), camera_pos=[0.5, 0.2, -3.0, 0.3]),
     "krasnikov_cylindrical": dict(size=(48, 27), camera_pos=[0.5, 0.2, -3.0, 0.3]),
-    "symmetric_warp_drive": dict(size=(48, 27)),
+    "symmetric_warp_drive": dict(size=(48, 27)),   # the default pose and settings: every ray ends non-finite, the frame is black on both sides
+    # ... and as the script's own description says to look at it ("Set the universe size to 100, precision radius to 100, and camera time
+    # to ~100", symmetric_warp_drive.json): every ray reaches the sky; at half that camera time, from further out, a fifth of them does not
+    "symmetric_warp_drive_as_described": dict(metric="symmetric_warp_drive", size=(48, 27), camera_pos=[100.0, 0.5, -8.0, 1.0],
+                                              features=dict(universe_size=100.0, precision_radius=100.0)),
+    "symmetric_warp_drive_earlier": dict(metric="symmetric_warp_drive", size=(48, 27), camera_pos=[50.0, 0.5, -20.0, 1.0],
+                                         features=dict(universe_size=100.0, precision_radius=100.0, redshift=1)),
     "configurable_wormhole": dict(size=(48, 27), camera_pos=[0.0, 0.0, -2.5, 0.3]),
     "ellis_drainhole": dict(size=(48, 27), camera_pos=[0.0, 0.0, -2.5, 0.3], features=dict(redshift=1)),
     "cosmic_string_bh": dict(size=(48, 27), camera_pos=OFF_AXIS),

@@ -116,7 +116,10 @@ SYMPY_CASES = [("schwarzschild", "schwarzschild"), ("schwarzschild", "schwarzsch
                # cylindrical-singularity flags with the terminator from the script's JSON)
                ("ernst", "refscripts/ernst"), ("double_schwarzschild", "refscripts/double_schwarzschild"),
                ("double_kerr", "refscripts/double_kerr"), ("minkowski", "minkowski"), ("minkowski", "minkowski_tilted"),
-               ("double_kerr_alt", "refscripts/double_kerr_alt"), ("symmetric_warp_drive", "refscripts/symmetric_warp_drive")]
+               ("double_kerr_alt", "refscripts/double_kerr_alt"), ("symmetric_warp_drive", "refscripts/symmetric_warp_drive"),
+               # round 6: the same script looked at the way its description says (every ray reaches the sky), and earlier from further out
+               ("symmetric_warp_drive", "refscripts/symmetric_warp_drive_as_described"),
+               ("symmetric_warp_drive", "refscripts/symmetric_warp_drive_earlier")]
 
 
 def sympy_argument_string(metric):
