@@ -746,6 +746,37 @@ def test_a_repeated_frame_takes_the_previous_frames_prepass_and_nothing_else_doe
     check(lib.gr_stream_destroy(side))
 
 
+@pytest.mark.parametrize("name,features,substituted", [("kerr_boyer", dict(adaptive_sampling=1, adaptive_sampling_threshold=32.0), True),
+                                                       ("kerr_boyer", dict(adaptive_sampling=1, adaptive_sampling_threshold=32.0), False),
+                                                       ("kerr_schild", dict(adaptive_sampling=0, redshift=1), False),
+                                                       ("kerr_newman_boyer", dict(adaptive_sampling=0), False)])
+def test_repeated_frames_of_other_programs_and_adaptive_sampling(name, features, substituted):
+    """reuse_still_camera on the other paths a whole fused frame takes: adaptive sampling (the prepass rides in front of the lattice launch,
+    the second launch reads the same verdicts), a Cartesian chart with redshift, a dynamic program with three parameters - four frames of
+    one camera: the last three reuse, and are the frames of a state that never does"""
+    w, h = 640, 384
+    metric = gra.Metric(name, SCRIPTS)
+    assert metric.info.use_prepass == 1
+    cfgv = metric.cfg_values()
+    feats = metric.features(**features)
+    prog = gra.Program(metric.argument_string(feats, static=substituted, cfg_values=cfgv if substituted else None), 0)
+    dbg, levels = background()
+    cam = gra.default_camera([0, 0.3, -5.0, 0.4])
+    frames = {}
+    for reuse in (0, 1):
+        state, out = gra.RenderState(w, h, 0), DeviceBuffer(0, w * h * 16)
+        frames[reuse] = []
+        for _ in range(4):
+            state.render(prog, metric, cam, out.ptr, (dbg.ptr, 1024, 512, levels), feats, cfgv,
+                         gra.frame_options(mode=gra.MODE_FUSED, guess_still_camera=0, reuse_still_camera=reuse))
+            state.synchronize()
+            frames[reuse].append(out.to_numpy(np.float32, (h, w, 4)))
+        assert state.prepass_reused() == (3 if reuse else 0)
+    for a, b in zip(frames[0], frames[1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(frames[1][0], frames[1][3])
+
+
 def test_a_guessed_next_camera_changes_no_pixel_and_is_used_only_when_it_was_right():
     """gr_frame_tuning.guess_still_camera (round 6): a frame that repeats the previous frame's camera takes "the same again" as the next
     camera - its prepass runs on the side stream during this frame's trace - and the next frame uses it only if its own key (camera,
