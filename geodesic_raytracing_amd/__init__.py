@@ -55,7 +55,7 @@ class FrameTuning(ctypes.Structure):
     _fields_ = [("ray_compaction", c_int), ("rays_per_lane", c_int), ("fused_shading", c_int), ("inline_prepass", c_int),
                 ("trace_waves_per_simd", c_int), ("tile_history", c_int), ("park_lanes", c_int), ("park_trips", c_int),
                 ("next_strip_rank", c_int), ("next_strip_rank2", c_int),
-                ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float), ("count_attempts", c_int), ("guess_still_camera", c_int), ("reuse_still_camera", c_int)]
+                ("next_geodesic_time", c_float), ("next_geodesic_time2", c_float), ("count_attempts", c_int), ("guess_still_camera", c_int), ("reuse_still_camera", c_int), ("speculative_classes", c_int)]
 
 
 class FrameOptions(ctypes.Structure):
@@ -109,7 +109,7 @@ class TraceFusedArgs(ctypes.Structure):
                 ("prepass_width", c_int), ("prepass_height", c_int), ("e0", c_void_p), ("e1", c_void_p), ("e2", c_void_p),
                 ("e3", c_void_p), ("cfg", c_void_p), ("dfg", c_void_p), ("attempt_counter", c_void_p), ("tile_order", c_void_p),
                 ("waves_per_simd", c_int), ("shading", TraceShading), ("lattice", c_int), ("pending_only", c_int), ("inline_prepass", c_int),
-                ("tile_cost", c_void_p), ("tile_order_by_history", c_int), ("lattice_rays", c_void_p), ("parking", ParkingLot)]
+                ("tile_cost", c_void_p), ("tile_order_by_history", c_int), ("lattice_rays", c_void_p), ("parking", ParkingLot), ("speculative_classes", c_int)]
 
 
 class Transport(ctypes.Structure):

@@ -44,6 +44,10 @@ int fail(gr_status code, const std::string& msg) {
     return (int)code;
 }
 
+#ifndef GR_DEFAULT_SPECULATIVE_CLASSES
+#define GR_DEFAULT_SPECULATIVE_CLASSES 5   // gr_trace_fused: the list's first classes do not wait for the prepass cells of their own launch
+#endif
+
 #define GR_TRY_BEGIN try {
 #define GR_TRY_END                                                                 \
     }                                                                              \
@@ -576,6 +580,7 @@ struct gr_program {
     std::atomic<unsigned> next_ticket{0};
     int compute_units = 256;
     bool tile_shading = false;   // built with -DGR_TILE_SHADING: gr_trace_fused can shade the inner pixels of its tiles
+    bool cell_rows = false;      // built with -DGR_CELL_BLOCK=0: a cell wave of an in-launch prepass is 64 cells of a row, not 8 x 8 cells
     int resident_groups_per_cu[K_COUNT] = {};   // of the trace kernels at the launch's workgroup size: 0 = not asked yet
     // The kernels a fused frame does not launch (PART_REST) are a code object of their own, loaded when first asked for: from the
     // cache when gr_program_create found it there, else from a build that started on a worker thread when the program was created.
@@ -937,6 +942,7 @@ int gr_program_create(const char* argument_string, int device, gr_program** out)
     {
         const char* extra = getenv("GR_EXTRA_FLAGS");
         p->tile_shading = p->arguments.find("-DGR_TILE_SHADING") != std::string::npos || (extra && strstr(extra, "-DGR_TILE_SHADING"));
+        p->cell_rows = p->arguments.find("-DGR_CELL_BLOCK=0") != std::string::npos || (extra && strstr(extra, "-DGR_CELL_BLOCK=0"));
     }
     static std::atomic<unsigned long long> next_serial{1};
     p->serial = next_serial.fetch_add(1);
@@ -1505,7 +1511,8 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
                         int prepass_height, const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg,
                         const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0, const void* tile_order = nullptr,
                         int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr, int inline_prepass = 0, void* tile_cost = nullptr,
-                        int tile_order_by_history = 0, void* lattice_rays = nullptr, const gr_parking_lot* parking = nullptr) {
+                        int tile_order_by_history = 0, void* lattice_rays = nullptr, const gr_parking_lot* parking = nullptr,
+                        int speculative_classes_in = 0) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
     // the prepass inside the launch: its cell waves are the first tickets (gr_trace_fused's prepass_tickets)
@@ -1515,7 +1522,8 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
             prepass_height <= 0 || prepass_width == width || prepass_height == height)
             return fail(GR_ERROR_INVALID_ARGUMENT, "inline_prepass: gr_trace_fused on every pixel of its rows (or the lattice launch of adaptive sampling), in image order or the order of "
                                                    "gr_order_tiles_by_history (gr_order_tiles' needs the prepass first), with a prepass grid");
-        prepass_tickets = (int)(((long long)prepass_width * prepass_height + 63) / 64);
+        // a cell wave is 8 x 8 cells (trace.hip: GR_CELL_BLOCK; a program built with -DGR_CELL_BLOCK=0 takes 64 cells of a row)
+        prepass_tickets = p->cell_rows ? (int)(((long long)prepass_width * prepass_height + 63) / 64) : ((prepass_width + 7) / 8) * ((prepass_height + 7) / 8);
     }
     if ((lattice != 1 && lattice != 2) || ((lattice == 2 || pending_only) && rays_per_lane != 1))
         return fail(GR_ERROR_INVALID_ARGUMENT, "lattice / pending_only: gr_trace_fused only");
@@ -1611,7 +1619,12 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     // (gr_order_tiles_by_history) is written into the list by the launch that made it, and the kernel reads it there; the caller's
     // flag only says which he thinks it is, for the checks above.
     int last_class_is_skipped = 0;   // (kept in the kernel's parameter list: 1 would force the promise, nothing passes it)
-    (void)tile_order_by_history;
+    // ... its upper bits: how many of the list's classes, dearest first, do not wait for the prepass cells they look at when those are
+    // traced by this launch (trace_fused_body: speculative tiles).  Classes are octaves of a tile's longest ray in the frame before,
+    // 16 384 attempts = class 0: the default, 5, are the tiles that had a ray of 1 024 attempts or more.
+    static const int speculative_classes = [] { const char* e = getenv("GR_SPECULATIVE_CLASSES"); int v = e ? atoi(e) : GR_DEFAULT_SPECULATIVE_CLASSES; return (v >= 0 && v <= 14) ? v : 0; }();
+    const int speculative = speculative_classes_in < 0 ? 0 : speculative_classes_in == 0 ? speculative_classes : std::min(speculative_classes_in, 14);
+    if (prepass_tickets && tile_order && tile_order_by_history && !parks) last_class_is_skipped |= speculative << 8;
     // the kernel's parking_lot, by value (same layout); an empty lot before every launch
     struct { void* records; void* words; int lanes, trips, slots, groups; } lot = {};
     if (parks) {
@@ -1751,7 +1764,7 @@ int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args
     return trace_launch(p, 1, stream, a->camera_generic, a->camera_quat, a->render_data, a->width, a->height, a->block_rows, a->strip_rank,
                         a->strip_count, a->termination_buffer, a->prepass_width, a->prepass_height, a->e0, a->e1, a->e2, a->e3, a->cfg, a->dfg,
                         a->attempt_counter, a->lattice == 2 ? 2 : 1, a->pending_only ? 1 : 0, a->tile_order, a->waves_per_simd, &a->shading,
-                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0, a->lattice == 2 ? a->lattice_rays : nullptr, &a->parking);
+                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0, a->lattice == 2 ? a->lattice_rays : nullptr, &a->parking, a->speculative_classes);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

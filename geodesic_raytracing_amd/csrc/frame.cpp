@@ -408,6 +408,7 @@ void gr_frame_tuning_default(gr_frame_tuning* t) {
     t->count_attempts = 0;
     t->guess_still_camera = -1;
     t->reuse_still_camera = -1;
+    t->speculative_classes = -1;
 }
 
 int gr_device_count(int* count) {
@@ -1212,6 +1213,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                     s->history_last_shift[0] = shift[0]; s->history_last_shift[1] = shift[1];
                     a.tile_order = s->tile_order;
                     a.tile_order_by_history = 1;
+                    a.speculative_classes = tune.speculative_classes < 0 ? 0 : tune.speculative_classes == 0 ? -1 : tune.speculative_classes;
                 }
                 if (record_history) {
                     a.tile_cost = s->tile_cost;

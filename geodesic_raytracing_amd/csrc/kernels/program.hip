@@ -143,6 +143,9 @@ struct dynamic_feature_config {
 #ifndef GR_TILE_COST_REACH
 #define GR_TILE_COST_REACH 1      // cells either side of the tile centre's whose rays' costs count for the tile's class
 #endif
+#ifndef GR_CELL_BLOCK
+#define GR_CELL_BLOCK 1           // the prepass cells a trace launch traces itself: 1 = a wave to 8 x 8 cells, 0 = to 64 cells of a row (capi.cpp: prepass_tickets)
+#endif
 #ifndef GR_TILE_CLASS_STEPS
 #define GR_TILE_CLASS_STEPS 1     // cost classes of gr_order_tiles per octave of attempts (finer ones measured no better)
 #endif

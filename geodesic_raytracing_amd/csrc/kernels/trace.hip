@@ -536,7 +536,10 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
                                            const trace_shading& shading, bool known_skipped, int cell_wave, bool cells_in_flight,
                                            unsigned int* __restrict__ tile_cost, float4* __restrict__ lattice_rays,
-                                           const parking_lot* lot = nullptr, int record = -1, bool from_lot = false) {
+                                           const parking_lot* lot = nullptr, int record = -1, bool from_lot = false, bool speculative = false) {
+    // speculative (wave-uniform; a launch with cells in flight only): the tile does not wait for the prepass cells its pixels look at -
+    // it traces every pixel at once and looks the verdicts up when its rays have ended; a pixel the prepass skips gets the skipped
+    // record then, as if its ray had never been traced (trace_fused_body says which tiles: the ones on the launch's critical path).
     // PARKING with from_lot (wave-uniform): this "tile" is up to 64 parked rays (claim_parked), lane by lane the record it was dealt.
     // cell_wave >= 0: this "tile" is 64 cells of the low-resolution prepass (prepass_cell, below) traced by the launch itself:
     // the ray of cell (cx, cy) of the prepass grid, and its verdict goes to the termination buffer instead of a record.
@@ -567,10 +570,19 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         cy = (int)((unsigned int)__float_as_int(where.z) >> 16);
         wave = __float_as_int(where.w);   // (per lane here: only the ray's cost, at its end, is filed under it)
     } else if (cell_wave >= 0) {
+        // a cell wave is 8 x 8 cells, not 64 of a row: a wave publishes its verdicts when its longest ray has ended, the long rays lie along
+        // the shadow's edge, and a curve crosses far fewer blocks than rows - the other waves' cells are known early (GR_CELL_BLOCK=0: rows)
+#if GR_CELL_BLOCK
+        const int blocks_x = (prepass_width + 7) / 8;
+        cx = (cell_wave % blocks_x) * 8 + lane % 8;
+        cy = (cell_wave / blocks_x) * 8 + lane / 8;
+        if (cx >= prepass_width || cy >= prepass_height) return;
+#else
         const int cell = cell_wave * 64 + lane;
         if (cell >= prepass_width * prepass_height) return;
         cx = cell % prepass_width;
         cy = cell / prepass_width;
+#endif
         // a device of a split frame traces the cells its rows look at; the others stay unknown and nobody asks for them
         if (!cell_row_matters(cy, prepass_height, image_height, device_block_rows, device_rank, device_count, 0)) return;
         ray_grid_width = prepass_width; ray_grid_height = prepass_height;
@@ -595,7 +607,9 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     // known_skipped: a tile of gr_order_tiles' last class - the 5x5 cells around it are all in the shadow, and the stencil of every
     // one of its pixels lies inside those (a pixel rounds to a cell at most one from the tile centre's) - needs no look-up at all
     int terminated = known_skipped ? 2 : 0;
-    if (cell_wave < 0 && !known_skipped && !pending_only && !(PARKING && from_lot) && termination_buffer && prepass_width != width && prepass_height != height) {
+    const bool looks_at_cells = cell_wave < 0 && !known_skipped && !pending_only && !(PARKING && from_lot) && termination_buffer && prepass_width != width &&
+                                prepass_height != height;
+    if (looks_at_cells && !speculative) {
         float fx = exact_ratio(cx, width);
         float fy = exact_ratio(cy, height);
         int lx = (int)roundf(fx * prepass_width);
@@ -699,6 +713,19 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
         dat = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated, cx, cy, cfg,
                                dfg, GET_FEATURE(redshift, dfg) != 0);
+        if (looks_at_cells && speculative) {
+            // the verdict, after the fact: by now the cells' rays have usually ended too (they are as long as this tile's, and began with it)
+            const int lx = (int)roundf(exact_ratio(cx, width) * prepass_width), ly = (int)roundf(exact_ratio(cy, height) * prepass_height);
+            if (early_terminate_stencil_when_known(lx, ly, prepass_width, prepass_height, termination_buffer)) {
+                dat.tex_coord = make_float2(0, 0);
+                dat.z_shift = 0;
+                dat.sx = cx;
+                dat.sy = cy;
+                dat.terminated = 2;
+                dat.side = 1;
+                tries = 0;   // (what the frame's counters and the next frame's order see: the attempts of the rays the frame needed)
+            }
+        }
         // The lattice launch of adaptive sampling leaves where its rays ended - position, velocity, the quaternion of the rotated frame -
         // for gr_adaptive_refine, which needs what the reference reads off its ray records (get_intersection_position of every
         // neighbour, also of rays whose record stays black: cl.cl:5260-5268).  Three stores of values that are live anyway: working the
@@ -788,8 +815,17 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
     const int tickets_total = total_waves + cell_tickets;
     const int singles = (tile_counter && tile_order) ? tickets_total - (int)tile_order[GR_TILE_CLASSES - 1] : tickets_total;
     // the list says itself whether its last class is a promise (program.hip GR_LIST_BY_PREPASS)
-    const bool list_promises = tile_order && (last_class_is_skipped || tile_order[GR_TILE_ORDER_HEADER + total_waves] == GR_LIST_BY_PREPASS);
+    const bool list_promises = tile_order && ((last_class_is_skipped & 1) || tile_order[GR_TILE_ORDER_HEADER + total_waves] == GR_LIST_BY_PREPASS);
     bool tickets_gone = false;   // PARKING: no tile left to draw, what the lot holds is all there is
+    // Speculative tiles (the upper bits of last_class_is_skipped: how many of the list's classes, dearest first): with the prepass's cells
+    // traced by this launch and the tiles in the order of the frame before's costs, the launch's critical path is the longest cell ray
+    // followed by the longest tile, which looks at that cell.  The tiles of the first classes - a few hundred of a 4K Kerr frame's 130 000 -
+    // are not held up: they trace all their pixels from t = 0 and take the verdicts afterwards (trace_tile).  What that wastes are the
+    // rays of their pixels the prepass would have skipped, in lanes that would have idled.
+    int speculative_tiles = 0;
+    if (!PARKING && tile_counter && tile_order && cell_tickets > 0 && !list_promises)
+        for (int c = 0; c < (last_class_is_skipped >> 8) && c < GR_TILE_CLASSES - 2; c++) speculative_tiles += (int)tile_order[c];
+    bool speculative = false;
     for (;;) {
         // (the pointers laundered - below - at the top of the loop here: one value on every way back to it)
         if (PARKING) asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));
@@ -826,6 +862,7 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
                 }
             }
             wave = (tile_order && cursor >= cell_tickets) ? cell_tickets + (int)tile_order[GR_TILE_ORDER_HEADER + cursor - cell_tickets] : cursor;
+            speculative = cursor >= cell_tickets && cursor - cell_tickets < speculative_tiles;
             cursor++;
             held--;
         }
@@ -842,7 +879,8 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
         GR_PROBE_TILE_BEGAN
         trace_tile<LATTICE_RAYS, PARKING>(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
                    termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
-                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost, lattice_rays, &lot, record, from_lot);
+                   known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost, lattice_rays, &lot, record, from_lot,
+                   speculative && lattice == 1 && !pending_only);
         GR_PROBE_TILE_ENDED
         if (!tile_counter) break;
     }

@@ -57,6 +57,8 @@ struct gr_frame_tuning {
                             * launches neither.  A viewer whose user has stopped moving renders the same camera again and again; the
                             * reference pays the prepass's single-ray latency on each of those frames (main.cpp:2384-2437).  0 = never;
                             * -1 = library default (on).  gr_render_state_prepass_reused counts the frames that did. */
+    int speculative_classes;  /* a whole frame that traces its prepass inside its trace launch and hands its tiles out by the frame before's
+                            * costs (tile_history): gr_trace_fused_args.speculative_classes of its launch - n classes, 0 = none, -1 = library default */
 };
 void gr_frame_tuning_default(gr_frame_tuning* out);
 
@@ -231,6 +233,11 @@ typedef struct gr_trace_fused_args {
     int tile_order_by_history;   /* 1: tile_order is gr_order_tiles_by_history's list (its last class is looked up like any tile) */
     void* lattice_rays;          /* lattice = 2: where the launch leaves its rays' end states for gr_adaptive_refine (see there); may be NULL */
     gr_parking_lot parking;      /* lanes > 0: gr_trace_fused_parking (every pixel, one ray per lane, no in-tile shading) */
+    int speculative_classes;     /* inline_prepass with tile_order_by_history: the tiles of the list's first n classes (octaves of a tile's
+                                  * longest ray in the frame before, 16 384 attempts = class 0) do not wait for the prepass cells their pixels
+                                  * look at: they trace every pixel from the start and take the verdicts when their rays have ended - the
+                                  * launch's critical path is otherwise the longest cell ray followed by the longest tile, which reads that
+                                  * cell.  Records are the same.  0 = library default (5: tiles that had a ray of 1 024 attempts or more), -1 = none */
 } gr_trace_fused_args;
 int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args* args);
 /* waves of gr_trace_fused the program's device holds at once (what a persistent launch fills it with): a frame of many more tiles than

@@ -692,6 +692,42 @@ def test_scheduled_reference_trace_writes_the_records_of_the_reference_launch():
     assert dearest_first.tobytes() == plain.tobytes()
 
 
+def test_speculative_tiles_and_cell_blocks_change_no_record():
+    """A frame that traces its prepass inside its trace launch, tiles in the order of the frame before's costs: the tiles of the list's first
+    classes do not wait for the cells they look at - they trace every pixel and take the verdicts afterwards (gr_frame_tuning.speculative_classes)
+    - and a cell wave is 8 x 8 cells instead of 64 of a row (-DGR_CELL_BLOCK=0: rows).  Scheduling only: records, verdicts, the frame's
+    attempt count and the costs left for the next frame's order are those of a launch that speculates on nothing, bit for bit."""
+    w, h = 1920, 1080
+    metric = gra.Metric("kerr_boyer", SCRIPTS)
+    cfgv = metric.cfg_values(a=0.45)
+    feats = metric.features(adaptive_sampling=0)
+    text = metric.argument_string(feats, static=True, cfg_values=cfgv)
+    cameras = [gra.default_camera([0, 0.01 * k, -4.0, 0]) for k in range(4)]
+    got = {}
+    for label, program_text, classes in (("none", text, 0), ("default", text, -1), ("every class", text, 14), ("rows of cells", text + " -DGR_CELL_BLOCK=0", -1)):
+        prog = gra.Program(program_text, 0)
+        state = gra.RenderState(w, h, 0)
+        frames = []
+        for cam in cameras:
+            state.render(prog, metric, cam, None, None, feats, cfgv,
+                         gra.frame_options(mode=gra.MODE_FUSED, use_prepass=1, inline_prepass=1, tile_history=1, count_attempts=1, reuse_still_camera=0,
+                                           guess_still_camera=0, speculative_classes=classes))
+            state.synchronize()
+            rd = download(0, state.buffer(gra.BUF_RENDER_DATA), RENDER_DATA_DTYPE, w * h)
+            term = download(0, state.buffer(gra.BUF_TERMINATION), np.int32, (w // 16) * (h // 16))
+            frames.append((rd.tobytes(), term.tobytes(), state.attempts()))
+        recorded, followed, _ = state.tile_history()
+        assert (recorded, followed) == (4, 3), label      # the order of the frame before was there to speculate on
+        got[label] = frames
+    skipped = np.frombuffer(got["none"][-1][0], dtype=RENDER_DATA_DTYPE)["terminated"] == 2
+    assert 0.2 < skipped.mean() < 0.8                      # there is a shadow: tiles on its edge hold pixels that are skipped and pixels that are not
+    for label in ("default", "every class", "rows of cells"):
+        for k, (a, b) in enumerate(zip(got["none"], got[label])):
+            assert a[0] == b[0], (label, k, "records")
+            assert a[1] == b[1], (label, k, "verdicts")
+            assert a[2] == b[2], (label, k, "attempts", a[2], b[2])
+
+
 def test_a_repeated_frame_takes_the_previous_frames_prepass_and_nothing_else_does():
     """gr_frame_tuning.reuse_still_camera (library default: on): a frame whose camera, parameters, features and program are the previous
     frame's of this render state, bit for bit, on the same stream, launches neither camera set-up nor prepass - what they would compute is

@@ -57,6 +57,8 @@ def run(name, params, label, inflight=1):
                     torch.cuda.synchronize()
                     times.append((time.perf_counter() - t) * 1e3)
                 pictures[(moving, history)] = out.clone()
+                if os.environ.get("TILE_HISTORY_CHECKSUM"):   # (to compare the last frame across processes: builds, environment switches)
+                    print(f"{label:18s} camera {'moving' if moving else 'still '} checksum of the last frame {int(out.view(torch.int32).to(torch.int64).sum().item())}", flush=True)
                 print(f"{label:18s} camera {'moving' if moving else 'still '} history {history:2d}: first {times[0]:6.2f} ms, then "
                       f"{sum(times[2:]) / len(times[2:]):6.2f} ms/frame  (min {min(times[2:]):6.2f}, max {max(times[2:]):6.2f})"
                       + ("  " + " ".join(f"{t:.1f}" for t in times[2:]) if os.environ.get("TILE_HISTORY_VERBOSE") else ""), flush=True)
