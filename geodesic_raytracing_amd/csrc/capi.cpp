@@ -1606,8 +1606,8 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         shading.bg_width = shading_in->bg_width; shading.bg_height = shading_in->bg_height; shading.bg_levels = shading_in->bg_levels;
         shading.most_probes = shading_in->max_probes; shading.compact_out = strip_count > 1 ? shading_in->compact_out : 0;
     }
-    if (tile_cost && (rays_per_lane != 1 || lattice != 1 || pending_only))
-        return fail(GR_ERROR_INVALID_ARGUMENT, "tile_cost: gr_trace_fused on every pixel of its rows");
+    if (tile_cost && (rays_per_lane != 1 || pending_only || (lattice == 2 && strip_count > 1)))
+        return fail(GR_ERROR_INVALID_ARGUMENT, "tile_cost: gr_trace_fused on every pixel of its rows, or the lattice launch of a whole frame");
     // (every argument has been checked by now: nothing below fails for a reason of the caller's, and nothing above has touched a buffer)
     if (prepass_tickets)   // every cell unknown (GR_CELL_UNKNOWN = -1) until its ray has been traced
         HIP_CHECK(hipMemsetAsync(const_cast<void*>(term), 0xff, (size_t)prepass_width * prepass_height * sizeof(int), (hipStream_t)stream));

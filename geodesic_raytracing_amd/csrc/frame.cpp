@@ -1004,10 +1004,15 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // the frame before if that one did too).
         // Not frames of more than 32 tiles per wave slot (8K Alcubierre: 72 short tiles of much the same cost; recording and sorting
         // them measured +3 % on the frame, with nothing to gain).
-        const long long tile_words = gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) / 8;
+        // An adaptively sampled whole frame: the same for its lattice launch - the tiles of the half-resolution grid, their costs left by the
+        // lattice launch of the frame before (GR_LATTICE_HISTORY=0: image order as before round 6's fifth session).
+        static const bool lattice_history = [] { const char* e = getenv("GR_LATTICE_HISTORY"); return !(e && e[0] == '0'); }();
+        const int hist_width = adaptive ? width / 2 : width, hist_height = adaptive ? height / 2 : height;
+        const int hist_block_rows = adaptive ? ((hist_height + 7) / 8) * 8 : block_rows;
+        const long long tile_words = gr_tile_order_bytes(hist_width, hist_height, hist_block_rows, strip_rank, strip_count) / 8;
         const bool history_wanted = (tune.tile_history < 0 ? history_default != 0 && strip_count == 1 && tile_words <= 32 * gr_trace_fused_wave_slots(p)
-                                                          : tune.tile_history != 0) && !adaptive &&
-                                    (size_t)gr_tile_order_bytes(width, height, block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
+                                                          : tune.tile_history != 0) && (!adaptive || (lattice_history && strip_count == 1)) &&
+                                    (size_t)gr_tile_order_bytes(hist_width, hist_height, hist_block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
         const bool device_busy = history_wanted && tune.tile_history < 0 && earlier_frame_still_running(s->device, stream);
         const bool tile_order_enabled = !history_wanted && (tile_order_mode == 1 || (tile_order_mode == -1 && strip_count > 1));
         const size_t cells = use_prepass ? (size_t)prepass_width * prepass_height : 0;
@@ -1054,7 +1059,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // (the kernels that record and follow the history are gr_trace_fused's: one ray per lane, no compaction)
         const bool record_history = history_wanted && !device_busy && keep_lanes == 0 && rays_per_lane == 1;
         if (history_wanted && !record_history) s->tile_cost_valid = false;   // (what is there would be older than the last frame)
-        const int shape[3] = {block_rows, strip_rank, strip_count};
+        const int shape[3] = {adaptive ? -hist_block_rows : block_rows, strip_rank, strip_count};   // (negative: the tiles of a lattice launch)
         static const float history_max_motion = [] { const char* e = getenv("GR_TILE_HISTORY_MAX_MOTION"); return e ? (float)atof(e) : 48.f; }();
         const bool history_order = record_history && s->tile_cost_valid && memcmp(shape, s->tile_cost_shape, sizeof(shape)) == 0 && !gc &&
                                    picture_motion(s->tile_cost_camera, *camera, features.field_of_view, width) <= history_max_motion;
@@ -1125,6 +1130,37 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // every device runs the (tiny) prepass itself; its own row blocks (+ one halo row each) are traced here
         bool shade_in_trace = false;
         GR_CHECK(begin(GR_STAGE_TRACE));
+        // the order of the frame before's costs and the record of this frame's, for the launch that traces the frame's tiles
+        // (gr_trace_fused on every pixel, or the lattice launch of adaptive sampling: tiles of 8 x 8 lattice pixels = 16 x 16 pixels)
+        auto follow_and_record_history = [&](gr_trace_fused_args& a) -> int {
+            float anchor[2] = {0, 0};
+            const bool anchored = record_history && !gc && origin_on_screen(*camera, features.field_of_view, width, height, anchor);
+            if (history_order) {
+                // how far the picture has moved since the costs were recorded, in tiles
+                int shift[2] = {0, 0};
+                static const bool follow_camera = [] { const char* e = getenv("GR_TILE_HISTORY_FOLLOW"); return !(e && e[0] == '0'); }();
+                if (follow_camera && anchored && s->tile_cost_anchored)
+                    for (int i = 0; i < 2; i++)
+                        shift[i] = (int)std::lround(std::max(-4096.f, std::min(4096.f, (anchor[i] - s->tile_cost_anchor[i]) / (adaptive ? 16.f : 8.f))));
+                GR_CHECK(gr_order_tiles_by_history(p, stream, s->tile_cost, hist_width, hist_height, hist_block_rows, strip_rank, strip_count, s->tile_order,
+                                                   shift[0], shift[1]));
+                s->history_followed++;
+                s->history_last_shift[0] = shift[0]; s->history_last_shift[1] = shift[1];
+                a.tile_order = s->tile_order;
+                a.tile_order_by_history = 1;
+                a.speculative_classes = tune.speculative_classes < 0 ? 0 : tune.speculative_classes == 0 ? -1 : tune.speculative_classes;
+            }
+            if (record_history) {
+                a.tile_cost = s->tile_cost;
+                s->history_recorded++;
+                memcpy(s->tile_cost_shape, shape, sizeof(shape));
+                s->tile_cost_valid = true;
+                s->tile_cost_anchored = anchored;
+                s->tile_cost_anchor[0] = anchor[0]; s->tile_cost_anchor[1] = anchor[1];
+                s->tile_cost_camera = *camera;
+            }
+            return GR_OK;
+        };
         if (keep_lanes > 0)
             GR_CHECK(gr_trace_compact(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, block_rows,
                                       strip_rank, strip_count, use_prepass ? s->termination_buffer : nullptr,
@@ -1147,7 +1183,9 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 if (!s->lattice_rays) HIP_CHECK(hipMalloc(&s->lattice_rays, gr_lattice_rays_bytes(width, height)));
                 if (!s->pending_list) HIP_CHECK(hipMalloc(&s->pending_list, gr_pending_list_bytes(width, height)));
                 a.lattice_rays = s->lattice_rays;
+                GR_CHECK(follow_and_record_history(a));
                 GR_CHECK(gr_trace_fused_launch(p, stream, &a));
+                a.tile_order = nullptr; a.tile_order_by_history = 0; a.tile_cost = nullptr;   // (the second launch below is not the lattice's)
                 GR_CHECK(end(GR_STAGE_TRACE));
                 GR_CHECK(begin(GR_STAGE_ADAPTIVE));
                 HIP_CHECK(hipMemsetAsync(s->rays_adaptive_count, 0, 4, stream));
@@ -1198,32 +1236,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.e0 = s->tetrad[0]; a.e1 = s->tetrad[1]; a.e2 = s->tetrad[2]; a.e3 = s->tetrad[3]; a.cfg = s->cfg; a.dfg = s->dfg;
                 a.attempt_counter = attempts;
                 a.tile_order = order_tiles ? s->tile_order : nullptr;
-                float anchor[2] = {0, 0};
-                const bool anchored = record_history && !gc && origin_on_screen(*camera, features.field_of_view, width, height, anchor);
-                if (history_order) {
-                    // how far the picture has moved since the costs were recorded, in tiles
-                    int shift[2] = {0, 0};
-                    static const bool follow_camera = [] { const char* e = getenv("GR_TILE_HISTORY_FOLLOW"); return !(e && e[0] == '0'); }();
-                    if (follow_camera && anchored && s->tile_cost_anchored)
-                        for (int i = 0; i < 2; i++)
-                            shift[i] = (int)std::lround(std::max(-4096.f, std::min(4096.f, (anchor[i] - s->tile_cost_anchor[i]) / 8.f)));
-                    GR_CHECK(gr_order_tiles_by_history(p, stream, s->tile_cost, width, height, block_rows, strip_rank, strip_count, s->tile_order,
-                                                       shift[0], shift[1]));
-                    s->history_followed++;
-                    s->history_last_shift[0] = shift[0]; s->history_last_shift[1] = shift[1];
-                    a.tile_order = s->tile_order;
-                    a.tile_order_by_history = 1;
-                    a.speculative_classes = tune.speculative_classes < 0 ? 0 : tune.speculative_classes == 0 ? -1 : tune.speculative_classes;
-                }
-                if (record_history) {
-                    a.tile_cost = s->tile_cost;
-                    s->history_recorded++;
-                    memcpy(s->tile_cost_shape, shape, sizeof(shape));
-                    s->tile_cost_valid = true;
-                    s->tile_cost_anchored = anchored;
-                    s->tile_cost_anchor[0] = anchor[0]; s->tile_cost_anchor[1] = anchor[1];
-                    s->tile_cost_camera = *camera;
-                }
+                GR_CHECK(follow_and_record_history(a));
                 a.waves_per_simd = tune.trace_waves_per_simd;
                 a.inline_prepass = inline_prepass ? 1 : 0;
                 // parking (gr_trace_fused_parking): the lot is the state's, allocated the first time a frame asks for it - room for an

@@ -732,7 +732,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         // sky angles out here gave the intersection's products a second use, the compiler then formed other fmas, and the records of
         // every launch came out rounded differently (Schwarzschild 1000 x 500 against gr_trace_compact, pixels apart by > 1e-4:
         // 3e-5 of the frame -> 1.3e-3); doing it on laundered copies cost the headline kernel a wave per SIMD.
-        if (LATTICE_RAYS && lattice_rays && lattice == 2) {
+        if (LATTICE_RAYS && lattice_rays && lattice == 2 && dat.terminated != 2) {   // (2: a speculative tile's pixel that the prepass skips after all - as if never traced)
             float4* record = lattice_rays + 3 * ((size_t)(cy / 2) * (image_width / 2) + cx / 2);
             record[0] = s.position;
             record[1] = s.velocity;
@@ -880,7 +880,7 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
         trace_tile<LATTICE_RAYS, PARKING>(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
                    termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
                    known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost, lattice_rays, &lot, record, from_lot,
-                   speculative && lattice == 1 && !pending_only);
+                   speculative && !pending_only);
         GR_PROBE_TILE_ENDED
         if (!tile_counter) break;
     }

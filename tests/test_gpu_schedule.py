@@ -692,15 +692,18 @@ def test_scheduled_reference_trace_writes_the_records_of_the_reference_launch():
     assert dearest_first.tobytes() == plain.tobytes()
 
 
-def test_speculative_tiles_and_cell_blocks_change_no_record():
+@pytest.mark.parametrize("adaptive", [0, 1])
+def test_speculative_tiles_and_cell_blocks_change_no_record(adaptive):
     """A frame that traces its prepass inside its trace launch, tiles in the order of the frame before's costs: the tiles of the list's first
     classes do not wait for the cells they look at - they trace every pixel and take the verdicts afterwards (gr_frame_tuning.speculative_classes)
     - and a cell wave is 8 x 8 cells instead of 64 of a row (-DGR_CELL_BLOCK=0: rows).  Scheduling only: records, verdicts, the frame's
-    attempt count and the costs left for the next frame's order are those of a launch that speculates on nothing, bit for bit."""
+    attempt count and the costs left for the next frame's order are those of a launch that speculates on nothing, bit for bit.
+    adaptive = 1: the same for the lattice launch of an adaptively sampled frame (its tiles are 8 x 8 lattice pixels; the costs its lattice
+    launch left the frame before order them), whose records the decisions and the second launch then read."""
     w, h = 1920, 1080
     metric = gra.Metric("kerr_boyer", SCRIPTS)
     cfgv = metric.cfg_values(a=0.45)
-    feats = metric.features(adaptive_sampling=0)
+    feats = metric.features(adaptive_sampling=adaptive, adaptive_sampling_threshold=32.0)
     text = metric.argument_string(feats, static=True, cfg_values=cfgv)
     cameras = [gra.default_camera([0, 0.01 * k, -4.0, 0]) for k in range(4)]
     got = {}
