@@ -144,6 +144,29 @@ bool pair_kernel_applies(const std::vector<std::string>& opts) {
     return total > 0 && total < 16384;
 }
 
+// Do the expressions the Verlet loop evaluates call the range-limited sin / cos (kernels/metric.hip GR_ACCEL_TRIG: the bare polynomials,
+// which answer an argument of 8 192 or more with a NaN so that the ray leaves the fast loop for the one that calls libm)?  A program whose
+// accelerations hold none - every Cartesian chart: Kerr-Schild, Alcubierre, Krasnikov ... - can never see such a NaN: its loop then treats
+// a non-finite rejected attempt the reference's way (retried with the smaller step in the same loop: -DGR_ACCEL_WITHOUT_TRIG,
+// integrator.hip) instead of leaving for the slow loop at the first overshoot into a singularity.
+bool accelerations_without_trig(const std::vector<std::string>& opts) {
+    static const char* const CALLS[] = {"sin(", "cos(", "gr_sin2(", "gr_cos2(", "gr_sincos("};
+    bool any = false;
+    for (auto& o : opts) {
+        const size_t eq = o.find('=');
+        if (o.rfind("-D", 0) != 0 || eq == std::string::npos) continue;
+        const std::string name = o.substr(2, eq - 2);
+        if (name.find("ACCEL") == std::string::npos && name.find("TEMPORARIES") == std::string::npos) continue;
+        any = true;
+        for (const char* call : CALLS)
+            for (size_t at = o.find(call, eq); at != std::string::npos; at = o.find(call, at + 1)) {
+                const char before = o[at - 1];
+                if (!(isalnum((unsigned char)before) || before == '_')) return false;   // ("asin(", "gm_cos(" ... are other functions)
+            }
+    }
+    return any;
+}
+
 // VGPRs and scratch bytes per lane of one kernel, read from the code object's metadata note (msgpack: the kernel's map holds
 // ".name", later ".private_segment_fixed_size" and ".vgpr_count" - keys are sorted).  false when the note is not understood.
 bool kernel_resources(const std::string& code, const char* kernel, int& vgprs, int& scratch_bytes, int* sgprs = nullptr) {
@@ -288,6 +311,7 @@ int compile_code_object(const std::string& argument_string, std::string& code, s
         else return fail(GR_ERROR_INVALID_ARGUMENT, "unsupported token in argument string: " + tok);
     }
     if (pair_kernel_applies(opts)) opts.push_back("-DGR_TWO_RAYS_PER_LANE");
+    if (accelerations_without_trig(opts)) opts.push_back("-DGR_ACCEL_WITHOUT_TRIG");
     if (const char* extra = getenv("GR_EXTRA_FLAGS"))
         for (auto& tok : split_arguments(extra)) opts.push_back(tok);
     opts.push_back(part == PART_FRAME ? "-DGR_BUILD_FRAME_PATH" : "-DGR_BUILD_REST");

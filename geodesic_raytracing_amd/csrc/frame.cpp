@@ -1005,13 +1005,15 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // Not frames of more than 32 tiles per wave slot (8K Alcubierre: 72 short tiles of much the same cost; recording and sorting
         // them measured +3 % on the frame, with nothing to gain).
         // An adaptively sampled whole frame: the same for its lattice launch - the tiles of the half-resolution grid, their costs left by the
-        // lattice launch of the frame before (GR_LATTICE_HISTORY=0: image order as before round 6's fifth session).
+        // lattice launch of the frame before (GR_LATTICE_HISTORY=0: image order as before round 6's fifth session).  Only where it pays: a
+        // lattice launch that traces its own prepass cells (the gain is the speculative tiles; the order alone measured nothing, and
+        // recording + sorting cost the 0.4 ms frames of the metrics without a prepass 5-10 %).
         static const bool lattice_history = [] { const char* e = getenv("GR_LATTICE_HISTORY"); return !(e && e[0] == '0'); }();
         const int hist_width = adaptive ? width / 2 : width, hist_height = adaptive ? height / 2 : height;
         const int hist_block_rows = adaptive ? ((hist_height + 7) / 8) * 8 : block_rows;
         const long long tile_words = gr_tile_order_bytes(hist_width, hist_height, hist_block_rows, strip_rank, strip_count) / 8;
         const bool history_wanted = (tune.tile_history < 0 ? history_default != 0 && strip_count == 1 && tile_words <= 32 * gr_trace_fused_wave_slots(p)
-                                                          : tune.tile_history != 0) && (!adaptive || (lattice_history && strip_count == 1)) &&
+                                                          : tune.tile_history != 0) && (!adaptive || (lattice_history && strip_count == 1 && use_prepass && !prefetched)) &&
                                     (size_t)gr_tile_order_bytes(hist_width, hist_height, hist_block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
         const bool device_busy = history_wanted && tune.tile_history < 0 && earlier_frame_still_running(s->device, stream);
         const bool tile_order_enabled = !history_wanted && (tile_order_mode == 1 || (tile_order_mode == -1 && strip_count > 1));

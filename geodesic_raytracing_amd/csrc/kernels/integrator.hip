@@ -331,6 +331,8 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
                 degenerate |= !(__builtin_fabsf(poison) <= 3.402823466e+38f);
             }
             dead |= !reject & degenerate;
+#ifndef GR_ACCEL_WITHOUT_TRIG   // (capi.cpp accelerations_without_trig: a program whose accelerations call no sin / cos has no such NaN to meet - and a
+                                // Kerr-Schild ray that overshoots the ring is retried right here, not sent to the slow loop for the rest of its 16 384 steps)
             if (!decltype(libm)::value) {
                 // The polynomial sin / cos poisons an argument outside its range with a NaN (metric.hip) - which the reference, with a
                 // full-range sine, would never have seen.  Such an attempt must not run through the controller (v_med3 hands a NaN error
@@ -341,6 +343,7 @@ __device__ __forceinline__ int integrate_pingpong(ray_state& s, cfg_t cfg, dfg_t
                 dead |= degenerate;
                 reject &= !degenerate;
             }
+#endif
             if (reject) {
                 overwrite(po, position);
                 overwrite(vo, velocity);
