@@ -242,6 +242,7 @@ _SIGNATURES = {
     "gr_geodesic_camera_interpolate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, ctypes.POINTER(c_float),
                                                ctypes.POINTER(c_float), ctypes.POINTER(c_float)]),
     "gr_geodesic_camera_buffer": (c_void_p, [c_void_p, c_int]),
+    "gr_argument_string_accelerations_call_trig": (c_int, [ctypes.c_char_p]),
     "gr_render_state_prepass_reused": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]),
     "gr_render_state_prepass_policy": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(c_float)]),
     "gr_render_state_stage_ms": (c_int, [c_void_p, c_int, ctypes.POINTER(c_float)]),

@@ -851,6 +851,14 @@ int gr_metric_substituted_op_counts(const gr_metric* m, const float* cfg_values,
     GR_TRY_END
 }
 
+int gr_argument_string_accelerations_call_trig(const char* argument_string) {
+    if (!argument_string) return -1;
+    std::vector<std::string> opts;
+    for (auto& tok : split_arguments(argument_string))
+        if (tok.rfind("-D", 0) == 0) opts.push_back(tok);
+    return accelerations_without_trig(opts) ? 0 : 1;
+}
+
 int gr_program_precompile(const char* argument_string) {
     if (!argument_string) return fail(GR_ERROR_INVALID_ARGUMENT, "null argument string");
     std::string code, rest, setup;

@@ -332,6 +332,10 @@ int gr_trace_compact(gr_program* p, void* stream, const void* camera_generic, co
  * the costs of the frame before, and the shift (in tiles) the last one that did applied.  Any pointer may be NULL. */
 int gr_render_state_tile_history(gr_render_state* s, unsigned long long* frames_recorded, unsigned long long* frames_followed,
                                  int last_shift[2]);
+/* Do the expressions a program's Verlet loop evaluates (its GEO_ACCEL* / GR_DEVICE_ACCEL* macros and their temporaries) call sin / cos?  1 yes,
+ * 0 no, -1 no string.  A program whose accelerations call neither is built with -DGR_ACCEL_WITHOUT_TRIG: its loop has no range-limited
+ * polynomial whose NaN it would have to tell from the metric's own (kernels/integrator.hip). */
+int gr_argument_string_accelerations_call_trig(const char* argument_string);
 /* How many frames of this render state took the previous frame's camera set-up and prepass (gr_frame_tuning.reuse_still_camera). */
 int gr_render_state_prepass_reused(gr_render_state* s, unsigned long long* frames);
 /* The two estimates tile_history works with (host arithmetic, no device).  gr_camera_origin_on_screen: the pixel at which the
