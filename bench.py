@@ -386,11 +386,11 @@ def main():
     args = parse()
     # Most frames of this benchmark repeat one camera.  The library's default for such a frame - take the previous frame's camera set-up and
     # prepass verdicts as they stand (gr_frame_tuning.reuse_still_camera) - would be work skipped inside the timed region: off for every
-    # frame here, except under the one label that measures it (frame_one_at_a_time_ms.still_camera_prepass_reused).  The work-preserving
-    # form (guess_still_camera: the next frame's prepass computed on a side stream during this frame's trace) stays on for frames that
-    # announce no next camera, as in the earlier round-6 lines.
+    # frame here, except under the one label that measures it (frame_one_at_a_time_ms.still_camera_prepass_reused).  Frames that announce no
+    # next camera are rendered as for a camera that moves every frame: the prepass inside the trace launch, the tiles on the critical path
+    # speculative.  (The work-preserving still-camera form - guess_still_camera: the next frame's prepass on a side stream during this
+    # frame's trace - was on in the earlier round-6 lines; it has its own label too, frame_one_at_a_time_ms.still_camera_next_prepass_guessed.)
     os.environ.setdefault("GR_REUSE_STILL_CAMERA", "0")
-    os.environ.setdefault("GR_GUESS_STILL_CAMERA", "1")
     world_env = int(os.environ["WORLD_SIZE"]) if os.environ.get("WORLD_SIZE") else None
     seen = 0
     if world_env is None and args.gpus > 1:
@@ -956,9 +956,10 @@ def main():
             pa = gra.Program(metric.argument_string(features=fa, static=True, cfg_values=cfg_values), local_rank)
             t = timed(camera, fa, cfg_values, pa, gra.MODE_FUSED)
             secondary["adaptive_sampling_on_threshold32_fused_substituted_fps"] = round(1 / t, 1)
-            # ... and with nothing known or guessed about the next camera (what a camera that moves every frame gets): the prepass cells inside the
-            # lattice launch, its tiles by the frame before's lattice costs, the first classes speculative
-            t_unannounced = timed(camera, fa, cfg_values, pa, gra.MODE_FUSED, guess_still_camera=0)
+            # (nothing known or guessed about the next camera - what a camera that moves every frame gets: the prepass cells inside the lattice
+            # launch, its tiles by the frame before's lattice costs, the first classes speculative)
+            t_unannounced = t
+            t = timed(camera, fa, cfg_values, pa, gra.MODE_FUSED, guess_still_camera=1)   # (the still-camera guess of the earlier round-6 lines)
             # ... its stages (one frame at a time: lattice launch with the prepass cells in front of its tiles, decisions + the list of
             # marked pixels + the launch over that list, texture pass), what it traces, and the same frames the way the headline is
             # measured (frames in flight, prepass look-ahead): the throughput adaptive sampling exists for
@@ -980,7 +981,7 @@ def main():
             barrier()
             tp = (time.perf_counter() - tp) / 12
             secondary["adaptive_sampling_on_threshold32_fused_substituted"] = {
-                "one_frame_at_a_time_ms": round(t * 1e3, 3), "one_frame_at_a_time_unannounced_camera_ms": round(t_unannounced * 1e3, 3), "pipelined_ms_per_frame": round(tp * 1e3, 3), "pipelined_Mpixels_per_s": round(W * H / tp / 1e6, 1),
+                "one_frame_at_a_time_ms": round(t_unannounced * 1e3, 3), "one_frame_at_a_time_next_prepass_guessed_ms": round(t * 1e3, 3), "pipelined_ms_per_frame": round(tp * 1e3, 3), "pipelined_Mpixels_per_s": round(W * H / tp / 1e6, 1),
                 "speed_up_over_every_pixel_pipelined": round(ms_per_step / (tp * 1e3), 3),
                 "stage_ms": {k: round(float(np.mean(v[1:])), 4) for k, v in stage_acc.items()},
                 "stage_note": "trace = the lattice launch (a quarter of the pixels; the prepass cells are its first tickets), adaptive = gr_adaptive_refine_list + gr_trace_pending",

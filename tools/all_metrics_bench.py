@@ -18,9 +18,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # as bench.py: every timed frame computes its own camera set-up and prepass although the camera never moves (the library's default for a
-# repeated frame, reuse_still_camera, would skip both); the work-preserving side-stream form stays on, as when the table was made
+# repeated frame, reuse_still_camera, would skip both), and nothing guesses the next camera (GR_GUESS_STILL_CAMERA=1: as the round's first table)
 os.environ.setdefault("GR_REUSE_STILL_CAMERA", "0")
-os.environ.setdefault("GR_GUESS_STILL_CAMERA", "1")
 MANIFEST = os.path.join(ROOT, "tools", "_manifests", "reference_scripts.json")
 REFERENCE_SCRIPTS = "/root/reference/scripts"
 W, H = 1920, 1080
