@@ -1,4 +1,4 @@
-"""Randomised soak of everything that only SCHEDULES a fused frame (GPU box): camera paths of a few frames - repeated cameras, small moves, jumps -
+"""Randomised soak of everything that only SCHEDULES a fused frame (GPU box): camera paths of a few frames - repeated cameras, small moves, jumps, sliders dragged and set -
 over five shipped scripts, the prepass on, adaptive sampling on and off, several frame sizes, dynamic programs with random parameters;
 every frame rendered twice: by a render state with the library's defaults (the previous frame's prepass reused for a repeated camera, tiles by
 the frame before's costs, speculative tiles, also in the lattice launch) and by one with all of it switched off (every frame its own prepass
@@ -37,22 +37,29 @@ def draw_cases(cases, seed):
                 pos = pos + np.array([0.0, rng.normal(0, 0.02), rng.normal(0, 0.02), rng.normal(0, 0.02)])
             elif kind == "jump":
                 pos = np.array([0.0, rng.uniform(-1.5, 1.5), -rng.uniform(3.5, 9.0), rng.uniform(-1.5, 1.5)])
-            path.append((kind, pos.copy()))
+            # ... and now and then a slider moves with the camera or instead of it: every parameter by a per cent or so (a "drag": the
+            # orders of the frame before are still followed), or to a new value altogether (they are not)
+            slider = str(rng.choice(["", "drag", "set"], p=[0.7, 0.2, 0.1])) if params else ""
+            if slider == "drag":
+                params = {k: float(np.clip(v * (1 + rng.normal(0, 0.01)) + rng.normal(0, 0.001), *METRICS[name][k])) for k, v in params.items()}
+            elif slider == "set":
+                params = {k: float(rng.uniform(*r)) for k, r in METRICS[name].items()}
+            path.append((kind + ("+" + slider if slider else ""), pos.copy(), dict(params)))
         yield case, name, metric, params, adaptive, size, path
 
 
 def run_case(name, metric, params, adaptive, size, path, device=0, peek_every=3):
     """-> (frames compared, frames that differ, frames of the default state that reused a prepass, frames that followed a history)"""
     w, h = size
-    cfg = metric.cfg_values(**params)
     feats = metric.features(adaptive_sampling=adaptive, adaptive_sampling_threshold=32.0)
     prog = gra.Program(metric.argument_string(), device)
     plain = dict(mode=gra.MODE_FUSED, use_prepass=1, count_attempts=1, guess_still_camera=0)
     variants = {"defaults": (gra.RenderState(w, h, device), dict(plain)),
                 "nothing": (gra.RenderState(w, h, device), dict(plain, reuse_still_camera=0, tile_history=0, inline_prepass=0, speculative_classes=0))}
     differ = 0
-    for k, (kind, pos) in enumerate(path):
+    for k, (kind, pos, frame_params) in enumerate(path):
         got = {}
+        cfg = metric.cfg_values(**frame_params)
         for label, (state, options) in variants.items():
             state.render(prog, metric, gra.default_camera([float(x) for x in pos]), None, None, feats, cfg, gra.frame_options(**options))
             state.synchronize()
@@ -75,7 +82,7 @@ if __name__ == "__main__":
         bad += differ
         reused += r
         followed += f
-        print(f"{case:3d} {name:26s} adaptive={adaptive} {size[0]:4d}x{size[1]:<4d} {' '.join(k for k, _ in path):36s} frames {n} differ {differ}  "
+        print(f"{case:3d} {name:26s} adaptive={adaptive} {size[0]:4d}x{size[1]:<4d} {' '.join(k for k, _, _ in path):44s} frames {n} differ {differ}  "
               f"(prepass reused {r}, history followed {f})", flush=True)
     print(f"{cases} cases, {total} frames rendered both ways: {bad} differ; the default states reused {reused} prepasses and followed {followed} histories")
     sys.exit(1 if bad else 0)

@@ -852,13 +852,13 @@ def test_a_guessed_next_camera_changes_no_pixel_and_is_used_only_when_it_was_rig
 
 
 def test_random_camera_paths_with_and_without_every_schedule():
-    """tests/fuzz_schedule.py, eight cases of seed 7: random camera paths (a camera that stays, steps, jumps) over five scripts with the prepass on,
+    """tests/fuzz_schedule.py, eight cases of seed 7: random camera paths (a camera that stays, steps, jumps; parameters dragged and set) over five scripts with the prepass on,
     adaptive sampling on and off, five frame sizes - every frame by a state with the library's defaults (reused prepass, history order,
     speculative tiles) and by one with all of that off: records, verdicts and attempts bit for bit, and each mechanism got its turn"""
     import fuzz_schedule
     frames = differ = reused = followed = 0
     for case, name, metric, params, adaptive, size, path in fuzz_schedule.draw_cases(8, 7):
         n, d, r, f = fuzz_schedule.run_case(name, metric, params, adaptive, size, path)
-        assert d == 0, (case, name, adaptive, size, [k for k, _ in path])
+        assert d == 0, (case, name, adaptive, size, [k for k, _, _ in path])
         frames, differ, reused, followed = frames + n, differ + d, reused + r, followed + f
     assert frames >= 32 and reused >= 3 and followed >= 8, (frames, reused, followed)
