@@ -267,6 +267,22 @@ static bool origin_on_screen(const gr_camera& c, float fov_degrees, int width, i
 // parallax of the origin, at the focal length.  A history the picture has moved more than 48 px away from is not followed: a wrong
 // order is worse than none (a camera rolling 5 degrees a frame, 170 px at the edge: 4K Kerr 7.8 -> 13.4 ms, a = 0.9 27 -> 85 ms following
 // it blindly; up to 43 px - 0.08 units sideways or 1 degree of roll a frame - it measured a gain or nothing).
+// the two parts on their own: a turn of the camera moves the picture rigidly (the history's shift follows it), a step moves it by parallax
+static bool picture_motion_parts(const gr_camera& a, const gr_camera& b, float fov_degrees, int width, float& turn_px, float& parallax_px) {
+    double dot = 0, na = 0, nb = 0, dp = 0, r = 0;
+    for (int i = 0; i < 4; i++) { dot += (double)a.quat[i] * b.quat[i]; na += (double)a.quat[i] * a.quat[i]; nb += (double)b.quat[i] * b.quat[i]; }
+    for (int i = 1; i < 4; i++) { dp += ((double)a.position[i] - b.position[i]) * ((double)a.position[i] - b.position[i]); r += (double)b.position[i] * b.position[i]; }
+    turn_px = parallax_px = 1e9f;
+    if (!(na > 0) || !(nb > 0)) return false;
+    if (a.flip != b.flip || memcmp(a.basis_speed, b.basis_speed, sizeof(a.basis_speed)) != 0) return false;
+    const double c = std::min(1.0, std::fabs(dot) / std::sqrt(na * nb));
+    const double f_stop = (width / 2.0) / std::tan(fov_degrees / 360.0 * M_PI);
+    const double turn = 2 * std::acos(c) * f_stop, parallax = std::sqrt(dp) / std::max(std::sqrt(r), 1e-3) * f_stop;
+    if (!std::isfinite(turn) || !std::isfinite(parallax)) return false;
+    turn_px = (float)turn; parallax_px = (float)parallax;
+    return true;
+}
+
 static float picture_motion(const gr_camera& a, const gr_camera& b, float fov_degrees, int width) {
     double dot = 0, na = 0, nb = 0, dp = 0, r = 0;
     for (int i = 0; i < 4; i++) { dot += (double)a.quat[i] * b.quat[i]; na += (double)a.quat[i] * a.quat[i]; nb += (double)b.quat[i] * b.quat[i]; }
@@ -1075,8 +1091,19 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         if (history_wanted && !record_history) s->tile_cost_valid = false;   // (what is there would be older than the last frame)
         const int shape[3] = {adaptive ? -hist_block_rows : block_rows, strip_rank, strip_count};   // (negative: the tiles of a lattice launch)
         static const float history_max_motion = [] { const char* e = getenv("GR_TILE_HISTORY_MAX_MOTION"); return e ? (float)atof(e) : 48.f; }();
-        const bool history_order = record_history && s->tile_cost_valid && memcmp(shape, s->tile_cost_shape, sizeof(shape)) == 0 && !gc &&
-                                   picture_motion(s->tile_cost_camera, *camera, features.field_of_view, width) <= history_max_motion;
+        // ... or, when the camera mostly TURNED (mouse look: the picture shifts rigidly and the order shifts with it - follow_and_record_history -
+        // as long as both frames see the coordinate origin), up to GR_TILE_HISTORY_MAX_TURN px of turn with at most the 48 px of parallax:
+        // 1.5 degrees a frame at 4K (50 px) rendered in 6.23 ms with the history dropped and in 5.24 with it (a = 0.9: 24.0 and 21.9), 2.2 degrees
+        // (73 px) in 6.36 and 5.50 (24.4 and 23.3); at 3 degrees (100 px) the a = 0.9 frame loses badly (23.9 -> 33.8 ms: the shift is the
+        // picture centre's, a perspective picture moves by 1 / cos^2 more towards its edges, and beyond the guard ring of 48 px tiles
+        // guessed empty are dear): 64 px.
+        static const float history_max_turn = [] { const char* e = getenv("GR_TILE_HISTORY_MAX_TURN"); return e ? (float)atof(e) : 64.f; }();
+        const bool history_order = record_history && s->tile_cost_valid && memcmp(shape, s->tile_cost_shape, sizeof(shape)) == 0 && !gc && [&] {
+            if (picture_motion(s->tile_cost_camera, *camera, features.field_of_view, width) <= history_max_motion) return true;
+            float turn = 0, parallax = 0, anchor[2];
+            return picture_motion_parts(s->tile_cost_camera, *camera, features.field_of_view, width, turn, parallax) && parallax <= history_max_motion &&
+                   turn <= history_max_turn && s->tile_cost_anchored && origin_on_screen(*camera, features.field_of_view, width, height, anchor);
+        }();
         if (!prefetched && one_launch_setup) {
             GR_CHECK(begin(GR_STAGE_PREPASS));
             GR_CHECK(gr_camera_prepass(p, stream, s->camera_pos_cart, camera->flip, camera->basis_speed, s->camera_pos_generic, s->tetrad[0],
