@@ -13,8 +13,10 @@ bg_np, levels = gra.pack_background(gra.synthetic_background(4096, 2048))
 bg = DeviceBuffer.from_numpy(0, bg_np)
 out = DeviceBuffer(0, W * H * 16)
 for name in sys.argv[1:] or ["kerr_schild", "kerr_boyer", "kerr_newman_boyer"]:
+    # name or name:parameter=value,... (kerr_schild:a=-0.5 is the reference script's default: an extremal hole)
+    name, _, overrides = name.partition(":")
     m = gra.Metric(name, scripts)
-    cfg = m.cfg_values()
+    cfg = m.cfg_values(**{k: float(v) for k, v in (kv.split("=") for kv in overrides.split(",") if kv)})
     for adaptive in (1, 0):
         f = m.features(adaptive_sampling=adaptive, adaptive_sampling_threshold=32.0)
         prog = gra.Program(m.argument_string(features=f, static=True, cfg_values=cfg), 0)
