@@ -109,7 +109,7 @@ class TraceFusedArgs(ctypes.Structure):
                 ("prepass_width", c_int), ("prepass_height", c_int), ("e0", c_void_p), ("e1", c_void_p), ("e2", c_void_p),
                 ("e3", c_void_p), ("cfg", c_void_p), ("dfg", c_void_p), ("attempt_counter", c_void_p), ("tile_order", c_void_p),
                 ("waves_per_simd", c_int), ("shading", TraceShading), ("lattice", c_int), ("pending_only", c_int), ("inline_prepass", c_int),
-                ("tile_cost", c_void_p), ("tile_order_by_history", c_int), ("lattice_rays", c_void_p), ("parking", ParkingLot), ("speculative_classes", c_int)]
+                ("tile_cost", c_void_p), ("tile_order_by_history", c_int), ("lattice_rays", c_void_p), ("parking", ParkingLot), ("speculative_classes", c_int), ("guessed", c_void_p)]
 
 
 class Transport(ctypes.Structure):
@@ -204,7 +204,9 @@ _SIGNATURES = {
     "gr_adaptive_refine_list": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),
     "gr_trace_pending": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gr_guessed_bytes": (ctypes.c_size_t, []),
+    "gr_apply_guessed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gr_adaptive_refine_strips": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gr_camera_prepass": (c_int, [c_void_p, c_void_p, c_void_p, c_float, ctypes.POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int]),

@@ -95,11 +95,11 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 const char* const KERNEL_NAMES[] = {
     "gr_cart_to_generic", "gr_init_basis_vectors", "gr_clear_termination_buffer", "gr_init_rays_generic",
     "gr_do_generic_rays", "gr_calculate_singularities", "gr_calculate_render_data",
-    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_setup", "gr_order_tiles", "gr_adaptive_refine", "gr_trace_pending", "gr_do_generic_rays_scheduled", "gr_sort_tiles_count", "gr_sort_tiles_place", "gr_trace_fused_parking", "gr_boost_tetrad", "gr_init_inertial_ray",
+    "gr_handle_adaptive_sampling", "gr_render", "gr_trace_fused", "gr_trace_fused_lattice", "gr_trace_pair", "gr_trace_compact", "gr_prepass_fused", "gr_camera_setup", "gr_order_tiles", "gr_adaptive_refine", "gr_trace_pending", "gr_apply_guessed", "gr_do_generic_rays_scheduled", "gr_sort_tiles_count", "gr_sort_tiles_place", "gr_trace_fused_parking", "gr_boost_tetrad", "gr_init_inertial_ray",
     "gr_get_geodesic_path", "gr_parallel_transport_quantity", "gr_handle_interpolating_geodesic"};
 enum KernelId {
     K_CART_TO_GENERIC, K_INIT_BASIS, K_CLEAR_TERM, K_INIT_RAYS, K_DO_RAYS, K_CALC_SING, K_CALC_RDATA,
-    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_SETUP, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_TRACE_PENDING, K_DO_RAYS_SCHEDULED, K_SORT_TILES_COUNT, K_SORT_TILES_PLACE, K_TRACE_FUSED_PARKING, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
+    K_ADAPTIVE, K_RENDER, K_TRACE_FUSED, K_TRACE_FUSED_LATTICE, K_TRACE_PAIR, K_TRACE_COMPACT, K_PREPASS_FUSED, K_CAMERA_SETUP, K_ORDER_TILES, K_ADAPTIVE_REFINE, K_TRACE_PENDING, K_APPLY_GUESSED, K_DO_RAYS_SCHEDULED, K_SORT_TILES_COUNT, K_SORT_TILES_PLACE, K_TRACE_FUSED_PARKING, K_BOOST_TETRAD, K_INIT_INERTIAL, K_GEODESIC_PATH, K_PARALLEL_TRANSPORT,
     K_INTERPOLATE_GEODESIC, K_COUNT
 };
 
@@ -1544,7 +1544,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
                         const void* dfg, void* attempt_counter, int lattice = 1, int pending_only = 0, const void* tile_order = nullptr,
                         int waves_per_simd = 0, const gr_trace_shading* shading_in = nullptr, int inline_prepass = 0, void* tile_cost = nullptr,
                         int tile_order_by_history = 0, void* lattice_rays = nullptr, const gr_parking_lot* parking = nullptr,
-                        int speculative_classes_in = 0) {
+                        int speculative_classes_in = 0, void* guessed = nullptr) {
     const int T = 8;
     if (!p) return fail(GR_ERROR_INVALID_ARGUMENT, "null program");
     // the prepass inside the launch: its cell waves are the first tickets (gr_trace_fused's prepass_tickets)
@@ -1613,7 +1613,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
         resident_groups = (long long)p->compute_units * 4 * forced_waves_per_simd * 64 / wg;
     else if (waves_per_simd >= 1 && waves_per_simd <= 8)
         resident_groups = std::min(resident_groups, (long long)p->compute_units * 4 * waves_per_simd * 64 / wg);
-    if ((persistent && groups > resident_groups) || prepass_tickets || parks) {   // prepass tickets need the ticket order whatever the size, and so does a lot
+    if ((persistent && groups > resident_groups) || prepass_tickets || parks || guessed) {   // (... and so do the pixels traced ahead)   // prepass tickets need the ticket order whatever the size, and so does a lot
         tickets = p->tickets + (p->next_ticket.fetch_add(1) % gr_program::TICKET_RING);
         HIP_CHECK(hipSetDevice(p->device));
         HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
@@ -1668,7 +1668,7 @@ static int trace_launch(gr_program* p, int rays_per_lane, void* stream, const vo
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &block_rows, &strip_rank, &strip_count, &term,
                     &prepass_width, &prepass_height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &total_waves,
                     &lattice, &pending_only, &tile_order, &shading, &prepass_tickets, &ticket_tiles, &tile_cost,
-                    &last_class_is_skipped, &lattice_rays, &lot};   // the last ten: gr_trace_fused only (gr_trace_pair's parameter list ends before them), the very last gr_trace_fused_parking only
+                    &last_class_is_skipped, &lattice_rays, &lot, &guessed};   // the last eleven: gr_trace_fused only (gr_trace_pair's parameter list ends before them), the lot gr_trace_fused_parking and (unused) gr_trace_fused_lattice, the very last gr_trace_fused_lattice only
     return launch(p, kernel_index, stream, (unsigned)groups, 1, wg, 1, args);
 }
 
@@ -1726,7 +1726,7 @@ int gr_adaptive_refine_list(gr_program* p, void* stream, void* rdata, void* pend
 
 int gr_trace_pending(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width, int height,
                      const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg, void* attempt_counter,
-                     const void* pending_list, int waves_per_simd, void* block_cost) {
+                     const void* pending_list, int waves_per_simd, void* block_cost, void* guessed_next) {
     if (!p || !rdata || !pending_list) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_trace_pending: null argument");
     if (width < 2 || height < 2) return GR_OK;
     const int wg = 256;
@@ -1741,8 +1741,16 @@ int gr_trace_pending(gr_program* p, void* stream, const void* camera_generic, co
     HIP_CHECK(hipSetDevice(p->device));
     HIP_CHECK(hipMemsetAsync(tickets, 0, sizeof(unsigned int), (hipStream_t)stream));
     void* args[] = {&camera_generic, &camera_quat, &rdata, &width, &height, &e0, &e1, &e2, &e3, &cfg, &dfg, &attempt_counter, &tickets, &pending_list,
-                    &block_cost};
+                    &block_cost, &guessed_next};
     return launch(p, K_TRACE_PENDING, stream, (unsigned)groups, 1, wg, 1, args);
+}
+
+size_t gr_guessed_bytes(void) { return (8 + (size_t)65536 * (1 + 1 + 8)) * sizeof(unsigned int); }   // program.hip: GR_GUESSED_HEADER, GR_GUESSED_CAPACITY pixels, attempts, records
+
+int gr_apply_guessed(gr_program* p, void* stream, void* rdata, int width, const void* guessed, void* guessed_next, void* block_cost, void* attempt_counter) {
+    if (!p || !rdata || !guessed || width < 2) return fail(GR_ERROR_INVALID_ARGUMENT, "gr_apply_guessed: null argument");
+    void* args[] = {&rdata, &width, &guessed, &guessed_next, &block_cost, &attempt_counter};
+    return launch(p, K_APPLY_GUESSED, stream, 65536 / 256, 1, 256, 1, args);
 }
 
 // gr_do_generic_rays over ray records in 8x8-tile slot order with the fused trace's scheduling (kernels/trace.hip): the device filled
@@ -1796,7 +1804,7 @@ int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args
     return trace_launch(p, 1, stream, a->camera_generic, a->camera_quat, a->render_data, a->width, a->height, a->block_rows, a->strip_rank,
                         a->strip_count, a->termination_buffer, a->prepass_width, a->prepass_height, a->e0, a->e1, a->e2, a->e3, a->cfg, a->dfg,
                         a->attempt_counter, a->lattice == 2 ? 2 : 1, a->pending_only ? 1 : 0, a->tile_order, a->waves_per_simd, &a->shading,
-                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0, a->lattice == 2 ? a->lattice_rays : nullptr, &a->parking, a->speculative_classes);
+                        a->inline_prepass ? 1 : 0, a->tile_cost, a->tile_order_by_history ? 1 : 0, a->lattice == 2 ? a->lattice_rays : nullptr, &a->parking, a->speculative_classes, a->lattice == 2 ? a->guessed : nullptr);
 }
 
 int gr_trace_pair(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* rdata, int width,

@@ -100,6 +100,11 @@ struct gr_render_state {
     // what each tile of the last fused frame cost (gr_trace_fused_args.tile_cost) and the frame shape that goes with it: the next
     // frame's tiles are handed out dearest first by it (gr_frame_options.tile_history)
     void* lattice_rays = nullptr;   // adaptive sampling on the fused path: gr_lattice_rays_bytes (allocated on first use)
+    // the pixels of the second launch traced ahead by the lattice launch (gr_apply_guessed): [0] what this frame's lattice launch traces,
+    // [1] what this frame's second launch leaves for the next; swapped every frame that keeps them
+    void* guessed[2] = {nullptr, nullptr};
+    bool guessed_valid = false;
+    unsigned long long guessed_applied_frames = 0;
     void* parking_records = nullptr;   // gr_trace_fused_parking's lot (gr_parking_lot_bytes; allocated the first time a frame parks)
     void* parking_words = nullptr;
     int parking_slots = 0;
@@ -558,7 +563,7 @@ void gr_render_state_destroy(gr_render_state* s) {
     std::vector<void*> ptrs = {s->camera_pos_cart, s->camera_quat, s->camera_pos_generic, s->tetrad[0], s->tetrad[1], s->tetrad[2],
                                s->tetrad[3], s->rays_count_in, s->rays_adaptive_count, s->render_data_count, s->cfg, s->dfg,
                                s->attempts, s->rays_in, s->rays_adaptive, s->render_data, s->termination_buffer, s->tile_order,
-                               s->tile_cost, s->lattice_rays, s->pending_list, s->block_cost, s->block_cost_before, s->ref_cost[0], s->ref_cost[1], s->ref_order, s->ref_sort_work, s->parking_records, s->parking_words};
+                               s->tile_cost, s->lattice_rays, s->guessed[0], s->guessed[1], s->pending_list, s->block_cost, s->block_cost_before, s->ref_cost[0], s->ref_cost[1], s->ref_order, s->ref_sort_work, s->parking_records, s->parking_words};
     for (auto& slot : s->pre) {
         if (slot.stream) { (void)hipStreamSynchronize(slot.stream); (void)hipStreamDestroy(slot.stream); }
         if (slot.ready) (void)hipEventDestroy(slot.ready);
@@ -1033,17 +1038,21 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
         // Not frames of more than 32 tiles per wave slot (8K Alcubierre: 72 short tiles of much the same cost; recording and sorting
         // them measured +3 % on the frame, with nothing to gain).
         // An adaptively sampled whole frame: the same for its lattice launch - the tiles of the half-resolution grid, their costs left by the
-        // lattice launch of the frame before (GR_LATTICE_HISTORY=0: image order as before round 6's fifth session).  Only where it pays: a
-        // lattice launch that traces its own prepass cells (the gain is the speculative tiles; the order alone measured nothing, and
-        // recording + sorting cost the 0.4 ms frames of the metrics without a prepass 5-10 %).
+        // lattice launch of the frame before (GR_LATTICE_HISTORY=0: image order as before round 6's fifth session).  Only for the metrics with a
+        // prepass - the ones with a shadow and long rays along its edge: there the launch gains by its speculative tiles when it traces
+        // its own cells, and by the order alone where it is long (4K Kerr a = 0.9, prepass reused: 12.2 -> 9.1 ms); recording + sorting cost
+        // the 0.4 ms frames of the metrics without a prepass 5-10 %.
         static const bool lattice_history = [] { const char* e = getenv("GR_LATTICE_HISTORY"); return !(e && e[0] == '0'); }();
         const int hist_width = adaptive ? width / 2 : width, hist_height = adaptive ? height / 2 : height;
         const int hist_block_rows = adaptive ? ((hist_height + 7) / 8) * 8 : block_rows;
         const long long tile_words = gr_tile_order_bytes(hist_width, hist_height, hist_block_rows, strip_rank, strip_count) / 8;
         const bool history_wanted = (tune.tile_history < 0 ? history_default != 0 && strip_count == 1 && tile_words <= 32 * gr_trace_fused_wave_slots(p)
-                                                          : tune.tile_history != 0) && (!adaptive || (lattice_history && strip_count == 1 && use_prepass && !prefetched)) &&
+                                                          : tune.tile_history != 0) && (!adaptive || (lattice_history && strip_count == 1 && use_prepass)) &&
                                     (size_t)gr_tile_order_bytes(hist_width, hist_height, hist_block_rows, strip_rank, strip_count) <= s->tile_order_bytes;
-        const bool device_busy = history_wanted && tune.tile_history < 0 && earlier_frame_still_running(s->device, stream);
+        // (the pixels traced ahead for the second launch of adaptive sampling - below - are for such lone frames too, prepass or not)
+        static const bool guess_default = [] { const char* e = getenv("GR_ADAPTIVE_GUESS"); return !(e && e[0] == '0'); }();
+        const bool guesses_wanted = guess_default && adaptive && strip_count == 1 && !opt.geodesic && tune.tile_history != 0 && history_default != 0;
+        const bool device_busy = (history_wanted || guesses_wanted) && tune.tile_history < 0 && earlier_frame_still_running(s->device, stream);
         const bool tile_order_enabled = !history_wanted && (tile_order_mode == 1 || (tile_order_mode == -1 && strip_count > 1));
         const size_t cells = use_prepass ? (size_t)prepass_width * prepass_height : 0;
         // (a frame whose prepass rides in its trace launch - below - has no costs to order by; the frames it announces still do)
@@ -1225,6 +1234,20 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 if (!s->pending_list) HIP_CHECK(hipMalloc(&s->pending_list, gr_pending_list_bytes(width, height)));
                 a.lattice_rays = s->lattice_rays;
                 GR_CHECK(follow_and_record_history(a));
+                // Tracing ahead what the second launch will ask for (gr_apply_guessed): where the frame before's second launch found pixels of
+                // 1 024 attempts and more, this frame's lattice launch traces the same pixels beside its tiles - while the picture has moved
+                // little, as for the list's order below.  Whole frames that find the device idle (GR_ADAPTIVE_GUESS=0: never).
+                // (a guess is a PIXEL: it is right when the picture has not moved - a viewer whose user is looking, or dragging a slider -
+                // and a ray traced for nothing otherwise: used up to half a pixel of motion, GR_ADAPTIVE_GUESS_MAX_MOTION)
+                static const float guess_max_motion = [] { const char* e = getenv("GR_ADAPTIVE_GUESS_MAX_MOTION"); return e ? (float)atof(e) : 0.5f; }();
+                const bool keep_guesses = guesses_wanted && !device_busy;
+                if (keep_guesses && !s->guessed[0])
+                    for (void*& g : s->guessed) { HIP_CHECK(hipMalloc(&g, gr_guessed_bytes())); HIP_CHECK(hipMemsetAsync(g, 0, 32, stream)); }
+                const bool use_guesses = keep_guesses && s->guessed_valid && s->block_cost_valid && !cfg_jumped && !features_changed &&
+                                         s->block_cost_program == gr_program_serial(p) &&
+                                         picture_motion(s->block_cost_camera, *camera, features.field_of_view, width) <= guess_max_motion;
+                if (keep_guesses && !use_guesses) HIP_CHECK(hipMemsetAsync(s->guessed[0], 0, 4, stream));   // (whatever is there is not for this picture)
+                a.guessed = keep_guesses ? s->guessed[0] : nullptr;
                 GR_CHECK(gr_trace_fused_launch(p, stream, &a));
                 a.tile_order = nullptr; a.tile_order_by_history = 0; a.tile_cost = nullptr;   // (the second launch below is not the lattice's)
                 GR_CHECK(end(GR_STAGE_TRACE));
@@ -1246,14 +1269,21 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                     HIP_CHECK(hipMemsetAsync(s->block_cost, 0, image_blocks * sizeof(unsigned int), stream));
                     GR_CHECK(gr_adaptive_refine_list(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows, strip_rank,
                                                      strip_count, s->lattice_rays, s->cfg, s->pending_list, by_history ? s->block_cost_before : nullptr));
+                    if (keep_guesses) {
+                        HIP_CHECK(hipMemsetAsync(s->guessed[1], 0, 4, stream));
+                        GR_CHECK(gr_apply_guessed(p, stream, s->render_data, width, s->guessed[0], s->guessed[1], s->block_cost, attempts));
+                    }
                     GR_CHECK(gr_trace_pending(p, stream, s->camera_pos_generic, s->camera_quat, s->render_data, width, height, s->tetrad[0],
                                               s->tetrad[1], s->tetrad[2], s->tetrad[3], s->cfg, s->dfg, attempts, s->pending_list,
-                                              tune.trace_waves_per_simd, s->block_cost));
+                                              tune.trace_waves_per_simd, s->block_cost, keep_guesses ? s->guessed[1] : nullptr));
+                    if (keep_guesses) std::swap(s->guessed[0], s->guessed[1]);
+                    s->guessed_valid = keep_guesses;
                     s->block_cost_valid = strip_count == 1;
                     s->block_cost_program = gr_program_serial(p);
                     s->block_cost_camera = *camera;
                 } else {
                     s->block_cost_valid = false;
+                    s->guessed_valid = false;
                     GR_CHECK(gr_adaptive_refine_strips(p, stream, s->render_data, s->rays_adaptive_count, width, height, s->dfg, block_rows,
                                                        strip_rank, strip_count, s->lattice_rays, s->cfg));
                     a.lattice = 1;
@@ -1371,7 +1401,7 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                                           strip_count > 1 ? opt.compact_out : 0, opt.max_probes, s->cfg, s->dfg));
             GR_CHECK(end(GR_STAGE_RENDER));
         }
-        if (history_wanted) mark_frame_end(s->device, stream);
+        if (history_wanted || guesses_wanted) mark_frame_end(s->device, stream);
         return GR_OK;
     }
 

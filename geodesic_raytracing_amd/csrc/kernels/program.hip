@@ -143,6 +143,14 @@ struct dynamic_feature_config {
 #ifndef GR_TILE_COST_REACH
 #define GR_TILE_COST_REACH 1      // cells either side of the tile centre's whose rays' costs count for the tile's class
 #endif
+// The pixels guessed for the second launch of adaptive sampling (trace.hip: trace_tile's guess waves, gr_apply_guessed, gr_trace_pending): one
+// buffer of GR_GUESSED_HEADER words (word 0: how many), GR_GUESSED_CAPACITY pixels, as many attempt counts, as many 32-byte records
+// (capi.cpp gr_guessed_bytes).  A pixel is worth guessing if it cost GR_GUESSED_ATTEMPTS attempts or more in the frame before.
+#define GR_GUESSED_HEADER 8
+#define GR_GUESSED_CAPACITY 65536
+#ifndef GR_GUESSED_ATTEMPTS
+#define GR_GUESSED_ATTEMPTS 4096u
+#endif
 #ifndef GR_CELL_BLOCK
 #define GR_CELL_BLOCK 1           // the prepass cells a trace launch traces itself: 1 = a wave to 8 x 8 cells, 0 = to 64 cells of a row (capi.cpp: prepass_tickets)
 #endif

@@ -536,7 +536,11 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
                                            unsigned long long* __restrict__ attempt_counter, int lattice, int pending_only,
                                            const trace_shading& shading, bool known_skipped, int cell_wave, bool cells_in_flight,
                                            unsigned int* __restrict__ tile_cost, float4* __restrict__ lattice_rays,
-                                           const parking_lot* lot = nullptr, int record = -1, bool from_lot = false, bool speculative = false) {
+                                           const parking_lot* lot = nullptr, int record = -1, bool from_lot = false, bool speculative = false,
+                                           int guess_wave = -1, unsigned int* __restrict__ guessed = nullptr) {
+    // guess_wave >= 0 (the lattice launch of adaptive sampling; `guessed`: gr_guessed_bytes): this "tile" is 64 pixels of the list of
+    // pixels the frame before had to trace in its second launch and found dear - traced here, beside the lattice, before anybody knows
+    // whether this frame's decisions will ask for them; their records wait in `guessed` for gr_apply_guessed.
     // speculative (wave-uniform; a launch with cells in flight only): the tile does not wait for the prepass cells its pixels look at -
     // it traces every pixel at once and looks the verdicts up when its rays have ended; a pixel the prepass skips gets the skipped
     // record then, as if its ray had never been traced (trace_fused_body says which tiles: the ones on the launch's critical path).
@@ -569,6 +573,13 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         cx = __float_as_int(where.z) & 0xffff;
         cy = (int)((unsigned int)__float_as_int(where.z) >> 16);
         wave = __float_as_int(where.w);   // (per lane here: only the ray's cost, at its end, is filed under it)
+    } else if (LATTICE_RAYS && guess_wave >= 0) {
+        const unsigned int entry = (unsigned int)guess_wave * 64u + (unsigned int)lane;
+        if (entry >= min(guessed[0], (unsigned int)GR_GUESSED_CAPACITY)) return;
+        const unsigned int pixel = guessed[GR_GUESSED_HEADER + entry];
+        cx = (int)(pixel % (unsigned int)image_width);
+        cy = (int)(pixel / (unsigned int)image_width);
+        width = image_width; height = image_height;
     } else if (cell_wave >= 0) {
         // a cell wave is 8 x 8 cells, not 64 of a row: a wave publishes its verdicts when its longest ray has ended, the long rays lie along
         // the shadow's edge, and a curve crosses far fewer blocks than rows - the other waves' cells are known early (GR_CELL_BLOCK=0: rows)
@@ -607,7 +618,7 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
     // known_skipped: a tile of gr_order_tiles' last class - the 5x5 cells around it are all in the shadow, and the stencil of every
     // one of its pixels lies inside those (a pixel rounds to a cell at most one from the tile centre's) - needs no look-up at all
     int terminated = known_skipped ? 2 : 0;
-    const bool looks_at_cells = cell_wave < 0 && !known_skipped && !pending_only && !(PARKING && from_lot) && termination_buffer && prepass_width != width &&
+    const bool looks_at_cells = cell_wave < 0 && !(LATTICE_RAYS && guess_wave >= 0) && !known_skipped && !pending_only && !(PARKING && from_lot) && termination_buffer && prepass_width != width &&
                                 prepass_height != height;
     if (looks_at_cells && !speculative) {
         float fx = exact_ratio(cx, width);
@@ -713,6 +724,13 @@ __device__ __forceinline__ void trace_tile(int wave, int lane, const float4* __r
         else { s.position = ray.position; s.velocity = ray.velocity; s.running_dlambda_dnew = 1; }
         dat = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated, cx, cy, cfg,
                                dfg, GET_FEATURE(redshift, dfg) != 0);
+        if (LATTICE_RAYS && guess_wave >= 0) {
+            // (what gr_trace_pending would have written, had the pixel been on its list already: gr_apply_guessed hands it over if it is)
+            const unsigned int entry = (unsigned int)guess_wave * 64u + (unsigned int)lane;
+            guessed[GR_GUESSED_HEADER + GR_GUESSED_CAPACITY + entry] = tries;
+            reinterpret_cast<render_data*>(guessed + GR_GUESSED_HEADER + 2 * GR_GUESSED_CAPACITY)[entry] = dat;
+            return;
+        }
         if (looks_at_cells && speculative) {
             // the verdict, after the fact: by now the cells' rays have usually ended too (they are as long as this tile's, and began with it)
             const int lx = (int)roundf(exact_ratio(cx, width) * prepass_width), ly = (int)roundf(exact_ratio(cy, height) * prepass_height);
@@ -790,7 +808,7 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
                int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
                int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped,
-               float4* __restrict__ lattice_rays, parking_lot lot = parking_lot()) {
+               float4* __restrict__ lattice_rays, parking_lot lot = parking_lot(), unsigned int* __restrict__ guessed = nullptr) {
     // prepass_tickets > 0 (persistent launches in image order only): the first prepass_tickets tickets are the waves of the
     // low-resolution prepass, then come the tiles, which wait for the cells they look at (trace_tile).  A frame whose camera was not
     // known in advance then pays the prepass's single-ray latency once per cell wave alongside the first tiles instead of as a
@@ -811,7 +829,9 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
     int held = 0, cursor = 0;   // tiles this wave still holds from its last ticket, and where in the list they start
     bool known_skipped = false;  // the ticket was a chunk of the last class
     // ticket space: the prepass's cell waves, then the tiles - in the list's order if there is one
-    const int cell_tickets = prepass_tickets > 0 ? prepass_tickets : 0;
+    // ... then (the lattice launch of adaptive sampling, `guessed`) the waves of the pixels guessed for the second launch (trace_tile), then the tiles
+    const int guess_tickets = (LATTICE_RAYS && guessed && tile_counter) ? (int)((min(guessed[0], (unsigned int)GR_GUESSED_CAPACITY) + 63u) / 64u) : 0;
+    const int cell_tickets = (prepass_tickets > 0 ? prepass_tickets : 0) + guess_tickets;   // (everything in front of the tiles)
     const int tickets_total = total_waves + cell_tickets;
     const int singles = (tile_counter && tile_order) ? tickets_total - (int)tile_order[GR_TILE_CLASSES - 1] : tickets_total;
     // the list says itself whether its last class is a promise (program.hip GR_LIST_BY_PREPASS)
@@ -823,7 +843,7 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
     // are not held up: they trace all their pixels from t = 0 and take the verdicts afterwards (trace_tile).  What that wastes are the
     // rays of their pixels the prepass would have skipped, in lanes that would have idled.
     int speculative_tiles = 0;
-    if (!PARKING && tile_counter && tile_order && cell_tickets > 0 && !list_promises)
+    if (!PARKING && tile_counter && tile_order && prepass_tickets > 0 && !list_promises)
         for (int c = 0; c < (last_class_is_skipped >> 8) && c < GR_TILE_CLASSES - 2; c++) speculative_tiles += (int)tile_order[c];
     bool speculative = false;
     for (;;) {
@@ -836,7 +856,7 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
             from_lot = __builtin_amdgcn_readfirstlane(claim_parked(lot, lane, tickets_gone, record)) > 0;
             if (!from_lot && tickets_gone) break;
         }
-        int cell_wave = -1;
+        int cell_wave = -1, guess_wave = -1;
         if (PARKING && from_lot) { wave = 0; known_skipped = false; }
         else {
         if (tile_counter) {
@@ -866,9 +886,10 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
             cursor++;
             held--;
         }
-        if (prepass_tickets > 0) {
+        if (cell_tickets > 0) {
             if (wave < prepass_tickets) { cell_wave = wave; wave = 0; }
-            else wave -= prepass_tickets;
+            else if (wave < cell_tickets) { guess_wave = wave - (prepass_tickets > 0 ? prepass_tickets : 0); wave = 0; }
+            else wave -= cell_tickets;
         }
         if (wave >= total_waves) break;
         }
@@ -880,7 +901,7 @@ __device__ __forceinline__ void trace_fused_body(const float4* __restrict__ g_ge
         trace_tile<LATTICE_RAYS, PARKING>(wave, lane, g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count,
                    termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg, dfg, attempt_counter, lattice, pending_only, shading,
                    known_skipped && lattice == 1 && !pending_only, cell_wave, prepass_tickets > 0, tile_cost, lattice_rays, &lot, record, from_lot,
-                   speculative && !pending_only);
+                   speculative && !pending_only, guess_wave, guessed);
         GR_PROBE_TILE_ENDED
         if (!tile_counter) break;
     }
@@ -916,8 +937,8 @@ gr_trace_fused_lattice(const float4* __restrict__ g_generic_camera_in, const flo
                cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter, unsigned int* __restrict__ tile_counter,
                int total_waves, int lattice, int pending_only, const unsigned int* __restrict__ tile_order, trace_shading shading,
                int prepass_tickets, int ticket_tiles, unsigned int* __restrict__ tile_cost, int last_class_is_skipped,
-               float4* __restrict__ lattice_rays) {
-    trace_fused_body<true>(g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg_in, dfg_in, attempt_counter, tile_counter, total_waves, lattice, pending_only, tile_order, shading, prepass_tickets, ticket_tiles, tile_cost, last_class_is_skipped, lattice_rays);
+               float4* __restrict__ lattice_rays, parking_lot unused_lot, unsigned int* __restrict__ guessed) {
+    trace_fused_body<true>(g_generic_camera_in, g_camera_quat, rdata, width, height, block_rows, strip_rank, strip_count, termination_buffer, prepass_width, prepass_height, e0, e1, e2, e3, cfg_in, dfg_in, attempt_counter, tile_counter, total_waves, lattice, pending_only, tile_order, shading, prepass_tickets, ticket_tiles, tile_cost, last_class_is_skipped, lattice_rays, parking_lot(), guessed);
 }
 #endif  // GR_ADAPTIVE_KERNELS
 
@@ -1476,7 +1497,10 @@ extern "C" __global__ void __launch_bounds__(GR_TRACE_BLOCK, GR_FUSED_WAVES)
 gr_trace_pending(const float4* __restrict__ g_generic_camera_in, const float4* __restrict__ g_camera_quat, render_data* __restrict__ rdata,
                  int width, int height, const float4* __restrict__ e0, const float4* __restrict__ e1, const float4* __restrict__ e2,
                  const float4* __restrict__ e3, cfg_t cfg_in, dfg_t dfg_in, unsigned long long* __restrict__ attempt_counter,
-                 unsigned int* __restrict__ ticket_counter, const unsigned int* __restrict__ pending_list, unsigned int* __restrict__ block_cost) {
+                 unsigned int* __restrict__ ticket_counter, const unsigned int* __restrict__ pending_list, unsigned int* __restrict__ block_cost,
+                 unsigned int* __restrict__ guessed_next) {
+    // guessed_next (may be NULL; its count zeroed by the caller): the pixels that cost GR_GUESSED_ATTEMPTS attempts or more are left there for the
+    // next frame's lattice launch to trace ahead (trace_tile's guess waves); a pixel gr_apply_guessed has served already is passed over
     // block_cost (may be NULL; zeroed by the caller): one word per 2x2 block of the image, left holding what the dearest of the block's
     // rays cost - the order of the next frame's list (gr_adaptive_refine's block_cost_before)
     GR_PARAMETERS_IN_REGISTERS
@@ -1490,8 +1514,8 @@ gr_trace_pending(const float4* __restrict__ g_generic_camera_in, const float4* _
         if (first >= total) break;
         asm volatile("" : "+s"(g_generic_camera_in), "+s"(g_camera_quat), "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3));   // (as gr_trace_fused: nothing of the set-up hoisted over the loop)
         unsigned int tries = 0;
-        if (first + lane < total) {
-            const unsigned int pixel = pending_list[GR_PENDING_HEADER + first + lane];
+        const unsigned int pixel = first + lane < total ? pending_list[GR_PENDING_HEADER + first + lane] : 0u;
+        if (first + lane < total && (!guessed_next || rdata[pixel].terminated == GR_PENDING)) {
             const int cx = (int)(pixel % (unsigned int)width), cy = (int)(pixel / (unsigned int)width);
             lightray ray = make_pixel_ray(cx, cy, width, height, *g_generic_camera_in, *g_camera_quat, *e0, *e1, *e2, *e3, 0, cfg, dfg);
             ray_state s;
@@ -1505,8 +1529,33 @@ gr_trace_pending(const float4* __restrict__ g_generic_camera_in, const float4* _
             rdata[cy * width + cx] = make_render_data(s.position, s.velocity, ray.initial_quat, ray.ku_uobsu, s.running_dlambda_dnew, terminated,
                                                       cx, cy, cfg, dfg, GET_FEATURE(redshift, dfg) != 0);
             if (block_cost) atomicMax(block_cost + (size_t)(cy / 2) * (width / 2) + cx / 2, tries);
+            if (guessed_next && tries >= GR_GUESSED_ATTEMPTS) {
+                const unsigned int slot = atomicAdd(guessed_next, 1u);
+                if (slot < GR_GUESSED_CAPACITY) guessed_next[GR_GUESSED_HEADER + slot] = pixel;
+            }
         }
         if (attempt_counter) atomicAdd(attempt_counter + GR_ATTEMPT_COUNTERS_AT + (blockIdx.x % GR_ATTEMPT_COUNTERS), (unsigned long long)tries);
+    }
+}
+
+// The guesses of the lattice launch (trace_tile's guess waves) against this frame's decisions: a guessed pixel that gr_adaptive_refine marked
+// GR_PENDING gets the record traced ahead for it - the ray of a pixel is the ray of a pixel, whoever traces it and when - with its attempts
+// counted and its cost left where gr_trace_pending would have left them; a guess the decisions did not ask for is dropped.  One lane per guess.
+extern "C" __global__ void gr_apply_guessed(render_data* __restrict__ rdata, int width, const unsigned int* __restrict__ guessed,
+                                            unsigned int* __restrict__ guessed_next, unsigned int* __restrict__ block_cost,
+                                            unsigned long long* __restrict__ attempt_counter) {
+    const unsigned int entry = blockIdx.x * blockDim.x + threadIdx.x;
+    if (entry >= min(guessed[0], (unsigned int)GR_GUESSED_CAPACITY)) return;
+    const unsigned int pixel = guessed[GR_GUESSED_HEADER + entry];
+    if (rdata[pixel].terminated != GR_PENDING) return;
+    const unsigned int tries = guessed[GR_GUESSED_HEADER + GR_GUESSED_CAPACITY + entry];
+    rdata[pixel] = reinterpret_cast<const render_data*>(guessed + GR_GUESSED_HEADER + 2 * GR_GUESSED_CAPACITY)[entry];
+    const int cx = (int)(pixel % (unsigned int)width), cy = (int)(pixel / (unsigned int)width);
+    if (block_cost) atomicMax(block_cost + (size_t)(cy / 2) * (width / 2) + cx / 2, tries);
+    if (attempt_counter) atomicAdd(attempt_counter + GR_ATTEMPT_COUNTERS_AT + (blockIdx.x % GR_ATTEMPT_COUNTERS), (unsigned long long)tries);
+    if (guessed_next && tries >= GR_GUESSED_ATTEMPTS) {
+        const unsigned int slot = atomicAdd(guessed_next, 1u);
+        if (slot < GR_GUESSED_CAPACITY) guessed_next[GR_GUESSED_HEADER + slot] = pixel;
     }
 }
 #endif  // GR_ADAPTIVE_KERNELS

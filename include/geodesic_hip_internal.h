@@ -238,6 +238,10 @@ typedef struct gr_trace_fused_args {
                                   * look at: they trace every pixel from the start and take the verdicts when their rays have ended - the
                                   * launch's critical path is otherwise the longest cell ray followed by the longest tile, which reads that
                                   * cell.  Records are the same.  0 = library default (5: tiles that had a ray of 1 024 attempts or more), -1 = none */
+    void* guessed;               /* lattice = 2 (persistent launch): gr_guessed_bytes of device memory whose first word says how many pixels of
+                                  * its list the launch is to trace ahead, beside the lattice - the pixels the frame before traced in its second
+                                  * launch and found dear (gr_trace_pending leaves them) - each record into the same buffer for
+                                  * gr_apply_guessed; NULL or a count of 0: none */
 } gr_trace_fused_args;
 int gr_trace_fused_launch(gr_program* p, void* stream, const gr_trace_fused_args* args);
 /* waves of gr_trace_fused the program's device holds at once (what a persistent launch fills it with): a frame of many more tiles than
@@ -278,7 +282,16 @@ int gr_adaptive_refine_list(gr_program* p, void* stream, void* render_data, void
                             const void* block_cost_before);
 int gr_trace_pending(gr_program* p, void* stream, const void* camera_generic, const void* camera_quat, void* render_data, int width, int height,
                      const void* e0, const void* e1, const void* e2, const void* e3, const void* cfg, const void* dfg, void* attempt_counter,
-                     const void* pending_list, int waves_per_simd, void* block_cost);
+                     const void* pending_list, int waves_per_simd, void* block_cost, void* guessed_next);
+/* Tracing ahead what the second launch will ask for (round 6).  An adaptively sampled frame is two dependent launches, and where single rays
+ * run to the step cap (an extremal hole at 1080p) each lasts as long as its longest ray: 2 x 14 ms.  gr_trace_pending leaves the pixels that
+ * cost 1 024 attempts or more in guessed_next (gr_guessed_bytes; its first word zeroed by the caller; NULL: nothing kept, nothing passed
+ * over); the next frame's lattice launch traces them beside its tiles (gr_trace_fused_args.guessed), gr_apply_guessed - after
+ * gr_adaptive_refine_list, before gr_trace_pending - hands a guessed pixel that IS marked its record, attempts and cost (and keeps it
+ * guessed for the frame after), and gr_trace_pending passes over what is no longer marked.  Records are those of a frame that guesses nothing. */
+size_t gr_guessed_bytes(void);
+int gr_apply_guessed(gr_program* p, void* stream, void* render_data, int width, const void* guessed, void* guessed_next, void* block_cost,
+                     void* attempt_counter);
 /* lattice_rays: gr_lattice_rays_bytes(width, height) bytes - 3 x float4 per lattice pixel, and behind those one unsigned per lattice
  * pixel: the attempts its ray took (the cost estimate of gr_adaptive_refine_list) - written by the lattice launch (lattice = 2) and
  * read by gr_adaptive_refine: where every lattice ray ended (position, velocity, the quaternion of its rotated frame) - what the

@@ -594,7 +594,7 @@ def test_pending_list_of_adaptive_sampling_holds_the_marked_pixels_dearest_first
     klass = 63 - np.minimum(fine, 63)
     assert (np.diff(klass) >= 0).all() and np.array_equal(np.bincount(klass, minlength=64), counts)
     check(lib.gr_trace_pending(prog.handle, None, buf(gra.BUF_CAMERA_GENERIC), buf(gra.BUF_CAMERA_QUAT), records_b.ptr, w, h, buf(gra.BUF_TETRAD0),
-                               buf(gra.BUF_TETRAD1), buf(gra.BUF_TETRAD2), buf(gra.BUF_TETRAD3), buf(gra.BUF_CFG), buf(gra.BUF_DFG), None, pending.ptr, 0, None))
+                               buf(gra.BUF_TETRAD1), buf(gra.BUF_TETRAD2), buf(gra.BUF_TETRAD3), buf(gra.BUF_CFG), buf(gra.BUF_DFG), None, pending.ptr, 0, None, None))
     frame_b = records_b.to_numpy(RENDER_DATA_DTYPE, w * h)
     assert (frame_b["terminated"] >= 0).all() and (frame_a["terminated"] >= 0).all()
     differ = frame_a["terminated"] != frame_b["terminated"]

@@ -1,6 +1,6 @@
 """The slowest shipped scripts at 1920x1080 with the GUI's defaults (adaptive sampling on, threshold 32), one frame at a time: stage times with the
 prepass as a launch of its own / inside the lattice launch / taken from the previous frame (still camera), and with every pixel traced.
-usage: python tools/slow_scripts_probe.py [script ...]"""
+usage: python tools/slow_scripts_probe.py [script[:parameter=value,...] ...]      PROBE_SIZE=WxH, PROBE_MOVE=<units sideways per frame>"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -29,7 +29,7 @@ for name in sys.argv[1:] or ["kerr_schild", "kerr_boyer", "kerr_newman_boyer"]:
             for i in range(7):
                 st.synchronize()
                 t = time.perf_counter()
-                st.render(prog, m, gra.default_camera(), out.ptr, (bg.ptr, 4096, 2048, levels), f, cfg, o)
+                st.render(prog, m, gra.default_camera([0, float(os.environ.get("PROBE_MOVE", "0")) * i, -4, 0]), out.ptr, (bg.ptr, 4096, 2048, levels), f, cfg, o)
                 st.synchronize()
                 if i >= 2:
                     wall.append((time.perf_counter() - t) * 1e3)
