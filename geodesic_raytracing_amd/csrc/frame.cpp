@@ -104,7 +104,6 @@ struct gr_render_state {
     // [1] what this frame's second launch leaves for the next; swapped every frame that keeps them
     void* guessed[2] = {nullptr, nullptr};
     bool guessed_valid = false;
-    unsigned long long guessed_applied_frames = 0;
     void* parking_records = nullptr;   // gr_trace_fused_parking's lot (gr_parking_lot_bytes; allocated the first time a frame parks)
     void* parking_words = nullptr;
     int parking_slots = 0;

@@ -70,7 +70,10 @@ void* gr_geodesic_camera_buffer(gr_geodesic_camera* g, int which);
 enum { GR_BUF_RAYS_IN = 0, GR_BUF_RAYS_COUNT = 1, GR_BUF_RENDER_DATA = 2, GR_BUF_TERMINATION = 3, GR_BUF_CAMERA_GENERIC = 4,
        GR_BUF_TETRAD0 = 5, GR_BUF_TETRAD1 = 6, GR_BUF_TETRAD2 = 7, GR_BUF_TETRAD3 = 8, GR_BUF_RAYS_ADAPTIVE = 9,
        GR_BUF_RAYS_ADAPTIVE_COUNT = 10, GR_BUF_CFG = 11, GR_BUF_DFG = 12, GR_BUF_CAMERA_QUAT = 13 };
-/* device pointer of one of the state's buffers (NULL if not allocated) */
+/* device pointer of one of the state's buffers (NULL if not allocated).  Asking for the camera set, the prepass verdicts or the parameters
+ * (anything but the ray and render-data records) tells the state that they may be written from outside: the next frame then does its own
+ * camera set-up and prepass whatever gr_frame_tuning.reuse_still_camera says.  That holds for the NEXT frame only - a caller that keeps such
+ * a pointer and writes through it in later frames renders those with reuse_still_camera = 0. */
 void* gr_render_state_buffer(gr_render_state* s, int which);
 
 /* counters of a program manager: out[0] parameter changes taken (gr_program_manager_update), [1] substituted programs swapped in, [2] substituted
