@@ -1234,8 +1234,8 @@ int gr_render_frame(gr_render_state* s, gr_program* p, const gr_metric* m, void*
                 a.lattice_rays = s->lattice_rays;
                 GR_CHECK(follow_and_record_history(a));
                 // Tracing ahead what the second launch will ask for (gr_apply_guessed): where the frame before's second launch found pixels of
-                // 1 024 attempts and more, this frame's lattice launch traces the same pixels beside its tiles - while the picture has moved
-                // little, as for the list's order below.  Whole frames that find the device idle (GR_ADAPTIVE_GUESS=0: never).
+                // 4 096 attempts and more (program.hip GR_GUESSED_ATTEMPTS), this frame's lattice launch traces the same pixels beside its
+                // tiles.  Whole frames that find the device idle (GR_ADAPTIVE_GUESS=0: never).
                 // (a guess is a PIXEL: it is right when the picture has not moved - a viewer whose user is looking, or dragging a slider -
                 // and a ray traced for nothing otherwise: used up to half a pixel of motion, GR_ADAPTIVE_GUESS_MAX_MOTION)
                 static const float guess_max_motion = [] { const char* e = getenv("GR_ADAPTIVE_GUESS_MAX_MOTION"); return e ? (float)atof(e) : 0.5f; }();

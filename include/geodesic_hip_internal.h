@@ -288,7 +288,7 @@ int gr_trace_pending(gr_program* p, void* stream, const void* camera_generic, co
                      const void* pending_list, int waves_per_simd, void* block_cost, void* guessed_next);
 /* Tracing ahead what the second launch will ask for (round 6).  An adaptively sampled frame is two dependent launches, and where single rays
  * run to the step cap (an extremal hole at 1080p) each lasts as long as its longest ray: 2 x 14 ms.  gr_trace_pending leaves the pixels that
- * cost 1 024 attempts or more in guessed_next (gr_guessed_bytes; its first word zeroed by the caller; NULL: nothing kept, nothing passed
+ * cost 4 096 attempts or more in guessed_next (gr_guessed_bytes; its first word zeroed by the caller; NULL: nothing kept, nothing passed
  * over); the next frame's lattice launch traces them beside its tiles (gr_trace_fused_args.guessed), gr_apply_guessed - after
  * gr_adaptive_refine_list, before gr_trace_pending - hands a guessed pixel that IS marked its record, attempts and cost (and keeps it
  * guessed for the frame after), and gr_trace_pending passes over what is no longer marked.  Records are those of a frame that guesses nothing. */
